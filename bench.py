@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the wavefront path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torchrun, one rank per GPU)
+
+One step = one complete render of the workload through the C ABI (tyr_reset_accum +
+tyr_render: top-up -> extend -> shade -> connect until every path has finished) plus, for
+N > 1, the RCCL sum-reduction of the accumulation buffer onto rank 0.  The scene lives in HBM
+before the timed region starts; nothing crosses PCIe inside it except 120-byte counter reads.
+
+Workloads (BASELINE.json configs):
+    c2  Cornell box + 10,000 seeded random diffuse triangles, 1920x1080, 8 spp     (default: configs[1])
+    c3  room + 706x706 height-field mesh (996,882 triangles), 30 % SPEC, 1920x1080, 8 spp
+At N GPUs the frame is pixel-sharded (rows y % N == rank) and rendered at 8*N spp, so each
+GPU traces what one GPU traces at N = 1: weak scaling (N = 8 is BASELINE config C4's 64 spp).
+
+Mrays/s = (extend rays + shadow rays traced by all ranks) / wall time.
+roofline: the extend kernel; achieved = algorithmic bytes / hipEvent time of its launches
+inside the timed region, algorithmic bytes per ray = 24 + 8 + 32 * nodes + 36 * triangles
+with nodes / triangles per ray counted by the library's counting build of the same kernel
+in an untimed pass.  cpu_baseline: the oracle's serial loop on this host, 1 core, on the
+first wavefront iterations of the same workload (N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_workload(name: str, binding, scenes):
+    if name == "c2":
+        sc = scenes.cornell_soup(10000)
+        label = "C2: Cornell box (36 tris) + 10,000 seeded random diffuse triangles"
+    elif name == "c3":
+        sc = scenes.mesh_scene(706)
+        label = "C3: room + 706x706 height-field mesh (996,882 tris), 70% DIFF / 30% SPEC"
+    elif name == "c1":
+        sc = scenes.cornell_box()
+        label = "C1: Cornell box (36 tris)"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    t0 = time.perf_counter()
+    nodes, prims = binding.bvh_build(sc.triangles)  # host SAH build (bvh.cpp:3-225), outside the timed region
+    return sc, nodes, prims, label, time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=8, help="samples per pixel per GPU (total spp = spp * gpus)")
+    ap.add_argument("--queue", type=int, default=2097152, help="ray_queue_buffer_size (variables.h:44)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iterations", type=int, default=3)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from tyrant_amd import binding, scenes
+    from tyrant_amd import dist as tdist
+
+    rank, local_rank, world = tdist.env_rank_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 needs `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = tdist.init_process_group("nccl") if world > 1 else None
+
+    W, H, N = args.width, args.height, args.queue
+    spp_total = args.spp * world
+    sc, nodes, prims, label, t_build = build_workload(args.workload, binding, scenes)
+    flags = binding.TYR_FLAG_PROFILE | (binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0)
+    shard = tdist.shard_spec(rank, world, H)
+
+    # the caller owns blit_buffer (main.cpp:129-130); here it is a torch tensor so RCCL can reduce it in place
+    accum = torch.zeros(H * W * 4, dtype=torch.float32, device=f"cuda:{local_rank}")
+    torch.cuda.synchronize()  # the library launches on its own stream
+    r = binding.Renderer(W, H, N, device=local_rank, flags=flags, blit_buffer=accum.data_ptr(), **shard)
+    r.load_scene(sc, nodes, prims)
+
+    def step():
+        r.reset_accum()
+        it = r.render(spp_total)
+        if world > 1:
+            tdist.reduce_accum(accum, dst=0)
+        return it
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed: nodes / triangles per ray from the counting build of the same kernels (one render, rank 0's shard)
+    rc = binding.Renderer(W, H, N, device=local_rank, flags=flags | binding.TYR_FLAG_COUNT_VISITS, **shard)
+    rc.load_scene(sc, nodes, prims)
+    rc.render(spp_total)
+    kc = rc.counters()
+    nodes_per_ext = kc["nodes_extend"] / max(kc["total_extend_rays"], 1)
+    tris_per_ext = kc["tris_extend"] / max(kc["total_extend_rays"], 1)
+    nodes_per_con = kc["nodes_connect"] / max(kc["total_shadow_rays"], 1)
+    tris_per_con = kc["tris_connect"] / max(kc["total_shadow_rays"], 1)
+    rc.close()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    k0 = r.counters()
+    r.timings(reset=True)
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(args.steps):
+        iters += step()
+    fence()
+    dt = time.perf_counter() - t0
+    k1 = r.counters()
+    tm = r.timings()
+    assert k1["device_error"] == 0, k1
+
+    ext = k1["total_extend_rays"] - k0["total_extend_rays"]
+    shd = k1["total_shadow_rays"] - k0["total_shadow_rays"]
+    stats = torch.tensor([float(ext), float(shd), dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        tmax = stats[2:3].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats[0:2], op=dist.ReduceOp.SUM)
+        stats[2] = tmax[0]
+    ext_all, shd_all, dt_all = (float(x) for x in stats.tolist())
+
+    if rank == 0:
+        # sanity of the reduced frame: every pixel has exactly spp_total completed paths
+        a = accum.view(H * W, 4)[:, 3]
+        assert float(a.min()) == float(a.max()) == float(spp_total), (float(a.min()), float(a.max()), spp_total)
+
+        mrays = (ext_all + shd_all) / dt_all / 1e6
+        # roofline of the dominant kernel (extend), this rank's launches inside the timed region
+        bytes_per_ext = 24 + 8 + 32 * nodes_per_ext + 36 * tris_per_ext
+        ext_ms, ext_launches = tm["extend"]["ms"], max(tm["extend"]["launches"], 1)
+        bytes_per_launch = bytes_per_ext * ext / ext_launches
+        achieved = (bytes_per_launch / (ext_ms / ext_launches * 1e-3)) / 1e9 if ext_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s at 1080p 8spp",
+            "value": round(mrays, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt_all / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": label,
+                "resolution": f"{W}x{H}",
+                "spp_total": spp_total,
+                "spp_per_gpu": args.spp,
+                "queue_size": N,
+                "triangles": int(prims.shape[0]),
+                "bvh_nodes": int(nodes.shape[0]),
+                "sharding": f"rows y % {world} == rank, RCCL reduce of the accumulation buffer" if world > 1 else "none",
+                "wavefront_iterations_per_step": iters / args.steps,
+                "extend_Mrays/s": round(ext_all / dt_all / 1e6, 3),
+                "shadow_Mrays/s": round(shd_all / dt_all / 1e6, 3),
+                "host_bvh_build_s": round(t_build, 3),
+            },
+            "roofline": {
+                "kernel": "k_extend",
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_ray": round(bytes_per_ext, 1),
+                "nodes_per_ray": round(nodes_per_ext, 2),
+                "tris_per_ray": round(tris_per_ext, 3),
+                "avg_launch_ms": round(ext_ms / ext_launches, 4),
+                "launches": ext_launches,
+                "connect_nodes_per_ray": round(nodes_per_con, 2),
+                "connect_tris_per_ray": round(tris_per_con, 3),
+                "kernel_ms": {k: round(v["ms"], 3) for k, v in tm.items()},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, W, H, N, args.cpu_iterations, sc.triangle_materials)
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, W, H, N, iterations, tri_materials):
+    """the oracle (a serial CPU port of the reference's loop) on the first `iterations` wavefront
+    iterations of the same workload: same scene, resolution, queue size, seeds; 1 core"""
+    from oracle import pyorc
+    from tyrant_amd import scenes
+
+    t0 = time.perf_counter()
+    nodes, prims = pyorc.bvh_build(sc.triangles, scenes.triangle_bboxes(sc.triangles))
+    t_build = time.perf_counter() - t0
+    o = pyorc.Oracle(W, H, N, flags=1 if tri_materials else 0)
+    o.load_scene(sc, nodes, prims)
+    t0 = time.perf_counter()
+    for _ in range(iterations):
+        o.launch_kernels()
+    dt = time.perf_counter() - t0
+    k = o.counters()
+    rays = k["total_extend_rays"] + k["total_shadow_rays"]
+    return {
+        "value": round(rays / dt / 1e6, 4),
+        "unit": "Mrays/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {iterations} wavefront iterations of the same workload ({k['total_extend_rays']} extend + {k['total_shadow_rays']} shadow rays) in {dt:.1f} s",
+        "bvh_build_s": round(t_build, 3),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,232 @@
+/*
+ * include/tyr_c.h -- C ABI of libtyrant_hip.so, the MI355X-native drop-in for the
+ * wavefront render loop of stijnherfst/Tyrant.
+ *
+ * Every entry point cites the reference interface it replaces (file:line under
+ * PathTracer/).  Plain pointers and sizes only; record layouts are byte-for-byte
+ * the reference's structs so a cgo/FFI/C++ caller can pass its own arrays.
+ * All functions return 0 on success or a negative tyr_status / positive
+ * hipError_t; nothing in the library calls exit() (the reference's cuda() macro
+ * does, assert_cuda.cpp:3-14 -- a caller wanting that wraps calls in TYR_CHECK).
+ *
+ * Threading: one tyr_ctx per device, one HIP stream per ctx, calls on one ctx
+ * are not thread-safe (the reference is single-threaded with function statics,
+ * kernel.cu:665-667).
+ */
+#ifndef TYR_C_H
+#define TYR_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TYR_ABI_VERSION 1
+
+/* ---- record layouts (identical to the reference structs) ------------------ */
+
+/* loader.h:13-19  struct Triangle  (40 B) */
+typedef struct tyr_triangle {
+	float vert[3];
+	float e1[3];
+	float e2[3];
+	uint8_t materialType;
+	uint8_t pad_[3];
+} tyr_triangle;
+
+/* Bbox.h:3-5  struct BBox  (24 B): bounds[0] = bottom, bounds[1] = top */
+typedef struct tyr_bbox {
+	float bounds[2][3];
+} tyr_bbox;
+
+/* bvh.h:55-68  BVH::BVHNode  (32 B), depth-first, left child = index + 1 */
+typedef struct tyr_bvh_node {
+	tyr_bbox bbox;
+	int32_t offset; /* union { primitiveOffset; secondChildOffset; } */
+	uint16_t primitiveCount;
+	uint8_t splitAxis;
+	uint8_t pad;
+} tyr_bvh_node;
+
+/* variables.h:24-34  struct RayQueue  (60 B) -- import/export format only; device queues are SoA */
+typedef struct tyr_ray_queue {
+	float origin[3];
+	float direction[3];
+	float direct[3];
+	float distance;
+	int32_t identifier;
+	int32_t bounces;
+	int32_t index;
+	int32_t geometry_type; /* variables.h:20-22: Sphere = 0, Triangle = 1 */
+	uint8_t lastSpecular;
+	uint8_t pad_[3];
+} tyr_ray_queue;
+
+/* variables.h:36-42  struct ShadowQueue  (44 B) */
+typedef struct tyr_shadow_queue {
+	float origin[3];
+	float direction[3];
+	float color[3];
+	int32_t buffer_index;
+	float closestDistance;
+} tyr_shadow_queue;
+
+/* kernel.cu:67-81  enum Refl_t, struct Sphere  (44 B) */
+enum { TYR_DIFF = 0, TYR_SPEC = 1, TYR_REFR = 2, TYR_PHONG = 3, TYR_LIGHT = 4 };
+#define TYR_NUM_SPHERES 7 /* kernel.cu:14 */
+typedef struct tyr_sphere {
+	float radius;
+	float position[3];
+	float color[3];
+	float emmission[3];
+	int32_t refl;
+} tyr_sphere;
+
+/* camera.h:3-9  struct Camera: the fields launch_kernels reads (kernel.cu:699-702, 719) */
+typedef struct tyr_camera {
+	float position[3];
+	float direction[3];
+	float up[3];
+	float focalDistance;
+	float lensRadius;
+} tyr_camera;
+
+/* ---- status codes ---------------------------------------------------------- */
+enum {
+	TYR_OK = 0,
+	TYR_ERR_INVALID = -1,    /* bad argument (null, zero size, non-finite geometry, ...) */
+	TYR_ERR_NO_DEVICE = -2,  /* no HIP device: the product path has no CPU fallback */
+	TYR_ERR_NO_SCENE = -3,
+	TYR_ERR_NO_BUFFER = -4,  /* no blit_buffer bound */
+	TYR_ERR_OOM = -5,
+	TYR_ERR_DEVICE = -6,     /* a kernel reported an internal error (stack overflow, scan timeout) */
+	TYR_ERR_UNSUPPORTED = -7
+};
+const char* tyr_status_string(int status);
+int tyr_abi_version(void);
+
+/* ---- context --------------------------------------------------------------- */
+
+/* Replaces the compile-time constants render_width/render_height/ray_queue_buffer_size
+ * (variables.h:9-10, 44), argv[1] device pick (main.cpp:91) and sm_cores (variables.h:18). */
+typedef struct tyr_config {
+	uint32_t width;        /* variables.h:9 */
+	uint32_t height;       /* variables.h:10 */
+	uint32_t queue_size;   /* variables.h:44 ray_queue_buffer_size */
+	int32_t device;        /* main.cpp:91 */
+	uint32_t rank;         /* pixel sharding: this ctx owns image rows y with y % nranks == rank */
+	uint32_t nranks;       /* 1 = reference behaviour */
+	uint32_t flags;        /* TYR_FLAG_* */
+	void* stream;          /* hipStream_t to launch on; NULL = the ctx creates its own */
+} tyr_config;
+
+#define TYR_FLAG_TRIANGLE_MATERIALS 1u /* shade switch driven by Triangle::materialType (loader.h:16) instead of hard-wired DIFF (kernel.cu:380-383) */
+#define TYR_FLAG_PROFILE 2u            /* bracket every kernel with hipEvents on the ctx stream (tyr_get_timings) */
+#define TYR_FLAG_COUNT_VISITS 4u       /* counting build of extend/connect: nodes visited / triangles tested (bvh.h:164-209) */
+
+typedef struct tyr_ctx tyr_ctx;
+
+int tyr_create(tyr_ctx** out, const tyr_config* cfg);
+int tyr_destroy(tyr_ctx* ctx);
+
+/* Scene::Load's upload half, Scene.cpp:55-67: copies the flat node array and the
+ * (builder-reordered) triangle array to the device.  The device layout behind the
+ * ABI is private; the traversal visit order of bvh.h:118-161 is preserved. */
+int tyr_scene_upload(tyr_ctx* ctx, const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims);
+
+/* kernel.cu:674-681: the __constant__ sphere table (7 entries, light = slot 6). NULL = the reference's table. */
+int tyr_set_spheres(tyr_ctx* ctx, const tyr_sphere* spheres);
+/* the global `camera` (camera.h:24) read at kernel.cu:699-702, 719 */
+int tyr_set_camera(tyr_ctx* ctx, const tyr_camera* cam);
+/* sun_position / sun_position_changed (variables.h:16-17, kernel.cu:704-710) */
+int tyr_set_sun_position(tyr_ctx* ctx, float x, float y);
+/* blit_buffer: caller-allocated device float4[width*height] (main.cpp:129-130), argument 2 of launch_kernels.
+ * NULL = the ctx allocates and owns one. */
+int tyr_set_blit_buffer(tyr_ctx* ctx, void* device_float4);
+void* tyr_get_blit_buffer(tyr_ctx* ctx);
+
+/* ---- the per-frame entry point --------------------------------------------- */
+
+/* cudaError launch_kernels(array, blit_buffer, gpuScene, queue, queue2, shadowQueue)  interop.h:25, kernel.cu:664-748
+ * plus the caller's std::swap of the two ray buffers (main.cpp:169): exactly one wavefront iteration
+ * (top-up -> extend -> shade -> connect), frame counter advanced.  Returns after the stream is idle
+ * (kernel.cu:733 cudaDeviceSynchronize).  The GL surface write (kernel.cu:731) is tyr_resolve. */
+int tyr_launch_kernels(tyr_ctx* ctx);
+
+/* Primary-ray budget (extension; the reference streams forever): after `n` more primaries
+ * the queue is no longer topped up.  UINT64_MAX = reference behaviour. */
+int tyr_set_budget(tyr_ctx* ctx, uint64_t primary_rays);
+
+typedef struct tyr_counters {
+	uint32_t primary_ray_cnt; /* kernel.cu:211 survivors written by the last shade */
+	uint32_t start_position;  /* kernel.cu:214 */
+	uint32_t shadow_ray_cnt;  /* kernel.cu:224 */
+	uint32_t n_live;          /* rays in the work queue after top-up (== queue_size in the reference) */
+	uint32_t frame;           /* kernel.cu:667 */
+	uint32_t device_error;    /* non-zero: TYR_ERR_DEVICE detail bits */
+	uint64_t budget_remaining;
+	uint64_t total_extend_rays; /* sum of n_live over iterations */
+	uint64_t total_shadow_rays; /* sum of shadow_ray_cnt over iterations */
+	uint64_t total_primary_rays;
+	uint64_t nodes_extend, tris_extend;   /* TYR_FLAG_COUNT_VISITS only */
+	uint64_t nodes_connect, tris_connect; /* TYR_FLAG_COUNT_VISITS only */
+	uint64_t n_survive, n_shadow_visible;
+} tyr_counters;
+int tyr_get_counters(tyr_ctx* ctx, tyr_counters* out);
+
+/* The render loop of main.cpp:139-170 without the window: iterate launch_kernels until
+ * spp * (width*height/nranks) primaries were generated and every path finished.
+ * iterations_out may be NULL. */
+int tyr_render(tyr_ctx* ctx, uint32_t spp, uint32_t max_iterations, uint32_t* iterations_out);
+
+/* blit_onto_framebuffer, kernel.cu:648-662: rgb/a -> c/(c+1) -> gamma 1/2.2, written to a linear
+ * RGBA32F device buffer (float4[width*height]) instead of a GL surface. */
+int tyr_resolve(tyr_ctx* ctx, void* device_rgba_out);
+/* cudaMemset(blit_buffer) + primary_ray_cnt = 0, kernel.cu:712-718 */
+int tyr_reset_accum(tyr_ctx* ctx);
+/* copy blit_buffer to host float4[width*height] */
+int tyr_read_accum(tyr_ctx* ctx, float* host_float4);
+
+/* ---- stage-level entry points (one kernel of kernel.cu each; parity tests) -- */
+int tyr_stage_begin(tyr_ctx* ctx);   /* host prologue of launch_kernels, kernel.cu:671-718 */
+int tyr_stage_primary(tyr_ctx* ctx); /* primary_rays + set_wavefront_globals, kernel.cu:227-297 */
+int tyr_stage_extend(tyr_ctx* ctx);  /* extend, kernel.cu:331-343 */
+int tyr_stage_shade(tyr_ctx* ctx);   /* shade, kernel.cu:347-627 */
+int tyr_stage_connect(tyr_ctx* ctx); /* connect, kernel.cu:630-646 */
+int tyr_stage_end(tyr_ctx* ctx);     /* frame++ (kernel.cu:735-745) and the caller's swap (main.cpp:169) */
+int tyr_sync(tyr_ctx* ctx);
+
+/* AoS import/export of the SoA device queues in the reference's record formats.
+ * which: 0 = work queue (input of the next extend), 1 = next queue (survivors of the last shade). */
+int tyr_queue_export(tyr_ctx* ctx, int which, tyr_ray_queue* host, uint32_t count);
+int tyr_queue_import(tyr_ctx* ctx, const tyr_ray_queue* host, uint32_t n_survivors);
+int tyr_shadow_export(tyr_ctx* ctx, tyr_shadow_queue* host, uint32_t count);
+
+/* ---- measurement ------------------------------------------------------------ */
+enum { TYR_K_PRIMARY = 0, TYR_K_EXTEND = 1, TYR_K_SHADE = 2, TYR_K_CONNECT = 3, TYR_K_RESOLVE = 4, TYR_K_COUNT = 5 };
+typedef struct tyr_timings {
+	double ms[TYR_K_COUNT];        /* summed hipEvent time per kernel since the last reset */
+	uint64_t launches[TYR_K_COUNT];
+} tyr_timings;
+int tyr_get_timings(tyr_ctx* ctx, tyr_timings* out, int reset);
+
+/* ---- host side of the hot path ---------------------------------------------- */
+
+/* class BVH, bvh.h:49-108 / bvh.cpp:3-225: binned-SAH build emitting the flat depth-first
+ * node array; reorders `prims` in place (bvh.cpp:24).  bboxes: one per primitive (Scene.cpp:29-33).
+ * nodes_out must hold 2*n-1 nodes.  algo: 1 = EqualCounts, 2 = SAH (bvh.h:45-47).
+ * Returns the node count (>= 0) or a negative status. */
+int tyr_bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo);
+/* Scene.cpp:22-33: per-face bounding boxes */
+int tyr_triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out);
+/* Camera::update, camera.cpp:46-52 */
+int tyr_camera_update(double horizontal_angle, double vertical_angle, float direction_out[3]);
+/* the reference's hard-wired sphere table, kernel.cu:674-680 */
+int tyr_default_spheres(tyr_sphere* out7);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -195,6 +195,11 @@ static void recursive_build(builder* B, int start, int end) {
 			}
 		}
 		float leaf_cost = INTERSECTION_COST * (float)nPrimitives;
+		if (min_split_bucket < 0) {
+			/* bvh.cpp:167 assert(min_split_bucket != -1): zero-area node box; keep the tree valid with a leaf */
+			emit_leaf(B, currentNode, start, end, &nodeBBox);
+			return;
+		}
 		if (nPrimitives > MAX_PRIM_NUMBER || min_split_cost < leaf_cost) {
 			/* std::partition(first, last, bucket <= min_split_bucket), bidirectional form */
 			int first = start, last = end;

@@ -1,0 +1,81 @@
+"""Shared fixtures.
+
+`-m "not gpu"`: oracle vs golden vectors / the reference-header harness, host logic,
+C-ABI symbol checks -- no GPU, no /root/reference at run time (the harness .so is prebuilt).
+`-m gpu`: parity of the HIP path (through the C ABI) against the oracle on an MI355X.
+"""
+from __future__ import annotations
+
+import functools
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import pyorc
+
+    pyorc.lib()  # builds oracle/_build/liborc.so on first use
+    return pyorc
+
+
+@pytest.fixture(scope="session")
+def ref(orc):
+    r = orc.ref()
+    if r is None:
+        pytest.skip("oracle/_ref/libref_traverse.so not built (needs /root/reference; run `make -C oracle ref`)")
+    return r
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(GOLDEN, "kat.json")) as f:
+        return json.load(f)
+
+
+@functools.lru_cache(maxsize=None)
+def built_scene(name: str):
+    """(scene, nodes, prims) with the BVH built by the ORACLE's builder (tests only)."""
+    from oracle import pyorc
+    from tyrant_amd import scenes
+
+    makers = {
+        "cornell36": scenes.cornell_box,
+        "cornell_soup2k": lambda: scenes.cornell_soup(2000),
+        "cornell_soup10k": lambda: scenes.cornell_soup(10000),
+        "mesh32": lambda: scenes.mesh_scene(32),
+        "mesh128": lambda: scenes.mesh_scene(128),
+        "mesh706": lambda: scenes.mesh_scene(706),
+        "tyrant_default": scenes.tyrant_default,
+    }
+    sc = makers[name]()
+    nodes, prims = pyorc.bvh_build(sc.triangles, scenes.triangle_bboxes(sc.triangles))
+    return sc, nodes, prims
+
+
+def bits(a: np.ndarray) -> np.ndarray:
+    """float32 array -> uint32 bit patterns (for exact comparisons that treat NaN == NaN)"""
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """the product library through its C ABI; GPU tests fail loudly when it is missing"""
+    from tyrant_amd import binding
+
+    binding.lib()
+    return binding

@@ -1,0 +1,128 @@
+"""Host side of the hot path (BVH builder, bboxes, camera) and the C-ABI surface.  CPU only:
+the library loads and exports every symbol include/tyr_c.h declares; no compute call needs a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, built_scene
+
+
+def test_library_exports_every_declared_symbol(hip):
+    """every function declared in include/tyr_c.h is exported, and the binding lists exactly those"""
+    hdr = open(os.path.join(ROOT, "include", "tyr_c.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tyr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = hip.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in tyr_c.h but not exported"
+    assert declared == set(hip.SYMBOLS), (declared ^ set(hip.SYMBOLS))
+    assert L.tyr_abi_version() == 1
+
+
+def test_abi_struct_sizes(hip):
+    from tyrant_amd import scenes
+
+    assert C.sizeof(hip.Config) == 40
+    assert C.sizeof(hip.CameraC) == 44
+    assert C.sizeof(hip.Counters) == 24 + 10 * 8
+    assert scenes.TRIANGLE_DTYPE.itemsize == 40 and scenes.NODE_DTYPE.itemsize == 32
+    assert scenes.RAY_DTYPE.itemsize == 60 and scenes.SHADOW_DTYPE.itemsize == 44 and scenes.SPHERE_DTYPE.itemsize == 44
+
+
+def test_error_paths_without_compute(hip):
+    L = hip.lib()
+    assert L.tyr_status_string(0) == b"ok"
+    assert b"no HIP device" in L.tyr_status_string(-2)
+    h = C.c_void_p()
+    assert L.tyr_create(C.byref(h), None) == -1
+    bad = hip.Config(0, 64, 1024, 0, 0, 1, 0, None)
+    assert L.tyr_create(C.byref(h), C.byref(bad)) == -1
+    bad = hip.Config(64, 64, 1024, 0, 3, 2, 0, None)  # rank >= nranks
+    assert L.tyr_create(C.byref(h), C.byref(bad)) == -1
+    bad = hip.Config(64, 63, 1024, 0, 0, 2, 0, None)  # rows not divisible by nranks
+    assert L.tyr_create(C.byref(h), C.byref(bad)) == -1
+    assert L.tyr_launch_kernels(None) == -1 and L.tyr_destroy(None) == 0
+    assert L.tyr_bvh_build(None, -1, None, None, 2) == -1
+    assert L.tyr_bvh_build(None, 0, None, None, 2) == 0  # bvh.cpp:8-10: empty input, no nodes
+    assert L.tyr_bvh_build(None, 0, None, None, 0) == -1  # PartitionAlgorithm::Middle is unimplemented (bvh.cpp:190-193)
+
+
+@pytest.mark.parametrize("name", ["cornell36", "cornell_soup2k", "mesh32", "mesh128", "tyrant_default"])
+def test_product_builder_matches_oracle_bytes(hip, orc, name):
+    """tyr_bvh_build emits the same node array and the same reordered triangles as the oracle's restatement"""
+    from tyrant_amd import scenes
+
+    sc, nodes_o, prims_o = built_scene(name)
+    bb = hip.triangle_bboxes(sc.triangles)
+    assert bb.tobytes() == scenes.triangle_bboxes(sc.triangles).tobytes()
+    nodes_p, prims_p = hip.bvh_build(sc.triangles, bb)
+    assert nodes_p.tobytes() == nodes_o.tobytes()
+    assert prims_p.tobytes() == prims_o.tobytes()
+
+
+def test_builder_structure(hip):
+    sc, nodes, prims = built_scene("cornell_soup2k")
+    n = prims.shape[0]
+    leaves = nodes[nodes["primitiveCount"] > 0]
+    inner = nodes[nodes["primitiveCount"] == 0]
+    assert len(nodes) == 2 * len(leaves) - 1  # full binary tree
+    assert leaves["primitiveCount"].sum() == n and leaves["primitiveCount"].max() <= 4  # bvh.h:78
+    assert np.all(leaves["splitAxis"] == 0) and np.all(nodes["pad"] == 0)  # value-initialised bytes (bvh.cpp:11)
+    assert np.all(inner["splitAxis"] <= 2)
+    # leaves partition [0, n) in depth-first order
+    offs = leaves["offset"].astype(np.int64)
+    assert offs[0] == 0 and np.all(np.diff(offs) == leaves["primitiveCount"][:-1])
+    # every child box is inside its parent's box; second child index is in range
+    idx = np.nonzero(nodes["primitiveCount"] == 0)[0]
+    for i in idx[:: max(1, len(idx) // 500)]:
+        for c in (i + 1, nodes["offset"][i]):
+            assert i < c < len(nodes)
+            assert np.all(nodes["bounds"][c, 0] >= nodes["bounds"][i, 0]) and np.all(nodes["bounds"][c, 1] <= nodes["bounds"][i, 1])
+    # the reordered triangles are a permutation of the input
+    key = lambda t: np.sort(t.view(np.uint8).reshape(-1, 40)[:, :37].copy().view(np.dtype((np.void, 37))).ravel())  # noqa: E731
+    assert np.array_equal(key(np.ascontiguousarray(sc.triangles)), key(np.ascontiguousarray(prims)))
+
+
+def test_builder_edge_cases(hip):
+    from tyrant_amd import scenes
+
+    # one triangle: the root is a leaf
+    t = scenes.make_triangles([[0, 0, 0]], [[1, 0, 0]], [[0, 1, 0]])
+    nodes, prims = hip.bvh_build(t)
+    assert len(nodes) == 1 and nodes["primitiveCount"][0] == 1 and nodes["offset"][0] == 0
+    # identical centroids: one leaf holds them all (bvh.cpp:103-111), also beyond 4 primitives
+    t = scenes.make_triangles(np.zeros((9, 3)), np.tile([1, 0, 0], (9, 1)), np.tile([0, 1, 0], (9, 1)))
+    nodes, prims = hip.bvh_build(t)
+    assert len(nodes) == 1 and nodes["primitiveCount"][0] == 9
+    # non-finite geometry is rejected instead of producing a broken tree
+    bad = scenes.make_triangles([[0, 0, 0]], [[np.inf, 0, 0]], [[0, 1, 0]])
+    with pytest.raises(hip.TyrError):
+        hip.bvh_build(np.concatenate([t, bad]))
+    # EqualCounts splits at the median
+    t = scenes.random_soup(257, seed=3)
+    nodes, prims = hip.bvh_build(t, algo=1)
+    leaves = nodes[nodes["primitiveCount"] > 0]
+    assert leaves["primitiveCount"].sum() == 257 and len(nodes) == 2 * len(leaves) - 1
+
+
+def test_camera_update(hip):
+    """Camera::update, camera.cpp:46-52"""
+    for h, v in ((0.0, 0.0), (0.3, -0.2), (-1.476, -0.398), (3.0, 1.5)):
+        d = hip.camera_update(h, v)
+        want = np.array([np.cos(v) * np.sin(h), np.cos(v) * np.cos(h), np.sin(v)])
+        assert np.allclose(d, want / np.linalg.norm(want), atol=2e-7)
+    assert list(hip.camera_update(0.0, 0.0)) == [0.0, 1.0, 0.0]
+
+
+def test_default_spheres_match_oracle(hip, orc):
+    from tyrant_amd import scenes
+
+    s = hip.default_spheres()
+    o = np.zeros(7, dtype=scenes.SPHERE_DTYPE)
+    orc.lib().orc_default_spheres(o.ctypes.data)
+    assert s.tobytes() == o.tobytes() == scenes.reference_spheres().tobytes()
+    assert s["refl"][6] == scenes.LIGHT and s["radius"][4] == np.float32(1e4)  # kernel.cu:678, 680

@@ -1,0 +1,205 @@
+"""The oracle against the known answers of SURVEY.md section 8c (tests/golden/kat.json),
+the committed reference-traversal fixtures, and -- when it has been built -- the
+reference's own header code in oracle/_ref.  CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits
+
+
+def _f(x):
+    return np.float32(x)
+
+
+def _close9(a, b):
+    """agreement to the 9 significant digits the known answers were printed with"""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.all(np.abs(a - b) <= 6e-9 * np.maximum(np.abs(b), 1e-30) + 1e-30)
+
+
+def test_xorshift_known_answer(orc, golden):
+    L = orc.lib()
+    s = C.c_uint32(1)
+    assert [L.orc_random_int(C.byref(s)) for _ in range(3)] == golden["xorshift32_seed1"]
+    # seed 0 sticks (kernel.cu:23-28)
+    z = C.c_uint32(0)
+    assert L.orc_random_int(C.byref(z)) == 0 and z.value == 0
+
+
+def test_random_float_range_and_stratum_alias(orc):
+    L = orc.lib()
+    # RandomFloat can return exactly 1.0f (u32 >= 2^32 - 128 rounds to 2^32): kernel.cu:31-33
+    # find a state whose next output is 0xFFFFFFFF by inverting is unnecessary: check the arithmetic directly
+    assert np.float32(np.float32(4294967295) * np.float32(2.3283064365387e-10)) == np.float32(1.0)
+    # RandomIntBetween0AndMax(seed, 16) reaches 16 (quirk 2): int(f * 16.99999f) with f close to 1
+    assert int(np.float32(0.9999999) * (np.float32(16) + np.float32(0.99999))) == 16
+    s = C.c_uint32(12345)
+    vals = [L.orc_random_int_between_0_and_max(C.byref(s), 16) for _ in range(20000)]
+    assert min(vals) == 0 and max(vals) == 16
+
+
+def test_sun_sky_known_answers(orc, golden):
+    S = orc.sun_setup(tuple(golden["sun_position"]))
+    assert _close9(S.sunDirection[:], golden["sunDirection"])
+    assert _close9([S.sunAngularDiameterCos], [golden["sunAngularDiameterCos"]])
+    n = _f(1) / np.sqrt(_f(3))
+    for e in golden["sky"]:
+        d = (n, n, n) if e["dir"] == "norm111" else e["dir"]
+        assert _close9(orc.sky(S, d), e["value"]), e
+    sd = S.sunDirection[:]
+    assert _close9(orc.sun(S, sd), golden["sun_at_sunDirection"])
+    assert _close9(orc.sunsky(S, sd), golden["sunsky_at_sunDirection"])
+
+
+def test_cone_sample_known_answer(orc, golden):
+    S = orc.sun_setup(tuple(golden["sun_position"]))
+    k = golden["cone_sample"]
+    seed = C.c_uint32(k["seed"])
+    out = (C.c_float * 3)()
+    orc.lib().orc_cone_sample(C.byref(S), C.byref(seed), out)
+    assert _close9(out[:], k["value"])
+    assert seed.value == k["seed_after"]
+
+
+def test_sunsky_quirks(orc):
+    # sunsky() returns pure red when sunAngularDiameterCos == 1 (sunsky.cu:121-123)
+    S = orc.sun_setup()
+    S.sunAngularDiameterCos = 1.0
+    assert list(orc.sunsky(S, (0, 0, 1))) == [1.0, 0.0, 0.0]
+    # sun(): the disk term of sunsky.cu:70 is 1 for any non-zero cosine, also far from the sun
+    S = orc.sun_setup()
+    away = [-S.sunDirection[0], -S.sunDirection[1], abs(S.sunDirection[2])]
+    assert np.all(orc.sun(S, away) > 0)
+
+
+def test_layout_matches_golden_and_reference(orc, golden, ref):
+    from tyrant_amd import scenes
+
+    lay = golden["layout"]
+    assert scenes.RAY_DTYPE.itemsize == lay["RayQueue"]["size"]
+    for f in ("origin", "direction", "direct", "distance", "identifier", "bounces", "index", "geometry_type", "lastSpecular"):
+        assert scenes.RAY_DTYPE.fields[f][1] == lay["RayQueue"][f], f
+    for f in ("origin", "direction", "color", "buffer_index", "closestDistance"):
+        assert scenes.SHADOW_DTYPE.fields[f][1] == lay["ShadowQueue"][f], f
+    for f in ("vert", "e1", "e2", "materialType"):
+        assert scenes.TRIANGLE_DTYPE.fields[f][1] == lay["Triangle"][f], f
+    assert scenes.NODE_DTYPE.fields["offset"][1] == lay["BVHNode"]["primitiveOffset"]
+    assert scenes.NODE_DTYPE.fields["primitiveCount"][1] == lay["BVHNode"]["primitiveCount"]
+    assert scenes.NODE_DTYPE.fields["splitAxis"][1] == lay["BVHNode"]["splitAxis"]
+    # the same numbers straight from the reference headers
+    out = (C.c_int * 64)()
+    n = ref.ref_layout(out, 64)
+    got = list(out[:n])
+    R, S, T, N = lay["RayQueue"], lay["ShadowQueue"], lay["Triangle"], lay["BVHNode"]
+    want = [R["size"], R["origin"], R["direction"], R["direct"], R["distance"], R["identifier"], R["bounces"], R["index"], R["geometry_type"], R["lastSpecular"]]
+    want += [S["size"], S["origin"], S["direction"], S["color"], S["buffer_index"], S["closestDistance"]]
+    want += [T["size"], T["vert"], T["e1"], T["e2"], T["materialType"]]
+    want += [N["size"], N["bbox"], N["primitiveOffset"], N["secondChildOffset"], N["primitiveCount"], N["splitAxis"], lay["BBox"]["size"]]
+    assert got == want
+
+
+def test_reference_constants(ref, golden):
+    out = (C.c_double * 64)()
+    n = ref.ref_constants(out, 64)
+    v = list(out[:n])
+    k = golden["constants"]
+    assert np.float32(v[0]) == np.float32(k["pi"])
+    assert v[2] == k["render_width"] and v[3] == k["render_height"]
+    assert np.float32(v[4]) == np.float32(k["epsilon"]) and v[5] == k["ray_queue_buffer_size"]
+    # RayQueue defaults: geometry_type = Triangle (1), lastSpecular = true (variables.h:32-33); ShadowQueue closestDistance 1e20f
+    assert v[6] == 1 and v[7] == 1 and np.float32(v[8]) == np.float32(1e20)
+    # sunsky.cuh:26-43
+    assert np.float32(v[9]) == np.float32(1.5) and np.float32(v[14]) == np.float32(0.005) and np.float32(v[15]) == np.float32(0.8)
+
+
+@pytest.mark.parametrize("name", ["cornell36", "soup2k", "mesh32"])
+def test_traversal_matches_reference_fixture(orc, name):
+    """orc_bvh_intersect / _simple reproduce the committed answers of the reference's bvh.h code bit for bit"""
+    from tyrant_amd import scenes
+
+    z = np.load(os.path.join(GOLDEN, f"ref_traverse_{name}.npz"))
+    nodes = np.ascontiguousarray(z["nodes"]).view(scenes.NODE_DTYPE).reshape(-1)
+    prims = np.ascontiguousarray(z["prims"]).view(scenes.TRIANGLE_DTYPE).reshape(-1)
+    n = z["origin"].shape[0]
+    L = orc.lib()
+    rays = np.zeros(n, dtype=scenes.RAY_DTYPE)
+    rays["origin"], rays["direction"], rays["distance"], rays["identifier"] = z["origin"], z["direction"], z["distance_in"], -7
+    hit = np.zeros(n, dtype=np.int32)
+    nn = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        cnt = (C.c_uint64 * 2)()
+        hit[i] = L.orc_bvh_intersect(nodes.ctypes.data, prims.ctypes.data, rays[i : i + 1].ctypes.data, cnt)
+        nn[i] = cnt[0]
+    assert np.array_equal(hit, z["hit"])
+    assert np.array_equal(rays["identifier"], z["identifier"])
+    assert np.array_equal(bits(rays["distance"]), bits(z["distance"]))
+    # intersect_debug counts loop iterations - 1 (bvh.h:173-175)
+    assert np.array_equal(nn - 1, z["traversals"])
+    sh = np.zeros(n, dtype=scenes.SHADOW_DTYPE)
+    sh["origin"], sh["direction"], sh["closestDistance"] = z["origin"], z["direction"], z["closest"]
+    anyhit = np.array([L.orc_bvh_intersect_simple(nodes.ctypes.data, prims.ctypes.data, sh[i : i + 1].ctypes.data, float(sh["closestDistance"][i]), None) for i in range(n)])
+    assert np.array_equal(anyhit, z["anyhit"])
+
+
+def test_traversal_matches_live_reference(orc, ref):
+    """same comparison against the reference headers compiled here, on a fresh ray set"""
+    from conftest import built_scene
+    from tyrant_amd import scenes
+
+    sc, nodes, prims = built_scene("cornell_soup2k")
+    rng = np.random.default_rng(99)
+    n = 3000
+    rays = np.zeros(n, dtype=scenes.RAY_DTYPE)
+    rays["origin"] = rng.uniform(-49, 49, size=(n, 3)).astype(np.float32) + np.array([0, 0, 50], dtype=np.float32)
+    d = rng.normal(size=(n, 3))
+    rays["direction"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["distance"] = 1e20
+    a, b = rays.copy(), rays.copy()
+    L = orc.lib()
+    for i in range(n):
+        L.orc_bvh_intersect(nodes.ctypes.data, prims.ctypes.data, a[i : i + 1].ctypes.data, None)
+    hit = np.zeros(n, dtype=np.int32)
+    ref.ref_bvh_intersect(nodes.ctypes.data, prims.ctypes.data, b.ctypes.data, n, hit.ctypes.data_as(C.POINTER(C.c_int)), None)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_bbox_and_triangle_primitives_match_reference(orc, ref):
+    rng = np.random.default_rng(5)
+    L = orc.lib()
+    fp = C.POINTER(C.c_float)
+    for _ in range(2000):
+        lo = rng.uniform(-10, 10, 3)
+        box = np.array([lo, lo + rng.uniform(0, 8, 3)], dtype=np.float32)
+        o = rng.uniform(-20, 20, 3).astype(np.float32)
+        d = rng.normal(size=3).astype(np.float32)
+        if rng.random() < 0.2:
+            d[rng.integers(3)] = 0.0  # inf / NaN slabs
+        with np.errstate(divide="ignore"):
+            inv = (np.float32(1) / d).astype(np.float32)
+        neg = (inv < 0).astype(np.int32)
+        lowest = np.float32(rng.uniform(0.1, 100))
+        a = L.orc_bbox_intersect(box.ctypes.data, o.ctypes.data_as(fp), inv.ctypes.data_as(fp), neg.ctypes.data_as(C.POINTER(C.c_int)), lowest)
+        b = ref.ref_bbox_intersect(box.ctypes.data, o.ctypes.data_as(fp), inv.ctypes.data_as(fp), neg.ctypes.data_as(C.POINTER(C.c_int)), lowest)
+        assert a == b
+        tri = np.zeros(10, dtype=np.float32)
+        tri[:9] = rng.uniform(-5, 5, 9)
+        ta = L.orc_triangle_intersect(tri.ctypes.data, o.ctypes.data_as(fp), d.ctypes.data_as(fp))
+        tb = ref.ref_triangle_intersect(tri.ctypes.data, o.ctypes.data_as(fp), d.ctypes.data_as(fp))
+        assert np.float32(ta).view(np.uint32) == np.float32(tb).view(np.uint32)
+
+
+def test_triangle_culls_back_faces(orc):
+    """loader.h:28-29: det < 1e-7 -> miss; the same triangle seen from behind is invisible"""
+    L = orc.lib()
+    fp = C.POINTER(C.c_float)
+    tri = np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0], dtype=np.float32)  # normal +z
+    o_front = np.array([0.2, 0.2, 1], dtype=np.float32)
+    o_back = np.array([0.2, 0.2, -1], dtype=np.float32)
+    down = np.array([0, 0, -1], dtype=np.float32)
+    up = np.array([0, 0, 1], dtype=np.float32)
+    assert L.orc_triangle_intersect(tri.ctypes.data, o_front.ctypes.data_as(fp), down.ctypes.data_as(fp)) == pytest.approx(1.0)
+    assert L.orc_triangle_intersect(tri.ctypes.data, o_back.ctypes.data_as(fp), up.ctypes.data_as(fp)) == 0.0

@@ -1,0 +1,281 @@
+"""ctypes binding of tyrant_amd/lib/libtyrant_hip.so (the C ABI of include/tyr_c.h).
+
+This is glue for the tests and bench.py; the product is the shared library.  There is
+no fallback: if the library is missing or no HIP device is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import scenes
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtyrant_hip.so")
+
+TYR_FLAG_TRIANGLE_MATERIALS = 1
+TYR_FLAG_PROFILE = 2
+TYR_FLAG_COUNT_VISITS = 4
+TYR_ERR_NO_DEVICE = -2
+KERNEL_NAMES = ("primary", "extend", "shade", "connect", "resolve")
+
+c_f, c_u32, c_u64, c_i32, P = C.c_float, C.c_uint32, C.c_uint64, C.c_int32, C.c_void_p
+
+
+class TyrError(RuntimeError):
+    def __init__(self, status: int, what: str):
+        self.status = status
+        super().__init__(f"{what}: status {status} ({status_string(status)})")
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("width", c_u32),
+        ("height", c_u32),
+        ("queue_size", c_u32),
+        ("device", c_i32),
+        ("rank", c_u32),
+        ("nranks", c_u32),
+        ("flags", c_u32),
+        ("stream", P),
+    ]
+
+
+class CameraC(C.Structure):
+    _fields_ = [("position", c_f * 3), ("direction", c_f * 3), ("up", c_f * 3), ("focalDistance", c_f), ("lensRadius", c_f)]
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("primary_ray_cnt", c_u32),
+        ("start_position", c_u32),
+        ("shadow_ray_cnt", c_u32),
+        ("n_live", c_u32),
+        ("frame", c_u32),
+        ("device_error", c_u32),
+        ("budget_remaining", c_u64),
+        ("total_extend_rays", c_u64),
+        ("total_shadow_rays", c_u64),
+        ("total_primary_rays", c_u64),
+        ("nodes_extend", c_u64),
+        ("tris_extend", c_u64),
+        ("nodes_connect", c_u64),
+        ("tris_connect", c_u64),
+        ("n_survive", c_u64),
+        ("n_shadow_visible", c_u64),
+    ]
+
+    def asdict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms", C.c_double * 5), ("launches", c_u64 * 5)]
+
+
+# every symbol include/tyr_c.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "tyr_status_string": (C.c_char_p, [C.c_int]),
+    "tyr_abi_version": (C.c_int, []),
+    "tyr_create": (C.c_int, [C.POINTER(P), C.POINTER(Config)]),
+    "tyr_destroy": (C.c_int, [P]),
+    "tyr_scene_upload": (C.c_int, [P, P, c_i32, P, c_i32]),
+    "tyr_set_spheres": (C.c_int, [P, P]),
+    "tyr_set_camera": (C.c_int, [P, C.POINTER(CameraC)]),
+    "tyr_set_sun_position": (C.c_int, [P, c_f, c_f]),
+    "tyr_set_blit_buffer": (C.c_int, [P, P]),
+    "tyr_get_blit_buffer": (P, [P]),
+    "tyr_launch_kernels": (C.c_int, [P]),
+    "tyr_set_budget": (C.c_int, [P, c_u64]),
+    "tyr_get_counters": (C.c_int, [P, C.POINTER(Counters)]),
+    "tyr_render": (C.c_int, [P, c_u32, c_u32, C.POINTER(c_u32)]),
+    "tyr_resolve": (C.c_int, [P, P]),
+    "tyr_reset_accum": (C.c_int, [P]),
+    "tyr_read_accum": (C.c_int, [P, P]),
+    "tyr_stage_begin": (C.c_int, [P]),
+    "tyr_stage_primary": (C.c_int, [P]),
+    "tyr_stage_extend": (C.c_int, [P]),
+    "tyr_stage_shade": (C.c_int, [P]),
+    "tyr_stage_connect": (C.c_int, [P]),
+    "tyr_stage_end": (C.c_int, [P]),
+    "tyr_sync": (C.c_int, [P]),
+    "tyr_queue_export": (C.c_int, [P, C.c_int, P, c_u32]),
+    "tyr_queue_import": (C.c_int, [P, P, c_u32]),
+    "tyr_shadow_export": (C.c_int, [P, P, c_u32]),
+    "tyr_get_timings": (C.c_int, [P, C.POINTER(Timings), C.c_int]),
+    "tyr_bvh_build": (C.c_int, [P, c_i32, P, P, c_i32]),
+    "tyr_triangle_bboxes": (C.c_int, [P, c_i32, P]),
+    "tyr_camera_update": (C.c_int, [C.c_double, C.c_double, C.POINTER(c_f)]),
+    "tyr_default_spheres": (C.c_int, [P]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` (there is no fallback path)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the ABI and the header disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def status_string(status: int) -> str:
+    return lib().tyr_status_string(status).decode()
+
+
+def _check(status: int, what: str):
+    if status != 0:
+        raise TyrError(status, what)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(P)
+
+
+# ---- host side of the hot path ---------------------------------------------------------------
+
+
+def triangle_bboxes(tris: np.ndarray) -> np.ndarray:
+    """Scene.cpp:22-33"""
+    t = np.ascontiguousarray(tris)
+    out = np.zeros(t.shape[0], dtype=scenes.BBOX_DTYPE)
+    _check(lib().tyr_triangle_bboxes(_ptr(t), t.shape[0], _ptr(out)), "tyr_triangle_bboxes")
+    return out
+
+
+def bvh_build(tris: np.ndarray, bboxes: np.ndarray | None = None, algo: int = 2):
+    """class BVH (bvh.cpp:3-25): returns (nodes[:nNodes], reordered triangles)"""
+    prims = np.ascontiguousarray(tris.copy())
+    n = prims.shape[0]
+    bb = np.ascontiguousarray(bboxes) if bboxes is not None else triangle_bboxes(prims)
+    nodes = np.zeros(max(2 * n - 1, 1), dtype=scenes.NODE_DTYPE)
+    nn = lib().tyr_bvh_build(_ptr(prims), n, _ptr(bb), _ptr(nodes), algo)
+    if nn < 0:
+        raise TyrError(nn, "tyr_bvh_build")
+    return nodes[:nn].copy(), prims
+
+
+def camera_update(horizontal_angle: float, vertical_angle: float) -> np.ndarray:
+    """Camera::update (camera.cpp:46-52)"""
+    out = (c_f * 3)()
+    _check(lib().tyr_camera_update(horizontal_angle, vertical_angle, out), "tyr_camera_update")
+    return np.array(out[:], dtype=np.float32)
+
+
+def default_spheres() -> np.ndarray:
+    s = np.zeros(7, dtype=scenes.SPHERE_DTYPE)
+    _check(lib().tyr_default_spheres(_ptr(s)), "tyr_default_spheres")
+    return s
+
+
+# ---- the renderer ------------------------------------------------------------------------------
+
+
+class Renderer:
+    """one tyr_ctx"""
+
+    def __init__(self, width, height, queue_size, device=0, rank=0, nranks=1, flags=0, stream=None, blit_buffer=None):
+        self.L = lib()
+        self.W, self.H, self.N = width, height, queue_size
+        cfg = Config(width, height, queue_size, device, rank, nranks, flags, stream)
+        h = P()
+        _check(self.L.tyr_create(C.byref(h), C.byref(cfg)), "tyr_create")
+        self.h = h
+        _check(self.L.tyr_set_blit_buffer(self.h, blit_buffer), "tyr_set_blit_buffer")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.tyr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, nodes: np.ndarray, prims: np.ndarray):
+        nodes = np.ascontiguousarray(nodes)
+        prims = np.ascontiguousarray(prims)
+        _check(self.L.tyr_scene_upload(self.h, _ptr(nodes), nodes.shape[0], _ptr(prims), prims.shape[0]), "tyr_scene_upload")
+
+    def set_spheres(self, spheres: np.ndarray | None):
+        if spheres is None:
+            _check(self.L.tyr_set_spheres(self.h, None), "tyr_set_spheres")
+            return
+        s = np.ascontiguousarray(spheres)
+        _check(self.L.tyr_set_spheres(self.h, _ptr(s)), "tyr_set_spheres")
+
+    def set_camera(self, cam):
+        f3 = lambda x: (c_f * 3)(*[float(v) for v in x])  # noqa: E731
+        c = CameraC(f3(cam.position), f3(cam.direction), f3(cam.up), cam.focalDistance, cam.lensRadius)
+        _check(self.L.tyr_set_camera(self.h, C.byref(c)), "tyr_set_camera")
+
+    def set_sun_position(self, x, y):
+        _check(self.L.tyr_set_sun_position(self.h, x, y), "tyr_set_sun_position")
+
+    def load_scene(self, scene, nodes, prims):
+        self.upload(nodes, prims)
+        self.set_spheres(scene.spheres)
+        self.set_camera(scene.camera)
+        self.set_sun_position(*scene.sun_position)
+
+    def set_budget(self, n):
+        _check(self.L.tyr_set_budget(self.h, n), "tyr_set_budget")
+
+    def launch_kernels(self):
+        _check(self.L.tyr_launch_kernels(self.h), "tyr_launch_kernels")
+
+    def render(self, spp, max_iterations=0xFFFFFFFF) -> int:
+        it = c_u32(0)
+        _check(self.L.tyr_render(self.h, spp, max_iterations, C.byref(it)), "tyr_render")
+        return it.value
+
+    def stage(self, name):
+        _check(getattr(self.L, "tyr_stage_" + name)(self.h), "tyr_stage_" + name)
+
+    def counters(self) -> dict:
+        k = Counters()
+        _check(self.L.tyr_get_counters(self.h, C.byref(k)), "tyr_get_counters")
+        return k.asdict()
+
+    def timings(self, reset=False) -> dict:
+        t = Timings()
+        _check(self.L.tyr_get_timings(self.h, C.byref(t), int(reset)), "tyr_get_timings")
+        return {n: {"ms": t.ms[i], "launches": int(t.launches[i])} for i, n in enumerate(KERNEL_NAMES)}
+
+    def reset_accum(self):
+        _check(self.L.tyr_reset_accum(self.h), "tyr_reset_accum")
+
+    def blit_buffer(self) -> np.ndarray:
+        out = np.zeros((self.H * self.W, 4), dtype=np.float32)
+        _check(self.L.tyr_read_accum(self.h, _ptr(out)), "tyr_read_accum")
+        return out
+
+    def resolve_into(self, device_ptr):
+        _check(self.L.tyr_resolve(self.h, device_ptr), "tyr_resolve")
+
+    def ray_queue(self, which=0, count=None) -> np.ndarray:
+        n = self.N if count is None else count
+        out = np.zeros(n, dtype=scenes.RAY_DTYPE)
+        _check(self.L.tyr_queue_export(self.h, which, _ptr(out), n), "tyr_queue_export")
+        return out
+
+    def shadow_queue(self, count=None) -> np.ndarray:
+        n = self.N if count is None else count
+        out = np.zeros(n, dtype=scenes.SHADOW_DTYPE)
+        _check(self.L.tyr_shadow_export(self.h, _ptr(out), n), "tyr_shadow_export")
+        return out
+
+    def import_work_queue(self, rays: np.ndarray, n_survivors: int):
+        r = np.ascontiguousarray(rays)
+        _check(self.L.tyr_queue_import(self.h, _ptr(r), n_survivors), "tyr_queue_import")

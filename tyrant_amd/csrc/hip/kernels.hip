@@ -1,0 +1,707 @@
+// kernels.hip -- the wavefront path-tracing kernels for gfx950 (MI355X, wave64).
+//
+// One file = one code object: primary_rays, set_wavefront_globals, extend, shade,
+// connect, blit (reference: kernel.cu:227-662).  Differences of STRUCTURE, not of
+// arithmetic (DESIGN.md has the full account):
+//   - no persistent-thread `while(true){atomicAdd(&raynr_x,1)}` loops (kernel.cu:250-255,
+//     332-337, 349-354, 631-636): slot = global thread id, so the four hot atomic
+//     addresses disappear and every queue access is coalesced SoA;
+//   - survivors and shadow rays are appended by a STABLE device-wide compaction
+//     (wave ballot + mbcnt, LDS across the four waves, decoupled look-back across
+//     workgroups) instead of `atomicAdd(&primary_ray_cnt,1)` (kernel.cu:607): slot order
+//     equals the serial ticket order, which makes a fixed-seed render reproducible
+//     (the RNG seed depends on the slot, kernel.cu:363) and keeps pixels sorted inside
+//     each generation of rays;
+//   - traversal uses 64-byte child-pair nodes (hip/traverse.hpp);
+//   - zero contributions are not added to the pixel (kernel.cu:621 TODO), which is
+//     value-identical.
+#include <hip/hip_runtime.h>
+
+#include "detmath.hpp"
+#include "kernels.hpp"
+#include "sunsky.hpp"
+#include "traverse.hpp"
+#include "vecmath.hpp"
+
+namespace tyr {
+
+// ---- RNG, kernel.cu:23-41 ----------------------------------------------------------------
+__device__ __forceinline__ uint32_t rng_int(uint32_t& s) {
+	s ^= s << 13;
+	s ^= s >> 17;
+	s ^= s << 5;
+	return s;
+}
+__device__ __forceinline__ float rng_float(uint32_t& s) { return (float)rng_int(s) * 2.3283064365387e-10f; }
+__device__ __forceinline__ float rng_float2(uint32_t& s) { return (float)(rng_int(s) >> 16) / 65535.0f; }
+__device__ __forceinline__ int rng_int_0_max(uint32_t& s, int max) { return (int)(rng_float(s) * ((float)max + 0.99999f)); }
+
+// kernel.cu:44-65 (chosenStratum is 0..16: stratum 16 aliases (0,0))
+__device__ __forceinline__ void stratified_sample(uint32_t& s, float& sx, float& sy) {
+	constexpr int width2D = 4, height2D = 4;
+	constexpr float pixelWidth = 1.0f / width2D, pixelHeight = 1.0f / height2D;
+	const int chosenStratum = rng_int_0_max(s, width2D * height2D);
+	const int stratumX = chosenStratum % width2D;
+	const int stratumY = (chosenStratum / width2D) % height2D;
+	const float stratumXStart = pixelWidth * stratumX;
+	const float stratumYStart = pixelHeight * stratumY;
+	sx = stratumXStart + (rng_float(s) * pixelWidth);
+	sy = stratumYStart + (rng_float(s) * pixelHeight);
+}
+
+// kernel.cu:190-208
+__device__ __forceinline__ void concentric_sample_disk(float ux, float uy, float& dx, float& dy) {
+	const float ox = 2.f * ux - 1.0f, oy = 2.f * uy - 1.0f;
+	if (ox == 0 && oy == 0) {
+		dx = 0;
+		dy = 0;
+		return;
+	}
+	float theta, r;
+	if (fabsf(ox) > fabsf(oy)) {
+		r = ox;
+		theta = kPi / 4 * (oy / ox);
+	} else {
+		r = oy;
+		theta = kPi / 2 - kPi / 4 * (ox / oy);
+	}
+	float s, c;
+	dm::sincosf_det(theta, s, c);
+	dx = r * c;
+	dy = r * s;
+}
+
+// kernel.cu:181-189
+__device__ __forceinline__ void orthonormal_basis_naive(f3 w, f3& u, f3& v) {
+	if ((double)fabsf(w.x) > .9)
+		u = mk3(0.0f, 1.0f, 0.0f);
+	else
+		u = mk3(1.0f, 0.0f, 0.0f);
+	u = normalize(cross(u, w));
+	v = cross(w, u);
+}
+
+// sunsky.cu:170-185 with the basis precomputed per sun change
+__device__ __forceinline__ f3 cone_sample(const SunParams& S, uint32_t& seed) {
+	float rx = rng_float2(seed);
+	float ry = rng_float2(seed);
+	rx = rx * 2.f * kPi;
+	ry = 1.0f - ry * S.coneExtent;
+	const float oneminus = sqrtf(1.0f - ry * ry);
+	float s, c;
+	dm::sincosf_det(rx, s, c);
+	return (c * oneminus) * ld3(S.coneO1) + (s * oneminus) * ld3(S.coneO2) + ry * ld3(S.coneDir);
+}
+
+// kernel.cu:83-93 / 95-105
+__device__ __forceinline__ float sphere_intersect(const tyr_sphere& sp, f3 origin, f3 direction) {
+	const f3 op = ld3(sp.position) - origin;
+	float t;
+	const float b = dot(op, direction);
+	float disc = b * b - dot(op, op) + sp.radius * sp.radius;
+	if (disc < 0)
+		return 0;
+	disc = sqrtf(disc);
+	return (t = b - disc) > kEpsilon ? t : ((t = b + disc) > kEpsilon ? t : 0);
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// wave-aggregated 64-bit counter add (one atomic per wave)
+__device__ __forceinline__ void wave_add_u64(unsigned long long* p, uint32_t v) {
+	unsigned long long sum = v;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		sum += __shfl_xor(sum, o, 64);
+	if (lane_id() == 0 && sum)
+		atomicAdd(p, sum);
+}
+
+// ======================================================================================
+// primary_rays, kernel.cu:247-297.  One thread per new queue slot.
+// ======================================================================================
+__global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
+	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t cnt = P.k->primary_ray_cnt; // survivors already in the buffer (kernel.cu:253)
+	const unsigned long long room = (unsigned long long)(P.N - cnt);
+	const unsigned long long budget = P.k->budget_remaining;
+	const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
+	if (index >= nNew)
+		return;
+	const uint32_t slot = index + cnt;
+	uint32_t seed = (P.frame * 147565741u) * 720898027u * index; // kernel.cu:258
+
+	const uint32_t start = P.k->start_position;
+	const int x = (int)((start + index) % P.W);
+	const int yl = (int)(((start + index) / P.W) % P.localRows);
+	const int y = yl * (int)P.nranks + (int)P.rank; // nranks == 1: kernel.cu:264
+
+	float sx, sy;
+	stratified_sample(seed, sx, sy);
+	const float rand_point_pixelX = (float)x - sx; // kernel.cu:268-269 (jitter is subtracted)
+	const float rand_point_pixelY = (float)y - sy;
+	const float normalized_i = (rand_point_pixelX / (float)P.W) - 0.5f;
+	const float normalized_j = (((float)P.H - rand_point_pixelY) / (float)P.H) - 0.5f;
+
+	const f3 O = ld3(P.camPos), camera_direction = ld3(P.camDir), camera_right = ld3(P.camRight), camera_up = ld3(P.camUp);
+	f3 directionToFocalPlane = camera_direction + normalized_i * camera_right + normalized_j * camera_up;
+	directionToFocalPlane = normalize(directionToFocalPlane);
+	const int ImGui_slider_hack = 3; // kernel.cu:286
+	const f3 convergencePoint = O + (P.focalDistance * (float)ImGui_slider_hack) * directionToFocalPlane;
+
+	const float l0 = rng_float(seed);
+	const float l1 = rng_float(seed);
+	float dx, dy;
+	concentric_sample_disk(l0, l1, dx, dy);
+	const float pLx = P.lensRadius * dx, pLy = P.lensRadius * dy;
+	const f3 newOrigin = O + camera_right * pLx + camera_up * pLy;
+	const f3 direction = normalize(convergencePoint - newOrigin);
+
+	// kernel.cu:295: {origin, direction, {1,1,1}, 0, 0, 0, pixel}; lastSpecular defaults to true (variables.h:33)
+	P.work.o_dx[slot] = make_float4(newOrigin.x, newOrigin.y, newOrigin.z, direction.x);
+	P.work.dyz[slot] = make_float2(direction.y, direction.z);
+	P.work.direct_ix[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(y * (int)P.W + x));
+	P.work.flags[slot] = 0u | (1u << 8);
+}
+
+// ======================================================================================
+// set_wavefront_globals, kernel.cu:227-244 (+ reset of the compaction descriptors)
+// ======================================================================================
+__global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_t nDesc) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i < nDesc)
+		P.scanDesc[i] = 0ull;
+	if (i == 0) {
+		DevCounters* k = P.k;
+		const uint32_t cnt = k->primary_ray_cnt;
+		const unsigned long long room = (unsigned long long)(P.N - cnt);
+		const unsigned long long budget = k->budget_remaining;
+		const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
+		k->start_position = (uint32_t)(((unsigned long long)k->start_position + nNew) % P.localPixels);
+		k->n_live = cnt + nNew;
+		k->shadow_ray_cnt = 0;
+		k->primary_ray_cnt = 0;
+		k->shade_ticket = 0;
+		if (budget != ~0ull)
+			k->budget_remaining = budget - nNew;
+		k->total_primary_rays += nNew;
+		k->total_extend_rays += cnt + nNew;
+	}
+}
+
+// ======================================================================================
+// extend, kernel.cu:331-343 via intersect_scene, kernel.cu:125-142
+// ======================================================================================
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_extend(const FrameParams P) {
+	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t nLive = P.k->n_live;
+	VisitCount vc{ 0, 0 };
+	bool overflow = false;
+	if (slot < nLive) {
+		const float4 a = P.work.o_dx[slot];
+		const float2 b = P.work.dyz[slot];
+		const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+		float dist = kVeryFar;
+		uint32_t id = 0;
+#pragma unroll
+		for (int i = TYR_NUM_SPHERES; i--;) {
+			const float t = sphere_intersect(P.spheres[i], o, d);
+			if (t && t < dist) {
+				dist = t;
+				id = kHitSphere | (uint32_t)i;
+			}
+		}
+		if (P.scene.rootRef != kRefDone) {
+			const RayConst r = make_ray(o, d);
+			ScratchStack st;
+			int prim = 0;
+			if (bvh_closest<COUNT>(P.scene, r, dist, prim, st, vc))
+				id = (uint32_t)prim;
+			overflow = st.overflow;
+		}
+		P.work.hit[slot] = make_float2(dist, __uint_as_float(id));
+	}
+	if (overflow)
+		atomicOr(&P.k->device_error, kErrStackOverflow);
+	if (COUNT) {
+		wave_add_u64(&P.k->nodes_extend, vc.nodes);
+		wave_add_u64(&P.k->tris_extend, vc.tris);
+	}
+}
+
+// ======================================================================================
+// shade, kernel.cu:347-627
+// ======================================================================================
+struct ShadeOut {
+	bool survive, shadow;
+	f3 origin, direction, direct; // survivor state
+	uint32_t flags;
+	f3 sOrigin, sDir, sColor;      // shadow ray
+	float sClosest;
+};
+
+// NEE toward spheres[6], kernel.cu:419-447 / 559-590 (common part)
+struct LightSample {
+	f3 lightDir, lightVector;
+	float cosSurfaceToLight, cosLightToSurface;
+	bool valid;
+};
+__device__ __forceinline__ LightSample sample_sphere_light(const tyr_sphere& ls, uint32_t& seed, f3 origin, f3 normal) {
+	LightSample L;
+	const float cosPhi = 2.0f * rng_float(seed) - 1.0f;
+	const float sinPhi = sqrtf(1.0f - cosPhi * cosPhi);
+	const float theta = 2.0f * kPi * rng_float(seed);
+	float st, ct;
+	dm::sincosf_det(theta, st, ct);
+	const float x = ls.position[0] + ls.radius * sinPhi * st;
+	const float y = ls.position[1] + ls.radius * cosPhi;
+	const float z = ls.position[2] + ls.radius * sinPhi * ct;
+	const f3 p = mk3(x, y, z);
+	L.lightVector = p - origin;
+	const f3 nL = normalize(p - ld3(ls.position));
+	L.lightDir = normalize(L.lightVector);
+	L.cosSurfaceToLight = dot(normal, L.lightDir);
+	L.cosLightToSurface = dot(nL, -L.lightDir);
+	L.valid = L.cosSurfaceToLight > 0 && L.cosLightToSurface > 0;
+	return L;
+}
+
+__device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, ShadeOut& out) {
+	const float4 a = P.work.o_dx[slot];
+	const float2 b = P.work.dyz[slot];
+	const float2 h = P.work.hit[slot];
+	const float4 dq = P.work.direct_ix[slot];
+	const uint32_t fl = P.work.flags[slot];
+
+	f3 origin = mk3(a.x, a.y, a.z), direction = mk3(a.w, b.x, b.y), direct = mk3(dq.x, dq.y, dq.z);
+	const int pixel = __float_as_int(dq.w);
+	const float distance = h.x;
+	const uint32_t ident = __float_as_uint(h.y);
+	int bounces = (int)(fl & 0xffu);
+	bool lastSpecular = ((fl >> 8) & 1u) != 0;
+
+	int new_frame = 0;
+	f3 color = mk3(0.f, 0.f, 0.f);
+	f3 object_color = mk3(0.f, 0.f, 0.f);
+	uint32_t seed = (P.frame * (uint32_t)pixel * 147565741u) * 720898027u * slot; // kernel.cu:363
+	int reflection_type = TYR_DIFF;
+	out.survive = false;
+	out.shadow = false;
+
+	if (distance < kVeryFar) {
+		origin = origin + direction * distance;
+		f3 normal;
+		if (ident & kHitSphere) {
+			const tyr_sphere& object = P.spheres[ident & 7u];
+			normal = (origin - ld3(object.position)) / object.radius;
+			reflection_type = object.refl;
+			if (reflection_type != TYR_REFR && reflection_type != TYR_LIGHT)
+				direct = direct * ld3(object.color);
+			object_color = ld3(object.color);
+		} else {
+			// kernel.cu:380-383: normal from e1 x e2, white DIFF
+			const float4 t0 = P.scene.tris[3 * ident + 0];
+			const float4 t1 = P.scene.tris[3 * ident + 1];
+			const float4 t2 = P.scene.tris[3 * ident + 2];
+			normal = normalize(cross(mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x)));
+			reflection_type = TYR_DIFF;
+			object_color = mk3(1.f, 1.f, 1.f);
+			if (P.flags & TYR_FLAG_TRIANGLE_MATERIALS) {
+				const uint32_t m = __float_as_uint(t2.y);
+				reflection_type = m <= (uint32_t)TYR_PHONG ? (int)m : TYR_DIFF;
+			}
+		}
+		const bool outside = dot(normal, direction) < 0;
+		normal = outside ? normal : normal * -1.f;
+		origin = origin + normal * kEpsilon;
+
+		if (reflection_type == TYR_LIGHT) {
+			if (lastSpecular) {
+				color = direct * ld3(P.spheres[ident & 7u].emmission);
+			} else {
+				color = mk3(0.f, 0.f, 0.f);
+				direct = mk3(0.f, 0.f, 0.f);
+			}
+		}
+		lastSpecular = false;
+		constexpr float phongexponent = 40.0f;
+		const tyr_sphere& lightsource = P.spheres[6]; // kernel.cu:421, 561
+		switch (reflection_type) {
+		case TYR_LIGHT:
+			break;
+		case TYR_DIFF: {
+			const f3 sunSampleDir = cone_sample(P.sun, seed);
+			const float sunLight = dot(normal, sunSampleDir);
+			if (rng_float(seed) < 0.5f) {
+				if (sunLight > 0.f) {
+					out.shadow = true;
+					out.sOrigin = origin;
+					out.sDir = sunSampleDir;
+					out.sColor = (2.0f * direct) * ((sun_radiance(P.sun, sunSampleDir) * sunLight) * 1E-5f);
+					out.sClosest = 1e20f; // variables.h:41
+				}
+			} else {
+				const LightSample L = sample_sphere_light(lightsource, seed, origin, normal);
+				if (L.valid) {
+					const float closestAllowed = length(L.lightVector);
+					const float area = 4 * kPi * lightsource.radius * lightsource.radius;
+					const float solidAngle = (L.cosLightToSurface * area) / dot(L.lightVector, L.lightVector);
+					out.shadow = true;
+					out.sOrigin = origin;
+					out.sDir = L.lightDir;
+					out.sColor = ((((ld3(lightsource.emmission) * 2.0f) * direct) * solidAngle) * kInvPi) * L.cosSurfaceToLight;
+					out.sClosest = closestAllowed;
+				}
+			}
+			if (bounces < kMaxBounces) {
+				const float r1 = 2.f * kPi * rng_float(seed);
+				const float r2 = rng_float(seed);
+				const float r2s = sqrtf(r2);
+				f3 u, v;
+				orthonormal_basis_naive(normal, u, v);
+				float s1, c1;
+				dm::sincosf_det(r1, s1, c1);
+				direction = normalize((u * c1) * r2s + (v * s1) * r2s + normal * sqrtf(1 - r2));
+			}
+			break;
+		}
+		case TYR_SPEC: {
+			lastSpecular = true;
+			direction = reflect(direction, normal);
+			break;
+		}
+		case TYR_REFR: {
+			// kernel.cu:476-515 (n1/n2 = 1.2/1.0 "defying convention")
+			const float n1 = outside ? 1.2f : 1.0f;
+			const float n2 = outside ? 1.0f : 1.2f;
+			float fresnel = 0;
+			float r0 = (n1 - n2) / (n1 + n2);
+			r0 *= r0;
+			const float cosI = -dot(normal, direction);
+			const float n = n2 / n1;
+			const float sinT2 = n * n * (1.0f - cosI * cosI);
+			if (sinT2 > 1.0f) {
+				fresnel = 1.0f;
+			} else {
+				const float x = 1.0f - cosI;
+				fresnel = r0 + (1.0f - r0) * x * x * x * x * x;
+			}
+			if (rng_float(seed) < fresnel) {
+				lastSpecular = true;
+				direction = reflect(direction, normal);
+			} else {
+				origin = origin - (normal * 2.f) * kEpsilon;
+				const float cosT = sqrtf(1.0f - sinT2);
+				direction = n * direction + (n * cosI - cosT) * normal;
+			}
+			if (!outside) {
+				const f3 e = (-object_color) * distance;
+				direct = direct * mk3(dm::expf_det(e.x), dm::expf_det(e.y), dm::expf_det(e.z));
+			}
+			break;
+		}
+		case TYR_PHONG: {
+			f3 w, u, v, d;
+			do {
+				const float phi = 2 * kPi * rng_float(seed);
+				const float r2 = rng_float(seed);
+				const float cosTheta = dm::powf_det(1.0f - r2, 1.0f / (phongexponent + 1.0f));
+				const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+				w = direction - (normal * 2.0f) * dot(normal, direction);
+				w = normalize(w);
+				orthonormal_basis_naive(w, u, v);
+				float sp, cp;
+				dm::sincosf_det(phi, sp, cp);
+				d = (u * cp) * sinTheta + (v * sp) * sinTheta + w * cosTheta;
+				d = normalize(d);
+			} while (dot(d, normal) <= kEpsilon);
+
+			const f3 sunSampleDir = cone_sample(P.sun, seed);
+			float sunLight = dot(normal, sunSampleDir);
+			if (rng_float(seed) < 0.5f) {
+				if (sunLight > 0.f) {
+					const float phongCos = dot(sunSampleDir, w);
+					if (phongCos > kEpsilon) {
+						sunLight *= dm::powf_det(phongCos, phongexponent);
+						out.shadow = true;
+						out.sOrigin = origin;
+						out.sDir = sunSampleDir;
+						out.sColor = ((2.0f * direct) * ((phongexponent + 2) * 0.5f * kInvPi)) * ((sun_radiance(P.sun, sunSampleDir) * sunLight) * 1E-5f);
+						out.sClosest = 1e20f;
+					}
+				}
+			} else {
+				const LightSample L = sample_sphere_light(lightsource, seed, origin, normal);
+				if (L.valid) {
+					float phongCos = dot(L.lightDir, w);
+					if (phongCos > kEpsilon) {
+						phongCos = dm::powf_det(phongCos, phongexponent);
+						const float closestAllowed = length(L.lightVector);
+						const float area = 4.0f * kPi * lightsource.radius * lightsource.radius;
+						const float solidAngle = (L.cosLightToSurface * area) / dot(L.lightVector, L.lightVector);
+						f3 sc = (ld3(lightsource.emmission) * 2.0f) * direct;
+						sc = sc * solidAngle;
+						sc = sc * (phongexponent + 2);
+						sc = sc * 0.5f;
+						sc = sc * kInvPi;
+						sc = sc * phongCos;
+						sc = sc * L.cosSurfaceToLight;
+						out.shadow = true;
+						out.sOrigin = origin;
+						out.sDir = L.lightDir;
+						out.sColor = sc;
+						out.sClosest = closestAllowed;
+					}
+				}
+			}
+			origin = origin + w * kEpsilon;
+			direction = d;
+			break;
+		}
+		}
+
+		// Russian roulette, kernel.cu:599-611
+		const float p = gmin(1.0f, gmax(direct.z, gmax(direct.x, direct.y)));
+		if (bounces < kMaxBounces && p > (0 + kEpsilon) && rng_float(seed) <= p) {
+			bounces++;
+			direct = direct * (1.0f / p);
+			out.survive = true;
+			out.origin = origin;
+			out.direction = direction;
+			out.direct = direct;
+			out.flags = (uint32_t)bounces | ((lastSpecular ? 1u : 0u) << 8);
+		} else {
+			new_frame++;
+		}
+	} else {
+		// kernel.cu:613-617: nothing hit
+		color = color + (lastSpecular == false ? direct * sky_radiance(P.sun, direction) : direct * sunsky_radiance(P.sun, direction));
+		new_frame++;
+	}
+
+	// kernel.cu:622-625; adding +0 leaves the pixel unchanged, so zero terms are skipped
+	float* px = reinterpret_cast<float*>(&P.blit[pixel]);
+	if (color.x != 0.0f)
+		atomicAdd(px + 0, color.x);
+	if (color.y != 0.0f)
+		atomicAdd(px + 1, color.y);
+	if (color.z != 0.0f)
+		atomicAdd(px + 2, color.z);
+	if (new_frame)
+		atomicAdd(px + 3, (float)new_frame);
+}
+
+// look-back descriptor: [63:62] status, [61:31] survivors, [30:0] shadow rays
+constexpr unsigned long long kDescAggregate = 1ull << 62;
+constexpr unsigned long long kDescInclusive = 2ull << 62;
+__device__ __forceinline__ unsigned long long desc_pack(uint32_t s, uint32_t h) { return ((unsigned long long)s << 31) | (unsigned long long)h; }
+__device__ __forceinline__ uint32_t desc_s(unsigned long long d) { return (uint32_t)((d >> 31) & 0x7fffffffull); }
+__device__ __forceinline__ uint32_t desc_h(unsigned long long d) { return (uint32_t)(d & 0x7fffffffull); }
+
+__global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P) {
+	__shared__ uint32_t sh[16];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63u, wave = tid >> 6;
+
+	// virtual block id in ticket order: every lower id has already started, so the look-back
+	// below can never wait on a block that is not running
+	if (tid == 0)
+		sh[0] = atomicAdd(&P.k->shade_ticket, 1u);
+	__syncthreads();
+	const uint32_t vb = sh[0];
+	const uint32_t slot = vb * kBlock + tid;
+	const uint32_t nLive = P.k->n_live;
+
+	ShadeOut out = {};
+	uint32_t pixelBits = 0;
+	if (slot < nLive) {
+		pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
+		shade_ray(P, slot, out);
+	}
+
+	// ---- stable compaction of survivors and shadow rays -------------------------------
+	const unsigned long long bs = __ballot(out.survive);
+	const unsigned long long bh = __ballot(out.shadow);
+	const unsigned long long below = (1ull << lane) - 1ull;
+	const uint32_t rs = __popcll(bs & below), rh = __popcll(bh & below);
+	__syncthreads(); // sh[0] has been read by everyone
+	if (lane == 0) {
+		sh[4 + wave] = __popcll(bs);
+		sh[8 + wave] = __popcll(bh);
+	}
+	__syncthreads();
+	uint32_t ws = 0, wh = 0, totS = 0, totH = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < kBlock / 64; ++w) {
+		const uint32_t cs = sh[4 + w], ch = sh[8 + w];
+		if (w < wave) {
+			ws += cs;
+			wh += ch;
+		}
+		totS += cs;
+		totH += ch;
+	}
+	if (tid == 0) {
+		uint32_t es = 0, eh = 0; // exclusive prefix over lower virtual blocks
+		if (vb == 0) {
+			__hip_atomic_store(&P.scanDesc[0], kDescInclusive | desc_pack(totS, totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		} else {
+			__hip_atomic_store(&P.scanDesc[vb], kDescAggregate | desc_pack(totS, totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			int j = (int)vb - 1;
+			bool timeout = false;
+			while (j >= 0) {
+				unsigned long long d = 0;
+				uint32_t spins = 0;
+				for (;;) {
+					d = __hip_atomic_load(&P.scanDesc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (d >> 62)
+						break;
+					if (++spins > (1u << 24)) {
+						timeout = true;
+						break;
+					}
+					__builtin_amdgcn_s_sleep(2);
+				}
+				if (timeout)
+					break;
+				es += desc_s(d);
+				eh += desc_h(d);
+				if ((d >> 62) == 2ull)
+					break;
+				--j;
+			}
+			if (timeout)
+				atomicOr(&P.k->device_error, kErrScanTimeout);
+			__hip_atomic_store(&P.scanDesc[vb], kDescInclusive | desc_pack(es + totS, eh + totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		sh[1] = es;
+		sh[2] = eh;
+		if (vb == gridDim.x - 1) {
+			// kernel.cu:607 / 416: the totals the next top-up and connect read
+			P.k->primary_ray_cnt = es + totS;
+			P.k->shadow_ray_cnt = eh + totH;
+			P.k->total_shadow_rays += eh + totH;
+			P.k->n_survive += es + totS;
+		}
+	}
+	__syncthreads();
+	if (out.survive) {
+		const uint32_t dst = sh[1] + ws + rs; // kernel.cu:607-608, in slot order
+		P.next.o_dx[dst] = make_float4(out.origin.x, out.origin.y, out.origin.z, out.direction.x);
+		P.next.dyz[dst] = make_float2(out.direction.y, out.direction.z);
+		P.next.direct_ix[dst] = make_float4(out.direct.x, out.direct.y, out.direct.z, __uint_as_float(pixelBits));
+		P.next.flags[dst] = out.flags;
+	}
+	if (out.shadow) {
+		const uint32_t dst = sh[2] + wh + rh; // kernel.cu:416-417 etc., in slot order
+		P.shadow.o_dx[dst] = make_float4(out.sOrigin.x, out.sOrigin.y, out.sOrigin.z, out.sDir.x);
+		P.shadow.dyz_cd_ix[dst] = make_float4(out.sDir.y, out.sDir.z, out.sClosest, __uint_as_float(pixelBits));
+		P.shadow.color[dst] = make_float4(out.sColor.x, out.sColor.y, out.sColor.z, 0.0f);
+	}
+}
+
+// ======================================================================================
+// connect, kernel.cu:630-646 via intersect_scene_simple, kernel.cu:162-174
+// ======================================================================================
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_connect(const FrameParams P) {
+	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t n = P.k->shadow_ray_cnt;
+	VisitCount vc{ 0, 0 };
+	bool overflow = false;
+	uint32_t visible = 0;
+	if (index < n) {
+		const float4 a = P.shadow.o_dx[index];
+		const float4 b = P.shadow.dyz_cd_ix[index];
+		const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+		const float closest = b.z;
+		bool occluded = false;
+		if (P.scene.rootRef != kRefDone) {
+			const RayConst r = make_ray(o, d);
+			ScratchStack st;
+			occluded = bvh_any<COUNT>(P.scene, r, closest, st, vc);
+			overflow = st.overflow;
+		}
+		if (!occluded) {
+#pragma unroll
+			for (int i = TYR_NUM_SPHERES; i--;) {
+				const float t = sphere_intersect(P.spheres[i], o, d);
+				if (t && (t + kEpsilon) < closest) {
+					occluded = true;
+					break;
+				}
+			}
+		}
+		if (!occluded) {
+			const float4 c = P.shadow.color[index];
+			float* px = reinterpret_cast<float*>(&P.blit[__float_as_int(b.w)]);
+			if (c.x != 0.0f)
+				atomicAdd(px + 0, c.x);
+			if (c.y != 0.0f)
+				atomicAdd(px + 1, c.y);
+			if (c.z != 0.0f)
+				atomicAdd(px + 2, c.z);
+			visible = 1;
+		}
+	}
+	if (overflow)
+		atomicOr(&P.k->device_error, kErrStackOverflow);
+	wave_add_u64(&P.k->n_shadow_visible, visible);
+	if (COUNT) {
+		wave_add_u64(&P.k->nodes_connect, vc.nodes);
+		wave_add_u64(&P.k->tris_connect, vc.tris);
+	}
+}
+
+// ======================================================================================
+// blit_onto_framebuffer, kernel.cu:648-662 -> linear RGBA32F
+// ======================================================================================
+__global__ void __launch_bounds__(kBlock) k_resolve(const float4* __restrict__ blit, float4* __restrict__ out, uint32_t nPixels) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= nPixels)
+		return;
+	const float4 color = blit[i];
+	const float r = color.x / color.w, g = color.y / color.w, b = color.z / color.w;
+	constexpr float inv_gamma = 1.0f / 2.2f;
+	out[i] = make_float4(dm::powf_det(r / (r + 1.f), inv_gamma), dm::powf_det(g / (g + 1.f), inv_gamma), dm::powf_det(b / (b + 1.f), inv_gamma),
+		dm::powf_det(1.f / (1.f + 1.f), inv_gamma));
+}
+
+// ---- launch wrappers ---------------------------------------------------------------------
+static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
+void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
+	if (maxNew == 0)
+		return;
+	hipLaunchKernelGGL(k_primary, dim3(blocks_for(maxNew)), dim3(kBlock), 0, stream, P);
+}
+void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream) {
+	hipLaunchKernelGGL(k_globals, dim3(blocks_for(nDesc ? nDesc : 1)), dim3(kBlock), 0, stream, P, nDesc);
+}
+void launch_extend(const FrameParams& P, uint32_t maxLive, bool countVisits, hipStream_t stream) {
+	if (maxLive == 0)
+		return;
+	if (countVisits)
+		hipLaunchKernelGGL(k_extend<true>, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
+	else
+		hipLaunchKernelGGL(k_extend<false>, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
+}
+void launch_shade(const FrameParams& P, uint32_t maxLive, hipStream_t stream) {
+	if (maxLive == 0)
+		return;
+	hipLaunchKernelGGL(k_shade, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
+}
+void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, hipStream_t stream) {
+	if (maxShadow == 0)
+		return;
+	if (countVisits)
+		hipLaunchKernelGGL(k_connect<true>, dim3(blocks_for(maxShadow)), dim3(kBlock), 0, stream, P);
+	else
+		hipLaunchKernelGGL(k_connect<false>, dim3(blocks_for(maxShadow)), dim3(kBlock), 0, stream, P);
+}
+void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream) {
+	hipLaunchKernelGGL(k_resolve, dim3(blocks_for(nPixels)), dim3(kBlock), 0, stream, blit, out, nPixels);
+}
+
+} // namespace tyr

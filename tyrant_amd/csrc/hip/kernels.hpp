@@ -1,0 +1,87 @@
+// kernels.hpp -- launch interface between the host driver (host/driver.cpp) and the
+// gfx950 kernels (hip/kernels.hip): device-side data layout and by-value kernel arguments.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../../include/tyr_c.h"
+#include "sunsky.hpp"
+#include "traverse.hpp"
+
+namespace tyr {
+
+// ---- ray queues in HBM: structure of arrays, 16/8/4-byte lanes --------------------------
+// The reference's RayQueue is a 60-byte AoS record (variables.h:24-34): a wave touching one
+// field strides 60 B per lane.  Here each kernel reads exactly the arrays it needs with
+// consecutive lanes on consecutive 16/8/4-byte elements (1 KiB / 512 B / 256 B per wave
+// instruction):
+//   extend  reads  o_dx + dyz (24 B)                     writes hit (8 B)
+//   shade   reads  o_dx + dyz + hit + direct_ix + flags (52 B), writes 44 B per survivor
+struct RayQ {
+	float4* o_dx;        // origin.xyz, direction.x
+	float2* dyz;         // direction.y, direction.z
+	float4* direct_ix;   // direct.rgb (path throughput), pixel index (int bits)     variables.h:27,31
+	uint32_t* flags;     // bounces | lastSpecular << 8                               variables.h:30,33
+	float2* hit;         // distance, identifier (int bits; bit 31 = sphere)         variables.h:28,29,32
+};
+constexpr uint32_t kHitSphere = 0x80000000u;
+
+// ShadowQueue (variables.h:36-42), 44 B -> 32 B read by every connect ray + 16 B only when visible
+struct ShadowQ {
+	float4* o_dx;        // origin.xyz, direction.x
+	float4* dyz_cd_ix;   // direction.y, direction.z, closestDistance, buffer_index (int bits)
+	float4* color;       // color.rgb, unused
+};
+
+// kernel.cu:211-224 device counters + the extensions (budget, totals, visit counters)
+struct DevCounters {
+	uint32_t primary_ray_cnt;
+	uint32_t start_position;
+	uint32_t shadow_ray_cnt;
+	uint32_t n_live;
+	uint32_t shade_ticket;   // dynamic block id of the shade kernel (stable compaction)
+	uint32_t device_error;
+	uint32_t pad0, pad1;
+	unsigned long long budget_remaining;
+	unsigned long long total_extend_rays;
+	unsigned long long total_shadow_rays;
+	unsigned long long total_primary_rays;
+	unsigned long long nodes_extend, tris_extend;
+	unsigned long long nodes_connect, tris_connect;
+	unsigned long long n_survive, n_shadow_visible;
+};
+constexpr uint32_t kErrStackOverflow = 1u;
+constexpr uint32_t kErrScanTimeout = 2u;
+
+struct FrameParams {
+	uint32_t W, H, N;
+	uint32_t rank, nranks;
+	uint32_t localRows;      // H / nranks
+	uint32_t localPixels;    // W * localRows
+	uint32_t flags;
+	uint32_t frame;          // kernel.cu:667
+	float camPos[3], camDir[3], camRight[3], camUp[3]; // kernel.cu:699-700, 719
+	float focalDistance, lensRadius;
+	tyr_sphere spheres[TYR_NUM_SPHERES]; // kernel.cu:123 __constant__ spheres
+	SunParams sun;
+	DevScene scene;
+	RayQ work, next;
+	ShadowQ shadow;
+	float4* blit;            // main.cpp:129-130
+	DevCounters* k;
+	unsigned long long* scanDesc; // one look-back descriptor per shade block
+};
+
+constexpr int kBlock = 256; // 4 wave64 per workgroup
+
+// launches (all on `stream`); grids are sized by the host from upper bounds, kernels bound-check
+// against the device counters
+void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream);
+void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream);
+void launch_extend(const FrameParams& P, uint32_t maxLive, bool countVisits, hipStream_t stream);
+void launch_shade(const FrameParams& P, uint32_t maxLive, hipStream_t stream);
+void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, hipStream_t stream);
+void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream);
+
+} // namespace tyr

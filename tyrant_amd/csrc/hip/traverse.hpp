@@ -1,0 +1,353 @@
+// traverse.hpp -- BVH traversal on gfx950: closest hit (reference: CachedBVH::intersect,
+// bvh.h:118-161) and any hit (CachedBVH::intersectSimple, bvh.h:213-256), with
+// BBox::intersect (Bbox.h:38-62) and Triangle::intersect (loader.h:21-46).
+//
+// Device layout (private to the library, built by host/bvh_layout.cpp from the
+// reference's flat 32-byte node array):
+//
+//   PairNode, 64 B = 4 x dwordx4, one per INTERIOR node of the reference tree, holding
+//   the boxes of BOTH children, slab-major so one 16-byte load feeds one axis:
+//       q0 = { left.min.x, left.max.x, right.min.x, right.max.x }
+//       q1 = {      ..y                                         }
+//       q2 = {      ..z                                         }
+//       q3 = { leftRef, rightRef, splitAxis, 0 }
+//   left = the reference's node index+1, right = its secondChildOffset.
+//   ChildRef: bit 31 = leaf; leaf: [30:26] = primitiveCount-1, [25:0] = primitiveOffset;
+//             interior: index of the child's PairNode.
+//   Triangles: 48 B = 3 x dwordx4 { vert.xyz, e1.x | e1.yz, e2.xy | e2.z, material, 0, 0 }.
+//
+// Why this shape: the reference fetches a 32-byte node, tests ONE box, then fetches the
+// next node -- every box test is a dependent memory round trip.  A PairNode fetch is one
+// round trip for two box tests, leaves need no node fetch at all, and a child whose box
+// fails is never pushed or fetched.
+//
+// Visit-order equivalence (SURVEY.md section 7 "Traversal-order-dependent hits"): the
+// reference tests a node's box when the node is VISITED, against the ray's current
+// closest distance.  Here a child's box is tested when its PARENT is visited; the test
+// is `overlap && tMin < dist && tMax > 0` (Bbox.h:61) and only `tMin < dist` depends on
+// dist, which can only shrink, so (1) a child rejected early would also be rejected at
+// visit time, and (2) for a pushed child, re-checking `tMin < dist` at pop time with the
+// stored tMin reproduces the reference's decision exactly.  Near child first by
+// dirIsNeg[splitAxis] (bvh.h:146-152), leaf primitives in array order (bvh.h:131), so
+// the sequence of triangle tests -- and therefore the epsilon-dependent accept rule of
+// bvh.h:134 -- is identical.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "vecmath.hpp"
+
+namespace tyr {
+
+constexpr uint32_t kRefLeaf = 0x80000000u;
+constexpr uint32_t kRefDone = 0xFFFFFFFFu; // "leaf" with every bit set: never produced by the layout pass
+constexpr int kStackSize = 64;             // bvh.h:124 nodesToVisit[64]
+constexpr uint32_t kMaxLeafPrims = 32;
+constexpr uint32_t kMaxPrimOffset = 1u << 26;
+
+struct DevScene {
+	const float4* nodes; // PairNode array, 4 float4 each
+	const float4* tris;  // 3 float4 each
+	float rootMin[3];
+	float rootMax[3];
+	uint32_t rootRef;    // kRefDone when the scene has no triangles (Scene.cpp:49-52)
+	uint32_t nPairs;
+	uint32_t nPrims;
+};
+
+#ifdef __HIPCC__
+
+struct RayConst {
+	f3 o, d, inv;
+	bool nx, ny, nz;
+};
+
+__device__ __forceinline__ RayConst make_ray(f3 o, f3 d) {
+	RayConst r;
+	r.o = o;
+	r.d = d;
+	r.inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z); // bvh.h:120
+	r.nx = r.inv.x < 0;                           // bvh.h:121
+	r.ny = r.inv.y < 0;
+	r.nz = r.inv.z < 0;
+	return r;
+}
+
+// Bbox.h:38-62 with the sign-selected bounds already picked.  Returns the pass/fail of the
+// dist-independent part AND `tMin < lowest`; tMinOut is the entry distance used for the
+// pop-time re-check.
+__device__ __forceinline__ bool slab_test(const RayConst& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float lowest, float& tMinOut) {
+	float tMin = (lox - r.o.x) * r.inv.x;
+	float tMax = (hix - r.o.x) * r.inv.x;
+	const float tyMin = (loy - r.o.y) * r.inv.y;
+	const float tyMax = (hiy - r.o.y) * r.inv.y;
+	bool ok = !(tMin > tyMax || tyMin > tMax);
+	if (tyMin > tMin)
+		tMin = tyMin;
+	if (tyMax < tMax)
+		tMax = tyMax;
+	const float tzMin = (loz - r.o.z) * r.inv.z;
+	const float tzMax = (hiz - r.o.z) * r.inv.z;
+	ok = ok && !(tMin > tzMax || tzMin > tMax);
+	if (tzMin > tMin)
+		tMin = tzMin;
+	if (tzMax < tMax)
+		tMax = tzMax;
+	tMinOut = tMin;
+	return ok && (tMin < lowest) && (tMax > 0);
+}
+
+// loader.h:21-46: Moller-Trumbore, back faces culled (det < 1e-7), 0 = miss
+__device__ __forceinline__ float triangle_test(const float4* __restrict__ tris, uint32_t prim, const RayConst& r) {
+	const float4 a = tris[3 * prim + 0];
+	const float4 b = tris[3 * prim + 1];
+	const float4 c = tris[3 * prim + 2];
+	const f3 vert = mk3(a.x, a.y, a.z);
+	const f3 e1 = mk3(a.w, b.x, b.y);
+	const f3 e2 = mk3(b.z, b.w, c.x);
+	const f3 pvec = cross(r.d, e2);
+	const float det = dot(e1, pvec);
+	if (det < 0.0000001f)
+		return 0.0f;
+	const float invDet = 1 / det;
+	const f3 tvec = r.o - vert;
+	const float u = dot(tvec, pvec) * invDet;
+	if (u < 0 || u > 1)
+		return 0.0f;
+	const f3 qvec = cross(tvec, e1);
+	const float v = dot(r.d, qvec) * invDet;
+	if (v < 0 || u + v > 1)
+		return 0.0f;
+	return dot(e2, qvec) * invDet;
+}
+
+// Per-lane traversal stack in private (scratch) memory with the top entry cached in
+// registers: the common push-then-pop pair never touches memory.
+struct ScratchStack {
+	uint32_t ref[kStackSize];
+	float tmin[kStackSize];
+	int n; // entries in memory
+	uint32_t topRef;
+	float topT;
+	bool hasTop;
+	bool overflow;
+	__device__ __forceinline__ void reset() {
+		n = 0;
+		hasTop = false;
+		overflow = false;
+	}
+	__device__ __forceinline__ void push(uint32_t r, float t) {
+		if (hasTop) {
+			if (n < kStackSize - 1) {
+				ref[n] = topRef;
+				tmin[n] = topT;
+				++n;
+			} else {
+				overflow = true; // the reference's 64-entry array would be overrun here (bvh.h:124)
+			}
+		}
+		topRef = r;
+		topT = t;
+		hasTop = true;
+	}
+	__device__ __forceinline__ bool pop(uint32_t& r, float& t) {
+		if (hasTop) {
+			r = topRef;
+			t = topT;
+			hasTop = false;
+			return true;
+		}
+		if (n == 0)
+			return false;
+		--n;
+		r = ref[n];
+		t = tmin[n];
+		return true;
+	}
+};
+
+struct PairTest {
+	uint32_t nearRef, farRef;
+	float nearT, farT;
+	bool nearHit, farHit;
+	bool synthetic; // axis 3: continuation of an over-long leaf, not a node of the reference tree
+};
+
+__device__ __forceinline__ PairTest test_pair(const float4* __restrict__ nodes, uint32_t idx, const RayConst& r, float dist) {
+	const float4 qx = nodes[4 * idx + 0];
+	const float4 qy = nodes[4 * idx + 1];
+	const float4 qz = nodes[4 * idx + 2];
+	const float4 qr = nodes[4 * idx + 3];
+	const uint32_t leftRef = __float_as_uint(qr.x), rightRef = __float_as_uint(qr.y), axis = __float_as_uint(qr.z);
+	float tL, tR;
+	// bounds[dirIsNeg] is the entry plane, bounds[1 - dirIsNeg] the exit plane (Bbox.h:39-42)
+	const bool hL = slab_test(r, r.nx ? qx.y : qx.x, r.nx ? qx.x : qx.y, r.ny ? qy.y : qy.x, r.ny ? qy.x : qy.y, r.nz ? qz.y : qz.x, r.nz ? qz.x : qz.y, dist, tL);
+	const bool hR = slab_test(r, r.nx ? qx.w : qx.z, r.nx ? qx.z : qx.w, r.ny ? qy.w : qy.z, r.ny ? qy.z : qy.w, r.nz ? qz.w : qz.z, r.nz ? qz.z : qz.w, dist, tR);
+	// bvh.h:146-152: dirIsNeg[splitAxis] -> second child first.  axis 3 (synthetic chain) = left first.
+	const bool rightFirst = (axis == 0) ? r.nx : (axis == 1) ? r.ny : (axis == 2) ? r.nz : false;
+	PairTest p;
+	p.nearRef = rightFirst ? rightRef : leftRef;
+	p.farRef = rightFirst ? leftRef : rightRef;
+	p.nearT = rightFirst ? tR : tL;
+	p.farT = rightFirst ? tL : tR;
+	p.nearHit = rightFirst ? hR : hL;
+	p.farHit = rightFirst ? hL : hR;
+	p.synthetic = (axis == 3);
+	if (p.synthetic) {
+		// synthetic split of an over-long leaf: the reference tests every primitive of a leaf once
+		// the leaf's box passed (bvh.h:131), so neither half is re-tested here or at pop time
+		p.nearHit = true;
+		p.farHit = true;
+		p.farT = -__builtin_inff();
+	}
+	return p;
+}
+
+struct VisitCount {
+	uint32_t nodes, tris;
+};
+
+// Closest hit.  `dist` / `prim` are updated like ray.distance / ray.identifier (bvh.h:135-136).
+// COUNT: also count nodes visited / triangles tested by the reference's rule (bvh.h:164-209:
+// one per loop iteration = every node fetched, including those whose box test fails).
+template <bool COUNT>
+__device__ __forceinline__ bool bvh_closest(const DevScene& sc, const RayConst& r, float& dist, int& prim, ScratchStack& st, VisitCount& vc) {
+	bool hit = false;
+	st.reset();
+	uint32_t ref;
+	{
+		float t0;
+		const bool ok = slab_test(r, r.nx ? sc.rootMax[0] : sc.rootMin[0], r.nx ? sc.rootMin[0] : sc.rootMax[0], r.ny ? sc.rootMax[1] : sc.rootMin[1], r.ny ? sc.rootMin[1] : sc.rootMax[1],
+			r.nz ? sc.rootMax[2] : sc.rootMin[2], r.nz ? sc.rootMin[2] : sc.rootMax[2], dist, t0);
+		if (COUNT)
+			vc.nodes += 1;
+		ref = ok ? sc.rootRef : kRefDone;
+	}
+	while (ref != kRefDone) {
+		// interior nodes: keep descending until this lane holds a leaf (or is done)
+		while ((int)ref >= 0) {
+			const PairTest p = test_pair(sc.nodes, ref, r, dist);
+			if (COUNT && !p.synthetic)
+				vc.nodes += 2; // closest hit never exits early: both children are visited by the reference
+			if (p.nearHit) {
+				if (p.farHit)
+					st.push(p.farRef, p.farT);
+				ref = p.nearRef;
+			} else if (p.farHit) {
+				ref = p.farRef;
+			} else {
+				ref = kRefDone;
+				uint32_t pr;
+				float pt;
+				while (st.pop(pr, pt)) {
+					if (pt < dist) { // the pop-time half of Bbox.h:61
+						ref = pr;
+						break;
+					}
+				}
+			}
+		}
+		if (ref == kRefDone)
+			break;
+		// leaf: bvh.h:129-140
+		const uint32_t off = ref & (kMaxPrimOffset - 1);
+		const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+		for (uint32_t i = 0; i < cnt; ++i) {
+			const float t = triangle_test(sc.tris, off + i, r);
+			if (COUNT)
+				vc.tris += 1;
+			if (t > kEpsilon && t < dist && ((dist - t) > kEpsilon)) {
+				prim = (int)(off + i);
+				dist = t;
+				hit = true;
+			}
+		}
+		ref = kRefDone;
+		uint32_t pr;
+		float pt;
+		while (st.pop(pr, pt)) {
+			if (pt < dist) {
+				ref = pr;
+				break;
+			}
+		}
+	}
+	return hit;
+}
+
+// Any hit within `closest` (bvh.h:213-256).  The bound never shrinks, so the result does not
+// depend on visit order; the same near-first order is kept so COUNT reproduces the reference's
+// visit counts (nodes popped before the early return).
+template <bool COUNT>
+__device__ __forceinline__ bool bvh_any(const DevScene& sc, const RayConst& r, float closest, ScratchStack& st, VisitCount& vc) {
+	st.reset();
+	uint32_t ref;
+	{
+		float t0;
+		const bool ok = slab_test(r, r.nx ? sc.rootMax[0] : sc.rootMin[0], r.nx ? sc.rootMin[0] : sc.rootMax[0], r.ny ? sc.rootMax[1] : sc.rootMin[1], r.ny ? sc.rootMin[1] : sc.rootMax[1],
+			r.nz ? sc.rootMax[2] : sc.rootMin[2], r.nz ? sc.rootMin[2] : sc.rootMax[2], closest, t0);
+		if (COUNT)
+			vc.nodes += 1;
+		ref = ok ? sc.rootRef : kRefDone;
+	}
+	const float kFailed = __builtin_inff(); // COUNT only: a far child that failed its box test but is still "visited" when popped
+	while (ref != kRefDone) {
+		while ((int)ref >= 0) {
+			const PairTest p = test_pair(sc.nodes, ref, r, closest);
+			if (COUNT && !p.synthetic) {
+				vc.nodes += 1; // the near child is visited next
+				st.push(p.farRef, p.farHit ? p.farT : kFailed);
+				ref = p.nearHit ? p.nearRef : kRefDone;
+			} else {
+				if (p.nearHit) {
+					if (p.farHit)
+						st.push(p.farRef, p.farT);
+					ref = p.nearRef;
+				} else if (p.farHit) {
+					ref = p.farRef;
+				} else {
+					ref = kRefDone;
+				}
+			}
+			if (ref == kRefDone) {
+				uint32_t pr;
+				float pt;
+				while (st.pop(pr, pt)) {
+					if (COUNT)
+						vc.nodes += 1;
+					if (pt < closest) {
+						ref = pr;
+						break;
+					}
+				}
+			}
+		}
+		if (ref == kRefDone)
+			break;
+		const uint32_t off = ref & (kMaxPrimOffset - 1);
+		const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+		for (uint32_t i = 0; i < cnt; ++i) {
+			const float t = triangle_test(sc.tris, off + i, r);
+			if (COUNT)
+				vc.tris += 1;
+			if (t > kEpsilon && ((closest - t) > kEpsilon))
+				return true; // bvh.h:232-236
+		}
+		ref = kRefDone;
+		uint32_t pr;
+		float pt;
+		while (st.pop(pr, pt)) {
+			if (COUNT)
+				vc.nodes += 1;
+			if (pt < closest) {
+				ref = pr;
+				break;
+			}
+		}
+	}
+	return false;
+}
+
+#endif // __HIPCC__
+
+} // namespace tyr

@@ -1,0 +1,159 @@
+// bvh_layout.cpp -- the upload half of Scene::Load (Scene.cpp:55-67) for gfx950: turns the
+// reference's flat depth-first 32-byte node array (bvh.h:55-68) into the private device
+// layout documented in hip/traverse.hpp (64-byte child-pair nodes, 48-byte triangles).
+// The tree itself -- which primitive is in which leaf, which child is "first", every box --
+// is unchanged, so the traversal visit order of bvh.h:118-161 is preserved.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "host.hpp"
+
+namespace tyr {
+
+namespace {
+
+inline uint32_t leaf_ref(uint32_t off, uint32_t cnt) { return kRefLeaf | ((cnt - 1u) << 26) | off; }
+inline float bits(uint32_t u) {
+	float f;
+	std::memcpy(&f, &u, 4);
+	return f;
+}
+inline bool finite3(const float* p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
+
+struct Emit {
+	std::vector<float>& out;
+	// appends one pair node, returns its index
+	uint32_t pair(const tyr_bbox& l, const tyr_bbox& r, uint32_t lref, uint32_t rref, uint32_t axis) {
+		const uint32_t idx = static_cast<uint32_t>(out.size() / 16);
+		out.resize(out.size() + 16);
+		write(idx, l, r, lref, rref, axis);
+		return idx;
+	}
+	void write(uint32_t idx, const tyr_bbox& l, const tyr_bbox& r, uint32_t lref, uint32_t rref, uint32_t axis) {
+		float* q = &out[static_cast<size_t>(idx) * 16];
+		for (int k = 0; k < 3; ++k) {
+			q[4 * k + 0] = l.bounds[0][k];
+			q[4 * k + 1] = l.bounds[1][k];
+			q[4 * k + 2] = r.bounds[0][k];
+			q[4 * k + 3] = r.bounds[1][k];
+		}
+		q[12] = bits(lref);
+		q[13] = bits(rref);
+		q[14] = bits(axis);
+		q[15] = 0.0f;
+	}
+};
+
+} // namespace
+
+int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims, DeviceLayout& L) {
+	L.pairNodes.clear();
+	L.tris.clear();
+	L.nPairs = 0;
+	L.rootRef = kRefDone;
+	for (int k = 0; k < 3; ++k) {
+		L.rootMin[k] = 0.0f;
+		L.rootMax[k] = 0.0f;
+	}
+	if (nPrims <= 0 || nNodes <= 0)
+		return TYR_OK; // Scene.cpp:49-52: empty scene, no BVH
+	if (!nodes || !prims || static_cast<uint32_t>(nPrims) > kMaxPrimOffset)
+		return TYR_ERR_INVALID;
+
+	// triangles
+	L.tris.resize(static_cast<size_t>(nPrims) * 12);
+	for (int32_t i = 0; i < nPrims; ++i) {
+		const tyr_triangle& t = prims[i];
+		if (!finite3(t.vert) || !finite3(t.e1) || !finite3(t.e2))
+			return TYR_ERR_INVALID;
+		float* q = &L.tris[static_cast<size_t>(i) * 12];
+		q[0] = t.vert[0];
+		q[1] = t.vert[1];
+		q[2] = t.vert[2];
+		q[3] = t.e1[0];
+		q[4] = t.e1[1];
+		q[5] = t.e1[2];
+		q[6] = t.e2[0];
+		q[7] = t.e2[1];
+		q[8] = t.e2[2];
+		q[9] = bits(static_cast<uint32_t>(t.materialType));
+		q[10] = 0.0f;
+		q[11] = 0.0f;
+	}
+
+	// pass 1: validate, and number the interior nodes in depth-first (array) order
+	std::vector<uint32_t> pairIndex(static_cast<size_t>(nNodes), 0xFFFFFFFFu);
+	uint32_t nInterior = 0;
+	for (int32_t i = 0; i < nNodes; ++i) {
+		const tyr_bvh_node& n = nodes[i];
+		if (!finite3(n.bbox.bounds[0]) || !finite3(n.bbox.bounds[1]))
+			return TYR_ERR_INVALID;
+		if (n.primitiveCount > 0) {
+			if (n.offset < 0 || static_cast<int64_t>(n.offset) + n.primitiveCount > nPrims)
+				return TYR_ERR_INVALID;
+		} else {
+			if (n.splitAxis > 2 || n.offset <= i + 1 || n.offset >= nNodes || i + 1 >= nNodes)
+				return TYR_ERR_INVALID;
+			pairIndex[static_cast<size_t>(i)] = nInterior++;
+		}
+	}
+	// every node except the root must be referenced exactly once (a depth-first tree)
+	{
+		std::vector<uint8_t> seen(static_cast<size_t>(nNodes), 0);
+		seen[0] = 1;
+		for (int32_t i = 0; i < nNodes; ++i) {
+			if (nodes[i].primitiveCount == 0) {
+				const int32_t c[2] = { i + 1, nodes[i].offset };
+				for (int32_t ci : c) {
+					if (seen[static_cast<size_t>(ci)])
+						return TYR_ERR_INVALID;
+					seen[static_cast<size_t>(ci)] = 1;
+				}
+			}
+		}
+		for (int32_t i = 0; i < nNodes; ++i)
+			if (!seen[static_cast<size_t>(i)])
+				return TYR_ERR_INVALID;
+	}
+
+	L.pairNodes.assign(static_cast<size_t>(nInterior) * 16, 0.0f);
+	Emit emit{ L.pairNodes };
+
+	// reference of a child node; leaves longer than kMaxLeafPrims become a chain of synthetic
+	// "left first" pair nodes (axis 3) that visits the same primitives in the same order
+	auto child_ref = [&](int32_t ci) -> uint32_t {
+		const tyr_bvh_node& c = nodes[ci];
+		if (c.primitiveCount == 0)
+			return pairIndex[static_cast<size_t>(ci)];
+		uint32_t off = static_cast<uint32_t>(c.offset), cnt = c.primitiveCount;
+		if (cnt <= kMaxLeafPrims)
+			return leaf_ref(off, cnt);
+		// build the chain back to front
+		const uint32_t chunks = (cnt + kMaxLeafPrims - 1) / kMaxLeafPrims;
+		uint32_t tailOff = off + (chunks - 1) * kMaxLeafPrims;
+		uint32_t ref = leaf_ref(tailOff, cnt - (chunks - 1) * kMaxLeafPrims);
+		for (uint32_t k = chunks - 1; k-- > 0;) {
+			const uint32_t o = off + k * kMaxLeafPrims;
+			ref = emit.pair(c.bbox, c.bbox, leaf_ref(o, kMaxLeafPrims), ref, 3u);
+		}
+		return ref;
+	};
+
+	for (int32_t i = 0; i < nNodes; ++i) {
+		const tyr_bvh_node& n = nodes[i];
+		if (n.primitiveCount > 0)
+			continue;
+		const int32_t li = i + 1, ri = n.offset;
+		const uint32_t lref = child_ref(li), rref = child_ref(ri);
+		emit.write(pairIndex[static_cast<size_t>(i)], nodes[li].bbox, nodes[ri].bbox, lref, rref, n.splitAxis);
+	}
+	L.nPairs = static_cast<uint32_t>(L.pairNodes.size() / 16);
+	std::memcpy(L.rootMin, nodes[0].bbox.bounds[0], 12);
+	std::memcpy(L.rootMax, nodes[0].bbox.bounds[1], 12);
+	L.rootRef = child_ref(0);
+	L.nPairs = static_cast<uint32_t>(L.pairNodes.size() / 16);
+	return TYR_OK;
+}
+
+} // namespace tyr

@@ -1,0 +1,836 @@
+// driver.cpp -- tyr_ctx and the C ABI of include/tyr_c.h: the host driver of the wavefront
+// loop (reference: launch_kernels, kernel.cu:664-748, and its caller main.cpp:112-170).
+//
+// State that the reference keeps in function statics and device globals (kernel.cu:211-224,
+// 665-667, 688-691) lives in tyr_ctx; constants arrive in the kernels as one by-value
+// argument block (FrameParams) instead of cudaMemcpyToSymbol (kernel.cu:681-684, 707-709).
+// There is no CPU fallback: without a HIP device tyr_create fails with TYR_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "host.hpp"
+
+using namespace tyr;
+
+#define HIPCHK(expr)                       \
+	do {                                   \
+		hipError_t e_ = (expr);            \
+		if (e_ != hipSuccess)              \
+			return static_cast<int>(e_);   \
+	} while (0)
+
+struct tyr_ctx {
+	tyr_config cfg{};
+	hipStream_t stream = nullptr;
+	bool ownStream = false;
+	uint32_t localRows = 0, localPixels = 0;
+
+	RayQ q[2]{};
+	int cur = 0; // q[cur] = work queue, q[cur ^ 1] = next (the caller's std::swap, main.cpp:169)
+	ShadowQ shadow{};
+	DevCounters* dK = nullptr;
+	DevCounters* hK = nullptr; // pinned host mirror
+	unsigned long long* scanDesc = nullptr;
+	uint32_t nDescCap = 0;
+	float4* blit = nullptr;
+	bool ownBlit = false;
+
+	float4* dNodes = nullptr;
+	float4* dTris = nullptr;
+	DevScene scene{};
+	bool haveScene = false;
+
+	tyr_sphere spheres[TYR_NUM_SPHERES]{};
+	tyr_camera cam{};
+	float sunPos[2] = { 0.05f, 0.3f }; // variables.cpp:3
+	bool sunChanged = true;             // variables.cpp:4
+	SunParams sun{};
+
+	// launch_kernels statics, kernel.cu:665-667, 688-691
+	bool firstTime = true;
+	uint32_t frame = 1;
+	float lastPos[3] = { 0, 0, 0 }, lastDir[3] = { 0, 0, 0 };
+	float lastFocal = 1.0f, lastLens = 0.02f;
+	float camRight[3]{}, camUp[3]{};
+
+	hipEvent_t ev[2 * TYR_K_COUNT]{};
+	bool evUsed[TYR_K_COUNT]{};
+	tyr_timings timings{};
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(T*& p, size_t count) {
+	void* v = nullptr;
+	hipError_t e = hipMalloc(&v, count * sizeof(T));
+	if (e != hipSuccess)
+		return e == hipErrorOutOfMemory ? TYR_ERR_OOM : static_cast<int>(e);
+	p = static_cast<T*>(v);
+	return TYR_OK;
+}
+template <class T>
+void dev_free(T*& p) {
+	if (p)
+		(void)hipFree(p);
+	p = nullptr;
+}
+
+int alloc_rayq(RayQ& q, size_t n) {
+	int rc;
+	if ((rc = dev_alloc(q.o_dx, n)))
+		return rc;
+	if ((rc = dev_alloc(q.dyz, n)))
+		return rc;
+	if ((rc = dev_alloc(q.direct_ix, n)))
+		return rc;
+	if ((rc = dev_alloc(q.flags, n)))
+		return rc;
+	if ((rc = dev_alloc(q.hit, n)))
+		return rc;
+	return TYR_OK;
+}
+void free_rayq(RayQ& q) {
+	dev_free(q.o_dx);
+	dev_free(q.dyz);
+	dev_free(q.direct_ix);
+	dev_free(q.flags);
+	dev_free(q.hit);
+}
+
+void default_spheres(tyr_sphere* s) {
+	// kernel.cu:674-680
+	const tyr_sphere t[TYR_NUM_SPHERES] = {
+		{ 16.5f, { 0, 40, 16.5f }, { 1, 1, 1 }, { 0, 0, 0 }, TYR_DIFF },
+		{ 16.5f, { 40, 0, 16.5f }, { 0.5f, 0.5f, 0.06f }, { 0, 0, 0 }, TYR_REFR },
+		{ 16.5f, { -40, -50, 36.5f }, { 0.6f, 0.5f, 0.4f }, { 0, 0, 0 }, TYR_PHONG },
+		{ 16.5f, { -40, -50, 16.5f }, { 0.6f, 0.5f, 0.4f }, { 0, 0, 0 }, TYR_SPEC },
+		{ 1e4f, { 0, 0, -1e4f - 20 }, { 1, 1, 1 }, { 0, 0, 0 }, TYR_DIFF },
+		{ 20, { 0, -80, 20 }, { 1.0f, 0.0f, 0.0f }, { 0, 0, 0 }, TYR_DIFF },
+		{ 9, { 0, -80, 120.0f }, { 0.0f, 1.0f, 0.0f }, { 3, 3, 3 }, TYR_LIGHT },
+	};
+	std::memcpy(s, t, sizeof(t));
+}
+
+bool finite_n(const float* p, int n) {
+	for (int i = 0; i < n; ++i)
+		if (!std::isfinite(p[i]))
+			return false;
+	return true;
+}
+
+int use_device(tyr_ctx* c) { return static_cast<int>(hipSetDevice(c->cfg.device)); }
+
+// refresh the pinned host mirror of the device counters; the stream is idle afterwards
+int sync_counters(tyr_ctx* c) {
+	HIPCHK(hipMemcpyAsync(c->hK, c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return TYR_OK;
+}
+int push_counters(tyr_ctx* c) {
+	HIPCHK(hipMemcpyAsync(c->dK, c->hK, sizeof(DevCounters), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return TYR_OK;
+}
+
+FrameParams make_params(const tyr_ctx* c) {
+	FrameParams P{};
+	P.W = c->cfg.width;
+	P.H = c->cfg.height;
+	P.N = c->cfg.queue_size;
+	P.rank = c->cfg.rank;
+	P.nranks = c->cfg.nranks;
+	P.localRows = c->localRows;
+	P.localPixels = c->localPixels;
+	P.flags = c->cfg.flags;
+	P.frame = c->frame;
+	std::memcpy(P.camPos, c->cam.position, 12);
+	std::memcpy(P.camDir, c->cam.direction, 12);
+	std::memcpy(P.camRight, c->camRight, 12);
+	std::memcpy(P.camUp, c->camUp, 12);
+	P.focalDistance = c->cam.focalDistance;
+	P.lensRadius = c->cam.lensRadius;
+	std::memcpy(P.spheres, c->spheres, sizeof(P.spheres));
+	P.sun = c->sun;
+	P.scene = c->scene;
+	P.work = c->q[c->cur];
+	P.next = c->q[c->cur ^ 1];
+	P.shadow = c->shadow;
+	P.blit = c->blit;
+	P.k = c->dK;
+	P.scanDesc = c->scanDesc;
+	return P;
+}
+
+struct KernelTimer {
+	tyr_ctx* c;
+	int k;
+	bool on;
+	KernelTimer(tyr_ctx* c_, int k_) : c(c_), k(k_), on((c_->cfg.flags & TYR_FLAG_PROFILE) != 0) {
+		if (on)
+			(void)hipEventRecord(c->ev[2 * k], c->stream);
+	}
+	~KernelTimer() {
+		if (on) {
+			(void)hipEventRecord(c->ev[2 * k + 1], c->stream);
+			c->evUsed[k] = true;
+		}
+	}
+};
+// after the stream went idle: fold the recorded event pairs into the running sums
+void collect_timings(tyr_ctx* c) {
+	if (!(c->cfg.flags & TYR_FLAG_PROFILE))
+		return;
+	for (int k = 0; k < TYR_K_COUNT; ++k) {
+		if (!c->evUsed[k])
+			continue;
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) == hipSuccess) {
+			c->timings.ms[k] += ms;
+			c->timings.launches[k] += 1;
+		}
+		c->evUsed[k] = false;
+	}
+}
+
+uint32_t planned_new(const tyr_ctx* c) {
+	const uint64_t room = c->cfg.queue_size - c->hK->primary_ray_cnt;
+	const uint64_t budget = c->hK->budget_remaining;
+	return static_cast<uint32_t>(std::min(room, budget));
+}
+
+// host prologue of launch_kernels, kernel.cu:671-718
+int stage_begin(tyr_ctx* c) {
+	if (!c->blit)
+		return TYR_ERR_NO_BUFFER;
+	c->firstTime = false;
+	const f3 dir = ld3(c->cam.direction), up = ld3(c->cam.up);
+	// kernel.cu:699-700
+	const f3 right = normalize(cross(dir, up)) * 1.5f * (static_cast<float>(c->cfg.width) / static_cast<float>(c->cfg.height));
+	const f3 upv = normalize(cross(right, dir)) * 1.5f;
+	c->camRight[0] = right.x;
+	c->camRight[1] = right.y;
+	c->camRight[2] = right.z;
+	c->camUp[0] = upv.x;
+	c->camUp[1] = upv.y;
+	c->camUp[2] = upv.z;
+	// kernel.cu:702
+	bool reset = false;
+	for (int k = 0; k < 3; ++k)
+		reset = reset || c->lastPos[k] != c->cam.position[k] || c->lastDir[k] != c->cam.direction[k];
+	reset = reset || c->lastFocal != c->cam.focalDistance || c->cam.lensRadius != c->lastLens;
+	if (c->sunChanged) { // kernel.cu:704-710
+		c->sunChanged = false;
+		reset = true;
+		sun_setup(c->sunPos[0], c->sunPos[1], c->sun);
+	}
+	if (reset) { // kernel.cu:712-718
+		HIPCHK(hipMemsetAsync(c->blit, 0, sizeof(float4) * static_cast<size_t>(c->cfg.width) * c->cfg.height, c->stream));
+		c->hK->primary_ray_cnt = 0;
+		HIPCHK(hipMemcpyAsync(&c->dK->primary_ray_cnt, &c->hK->primary_ray_cnt, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	}
+	return TYR_OK;
+}
+
+// enqueue one stage; the host mirror hK must be current for the sizes used here
+void enqueue_primary(tyr_ctx* c, const FrameParams& P, uint32_t nNew, uint32_t nLive) {
+	{
+		KernelTimer t(c, TYR_K_PRIMARY);
+		launch_primary(P, nNew, c->stream);
+	}
+	launch_globals(P, (nLive + kBlock - 1) / kBlock, c->stream);
+}
+void enqueue_extend(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
+	KernelTimer t(c, TYR_K_EXTEND);
+	launch_extend(P, nLive, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->stream);
+}
+void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
+	KernelTimer t(c, TYR_K_SHADE);
+	launch_shade(P, nLive, c->stream);
+}
+void enqueue_connect(tyr_ctx* c, const FrameParams& P, uint32_t maxShadow) {
+	KernelTimer t(c, TYR_K_CONNECT);
+	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->stream);
+}
+
+void stage_end(tyr_ctx* c) {
+	// kernel.cu:735-745
+	if (c->frame == 0xFFFFFFFFu)
+		c->frame = 0;
+	c->frame++;
+	std::memcpy(c->lastPos, c->cam.position, 12);
+	std::memcpy(c->lastDir, c->cam.direction, 12);
+	c->lastFocal = c->cam.focalDistance;
+	c->lastLens = c->cam.lensRadius;
+	c->cur ^= 1; // main.cpp:169
+}
+
+int check_device_error(const tyr_ctx* c) { return c->hK->device_error ? TYR_ERR_DEVICE : TYR_OK; }
+
+} // namespace
+
+extern "C" {
+
+const char* tyr_status_string(int status) {
+	switch (status) {
+	case TYR_OK: return "ok";
+	case TYR_ERR_INVALID: return "invalid argument";
+	case TYR_ERR_NO_DEVICE: return "no HIP device (the product path has no CPU fallback)";
+	case TYR_ERR_NO_SCENE: return "no scene uploaded";
+	case TYR_ERR_NO_BUFFER: return "no blit_buffer bound";
+	case TYR_ERR_OOM: return "out of device memory";
+	case TYR_ERR_DEVICE: return "device-side error (traversal stack overflow or compaction timeout)";
+	case TYR_ERR_UNSUPPORTED: return "unsupported";
+	default: return status > 0 ? hipGetErrorString(static_cast<hipError_t>(status)) : "unknown status";
+	}
+}
+
+int tyr_abi_version(void) { return TYR_ABI_VERSION; }
+
+int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
+	if (!out || !cfg)
+		return TYR_ERR_INVALID;
+	*out = nullptr;
+	if (cfg->width == 0 || cfg->height == 0 || cfg->queue_size == 0 || cfg->nranks == 0 || cfg->rank >= cfg->nranks || (cfg->height % cfg->nranks) != 0)
+		return TYR_ERR_INVALID;
+	if (static_cast<uint64_t>(cfg->width) * cfg->height >= (1ull << 31) || cfg->queue_size >= (1u << 31))
+		return TYR_ERR_INVALID;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+		return TYR_ERR_NO_DEVICE;
+	tyr_ctx* c = new (std::nothrow) tyr_ctx();
+	if (!c)
+		return TYR_ERR_OOM;
+	c->cfg = *cfg;
+	c->localRows = cfg->height / cfg->nranks;
+	c->localPixels = cfg->width * c->localRows;
+	default_spheres(c->spheres);
+	const tyr_camera cam = { { 1, 30, 90 }, { 1, 0, 0 }, { 0, 0, 1 }, 1.0f, 0.0f }; // camera.h:4-9
+	c->cam = cam;
+	int rc = use_device(c);
+	if (rc) {
+		delete c;
+		return rc;
+	}
+	auto fail = [&](int code) {
+		tyr_destroy(c);
+		return code;
+	};
+	if (cfg->stream) {
+		c->stream = static_cast<hipStream_t>(cfg->stream);
+	} else {
+		if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+			return fail(TYR_ERR_NO_DEVICE);
+		c->ownStream = true;
+	}
+	const size_t N = cfg->queue_size;
+	if ((rc = alloc_rayq(c->q[0], N)) || (rc = alloc_rayq(c->q[1], N)))
+		return fail(rc);
+	if ((rc = dev_alloc(c->shadow.o_dx, N)) || (rc = dev_alloc(c->shadow.dyz_cd_ix, N)) || (rc = dev_alloc(c->shadow.color, N)))
+		return fail(rc);
+	c->nDescCap = static_cast<uint32_t>((N + kBlock - 1) / kBlock);
+	if ((rc = dev_alloc(c->scanDesc, c->nDescCap)) || (rc = dev_alloc(c->dK, 1)))
+		return fail(rc);
+	if (hipHostMalloc(reinterpret_cast<void**>(&c->hK), sizeof(DevCounters), hipHostMallocDefault) != hipSuccess)
+		return fail(TYR_ERR_OOM);
+	std::memset(c->hK, 0, sizeof(DevCounters));
+	c->hK->budget_remaining = ~0ull;
+	if (hipMemcpy(c->dK, c->hK, sizeof(DevCounters), hipMemcpyHostToDevice) != hipSuccess)
+		return fail(TYR_ERR_NO_DEVICE);
+	for (auto& e : c->ev)
+		if (hipEventCreate(&e) != hipSuccess)
+			return fail(TYR_ERR_NO_DEVICE);
+	c->scene.rootRef = kRefDone;
+	*out = c;
+	return TYR_OK;
+}
+
+int tyr_destroy(tyr_ctx* c) {
+	if (!c)
+		return TYR_OK;
+	(void)hipSetDevice(c->cfg.device);
+	if (c->stream)
+		(void)hipStreamSynchronize(c->stream);
+	free_rayq(c->q[0]);
+	free_rayq(c->q[1]);
+	dev_free(c->shadow.o_dx);
+	dev_free(c->shadow.dyz_cd_ix);
+	dev_free(c->shadow.color);
+	dev_free(c->scanDesc);
+	dev_free(c->dK);
+	dev_free(c->dNodes);
+	dev_free(c->dTris);
+	if (c->ownBlit)
+		dev_free(c->blit);
+	if (c->hK)
+		(void)hipHostFree(c->hK);
+	for (auto& e : c->ev)
+		if (e)
+			(void)hipEventDestroy(e);
+	if (c->ownStream && c->stream)
+		(void)hipStreamDestroy(c->stream);
+	delete c;
+	return TYR_OK;
+}
+
+int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	DeviceLayout L;
+	if ((rc = build_device_layout(nodes, nNodes, prims, nPrims, L)))
+		return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	dev_free(c->dNodes);
+	dev_free(c->dTris);
+	c->scene = DevScene{};
+	c->scene.rootRef = kRefDone;
+	c->haveScene = true;
+	if (L.rootRef == kRefDone)
+		return TYR_OK; // Scene.cpp:49-52
+	// at least one element so the pointers are never null
+	const size_t nodeFloats = std::max<size_t>(L.pairNodes.size(), 16), triFloats = L.tris.size();
+	if ((rc = dev_alloc(c->dNodes, nodeFloats / 4)) || (rc = dev_alloc(c->dTris, triFloats / 4)))
+		return rc;
+	if (!L.pairNodes.empty())
+		HIPCHK(hipMemcpy(c->dNodes, L.pairNodes.data(), L.pairNodes.size() * sizeof(float), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(c->dTris, L.tris.data(), triFloats * sizeof(float), hipMemcpyHostToDevice));
+	c->scene.nodes = c->dNodes;
+	c->scene.tris = c->dTris;
+	std::memcpy(c->scene.rootMin, L.rootMin, 12);
+	std::memcpy(c->scene.rootMax, L.rootMax, 12);
+	c->scene.rootRef = L.rootRef;
+	c->scene.nPairs = L.nPairs;
+	c->scene.nPrims = static_cast<uint32_t>(nPrims);
+	return TYR_OK;
+}
+
+int tyr_set_spheres(tyr_ctx* c, const tyr_sphere* spheres) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	if (!spheres) {
+		default_spheres(c->spheres);
+		return TYR_OK;
+	}
+	for (int i = 0; i < TYR_NUM_SPHERES; ++i) {
+		const tyr_sphere& s = spheres[i];
+		if (!finite_n(&s.radius, 10) || s.refl < TYR_DIFF || s.refl > TYR_LIGHT)
+			return TYR_ERR_INVALID;
+	}
+	std::memcpy(c->spheres, spheres, sizeof(c->spheres));
+	return TYR_OK;
+}
+
+int tyr_set_camera(tyr_ctx* c, const tyr_camera* cam) {
+	if (!c || !cam || !finite_n(cam->position, 11))
+		return TYR_ERR_INVALID;
+	c->cam = *cam;
+	return TYR_OK;
+}
+
+int tyr_set_sun_position(tyr_ctx* c, float x, float y) {
+	if (!c || !std::isfinite(x) || !std::isfinite(y))
+		return TYR_ERR_INVALID;
+	c->sunPos[0] = x;
+	c->sunPos[1] = y;
+	c->sunChanged = true;
+	return TYR_OK;
+}
+
+int tyr_set_blit_buffer(tyr_ctx* c, void* device_float4) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (c->ownBlit)
+		dev_free(c->blit);
+	c->ownBlit = false;
+	c->blit = static_cast<float4*>(device_float4);
+	if (!c->blit) {
+		const size_t n = static_cast<size_t>(c->cfg.width) * c->cfg.height;
+		if ((rc = dev_alloc(c->blit, n)))
+			return rc;
+		c->ownBlit = true;
+		HIPCHK(hipMemset(c->blit, 0, n * sizeof(float4)));
+	}
+	return TYR_OK;
+}
+
+void* tyr_get_blit_buffer(tyr_ctx* c) { return c ? c->blit : nullptr; }
+
+int tyr_set_budget(tyr_ctx* c, uint64_t primary_rays) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if ((rc = sync_counters(c)))
+		return rc;
+	c->hK->budget_remaining = primary_rays;
+	return push_counters(c);
+}
+
+int tyr_get_counters(tyr_ctx* c, tyr_counters* out) {
+	if (!c || !out)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if ((rc = sync_counters(c)))
+		return rc;
+	const DevCounters& k = *c->hK;
+	out->primary_ray_cnt = k.primary_ray_cnt;
+	out->start_position = k.start_position;
+	out->shadow_ray_cnt = k.shadow_ray_cnt;
+	out->n_live = k.n_live;
+	out->frame = c->frame;
+	out->device_error = k.device_error;
+	out->budget_remaining = k.budget_remaining;
+	out->total_extend_rays = k.total_extend_rays;
+	out->total_shadow_rays = k.total_shadow_rays;
+	out->total_primary_rays = k.total_primary_rays;
+	out->nodes_extend = k.nodes_extend;
+	out->tris_extend = k.tris_extend;
+	out->nodes_connect = k.nodes_connect;
+	out->tris_connect = k.tris_connect;
+	out->n_survive = k.n_survive;
+	out->n_shadow_visible = k.n_shadow_visible;
+	return TYR_OK;
+}
+
+// ---- stage-level API -----------------------------------------------------------------------
+int tyr_stage_begin(tyr_ctx* c) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	if (!c->haveScene)
+		return TYR_ERR_NO_SCENE;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if ((rc = sync_counters(c)))
+		return rc;
+	if ((rc = stage_begin(c)))
+		return rc;
+	return sync_counters(c);
+}
+int tyr_stage_primary(tyr_ctx* c) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if ((rc = sync_counters(c)))
+		return rc;
+	const uint32_t nNew = planned_new(c), nLive = c->hK->primary_ray_cnt + nNew;
+	enqueue_primary(c, make_params(c), nNew, nLive);
+	HIPCHK(hipGetLastError());
+	rc = sync_counters(c);
+	collect_timings(c);
+	return rc;
+}
+int tyr_stage_extend(tyr_ctx* c) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if ((rc = sync_counters(c)))
+		return rc;
+	enqueue_extend(c, make_params(c), c->hK->n_live);
+	HIPCHK(hipGetLastError());
+	rc = sync_counters(c);
+	collect_timings(c);
+	return rc ? rc : check_device_error(c);
+}
+int tyr_stage_shade(tyr_ctx* c) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if ((rc = sync_counters(c)))
+		return rc;
+	enqueue_shade(c, make_params(c), c->hK->n_live);
+	HIPCHK(hipGetLastError());
+	rc = sync_counters(c);
+	collect_timings(c);
+	return rc ? rc : check_device_error(c);
+}
+int tyr_stage_connect(tyr_ctx* c) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if ((rc = sync_counters(c)))
+		return rc;
+	enqueue_connect(c, make_params(c), c->hK->shadow_ray_cnt);
+	HIPCHK(hipGetLastError());
+	rc = sync_counters(c);
+	collect_timings(c);
+	return rc ? rc : check_device_error(c);
+}
+int tyr_stage_end(tyr_ctx* c) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	stage_end(c);
+	return TYR_OK;
+}
+int tyr_sync(tyr_ctx* c) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	return sync_counters(c);
+}
+
+// ---- the per-frame entry point --------------------------------------------------------------
+int tyr_launch_kernels(tyr_ctx* c) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	if (!c->haveScene)
+		return TYR_ERR_NO_SCENE;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	// hK is current: every entry point that enqueues work ends with sync_counters
+	if ((rc = stage_begin(c)))
+		return rc;
+	const uint32_t nNew = planned_new(c), nLive = c->hK->primary_ray_cnt + nNew;
+	const FrameParams P = make_params(c);
+	enqueue_primary(c, P, nNew, nLive);
+	enqueue_extend(c, P, nLive);
+	enqueue_shade(c, P, nLive);
+	enqueue_connect(c, P, nLive); // at most one shadow ray per live ray
+	HIPCHK(hipGetLastError());
+	rc = sync_counters(c); // kernel.cu:733 cudaDeviceSynchronize
+	collect_timings(c);
+	stage_end(c);
+	return rc ? rc : check_device_error(c);
+}
+
+int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iterations_out) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	int rc = tyr_set_budget(c, static_cast<uint64_t>(spp) * c->localPixels);
+	if (rc)
+		return rc;
+	uint32_t it = 0;
+	while (it < max_iterations) {
+		if ((rc = tyr_launch_kernels(c)))
+			break;
+		++it;
+		if (c->hK->budget_remaining == 0 && c->hK->primary_ray_cnt == 0)
+			break;
+	}
+	if (iterations_out)
+		*iterations_out = it;
+	return rc;
+}
+
+int tyr_resolve(tyr_ctx* c, void* device_rgba_out) {
+	if (!c || !device_rgba_out)
+		return TYR_ERR_INVALID;
+	if (!c->blit)
+		return TYR_ERR_NO_BUFFER;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	{
+		KernelTimer t(c, TYR_K_RESOLVE);
+		launch_resolve(c->blit, static_cast<float4*>(device_rgba_out), c->cfg.width * c->cfg.height, c->stream);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(c->stream));
+	collect_timings(c);
+	return TYR_OK;
+}
+
+int tyr_reset_accum(tyr_ctx* c) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	if (!c->blit)
+		return TYR_ERR_NO_BUFFER;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if ((rc = sync_counters(c)))
+		return rc;
+	HIPCHK(hipMemsetAsync(c->blit, 0, sizeof(float4) * static_cast<size_t>(c->cfg.width) * c->cfg.height, c->stream));
+	c->hK->primary_ray_cnt = 0;
+	return push_counters(c);
+}
+
+int tyr_read_accum(tyr_ctx* c, float* host_float4) {
+	if (!c || !host_float4)
+		return TYR_ERR_INVALID;
+	if (!c->blit)
+		return TYR_ERR_NO_BUFFER;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipMemcpy(host_float4, c->blit, sizeof(float4) * static_cast<size_t>(c->cfg.width) * c->cfg.height, hipMemcpyDeviceToHost));
+	return TYR_OK;
+}
+
+// ---- AoS import / export (fixtures, parity tests) -------------------------------------------
+int tyr_queue_export(tyr_ctx* c, int which, tyr_ray_queue* host, uint32_t count) {
+	if (!c || !host || (which != 0 && which != 1) || count > c->cfg.queue_size)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	const RayQ& q = c->q[which == 0 ? c->cur : (c->cur ^ 1)];
+	std::vector<float4> a(count), d(count);
+	std::vector<float2> b(count), h(count);
+	std::vector<uint32_t> f(count);
+	if (count) {
+		HIPCHK(hipMemcpy(a.data(), q.o_dx, count * sizeof(float4), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(b.data(), q.dyz, count * sizeof(float2), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(d.data(), q.direct_ix, count * sizeof(float4), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(f.data(), q.flags, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(h.data(), q.hit, count * sizeof(float2), hipMemcpyDeviceToHost));
+	}
+	for (uint32_t i = 0; i < count; ++i) {
+		tyr_ray_queue& r = host[i];
+		std::memset(&r, 0, sizeof(r));
+		r.origin[0] = a[i].x;
+		r.origin[1] = a[i].y;
+		r.origin[2] = a[i].z;
+		r.direction[0] = a[i].w;
+		r.direction[1] = b[i].x;
+		r.direction[2] = b[i].y;
+		r.direct[0] = d[i].x;
+		r.direct[1] = d[i].y;
+		r.direct[2] = d[i].z;
+		std::memcpy(&r.index, &d[i].w, 4);
+		r.bounces = static_cast<int32_t>(f[i] & 0xffu);
+		r.lastSpecular = static_cast<uint8_t>((f[i] >> 8) & 1u);
+		r.distance = h[i].x;
+		uint32_t id;
+		std::memcpy(&id, &h[i].y, 4);
+		r.geometry_type = (id & kHitSphere) ? 0 : 1;
+		r.identifier = static_cast<int32_t>(id & ~kHitSphere);
+	}
+	return TYR_OK;
+}
+
+int tyr_queue_import(tyr_ctx* c, const tyr_ray_queue* host, uint32_t n) {
+	if (!c || (!host && n) || n > c->cfg.queue_size)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if ((rc = sync_counters(c)))
+		return rc;
+	const RayQ& q = c->q[c->cur];
+	std::vector<float4> a(n), d(n);
+	std::vector<float2> b(n), h(n);
+	std::vector<uint32_t> f(n);
+	for (uint32_t i = 0; i < n; ++i) {
+		const tyr_ray_queue& r = host[i];
+		a[i] = make_float4(r.origin[0], r.origin[1], r.origin[2], r.direction[0]);
+		b[i] = make_float2(r.direction[1], r.direction[2]);
+		float ix;
+		std::memcpy(&ix, &r.index, 4);
+		d[i] = make_float4(r.direct[0], r.direct[1], r.direct[2], ix);
+		f[i] = (static_cast<uint32_t>(r.bounces) & 0xffu) | ((r.lastSpecular ? 1u : 0u) << 8);
+		const uint32_t id = (r.geometry_type == 0 ? kHitSphere : 0u) | static_cast<uint32_t>(r.identifier);
+		float idf;
+		std::memcpy(&idf, &id, 4);
+		h[i] = make_float2(r.distance, idf);
+	}
+	if (n) {
+		HIPCHK(hipMemcpy(q.o_dx, a.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(q.dyz, b.data(), n * sizeof(float2), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(q.direct_ix, d.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(q.flags, f.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(q.hit, h.data(), n * sizeof(float2), hipMemcpyHostToDevice));
+	}
+	c->hK->primary_ray_cnt = n;
+	return push_counters(c);
+}
+
+int tyr_shadow_export(tyr_ctx* c, tyr_shadow_queue* host, uint32_t count) {
+	if (!c || !host || count > c->cfg.queue_size)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	std::vector<float4> a(count), b(count), col(count);
+	if (count) {
+		HIPCHK(hipMemcpy(a.data(), c->shadow.o_dx, count * sizeof(float4), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(b.data(), c->shadow.dyz_cd_ix, count * sizeof(float4), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(col.data(), c->shadow.color, count * sizeof(float4), hipMemcpyDeviceToHost));
+	}
+	for (uint32_t i = 0; i < count; ++i) {
+		tyr_shadow_queue& s = host[i];
+		s.origin[0] = a[i].x;
+		s.origin[1] = a[i].y;
+		s.origin[2] = a[i].z;
+		s.direction[0] = a[i].w;
+		s.direction[1] = b[i].x;
+		s.direction[2] = b[i].y;
+		s.closestDistance = b[i].z;
+		std::memcpy(&s.buffer_index, &b[i].w, 4);
+		s.color[0] = col[i].x;
+		s.color[1] = col[i].y;
+		s.color[2] = col[i].z;
+	}
+	return TYR_OK;
+}
+
+int tyr_get_timings(tyr_ctx* c, tyr_timings* out, int reset) {
+	if (!c || !out)
+		return TYR_ERR_INVALID;
+	*out = c->timings;
+	if (reset)
+		c->timings = tyr_timings{};
+	return TYR_OK;
+}
+
+// ---- host side of the hot path --------------------------------------------------------------
+int tyr_bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo) { return bvh_build(prims, n, bboxes, nodes_out, algo); }
+
+int tyr_triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out) {
+	if (n < 0 || (n > 0 && (!prims || !out)))
+		return TYR_ERR_INVALID;
+	triangle_bboxes(prims, n, out);
+	return TYR_OK;
+}
+
+int tyr_camera_update(double horizontal_angle, double vertical_angle, float direction_out[3]) {
+	if (!direction_out)
+		return TYR_ERR_INVALID;
+	// camera.cpp:46-52
+	f3 d = mk3(static_cast<float>(std::cos(vertical_angle) * std::sin(horizontal_angle)), static_cast<float>(std::cos(vertical_angle) * std::cos(horizontal_angle)),
+		static_cast<float>(std::sin(vertical_angle)));
+	d = normalize(d);
+	direction_out[0] = d.x;
+	direction_out[1] = d.y;
+	direction_out[2] = d.z;
+	return TYR_OK;
+}
+
+int tyr_default_spheres(tyr_sphere* out7) {
+	if (!out7)
+		return TYR_ERR_INVALID;
+	default_spheres(out7);
+	return TYR_OK;
+}
+
+} // extern "C"

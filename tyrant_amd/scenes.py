@@ -258,7 +258,7 @@ def tyrant_default(cells: int = 24, seed: int = 7) -> SceneData:
     hf["vert"] = hf["vert"] * np.float32(1.6) + np.array([0.0, 0.0, -50.0], dtype=np.float32)
     hf["e1"] = hf["e1"] * np.float32(1.6)
     hf["e2"] = hf["e2"] * np.float32(1.6)
-    cam = Camera(position=(1.0, 30.0, 90.0), direction=(0.0, -0.70710678, -0.70710678), up=(0.0, 0.0, 1.0))
+    cam = Camera(position=(0.0, -250.0, 95.0), direction=(0.0, 0.962964, -0.26962993), up=(0.0, 0.0, 1.0))
     return SceneData("tyrant_default", hf, reference_spheres(), cam)
 
 
