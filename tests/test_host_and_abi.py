@@ -28,7 +28,7 @@ def test_abi_struct_sizes(hip):
 
     assert C.sizeof(hip.Config) == 40
     assert C.sizeof(hip.CameraC) == 44
-    assert C.sizeof(hip.Counters) == 24 + 10 * 8
+    assert C.sizeof(hip.Counters) == 24 + 18 * 8
     assert scenes.TRIANGLE_DTYPE.itemsize == 40 and scenes.NODE_DTYPE.itemsize == 32
     assert scenes.RAY_DTYPE.itemsize == 60 and scenes.SHADOW_DTYPE.itemsize == 44 and scenes.SPHERE_DTYPE.itemsize == 44
 

@@ -65,10 +65,13 @@ class Counters(C.Structure):
         ("tris_connect", c_u64),
         ("n_survive", c_u64),
         ("n_shadow_visible", c_u64),
+        ("debug", c_u64 * 8),
     ]
 
     def asdict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "debug"}
+        d["debug"] = [int(x) for x in self.debug]
+        return d
 
 
 class Timings(C.Structure):
@@ -105,6 +108,7 @@ SYMBOLS = {
     "tyr_queue_import": (C.c_int, [P, P, c_u32]),
     "tyr_shadow_export": (C.c_int, [P, P, c_u32]),
     "tyr_get_timings": (C.c_int, [P, C.POINTER(Timings), C.c_int]),
+    "tyr_set_tuning": (C.c_int, [P, C.c_int, C.c_int]),
     "tyr_bvh_build": (C.c_int, [P, c_i32, P, P, c_i32]),
     "tyr_triangle_bboxes": (C.c_int, [P, c_i32, P]),
     "tyr_camera_update": (C.c_int, [C.c_double, C.c_double, C.POINTER(c_f)]),
@@ -252,6 +256,11 @@ class Renderer:
         t = Timings()
         _check(self.L.tyr_get_timings(self.h, C.byref(t), int(reset)), "tyr_get_timings")
         return {n: {"ms": t.ms[i], "launches": int(t.launches[i])} for i, n in enumerate(KERNEL_NAMES)}
+
+    def set_tuning(self, traversal_variant=None, refill_min_idle=None, waves_per_simd=None, stack_lds_depth=None, min_traversing=None, ticket_chunk=None):
+        for key, v in ((0, traversal_variant), (1, refill_min_idle), (2, waves_per_simd), (3, stack_lds_depth), (4, min_traversing), (5, ticket_chunk)):
+            if v is not None:
+                _check(self.L.tyr_set_tuning(self.h, key, int(v)), "tyr_set_tuning")
 
     def reset_accum(self):
         _check(self.L.tyr_reset_accum(self.h), "tyr_reset_accum")

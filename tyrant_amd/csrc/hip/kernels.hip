@@ -105,6 +105,20 @@ __device__ __forceinline__ float sphere_intersect(const tyr_sphere& sp, f3 origi
 	return (t = b - disc) > kEpsilon ? t : ((t = b + disc) > kEpsilon ? t : 0);
 }
 
+// stack policies of the traversal kernels: STACK_LDS == 0 -> scratch only, else that many entries per lane in LDS
+template <int STACK_LDS>
+struct StackSel {
+	using type = LdsStack<STACK_LDS>;
+	static constexpr int kLdsBytes = STACK_LDS * kBlock * 8;
+	__device__ static __forceinline__ void bind(type& st, uint2* smem) { st.lds = smem + threadIdx.x; }
+};
+template <>
+struct StackSel<0> {
+	using type = ScratchStack;
+	static constexpr int kLdsBytes = 0;
+	__device__ static __forceinline__ void bind(type&, uint2*) {}
+};
+
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // wave-aggregated 64-bit counter add (one atomic per wave)
@@ -182,6 +196,8 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 		k->shadow_ray_cnt = 0;
 		k->primary_ray_cnt = 0;
 		k->shade_ticket = 0;
+		k->extend_ticket = 0;
+		k->connect_ticket = 0;
 		if (budget != ~0ull)
 			k->budget_remaining = budget - nNew;
 		k->total_primary_rays += nNew;
@@ -192,8 +208,9 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 // ======================================================================================
 // extend, kernel.cu:331-343 via intersect_scene, kernel.cu:125-142
 // ======================================================================================
-template <bool COUNT>
+template <bool COUNT, int STACK_LDS>
 __global__ void __launch_bounds__(kBlock) k_extend(const FrameParams P) {
+	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
 	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t nLive = P.k->n_live;
 	VisitCount vc{ 0, 0 };
@@ -214,7 +231,8 @@ __global__ void __launch_bounds__(kBlock) k_extend(const FrameParams P) {
 		}
 		if (P.scene.rootRef != kRefDone) {
 			const RayConst r = make_ray(o, d);
-			ScratchStack st;
+			typename StackSel<STACK_LDS>::type st;
+			StackSel<STACK_LDS>::bind(st, smem);
 			int prim = 0;
 			if (bvh_closest<COUNT>(P.scene, r, dist, prim, st, vc))
 				id = (uint32_t)prim;
@@ -604,8 +622,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P) {
 // ======================================================================================
 // connect, kernel.cu:630-646 via intersect_scene_simple, kernel.cu:162-174
 // ======================================================================================
-template <bool COUNT>
+template <bool COUNT, int STACK_LDS>
 __global__ void __launch_bounds__(kBlock) k_connect(const FrameParams P) {
+	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
 	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t n = P.k->shadow_ray_cnt;
 	VisitCount vc{ 0, 0 };
@@ -619,7 +638,8 @@ __global__ void __launch_bounds__(kBlock) k_connect(const FrameParams P) {
 		bool occluded = false;
 		if (P.scene.rootRef != kRefDone) {
 			const RayConst r = make_ray(o, d);
-			ScratchStack st;
+			typename StackSel<STACK_LDS>::type st;
+			StackSel<STACK_LDS>::bind(st, smem);
 			occluded = bvh_any<COUNT>(P.scene, r, closest, st, vc);
 			overflow = st.overflow;
 		}
@@ -654,6 +674,671 @@ __global__ void __launch_bounds__(kBlock) k_connect(const FrameParams P) {
 	}
 }
 
+
+// ======================================================================================
+// Persistent traversal (variant 1): waves stay resident and every lane that finishes its
+// ray takes the next queue slot from a device-wide ticket.
+//
+// Why: with one thread per slot, rocprofv3 on MI355X shows k_extend issuing ~13,000 VALU
+// instructions per wave at 15 % lane utilisation (SQ_THREAD_CYCLES_VALU / (64 *
+// SQ_ACTIVE_INST_VALU)): a wave runs as long as its longest ray while rays that miss the
+// root box idle from the first instruction.  The kernel is VALU-issue bound, not memory
+// bound (L2 hit rate 96 %), so the lever is lanes doing work.  Refilling is done by the
+// wave as a whole (ballot, one atomicAdd per refill, ranks by popcount) once at least
+// `refillMinIdle` lanes are free, so the ~100-instruction ray set-up is not paid for one
+// lane at a time.  The seven sphere tests (kernel.cu:129-136) move into a coherent
+// one-thread-per-slot pre-pass: they are the same for every ray and would otherwise run
+// under a partial mask inside the refill.
+// Results do not depend on which lane traces which ray: each ray's answer goes to its
+// own slot.
+// ======================================================================================
+
+// extend pre-pass: kernel.cu:125-136 (spheres first; their distance bounds the BVH search)
+__global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) {
+	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+	if (slot == 0)
+		P.k->extend_ticket = 0; // the persistent kernel that follows on the stream starts from slot 0
+	if (slot >= P.k->n_live)
+		return;
+	const float4 a = P.work.o_dx[slot];
+	const float2 b = P.work.dyz[slot];
+	const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+	float dist = kVeryFar;
+	uint32_t id = 0;
+#pragma unroll
+	for (int i = TYR_NUM_SPHERES; i--;) {
+		const float t = sphere_intersect(P.spheres[i], o, d);
+		if (t && t < dist) {
+			dist = t;
+			id = kHitSphere | (uint32_t)i;
+		}
+	}
+	P.work.hit[slot] = make_float2(dist, __uint_as_float(id));
+}
+
+__device__ __forceinline__ uint32_t root_ref(const DevScene& sc, const RayConst& r, float bound) {
+	float t0;
+	const bool ok = slab_test(r, r.nx ? sc.rootMax[0] : sc.rootMin[0], r.nx ? sc.rootMin[0] : sc.rootMax[0], r.ny ? sc.rootMax[1] : sc.rootMin[1], r.ny ? sc.rootMin[1] : sc.rootMax[1],
+		r.nz ? sc.rootMax[2] : sc.rootMin[2], r.nz ? sc.rootMin[2] : sc.rootMax[2], bound, t0);
+	return ok ? sc.rootRef : kRefDone;
+}
+
+template <bool COUNT, int STACK_LDS>
+__global__ void __launch_bounds__(kBlock) k_extend_persistent(const FrameParams P) {
+	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
+	const uint32_t lane = lane_id();
+	const unsigned long long below = (1ull << lane) - 1ull;
+	const uint32_t nLive = P.k->n_live;
+	const DevScene& sc = P.scene;
+	typename StackSel<STACK_LDS>::type st;
+	StackSel<STACK_LDS>::bind(st, smem);
+	st.reset();
+	RayConst r = {};
+	float dist = 0.0f;
+	uint32_t ref = kRefDone, slot = 0;
+	int prim = 0;
+	bool hitTri = false, live = false, overflow = false;
+	VisitCount vc{ 0, 0 };
+	uint32_t dbg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // COUNT only
+#define TYR_DBG(i)                                                     \
+	if (COUNT) {                                                       \
+		const unsigned long long m_ = __ballot(1);                     \
+		if (lane == (uint32_t)__ffsll((long long)m_) - 1) {            \
+			dbg[i] += 1;                                               \
+			dbg[i + 1] += __popcll(m_);                                \
+		}                                                              \
+	}
+	bool exhausted = (sc.rootRef == kRefDone); // no triangles: the pre-pass already wrote every answer
+	uint32_t chunkNext = 0, chunkEnd = 0;
+
+	for (;;) {
+		const unsigned long long idleMask = __ballot(!live);
+		const uint32_t nIdle = __popcll(idleMask);
+		if (!exhausted && nIdle >= P.refillMinIdle) {
+			if (chunkNext >= chunkEnd) {
+				// one returning atomic per `ticketChunk` rays: a single device-wide word serves only ~88 dequeues/us
+				// (MI355X_MICROARCH.md "dequeue"), which capped this kernel at ~0.9 ms when every refill paid one
+				uint32_t base = 0;
+				if (lane == 0)
+					base = atomicAdd(&P.k->extend_ticket, P.ticketChunk);
+				base = __shfl(base, 0, 64);
+				chunkNext = base < nLive ? base : nLive;
+				chunkEnd = (base + P.ticketChunk) < nLive ? (base + P.ticketChunk) : nLive;
+				exhausted = (chunkNext >= chunkEnd);
+			}
+			const uint32_t take = (chunkEnd - chunkNext) < nIdle ? (chunkEnd - chunkNext) : nIdle;
+			const uint32_t base = chunkNext;
+			chunkNext += take;
+			if (!live) {
+				const uint32_t rank = __popcll(idleMask & below);
+				const uint32_t s = base + rank;
+				if (rank < take) {
+					TYR_DBG(6)
+					const float4 a = P.work.o_dx[s];
+					const float2 b = P.work.dyz[s];
+					const float2 h = P.work.hit[s];
+					r = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+					dist = h.x;
+					slot = s;
+					hitTri = false;
+					live = true;
+					st.reset();
+					ref = root_ref(sc, r, dist);
+					if (COUNT)
+						vc.nodes += 1;
+				}
+			}
+		}
+		if (__ballot(live) == 0ull) {
+			if (exhausted)
+				break;
+			continue;
+		}
+		// ---- one macro step: descend until every live lane holds a leaf (or is done), then the leaves ----
+		while ((int)ref >= 0) {
+			TYR_DBG(0)
+			const PairTest p = test_pair(sc.nodes, ref, r, dist);
+			if (COUNT && !p.synthetic)
+				vc.nodes += 2;
+			if (p.nearHit) {
+				if (p.farHit)
+					st.push(p.farRef, p.farT);
+				ref = p.nearRef;
+			} else if (p.farHit) {
+				ref = p.farRef;
+			} else {
+				ref = kRefDone;
+				uint32_t pr;
+				float pt;
+				while (st.pop(pr, pt)) {
+					TYR_DBG(2)
+					if (pt < dist) {
+						ref = pr;
+						break;
+					}
+				}
+			}
+		}
+		if (ref != kRefDone) {
+			const uint32_t off = ref & (kMaxPrimOffset - 1);
+			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+			for (uint32_t i = 0; i < cnt; ++i) {
+				TYR_DBG(4)
+				const float t = triangle_test(sc.tris, off + i, r);
+				if (COUNT)
+					vc.tris += 1;
+				if (t > kEpsilon && t < dist && ((dist - t) > kEpsilon)) {
+					prim = (int)(off + i);
+					dist = t;
+					hitTri = true;
+				}
+			}
+			ref = kRefDone;
+			uint32_t pr;
+			float pt;
+			while (st.pop(pr, pt)) {
+				TYR_DBG(2)
+				if (pt < dist) {
+					ref = pr;
+					break;
+				}
+			}
+		}
+		if (live && ref == kRefDone) {
+			// this ray is finished (bvh.h:155-156): a triangle hit replaces the sphere answer (kernel.cu:138-140)
+			if (hitTri)
+				P.work.hit[slot] = make_float2(dist, __uint_as_float((uint32_t)prim));
+			overflow = overflow || st.overflow;
+			live = false;
+		}
+	}
+	if (overflow)
+		atomicOr(&P.k->device_error, kErrStackOverflow);
+	if (COUNT) {
+		wave_add_u64(&P.k->nodes_extend, vc.nodes);
+		wave_add_u64(&P.k->tris_extend, vc.tris);
+		for (int i = 0; i < 8; ++i)
+			wave_add_u64(&P.k->debug[i], dbg[i]);
+	}
+#undef TYR_DBG
+}
+
+// connect pre-pass: the sphere half of intersect_scene_simple (kernel.cu:168-172).  Any-hit does not
+// depend on test order, so spheres go first and an occluded ray never enters the BVH.
+// color.w (unused by the reference's 44-byte record) carries the flag.
+__global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P) {
+	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
+	if (index == 0)
+		P.k->connect_ticket = 0;
+	if (index >= P.k->shadow_ray_cnt)
+		return;
+	const float4 a = P.shadow.o_dx[index];
+	const float4 b = P.shadow.dyz_cd_ix[index];
+	const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+	const float closest = b.z;
+	bool occluded = false;
+#pragma unroll
+	for (int i = TYR_NUM_SPHERES; i--;) {
+		const float t = sphere_intersect(P.spheres[i], o, d);
+		occluded = occluded || (t && (t + kEpsilon) < closest);
+	}
+	reinterpret_cast<float*>(&P.shadow.color[index])[3] = occluded ? 1.0f : 0.0f;
+}
+
+template <bool COUNT, int STACK_LDS>
+__global__ void __launch_bounds__(kBlock) k_connect_persistent(const FrameParams P) {
+	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
+	const uint32_t lane = lane_id();
+	const unsigned long long below = (1ull << lane) - 1ull;
+	const uint32_t nRays = P.k->shadow_ray_cnt;
+	const DevScene& sc = P.scene;
+	const bool haveBvh = (sc.rootRef != kRefDone);
+	typename StackSel<STACK_LDS>::type st;
+	StackSel<STACK_LDS>::bind(st, smem);
+	st.reset();
+	RayConst r = {};
+	float closest = 0.0f;
+	uint32_t ref = kRefDone, index = 0;
+	bool live = false, occluded = false, overflow = false;
+	VisitCount vc{ 0, 0 };
+	uint32_t visible = 0;
+	bool exhausted = false;
+	const float kFailed = __builtin_inff();
+
+	for (;;) {
+		const unsigned long long idleMask = __ballot(!live);
+		const uint32_t nIdle = __popcll(idleMask);
+		if (!exhausted && nIdle >= P.refillMinIdle) {
+			const uint32_t leader = __ffsll((long long)idleMask) - 1;
+			uint32_t base = 0;
+			if (lane == leader)
+				base = atomicAdd(&P.k->connect_ticket, nIdle);
+			base = __shfl(base, leader, 64);
+			exhausted = (base + nIdle >= nRays);
+			if (!live) {
+				const uint32_t s = base + __popcll(idleMask & below);
+				if (s < nRays) {
+					const float4 a = P.shadow.o_dx[s];
+					const float4 b = P.shadow.dyz_cd_ix[s];
+					const float sphereOccluded = reinterpret_cast<const float*>(&P.shadow.color[s])[3];
+					index = s;
+					closest = b.z;
+					occluded = (sphereOccluded != 0.0f);
+					live = true;
+					st.reset();
+					ref = kRefDone;
+					// COUNT keeps the reference's order (BVH first for every ray, kernel.cu:165) so the visit counts are its counts
+					if (haveBvh && (COUNT || !occluded)) {
+						r = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+						ref = root_ref(sc, r, closest);
+						if (COUNT)
+							vc.nodes += 1;
+					}
+				}
+			}
+		}
+		if (__ballot(live) == 0ull) {
+			if (exhausted)
+				break;
+			continue;
+		}
+		while ((int)ref >= 0) {
+			const PairTest p = test_pair(sc.nodes, ref, r, closest);
+			if (COUNT && !p.synthetic) {
+				vc.nodes += 1;
+				st.push(p.farRef, p.farHit ? p.farT : kFailed);
+				ref = p.nearHit ? p.nearRef : kRefDone;
+			} else {
+				if (p.nearHit) {
+					if (p.farHit)
+						st.push(p.farRef, p.farT);
+					ref = p.nearRef;
+				} else if (p.farHit) {
+					ref = p.farRef;
+				} else {
+					ref = kRefDone;
+				}
+			}
+			if (ref == kRefDone) {
+				uint32_t pr;
+				float pt;
+				while (st.pop(pr, pt)) {
+					if (COUNT)
+						vc.nodes += 1;
+					if (pt < closest) {
+						ref = pr;
+						break;
+					}
+				}
+			}
+		}
+		if (ref != kRefDone) {
+			const uint32_t off = ref & (kMaxPrimOffset - 1);
+			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+			bool found = false;
+			for (uint32_t i = 0; i < cnt && !found; ++i) {
+				const float t = triangle_test(sc.tris, off + i, r);
+				if (COUNT)
+					vc.tris += 1;
+				found = (t > kEpsilon && ((closest - t) > kEpsilon)); // bvh.h:232-236
+			}
+			ref = kRefDone;
+			if (found) {
+				occluded = true;
+			} else {
+				uint32_t pr;
+				float pt;
+				while (st.pop(pr, pt)) {
+					if (COUNT)
+						vc.nodes += 1;
+					if (pt < closest) {
+						ref = pr;
+						break;
+					}
+				}
+			}
+		}
+		if (live && ref == kRefDone) {
+			if (!occluded) { // kernel.cu:640-644
+				const float4 c = P.shadow.color[index];
+				const float4 b = P.shadow.dyz_cd_ix[index];
+				float* px = reinterpret_cast<float*>(&P.blit[__float_as_int(b.w)]);
+				if (c.x != 0.0f)
+					atomicAdd(px + 0, c.x);
+				if (c.y != 0.0f)
+					atomicAdd(px + 1, c.y);
+				if (c.z != 0.0f)
+					atomicAdd(px + 2, c.z);
+				visible += 1;
+			}
+			overflow = overflow || st.overflow;
+			live = false;
+		}
+	}
+	if (overflow)
+		atomicOr(&P.k->device_error, kErrStackOverflow);
+	wave_add_u64(&P.k->n_shadow_visible, visible);
+	if (COUNT) {
+		wave_add_u64(&P.k->nodes_connect, vc.nodes);
+		wave_add_u64(&P.k->tris_connect, vc.tris);
+	}
+}
+
+
+// ======================================================================================
+// Flat traversal (variant 2): persistent waves, lane refill, and NO nested divergent loops.
+//
+// Measured on variant 1 with the counting build (tools/loop_occupancy.py, C2 at 1080p): the
+// node-test loop ran at 19.7 % lane occupancy and the nested pop loop at 6 %, because (a) a lane
+// that reaches a leaf or finishes its ray waits until the LAST lane of the wave stops descending,
+// and (b) `while (pop) {...}` inside the divergent "both children missed" branch runs four lanes
+// wide while sixty wait.  Here every lane is a small state machine --
+//      interior ref | leaf ref | kRefPop (must pop) | kRefDone --
+// and one trip of the descent loop does at most ONE pop attempt and ONE pair test per lane, so
+// lanes in different states advance together.  The descent loop is left as soon as fewer than
+// `minTraversing` lanes are still descending and there is other work for the wave (leaves to
+// intersect, or enough free lanes for a refill).
+// ======================================================================================
+__device__ __forceinline__ bool ref_is_leaf(uint32_t ref) { return (ref & kRefLeaf) && ref < kRefPop; }
+__device__ __forceinline__ bool ref_is_traversing(uint32_t ref) { return ((int)ref >= 0) || ref == kRefPop; }
+
+#define TYR_DBG(i)                                                     \
+	if (COUNT) {                                                       \
+		const unsigned long long m_ = __ballot(1);                     \
+		if (lane == (uint32_t)__ffsll((long long)m_) - 1) {            \
+			dbg[i] += 1;                                               \
+			dbg[i + 1] += __popcll(m_);                                \
+		}                                                              \
+	}
+
+template <bool COUNT, int STACK_LDS>
+__global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
+	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
+	const uint32_t lane = lane_id();
+	const unsigned long long below = (1ull << lane) - 1ull;
+	const uint32_t nLive = P.k->n_live;
+	const DevScene& sc = P.scene;
+	typename StackSel<STACK_LDS>::type st;
+	StackSel<STACK_LDS>::bind(st, smem);
+	st.reset();
+	RayConst r = {};
+	bool regular = true;
+	float dist = 0.0f;
+	uint32_t ref = kRefDone, slot = 0;
+	int prim = 0;
+	bool hitTri = false, live = false, overflow = false;
+	VisitCount vc{ 0, 0 };
+	uint32_t dbg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	bool exhausted = (sc.rootRef == kRefDone);
+	uint32_t chunkNext = 0, chunkEnd = 0; // this wave's private range of queue slots (wave-uniform)
+
+	for (;;) {
+		// ---- refill free lanes from the queue ----
+		const unsigned long long idleMask = __ballot(!live);
+		const uint32_t nIdle = __popcll(idleMask);
+		if (!exhausted && nIdle >= P.refillMinIdle) {
+			if (chunkNext >= chunkEnd) {
+				// one returning atomic per `ticketChunk` rays: a single device-wide word serves only ~88 dequeues/us
+				// (MI355X_MICROARCH.md "dequeue"), which capped this kernel at ~0.9 ms when every refill paid one
+				uint32_t base = 0;
+				if (lane == 0)
+					base = atomicAdd(&P.k->extend_ticket, P.ticketChunk);
+				base = __shfl(base, 0, 64);
+				chunkNext = base < nLive ? base : nLive;
+				chunkEnd = (base + P.ticketChunk) < nLive ? (base + P.ticketChunk) : nLive;
+				exhausted = (chunkNext >= chunkEnd);
+			}
+			const uint32_t take = (chunkEnd - chunkNext) < nIdle ? (chunkEnd - chunkNext) : nIdle;
+			const uint32_t base = chunkNext;
+			chunkNext += take;
+			if (!live) {
+				const uint32_t rank = __popcll(idleMask & below);
+				const uint32_t s = base + rank;
+				if (rank < take) {
+					TYR_DBG(6)
+					const float4 a = P.work.o_dx[s];
+					const float2 b = P.work.dyz[s];
+					const float2 h = P.work.hit[s];
+					r = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+					regular = ray_is_regular(r);
+					dist = h.x;
+					slot = s;
+					hitTri = false;
+					live = true;
+					st.reset();
+					ref = root_ref(sc, r, dist);
+					if (COUNT)
+						vc.nodes += 1;
+				}
+			}
+		}
+		if (__ballot(live) == 0ull) {
+			if (exhausted)
+				break;
+			continue;
+		}
+		// ---- descent: one pop attempt + one pair test per lane per trip ----
+		for (;;) {
+			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
+			if (nTrav == 0)
+				break;
+			if (nTrav < P.minTraversing) {
+				const bool leafPending = __ballot(ref_is_leaf(ref)) != 0ull;
+				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
+				if (leafPending || canRefill)
+					break;
+			}
+			if (ref == kRefPop) {
+				TYR_DBG(2)
+				uint32_t pr;
+				float pt;
+				if (st.pop(pr, pt)) {
+					if (pt < dist) // the pop-time half of Bbox.h:61
+						ref = pr;
+				} else {
+					ref = kRefDone;
+				}
+			}
+			if ((int)ref >= 0) {
+				TYR_DBG(0)
+				const PairTest p = regular ? test_pair_fast(sc.nodes, ref, r, dist) : test_pair(sc.nodes, ref, r, dist);
+				if (COUNT && !p.synthetic)
+					vc.nodes += 2;
+				if (p.nearHit) {
+					if (p.farHit)
+						st.push(p.farRef, p.farT);
+					ref = p.nearRef;
+				} else if (p.farHit) {
+					ref = p.farRef;
+				} else {
+					ref = kRefPop;
+				}
+			}
+		}
+		// ---- leaves: bvh.h:129-140 ----
+		if (ref_is_leaf(ref)) {
+			const uint32_t off = ref & (kMaxPrimOffset - 1);
+			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+			for (uint32_t i = 0; i < cnt; ++i) {
+				TYR_DBG(4)
+				const float t = triangle_test(sc.tris, off + i, r);
+				if (COUNT)
+					vc.tris += 1;
+				if (t > kEpsilon && t < dist && ((dist - t) > kEpsilon)) {
+					prim = (int)(off + i);
+					dist = t;
+					hitTri = true;
+				}
+			}
+			ref = kRefPop;
+		}
+		// ---- finished rays: a triangle hit replaces the sphere answer of the pre-pass (kernel.cu:138-140) ----
+		if (live && ref == kRefDone) {
+			if (hitTri)
+				P.work.hit[slot] = make_float2(dist, __uint_as_float((uint32_t)prim));
+			overflow = overflow || st.overflow;
+			live = false;
+		}
+	}
+	if (overflow)
+		atomicOr(&P.k->device_error, kErrStackOverflow);
+	if (COUNT) {
+		wave_add_u64(&P.k->nodes_extend, vc.nodes);
+		wave_add_u64(&P.k->tris_extend, vc.tris);
+		for (int i = 0; i < 8; ++i)
+			wave_add_u64(&P.k->debug[i], dbg[i]);
+	}
+}
+
+template <bool COUNT, int STACK_LDS>
+__global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
+	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
+	const uint32_t lane = lane_id();
+	const unsigned long long below = (1ull << lane) - 1ull;
+	const uint32_t nRays = P.k->shadow_ray_cnt;
+	const DevScene& sc = P.scene;
+	const bool haveBvh = (sc.rootRef != kRefDone);
+	typename StackSel<STACK_LDS>::type st;
+	StackSel<STACK_LDS>::bind(st, smem);
+	st.reset();
+	RayConst r = {};
+	bool regular = true;
+	float closest = 0.0f;
+	uint32_t ref = kRefDone, index = 0;
+	bool live = false, occluded = false, overflow = false;
+	VisitCount vc{ 0, 0 };
+	uint32_t visible = 0;
+	bool exhausted = false;
+	uint32_t chunkNext = 0, chunkEnd = 0;
+	const float kFailed = __builtin_inff();
+
+	for (;;) {
+		const unsigned long long idleMask = __ballot(!live);
+		const uint32_t nIdle = __popcll(idleMask);
+		if (!exhausted && nIdle >= P.refillMinIdle) {
+			if (chunkNext >= chunkEnd) {
+				uint32_t base = 0;
+				if (lane == 0)
+					base = atomicAdd(&P.k->connect_ticket, P.ticketChunk);
+				base = __shfl(base, 0, 64);
+				chunkNext = base < nRays ? base : nRays;
+				chunkEnd = (base + P.ticketChunk) < nRays ? (base + P.ticketChunk) : nRays;
+				exhausted = (chunkNext >= chunkEnd);
+			}
+			const uint32_t take = (chunkEnd - chunkNext) < nIdle ? (chunkEnd - chunkNext) : nIdle;
+			const uint32_t base = chunkNext;
+			chunkNext += take;
+			if (!live) {
+				const uint32_t rank = __popcll(idleMask & below);
+				const uint32_t s = base + rank;
+				if (rank < take) {
+					const float4 a = P.shadow.o_dx[s];
+					const float4 b = P.shadow.dyz_cd_ix[s];
+					const float sphereOccluded = reinterpret_cast<const float*>(&P.shadow.color[s])[3];
+					index = s;
+					closest = b.z;
+					occluded = (sphereOccluded != 0.0f);
+					live = true;
+					st.reset();
+					ref = kRefDone;
+					if (haveBvh && (COUNT || !occluded)) {
+						r = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+						regular = ray_is_regular(r);
+						ref = root_ref(sc, r, closest);
+						if (COUNT)
+							vc.nodes += 1;
+					}
+				}
+			}
+		}
+		if (__ballot(live) == 0ull) {
+			if (exhausted)
+				break;
+			continue;
+		}
+		for (;;) {
+			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
+			if (nTrav == 0)
+				break;
+			if (nTrav < P.minTraversing) {
+				const bool leafPending = __ballot(ref_is_leaf(ref)) != 0ull;
+				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
+				if (leafPending || canRefill)
+					break;
+			}
+			if (ref == kRefPop) {
+				uint32_t pr;
+				float pt;
+				if (st.pop(pr, pt)) {
+					if (COUNT)
+						vc.nodes += 1; // the reference fetches the popped node before testing its box (bvh.h:222-224)
+					if (pt < closest)
+						ref = pr;
+				} else {
+					ref = kRefDone;
+				}
+			}
+			if ((int)ref >= 0) {
+				const PairTest p = regular ? test_pair_fast(sc.nodes, ref, r, closest) : test_pair(sc.nodes, ref, r, closest);
+				if (COUNT && !p.synthetic) {
+					vc.nodes += 1;
+					st.push(p.farRef, p.farHit ? p.farT : kFailed);
+					ref = p.nearHit ? p.nearRef : kRefPop;
+				} else if (p.nearHit) {
+					if (p.farHit)
+						st.push(p.farRef, p.farT);
+					ref = p.nearRef;
+				} else if (p.farHit) {
+					ref = p.farRef;
+				} else {
+					ref = kRefPop;
+				}
+			}
+		}
+		if (ref_is_leaf(ref)) {
+			const uint32_t off = ref & (kMaxPrimOffset - 1);
+			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+			bool found = false;
+			for (uint32_t i = 0; i < cnt && !found; ++i) {
+				const float t = triangle_test(sc.tris, off + i, r);
+				if (COUNT)
+					vc.tris += 1;
+				found = (t > kEpsilon && ((closest - t) > kEpsilon)); // bvh.h:232-236
+			}
+			if (found) {
+				occluded = true;
+				ref = kRefDone;
+			} else {
+				ref = kRefPop;
+			}
+		}
+		if (live && ref == kRefDone) {
+			if (!occluded) { // kernel.cu:640-644
+				const float4 c = P.shadow.color[index];
+				const float4 b = P.shadow.dyz_cd_ix[index];
+				float* px = reinterpret_cast<float*>(&P.blit[__float_as_int(b.w)]);
+				if (c.x != 0.0f)
+					atomicAdd(px + 0, c.x);
+				if (c.y != 0.0f)
+					atomicAdd(px + 1, c.y);
+				if (c.z != 0.0f)
+					atomicAdd(px + 2, c.z);
+				visible += 1;
+			}
+			overflow = overflow || st.overflow;
+			live = false;
+		}
+	}
+	if (overflow)
+		atomicOr(&P.k->device_error, kErrStackOverflow);
+	wave_add_u64(&P.k->n_shadow_visible, visible);
+	if (COUNT) {
+		wave_add_u64(&P.k->nodes_connect, vc.nodes);
+		wave_add_u64(&P.k->tris_connect, vc.tris);
+	}
+}
+#undef TYR_DBG
+
 // ======================================================================================
 // blit_onto_framebuffer, kernel.cu:648-662 -> linear RGBA32F
 // ======================================================================================
@@ -679,26 +1364,78 @@ void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
 void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream) {
 	hipLaunchKernelGGL(k_globals, dim3(blocks_for(nDesc ? nDesc : 1)), dim3(kBlock), 0, stream, P, nDesc);
 }
-void launch_extend(const FrameParams& P, uint32_t maxLive, bool countVisits, hipStream_t stream) {
+// persistent grids: as many 256-thread blocks as stay resident (no inter-block dependency, so a
+// larger grid would only queue), never more waves than there are rays
+template <class K>
+static uint32_t persistent_blocks(K kernel, uint32_t nItems, const Tuning& t, int numCUs) {
+	int perCU = 0;
+	if (t.wavesPerSimd > 0) {
+		perCU = t.wavesPerSimd; // 4 SIMDs x w waves = w blocks of 4 waves
+	} else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, 0) != hipSuccess || perCU <= 0) {
+		perCU = 4;
+	}
+	const uint32_t resident = (uint32_t)perCU * (uint32_t)numCUs;
+	const uint32_t needed = (nItems + kBlock - 1) / kBlock;
+	return needed < resident ? (needed ? needed : 1) : resident;
+}
+
+template <bool COUNT, int STACK_LDS>
+static void launch_extend_t(const FrameParams& P, uint32_t maxLive, const Tuning& t, int numCUs, hipStream_t stream) {
+	if (t.traversalVariant == 0) {
+		hipLaunchKernelGGL((k_extend<COUNT, STACK_LDS>), dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
+		return;
+	}
+	hipLaunchKernelGGL(k_extend_spheres, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
+	if (t.traversalVariant == 2)
+		hipLaunchKernelGGL((k_extend_flat<COUNT, STACK_LDS>), dim3(persistent_blocks(k_extend_flat<COUNT, STACK_LDS>, maxLive, t, numCUs)), dim3(kBlock), 0, stream, P);
+	else
+		hipLaunchKernelGGL((k_extend_persistent<COUNT, STACK_LDS>), dim3(persistent_blocks(k_extend_persistent<COUNT, STACK_LDS>, maxLive, t, numCUs)), dim3(kBlock), 0, stream, P);
+}
+template <bool COUNT, int STACK_LDS>
+static void launch_connect_t(const FrameParams& P, uint32_t maxShadow, const Tuning& t, int numCUs, hipStream_t stream) {
+	if (t.traversalVariant == 0) {
+		hipLaunchKernelGGL((k_connect<COUNT, STACK_LDS>), dim3(blocks_for(maxShadow)), dim3(kBlock), 0, stream, P);
+		return;
+	}
+	hipLaunchKernelGGL(k_connect_spheres, dim3(blocks_for(maxShadow)), dim3(kBlock), 0, stream, P);
+	if (t.traversalVariant == 2)
+		hipLaunchKernelGGL((k_connect_flat<COUNT, STACK_LDS>), dim3(persistent_blocks(k_connect_flat<COUNT, STACK_LDS>, maxShadow, t, numCUs)), dim3(kBlock), 0, stream, P);
+	else
+		hipLaunchKernelGGL((k_connect_persistent<COUNT, STACK_LDS>), dim3(persistent_blocks(k_connect_persistent<COUNT, STACK_LDS>, maxShadow, t, numCUs)), dim3(kBlock), 0, stream, P);
+}
+
+// the stack depths that are compiled in (tyr_set_tuning TYR_TUNE_STACK_LDS_DEPTH)
+#define TYR_DISPATCH_STACK(FN, COUNT, ...)          \
+	switch (t.stackLdsDepth) {                      \
+	case 0: FN<COUNT, 0>(__VA_ARGS__); break;       \
+	case 8: FN<COUNT, 8>(__VA_ARGS__); break;       \
+	case 12: FN<COUNT, 12>(__VA_ARGS__); break;     \
+	case 24: FN<COUNT, 24>(__VA_ARGS__); break;     \
+	default: FN<COUNT, 16>(__VA_ARGS__); break;     \
+	}
+
+void launch_extend(const FrameParams& P, uint32_t maxLive, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream) {
 	if (maxLive == 0)
 		return;
-	if (countVisits)
-		hipLaunchKernelGGL(k_extend<true>, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
-	else
-		hipLaunchKernelGGL(k_extend<false>, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
+	if (countVisits) {
+		TYR_DISPATCH_STACK(launch_extend_t, true, P, maxLive, t, numCUs, stream)
+	} else {
+		TYR_DISPATCH_STACK(launch_extend_t, false, P, maxLive, t, numCUs, stream)
+	}
 }
 void launch_shade(const FrameParams& P, uint32_t maxLive, hipStream_t stream) {
 	if (maxLive == 0)
 		return;
 	hipLaunchKernelGGL(k_shade, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
 }
-void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, hipStream_t stream) {
+void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream) {
 	if (maxShadow == 0)
 		return;
-	if (countVisits)
-		hipLaunchKernelGGL(k_connect<true>, dim3(blocks_for(maxShadow)), dim3(kBlock), 0, stream, P);
-	else
-		hipLaunchKernelGGL(k_connect<false>, dim3(blocks_for(maxShadow)), dim3(kBlock), 0, stream, P);
+	if (countVisits) {
+		TYR_DISPATCH_STACK(launch_connect_t, true, P, maxShadow, t, numCUs, stream)
+	} else {
+		TYR_DISPATCH_STACK(launch_connect_t, false, P, maxShadow, t, numCUs, stream)
+	}
 }
 void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream) {
 	hipLaunchKernelGGL(k_resolve, dim3(blocks_for(nPixels)), dim3(kBlock), 0, stream, blit, out, nPixels);

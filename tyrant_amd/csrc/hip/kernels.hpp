@@ -42,7 +42,8 @@ struct DevCounters {
 	uint32_t n_live;
 	uint32_t shade_ticket;   // dynamic block id of the shade kernel (stable compaction)
 	uint32_t device_error;
-	uint32_t pad0, pad1;
+	uint32_t extend_ticket;  // next queue slot to hand to a free lane of the persistent extend kernel
+	uint32_t connect_ticket; // same for connect
 	unsigned long long budget_remaining;
 	unsigned long long total_extend_rays;
 	unsigned long long total_shadow_rays;
@@ -50,6 +51,10 @@ struct DevCounters {
 	unsigned long long nodes_extend, tris_extend;
 	unsigned long long nodes_connect, tris_connect;
 	unsigned long long n_survive, n_shadow_visible;
+	// counting build only: where the extend kernel's lanes spend their wave-iterations.
+	// [0]/[1] node-test loop: wave iterations / lane iterations; [2]/[3] pop loop; [4]/[5] triangle loop;
+	// [6]/[7] refills / lanes refilled
+	unsigned long long debug[8];
 };
 constexpr uint32_t kErrStackOverflow = 1u;
 constexpr uint32_t kErrScanTimeout = 2u;
@@ -71,6 +76,19 @@ struct FrameParams {
 	float4* blit;            // main.cpp:129-130
 	DevCounters* k;
 	unsigned long long* scanDesc; // one look-back descriptor per shade block
+	uint32_t refillMinIdle;       // persistent traversal: refill a wave once this many lanes are free
+	uint32_t minTraversing;       // flat traversal: leave the descent loop below this many descending lanes
+	uint32_t ticketChunk;         // flat traversal: queue slots a wave takes per atomic
+};
+
+// traversal kernel structure (tyr_set_tuning)
+struct Tuning {
+	int traversalVariant = 2; // 0 = one thread per queue slot, 1 = persistent waves with lane refill, 2 = 1 + flat state machine
+	int minTraversing = 32;
+	int ticketChunk = 128;
+	int refillMinIdle = 16;
+	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
+	int stackLdsDepth = 12;   // traversal-stack entries per lane kept in LDS (0, 8, 12, 16, 24); the rest spill to scratch
 };
 
 constexpr int kBlock = 256; // 4 wave64 per workgroup
@@ -79,9 +97,9 @@ constexpr int kBlock = 256; // 4 wave64 per workgroup
 // against the device counters
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream);
 void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream);
-void launch_extend(const FrameParams& P, uint32_t maxLive, bool countVisits, hipStream_t stream);
+void launch_extend(const FrameParams& P, uint32_t maxLive, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream);
 void launch_shade(const FrameParams& P, uint32_t maxLive, hipStream_t stream);
-void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, hipStream_t stream);
+void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream);
 void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream);
 
 } // namespace tyr

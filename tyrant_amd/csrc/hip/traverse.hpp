@@ -41,8 +41,9 @@ namespace tyr {
 
 constexpr uint32_t kRefLeaf = 0x80000000u;
 constexpr uint32_t kRefDone = 0xFFFFFFFFu; // "leaf" with every bit set: never produced by the layout pass
+constexpr uint32_t kRefPop = 0xFFFFFFFEu;  // flat state machine: this lane must pop its stack next (a leaf needs count-1 < 31)
 constexpr int kStackSize = 64;             // bvh.h:124 nodesToVisit[64]
-constexpr uint32_t kMaxLeafPrims = 32;
+constexpr uint32_t kMaxLeafPrims = 31; // count-1 <= 30 keeps 0xFFFFFFFE / 0xFFFFFFFF out of the leaf encoding
 constexpr uint32_t kMaxPrimOffset = 1u << 26;
 
 struct DevScene {
@@ -166,6 +167,70 @@ struct ScratchStack {
 	}
 };
 
+
+// Traversal stack with its first LDS_DEPTH entries in LDS and the rest in scratch.
+// Why LDS: on CDNA, vmcnt retires loads AND stores in issue order, so a scratch push (a store)
+// sits in front of the next node fetch's wait and a scratch pop is a vector-memory round trip
+// on the critical path of "pop -> node address -> fetch".  LDS traffic is counted by lgkmcnt
+// instead and returns in ~64 cycles.  Layout [depth][thread]: a lane always hits its own pair of
+// banks whatever its depth (depth * 256 threads * 8 B is a whole number of 256-byte bank rows),
+// so divergent depths never conflict.  Deeper entries (rare: the stack holds only the pending
+// far children) spill to the scratch array, which costs nothing while unused.
+template <int LDS_DEPTH>
+struct LdsStack {
+	uint2* lds; // this thread's column: entry d at lds[d * kBlockThreads]
+	static constexpr int kBlockThreads = 256;
+	uint32_t spillRef[kStackSize - LDS_DEPTH];
+	float spillT[kStackSize - LDS_DEPTH];
+	int n;
+	uint32_t topRef;
+	float topT;
+	bool hasTop;
+	bool overflow;
+	__device__ __forceinline__ void reset() {
+		n = 0;
+		hasTop = false;
+		overflow = false;
+	}
+	__device__ __forceinline__ void push(uint32_t r, float t) {
+		if (hasTop) {
+			if (n < LDS_DEPTH) {
+				lds[n * kBlockThreads] = make_uint2(topRef, __float_as_uint(topT));
+				++n;
+			} else if (n < kStackSize - 1) {
+				spillRef[n - LDS_DEPTH] = topRef;
+				spillT[n - LDS_DEPTH] = topT;
+				++n;
+			} else {
+				overflow = true;
+			}
+		}
+		topRef = r;
+		topT = t;
+		hasTop = true;
+	}
+	__device__ __forceinline__ bool pop(uint32_t& r, float& t) {
+		if (hasTop) {
+			r = topRef;
+			t = topT;
+			hasTop = false;
+			return true;
+		}
+		if (n == 0)
+			return false;
+		--n;
+		if (n < LDS_DEPTH) {
+			const uint2 e = lds[n * kBlockThreads];
+			r = e.x;
+			t = __uint_as_float(e.y);
+		} else {
+			r = spillRef[n - LDS_DEPTH];
+			t = spillT[n - LDS_DEPTH];
+		}
+		return true;
+	}
+};
+
 struct PairTest {
 	uint32_t nearRef, farRef;
 	float nearT, farT;
@@ -203,6 +268,55 @@ __device__ __forceinline__ PairTest test_pair(const float4* __restrict__ nodes, 
 	return p;
 }
 
+
+// ---- fast exact pair test for rays whose 1/d components are all finite ---------------------
+// With finite inv there is no NaN anywhere in Bbox.h:38-62 (NaN needs 0 * inf), and multiplying
+// by inv is monotonic, so the sign-selected planes of Bbox.h:39-42 are min/max of the two
+// products; the two early-outs plus the running max/min of Bbox.h:44-59 are then exactly
+//      tMin = max3(near_x, near_y, near_z)   tMax = min3(far_x, far_y, far_z)
+//      hit  = tMin <= tMax  &&  tMin < lowest  &&  tMax > 0
+// (all nine near_i <= far_j comparisons of the reference collapse to max(near) <= min(far)).
+// That is ~25 VALU per box instead of ~45.  Rays with a zero direction component (inv = inf)
+// keep the generic path above.
+__device__ __forceinline__ bool slab_fast(const RayConst& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float lowest, float& tMinOut) {
+	const float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
+	const float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
+	const float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
+	const float tMin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+	const float tMax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+	tMinOut = tMin;
+	return (tMin <= tMax) && (tMin < lowest) && (tMax > 0);
+}
+__device__ __forceinline__ bool ray_is_regular(const RayConst& r) {
+	// |inv| < inf for all three components (also false for NaN)
+	return (fabsf(r.inv.x) < __builtin_inff()) && (fabsf(r.inv.y) < __builtin_inff()) && (fabsf(r.inv.z) < __builtin_inff());
+}
+__device__ __forceinline__ PairTest test_pair_fast(const float4* __restrict__ nodes, uint32_t idx, const RayConst& r, float dist) {
+	const float4 qx = nodes[4 * idx + 0];
+	const float4 qy = nodes[4 * idx + 1];
+	const float4 qz = nodes[4 * idx + 2];
+	const float4 qr = nodes[4 * idx + 3];
+	const uint32_t leftRef = __float_as_uint(qr.x), rightRef = __float_as_uint(qr.y), axis = __float_as_uint(qr.z);
+	float tL, tR;
+	const bool hL = slab_fast(r, qx.x, qx.y, qy.x, qy.y, qz.x, qz.y, dist, tL);
+	const bool hR = slab_fast(r, qx.z, qx.w, qy.z, qy.w, qz.z, qz.w, dist, tR);
+	const bool rightFirst = (axis == 0) ? r.nx : (axis == 1) ? r.ny : (axis == 2) ? r.nz : false;
+	PairTest p;
+	p.nearRef = rightFirst ? rightRef : leftRef;
+	p.farRef = rightFirst ? leftRef : rightRef;
+	p.nearT = rightFirst ? tR : tL;
+	p.farT = rightFirst ? tL : tR;
+	p.nearHit = rightFirst ? hR : hL;
+	p.farHit = rightFirst ? hL : hR;
+	p.synthetic = (axis == 3);
+	if (p.synthetic) {
+		p.nearHit = true;
+		p.farHit = true;
+		p.farT = -__builtin_inff();
+	}
+	return p;
+}
+
 struct VisitCount {
 	uint32_t nodes, tris;
 };
@@ -210,8 +324,8 @@ struct VisitCount {
 // Closest hit.  `dist` / `prim` are updated like ray.distance / ray.identifier (bvh.h:135-136).
 // COUNT: also count nodes visited / triangles tested by the reference's rule (bvh.h:164-209:
 // one per loop iteration = every node fetched, including those whose box test fails).
-template <bool COUNT>
-__device__ __forceinline__ bool bvh_closest(const DevScene& sc, const RayConst& r, float& dist, int& prim, ScratchStack& st, VisitCount& vc) {
+template <bool COUNT, class Stack>
+__device__ __forceinline__ bool bvh_closest(const DevScene& sc, const RayConst& r, float& dist, int& prim, Stack& st, VisitCount& vc) {
 	bool hit = false;
 	st.reset();
 	uint32_t ref;
@@ -278,8 +392,8 @@ __device__ __forceinline__ bool bvh_closest(const DevScene& sc, const RayConst& 
 // Any hit within `closest` (bvh.h:213-256).  The bound never shrinks, so the result does not
 // depend on visit order; the same near-first order is kept so COUNT reproduces the reference's
 // visit counts (nodes popped before the early return).
-template <bool COUNT>
-__device__ __forceinline__ bool bvh_any(const DevScene& sc, const RayConst& r, float closest, ScratchStack& st, VisitCount& vc) {
+template <bool COUNT, class Stack>
+__device__ __forceinline__ bool bvh_any(const DevScene& sc, const RayConst& r, float closest, Stack& st, VisitCount& vc) {
 	st.reset();
 	uint32_t ref;
 	{

@@ -59,6 +59,9 @@ struct tyr_ctx {
 	float lastFocal = 1.0f, lastLens = 0.02f;
 	float camRight[3]{}, camUp[3]{};
 
+	Tuning tuning{};
+	int numCUs = 256;
+
 	hipEvent_t ev[2 * TYR_K_COUNT]{};
 	bool evUsed[TYR_K_COUNT]{};
 	tyr_timings timings{};
@@ -165,6 +168,9 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.blit = c->blit;
 	P.k = c->dK;
 	P.scanDesc = c->scanDesc;
+	P.refillMinIdle = static_cast<uint32_t>(std::min(std::max(c->tuning.refillMinIdle, 1), 64));
+	P.minTraversing = static_cast<uint32_t>(std::min(std::max(c->tuning.minTraversing, 1), 64));
+	P.ticketChunk = static_cast<uint32_t>(std::min(std::max(c->tuning.ticketChunk, 64), 65536));
 	return P;
 }
 
@@ -248,7 +254,7 @@ void enqueue_primary(tyr_ctx* c, const FrameParams& P, uint32_t nNew, uint32_t n
 }
 void enqueue_extend(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	KernelTimer t(c, TYR_K_EXTEND);
-	launch_extend(P, nLive, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->stream);
+	launch_extend(P, nLive, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->stream);
 }
 void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	KernelTimer t(c, TYR_K_SHADE);
@@ -256,7 +262,7 @@ void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 }
 void enqueue_connect(tyr_ctx* c, const FrameParams& P, uint32_t maxShadow) {
 	KernelTimer t(c, TYR_K_CONNECT);
-	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->stream);
+	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->stream);
 }
 
 void stage_end(tyr_ctx* c) {
@@ -322,6 +328,11 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		tyr_destroy(c);
 		return code;
 	};
+	{
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+			c->numCUs = prop.multiProcessorCount; // the reference's sm_cores (main.cpp:102)
+	}
 	if (cfg->stream) {
 		c->stream = static_cast<hipStream_t>(cfg->stream);
 	} else {
@@ -505,6 +516,8 @@ int tyr_get_counters(tyr_ctx* c, tyr_counters* out) {
 	out->tris_connect = k.tris_connect;
 	out->n_survive = k.n_survive;
 	out->n_shadow_visible = k.n_shadow_visible;
+	for (int i = 0; i < 8; ++i)
+		out->debug[i] = k.debug[i];
 	return TYR_OK;
 }
 
@@ -792,6 +805,45 @@ int tyr_shadow_export(tyr_ctx* c, tyr_shadow_queue* host, uint32_t count) {
 		s.color[2] = col[i].z;
 	}
 	return TYR_OK;
+}
+
+int tyr_set_tuning(tyr_ctx* c, int key, int value) {
+	if (!c)
+		return TYR_ERR_INVALID;
+	switch (key) {
+	case TYR_TUNE_TRAVERSAL_VARIANT:
+		if (value < 0 || value > 2)
+			return TYR_ERR_INVALID;
+		c->tuning.traversalVariant = value;
+		return TYR_OK;
+	case TYR_TUNE_REFILL_MIN_IDLE:
+		if (value < 1 || value > 64)
+			return TYR_ERR_INVALID;
+		c->tuning.refillMinIdle = value;
+		return TYR_OK;
+	case TYR_TUNE_WAVES_PER_SIMD:
+		if (value < 0 || value > 8)
+			return TYR_ERR_INVALID;
+		c->tuning.wavesPerSimd = value;
+		return TYR_OK;
+	case TYR_TUNE_MIN_TRAVERSING:
+		if (value < 1 || value > 64)
+			return TYR_ERR_INVALID;
+		c->tuning.minTraversing = value;
+		return TYR_OK;
+	case TYR_TUNE_TICKET_CHUNK:
+		if (value < 64 || value > 65536)
+			return TYR_ERR_INVALID;
+		c->tuning.ticketChunk = value;
+		return TYR_OK;
+	case TYR_TUNE_STACK_LDS_DEPTH:
+		if (value != 0 && value != 8 && value != 12 && value != 16 && value != 24)
+			return TYR_ERR_INVALID;
+		c->tuning.stackLdsDepth = value;
+		return TYR_OK;
+	default:
+		return TYR_ERR_INVALID;
+	}
 }
 
 int tyr_get_timings(tyr_ctx* c, tyr_timings* out, int reset) {
