@@ -243,3 +243,23 @@ def test_cpp_host_api_example(hip):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "frame counter 25" in p.stdout, p.stdout  # kernel.cu:667, 739: starts at 1, +1 per call
     assert os.path.getsize(out) > 640 * 360 * 3
+
+
+@pytest.mark.parametrize("variant,lds", [(0, 0), (0, 8), (1, 0), (1, 16), (2, 12), (2, 0), (3, 12), (3, 0), (3, 24)])
+def test_every_traversal_variant_is_bit_exact(orc, hip, variant, lds):
+    """launch shape / node layout / stack placement never change results: each traversal variant reproduces
+    the oracle's queues bit for bit over several iterations (bounce rays included)"""
+    for name, W, H, N in (("cornell_soup2k", 80, 48, 4096), ("tyrant_default", 96, 64, 5000)):
+        o, g = pair(orc, hip, name, W, H, N)
+        g.set_tuning(traversal_variant=variant, stack_lds_depth=lds, refill_min_idle=8, min_traversing=24, ticket_chunk=64)
+        for it in range(4):
+            o.launch_kernels(), g.launch_kernels()
+            ko, kg = o.counters(), g.counters()
+            assert kg["device_error"] == 0
+            for f in ("primary_ray_cnt", "shadow_ray_cnt", "n_shadow_visible", "total_shadow_rays", "n_survive"):
+                assert ko[f] == kg[f], (name, variant, it, f)
+            ns, nh = ko["primary_ray_cnt"], ko["shadow_ray_cnt"]
+            assert_state_equal(o.ray_queue(0, ns), g.ray_queue(0, ns), f"{name} variant {variant} iteration {it}")
+            so, sg = o.shadow_queue(nh), g.shadow_queue(nh)
+            assert so.tobytes() == sg.tobytes()
+        assert_accum_close(o.blit_buffer(), g.blit_buffer(), f"{name} variant {variant}")

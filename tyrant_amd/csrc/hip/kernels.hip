@@ -105,19 +105,14 @@ __device__ __forceinline__ float sphere_intersect(const tyr_sphere& sp, f3 origi
 	return (t = b - disc) > kEpsilon ? t : ((t = b + disc) > kEpsilon ? t : 0);
 }
 
-// stack policies of the traversal kernels: STACK_LDS == 0 -> scratch only, else that many entries per lane in LDS
-template <int STACK_LDS>
-struct StackSel {
-	using type = LdsStack<STACK_LDS>;
-	static constexpr int kLdsBytes = STACK_LDS * kBlock * 8;
-	__device__ static __forceinline__ void bind(type& st, uint2* smem) { st.lds = smem + threadIdx.x; }
-};
-template <>
-struct StackSel<0> {
-	using type = ScratchStack;
-	static constexpr int kLdsBytes = 0;
-	__device__ static __forceinline__ void bind(type&, uint2*) {}
-};
+// traversal-stack storage of one thread: LDS column + private arrays, bound to a TravStack<STACK_LDS>
+#define TYR_DECLARE_STACK(st)                                                        \
+	__shared__ uint2 smem_[STACK_LDS ? STACK_LDS * kBlock : 1];                      \
+	uint32_t spillRef_[kStackSize - STACK_LDS];                                      \
+	float spillT_[kStackSize - STACK_LDS];                                           \
+	TravStack<STACK_LDS> st;                                                         \
+	st.bind(smem_ + threadIdx.x, spillRef_, spillT_);                                \
+	st.reset();
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -210,7 +205,7 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 // ======================================================================================
 template <bool COUNT, int STACK_LDS>
 __global__ void __launch_bounds__(kBlock) k_extend(const FrameParams P) {
-	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
+	TYR_DECLARE_STACK(st)
 	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t nLive = P.k->n_live;
 	VisitCount vc{ 0, 0 };
@@ -231,8 +226,6 @@ __global__ void __launch_bounds__(kBlock) k_extend(const FrameParams P) {
 		}
 		if (P.scene.rootRef != kRefDone) {
 			const RayConst r = make_ray(o, d);
-			typename StackSel<STACK_LDS>::type st;
-			StackSel<STACK_LDS>::bind(st, smem);
 			int prim = 0;
 			if (bvh_closest<COUNT>(P.scene, r, dist, prim, st, vc))
 				id = (uint32_t)prim;
@@ -624,7 +617,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P) {
 // ======================================================================================
 template <bool COUNT, int STACK_LDS>
 __global__ void __launch_bounds__(kBlock) k_connect(const FrameParams P) {
-	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
+	TYR_DECLARE_STACK(st)
 	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t n = P.k->shadow_ray_cnt;
 	VisitCount vc{ 0, 0 };
@@ -638,8 +631,6 @@ __global__ void __launch_bounds__(kBlock) k_connect(const FrameParams P) {
 		bool occluded = false;
 		if (P.scene.rootRef != kRefDone) {
 			const RayConst r = make_ray(o, d);
-			typename StackSel<STACK_LDS>::type st;
-			StackSel<STACK_LDS>::bind(st, smem);
 			occluded = bvh_any<COUNT>(P.scene, r, closest, st, vc);
 			overflow = st.overflow;
 		}
@@ -725,14 +716,11 @@ __device__ __forceinline__ uint32_t root_ref(const DevScene& sc, const RayConst&
 
 template <bool COUNT, int STACK_LDS>
 __global__ void __launch_bounds__(kBlock) k_extend_persistent(const FrameParams P) {
-	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
+	TYR_DECLARE_STACK(st)
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t nLive = P.k->n_live;
 	const DevScene& sc = P.scene;
-	typename StackSel<STACK_LDS>::type st;
-	StackSel<STACK_LDS>::bind(st, smem);
-	st.reset();
 	RayConst r = {};
 	float dist = 0.0f;
 	uint32_t ref = kRefDone, slot = 0;
@@ -887,15 +875,12 @@ __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P)
 
 template <bool COUNT, int STACK_LDS>
 __global__ void __launch_bounds__(kBlock) k_connect_persistent(const FrameParams P) {
-	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
+	TYR_DECLARE_STACK(st)
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t nRays = P.k->shadow_ray_cnt;
 	const DevScene& sc = P.scene;
 	const bool haveBvh = (sc.rootRef != kRefDone);
-	typename StackSel<STACK_LDS>::type st;
-	StackSel<STACK_LDS>::bind(st, smem);
-	st.reset();
 	RayConst r = {};
 	float closest = 0.0f;
 	uint32_t ref = kRefDone, index = 0;
@@ -1051,16 +1036,14 @@ __device__ __forceinline__ bool ref_is_traversing(uint32_t ref) { return ((int)r
 		}                                                              \
 	}
 
-template <bool COUNT, int STACK_LDS>
+template <bool COUNT, int STACK_LDS, bool QUAD>
 __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
-	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
+	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
+	TYR_DECLARE_STACK(st)
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t nLive = P.k->n_live;
 	const DevScene& sc = P.scene;
-	typename StackSel<STACK_LDS>::type st;
-	StackSel<STACK_LDS>::bind(st, smem);
-	st.reset();
 	RayConst r = {};
 	bool regular = true;
 	float dist = 0.0f;
@@ -1069,28 +1052,32 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 	bool hitTri = false, live = false, overflow = false;
 	VisitCount vc{ 0, 0 };
 	uint32_t dbg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	bool exhausted = (sc.rootRef == kRefDone);
-	uint32_t chunkNext = 0, chunkEnd = 0; // this wave's private range of queue slots (wave-uniform)
+	// Work distribution: this block owns queue slots [blockIdx.x * raysPerBlock, +raysPerBlock) and hands
+	// them to the free lanes of its four waves through a counter in LDS.  Balancing ACROSS blocks is the
+	// hardware dispatcher's (grid = slots / raysPerBlock blocks, more than fit at once).  The first
+	// versions pulled from one device-wide ticket: a single word serves only ~88 returning atomics per
+	// microsecond (MI355X_MICROARCH.md "dequeue"), and with >= 2 pulls per wave that alone was a
+	// 0.26 ms floor per launch, whatever the traversal cost.
+	__shared__ uint32_t blockNext;
+	const uint32_t blockBegin = blockIdx.x * P.raysPerBlock;
+	const uint32_t blockEnd = (blockBegin + P.raysPerBlock) < nLive ? (blockBegin + P.raysPerBlock) : nLive;
+	if (threadIdx.x == 0)
+		blockNext = blockBegin;
+	__syncthreads();
+	bool exhausted = (sc.rootRef == kRefDone) || (blockBegin >= nLive);
 
 	for (;;) {
 		// ---- refill free lanes from the queue ----
 		const unsigned long long idleMask = __ballot(!live);
 		const uint32_t nIdle = __popcll(idleMask);
 		if (!exhausted && nIdle >= P.refillMinIdle) {
-			if (chunkNext >= chunkEnd) {
-				// one returning atomic per `ticketChunk` rays: a single device-wide word serves only ~88 dequeues/us
-				// (MI355X_MICROARCH.md "dequeue"), which capped this kernel at ~0.9 ms when every refill paid one
-				uint32_t base = 0;
-				if (lane == 0)
-					base = atomicAdd(&P.k->extend_ticket, P.ticketChunk);
-				base = __shfl(base, 0, 64);
-				chunkNext = base < nLive ? base : nLive;
-				chunkEnd = (base + P.ticketChunk) < nLive ? (base + P.ticketChunk) : nLive;
-				exhausted = (chunkNext >= chunkEnd);
-			}
-			const uint32_t take = (chunkEnd - chunkNext) < nIdle ? (chunkEnd - chunkNext) : nIdle;
-			const uint32_t base = chunkNext;
-			chunkNext += take;
+			uint32_t base = 0;
+			if (lane == 0)
+				base = atomicAdd(&blockNext, nIdle); // LDS
+			base = __shfl(base, 0, 64);
+			const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+			const uint32_t take = avail < nIdle ? avail : nIdle;
+			exhausted = (base + nIdle >= blockEnd);
 			if (!live) {
 				const uint32_t rank = __popcll(idleMask & below);
 				const uint32_t s = base + rank;
@@ -1107,6 +1094,8 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 					live = true;
 					st.reset();
 					ref = root_ref(sc, r, dist);
+					if (QUAD && ref != kRefDone)
+						ref = sc.quadRootRef;
 					if (COUNT)
 						vc.nodes += 1;
 				}
@@ -1141,17 +1130,34 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 			}
 			if ((int)ref >= 0) {
 				TYR_DBG(0)
-				const PairTest p = regular ? test_pair_fast(sc.nodes, ref, r, dist) : test_pair(sc.nodes, ref, r, dist);
-				if (COUNT && !p.synthetic)
-					vc.nodes += 2;
-				if (p.nearHit) {
-					if (p.farHit)
-						st.push(p.farRef, p.farT);
-					ref = p.nearRef;
-				} else if (p.farHit) {
-					ref = p.farRef;
+				if (QUAD) {
+					const QuadHits q = test_quad(sc.quads, ref, r, regular, dist);
+					// the earliest hit in visit order is entered now, the later ones are pushed latest first
+					uint32_t cur = kRefPop;
+					float curT = 0.0f;
+#pragma unroll
+					for (int k = 3; k >= 0; --k) {
+						if (q.hit[k]) {
+							if (cur != kRefPop)
+								st.push(cur, curT);
+							cur = q.ref[k];
+							curT = q.t[k];
+						}
+					}
+					ref = cur;
 				} else {
-					ref = kRefPop;
+					const PairTest p = regular ? test_pair_fast(sc.nodes, ref, r, dist) : test_pair(sc.nodes, ref, r, dist);
+					if (COUNT && !p.synthetic)
+						vc.nodes += 2;
+					if (p.nearHit) {
+						if (p.farHit)
+							st.push(p.farRef, p.farT);
+						ref = p.nearRef;
+					} else if (p.farHit) {
+						ref = p.farRef;
+					} else {
+						ref = kRefPop;
+					}
 				}
 			}
 		}
@@ -1190,17 +1196,15 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 	}
 }
 
-template <bool COUNT, int STACK_LDS>
+template <bool COUNT, int STACK_LDS, bool QUAD>
 __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
-	__shared__ uint2 smem[STACK_LDS ? STACK_LDS * kBlock : 1];
+	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
+	TYR_DECLARE_STACK(st)
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t nRays = P.k->shadow_ray_cnt;
 	const DevScene& sc = P.scene;
 	const bool haveBvh = (sc.rootRef != kRefDone);
-	typename StackSel<STACK_LDS>::type st;
-	StackSel<STACK_LDS>::bind(st, smem);
-	st.reset();
 	RayConst r = {};
 	bool regular = true;
 	float closest = 0.0f;
@@ -1208,26 +1212,26 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 	bool live = false, occluded = false, overflow = false;
 	VisitCount vc{ 0, 0 };
 	uint32_t visible = 0;
-	bool exhausted = false;
-	uint32_t chunkNext = 0, chunkEnd = 0;
+	__shared__ uint32_t blockNext;
+	const uint32_t blockBegin = blockIdx.x * P.raysPerBlock;
+	const uint32_t blockEnd = (blockBegin + P.raysPerBlock) < nRays ? (blockBegin + P.raysPerBlock) : nRays;
+	if (threadIdx.x == 0)
+		blockNext = blockBegin;
+	__syncthreads();
+	bool exhausted = (blockBegin >= nRays);
 	const float kFailed = __builtin_inff();
 
 	for (;;) {
 		const unsigned long long idleMask = __ballot(!live);
 		const uint32_t nIdle = __popcll(idleMask);
 		if (!exhausted && nIdle >= P.refillMinIdle) {
-			if (chunkNext >= chunkEnd) {
-				uint32_t base = 0;
-				if (lane == 0)
-					base = atomicAdd(&P.k->connect_ticket, P.ticketChunk);
-				base = __shfl(base, 0, 64);
-				chunkNext = base < nRays ? base : nRays;
-				chunkEnd = (base + P.ticketChunk) < nRays ? (base + P.ticketChunk) : nRays;
-				exhausted = (chunkNext >= chunkEnd);
-			}
-			const uint32_t take = (chunkEnd - chunkNext) < nIdle ? (chunkEnd - chunkNext) : nIdle;
-			const uint32_t base = chunkNext;
-			chunkNext += take;
+			uint32_t base = 0;
+			if (lane == 0)
+				base = atomicAdd(&blockNext, nIdle); // LDS
+			base = __shfl(base, 0, 64);
+			const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+			const uint32_t take = avail < nIdle ? avail : nIdle;
+			exhausted = (base + nIdle >= blockEnd);
 			if (!live) {
 				const uint32_t rank = __popcll(idleMask & below);
 				const uint32_t s = base + rank;
@@ -1245,6 +1249,8 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 						r = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
 						regular = ray_is_regular(r);
 						ref = root_ref(sc, r, closest);
+						if (QUAD && ref != kRefDone)
+							ref = sc.quadRootRef;
 						if (COUNT)
 							vc.nodes += 1;
 					}
@@ -1279,6 +1285,22 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 				}
 			}
 			if ((int)ref >= 0) {
+				if (QUAD) {
+					const QuadHits q = test_quad(sc.quads, ref, r, regular, closest);
+					uint32_t cur = kRefPop;
+					float curT = 0.0f;
+#pragma unroll
+					for (int k = 3; k >= 0; --k) {
+						if (q.hit[k]) {
+							if (cur != kRefPop)
+								st.push(cur, curT);
+							cur = q.ref[k];
+							curT = q.t[k];
+						}
+					}
+					ref = cur;
+					continue;
+				}
 				const PairTest p = regular ? test_pair_fast(sc.nodes, ref, r, closest) : test_pair(sc.nodes, ref, r, closest);
 				if (COUNT && !p.synthetic) {
 					vc.nodes += 1;
@@ -1368,11 +1390,20 @@ void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream) {
 // larger grid would only queue), never more waves than there are rays
 template <class K>
 static uint32_t persistent_blocks(K kernel, uint32_t nItems, const Tuning& t, int numCUs) {
+	// the occupancy query is a host-side call of ~0.1-0.2 ms: ask once per kernel, not once per launch
+	// (at every launch it sat between the pre-pass and the persistent kernel with the GPU idle)
+	static int cachedPerCU = 0; // one instance per template instantiation = per kernel
 	int perCU = 0;
 	if (t.wavesPerSimd > 0) {
 		perCU = t.wavesPerSimd; // 4 SIMDs x w waves = w blocks of 4 waves
-	} else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, 0) != hipSuccess || perCU <= 0) {
-		perCU = 4;
+	} else {
+		if (cachedPerCU == 0) {
+			int q = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kernel, kBlock, 0) != hipSuccess || q <= 0)
+				q = 4;
+			cachedPerCU = q;
+		}
+		perCU = cachedPerCU;
 	}
 	const uint32_t resident = (uint32_t)perCU * (uint32_t)numCUs;
 	const uint32_t needed = (nItems + kBlock - 1) / kBlock;
@@ -1386,8 +1417,11 @@ static void launch_extend_t(const FrameParams& P, uint32_t maxLive, const Tuning
 		return;
 	}
 	hipLaunchKernelGGL(k_extend_spheres, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
-	if (t.traversalVariant == 2)
-		hipLaunchKernelGGL((k_extend_flat<COUNT, STACK_LDS>), dim3(persistent_blocks(k_extend_flat<COUNT, STACK_LDS>, maxLive, t, numCUs)), dim3(kBlock), 0, stream, P);
+	const uint32_t flatBlocks = (maxLive + P.raysPerBlock - 1) / P.raysPerBlock;
+	if (t.traversalVariant == 3 && !COUNT)
+		hipLaunchKernelGGL((k_extend_flat<false, STACK_LDS, true>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+	else if (t.traversalVariant >= 2)
+		hipLaunchKernelGGL((k_extend_flat<COUNT, STACK_LDS, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
 	else
 		hipLaunchKernelGGL((k_extend_persistent<COUNT, STACK_LDS>), dim3(persistent_blocks(k_extend_persistent<COUNT, STACK_LDS>, maxLive, t, numCUs)), dim3(kBlock), 0, stream, P);
 }
@@ -1398,8 +1432,11 @@ static void launch_connect_t(const FrameParams& P, uint32_t maxShadow, const Tun
 		return;
 	}
 	hipLaunchKernelGGL(k_connect_spheres, dim3(blocks_for(maxShadow)), dim3(kBlock), 0, stream, P);
-	if (t.traversalVariant == 2)
-		hipLaunchKernelGGL((k_connect_flat<COUNT, STACK_LDS>), dim3(persistent_blocks(k_connect_flat<COUNT, STACK_LDS>, maxShadow, t, numCUs)), dim3(kBlock), 0, stream, P);
+	const uint32_t flatBlocks = (maxShadow + P.raysPerBlock - 1) / P.raysPerBlock;
+	if (t.traversalVariant == 3 && !COUNT)
+		hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, true>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+	else if (t.traversalVariant >= 2)
+		hipLaunchKernelGGL((k_connect_flat<COUNT, STACK_LDS, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
 	else
 		hipLaunchKernelGGL((k_connect_persistent<COUNT, STACK_LDS>), dim3(persistent_blocks(k_connect_persistent<COUNT, STACK_LDS>, maxShadow, t, numCUs)), dim3(kBlock), 0, stream, P);
 }

@@ -78,14 +78,16 @@ struct FrameParams {
 	unsigned long long* scanDesc; // one look-back descriptor per shade block
 	uint32_t refillMinIdle;       // persistent traversal: refill a wave once this many lanes are free
 	uint32_t minTraversing;       // flat traversal: leave the descent loop below this many descending lanes
-	uint32_t ticketChunk;         // flat traversal: queue slots a wave takes per atomic
+	uint32_t ticketChunk;         // variant 1: queue slots a wave takes per global atomic
+	uint32_t raysPerBlock;        // variants 2/3: queue slots owned by one 256-thread block
 };
 
 // traversal kernel structure (tyr_set_tuning)
 struct Tuning {
-	int traversalVariant = 2; // 0 = one thread per queue slot, 1 = persistent waves with lane refill, 2 = 1 + flat state machine
+	int traversalVariant = 3; // 0 = one thread per queue slot, 1 = persistent waves with lane refill, 2 = 1 + flat state machine, 3 = 2 on quad nodes
 	int minTraversing = 32;
 	int ticketChunk = 128;
+	int raysPerBlock = 512;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
 	int stackLdsDepth = 12;   // traversal-stack entries per lane kept in LDS (0, 8, 12, 16, 24); the rest spill to scratch

@@ -47,7 +47,10 @@ constexpr uint32_t kMaxLeafPrims = 31; // count-1 <= 30 keeps 0xFFFFFFFE / 0xFFF
 constexpr uint32_t kMaxPrimOffset = 1u << 26;
 
 struct DevScene {
-	const float4* nodes; // PairNode array, 4 float4 each
+	const float4* quads; // QuadNode array, 8 float4 each (the production traversal)
+	uint32_t quadRootRef;
+	uint32_t nQuads;
+	const float4* nodes; // PairNode array, 4 float4 each (the counting build and variants 0/1)
 	const float4* tris;  // 3 float4 each
 	float rootMin[3];
 	float rootMax[3];
@@ -122,16 +125,37 @@ __device__ __forceinline__ float triangle_test(const float4* __restrict__ tris, 
 	return dot(e2, qvec) * invDet;
 }
 
-// Per-lane traversal stack in private (scratch) memory with the top entry cached in
-// registers: the common push-then-pop pair never touches memory.
-struct ScratchStack {
-	uint32_t ref[kStackSize];
-	float tmin[kStackSize];
-	int n; // entries in memory
+// Per-lane traversal stack: the first LDS_DEPTH entries in LDS, the rest in a private (scratch)
+// array, the top entry cached in registers (a push followed by a pop never touches memory).
+//
+// Why LDS: on CDNA, vmcnt retires loads AND stores in issue order, so a scratch push (a store)
+// sits in front of the next node fetch's wait and a scratch pop is a vector-memory round trip on
+// the critical path "pop -> node address -> fetch".  LDS traffic is counted by lgkmcnt instead and
+// returns in ~64 cycles.  Layout [depth][thread]: a lane always hits its own pair of banks whatever
+// its depth (depth * 256 threads * 8 B is a whole number of 256-byte bank rows), so divergent
+// depths never conflict.
+//
+// The arrays live OUTSIDE this struct (the kernel declares them and binds pointers): with the
+// arrays as members, the compiler kept the whole object -- n, hasTop, the cached top -- in scratch
+// (scratch_store_dword in the descent loop of the first build), because a struct holding a
+// dynamically indexed array is not split into registers.
+template <int LDS_DEPTH>
+struct TravStack {
+	static constexpr int kBlockThreads = 256;
+	static constexpr int kSpill = kStackSize - LDS_DEPTH; // entries of the private arrays
+	uint2* lds;          // this thread's column: entry d at lds[d * kBlockThreads]
+	uint32_t* spillRef;  // kSpill entries
+	float* spillT;
+	int n;               // entries in memory
 	uint32_t topRef;
 	float topT;
 	bool hasTop;
 	bool overflow;
+	__device__ __forceinline__ void bind(uint2* ldsColumn, uint32_t* refs, float* ts) {
+		lds = ldsColumn;
+		spillRef = refs;
+		spillT = ts;
+	}
 	__device__ __forceinline__ void reset() {
 		n = 0;
 		hasTop = false;
@@ -139,9 +163,12 @@ struct ScratchStack {
 	}
 	__device__ __forceinline__ void push(uint32_t r, float t) {
 		if (hasTop) {
-			if (n < kStackSize - 1) {
-				ref[n] = topRef;
-				tmin[n] = topT;
+			if (LDS_DEPTH > 0 && n < LDS_DEPTH) {
+				lds[n * kBlockThreads] = make_uint2(topRef, __float_as_uint(topT));
+				++n;
+			} else if (n < kStackSize - 1) {
+				spillRef[n - LDS_DEPTH] = topRef;
+				spillT[n - LDS_DEPTH] = topT;
 				++n;
 			} else {
 				overflow = true; // the reference's 64-entry array would be overrun here (bvh.h:124)
@@ -161,65 +188,7 @@ struct ScratchStack {
 		if (n == 0)
 			return false;
 		--n;
-		r = ref[n];
-		t = tmin[n];
-		return true;
-	}
-};
-
-
-// Traversal stack with its first LDS_DEPTH entries in LDS and the rest in scratch.
-// Why LDS: on CDNA, vmcnt retires loads AND stores in issue order, so a scratch push (a store)
-// sits in front of the next node fetch's wait and a scratch pop is a vector-memory round trip
-// on the critical path of "pop -> node address -> fetch".  LDS traffic is counted by lgkmcnt
-// instead and returns in ~64 cycles.  Layout [depth][thread]: a lane always hits its own pair of
-// banks whatever its depth (depth * 256 threads * 8 B is a whole number of 256-byte bank rows),
-// so divergent depths never conflict.  Deeper entries (rare: the stack holds only the pending
-// far children) spill to the scratch array, which costs nothing while unused.
-template <int LDS_DEPTH>
-struct LdsStack {
-	uint2* lds; // this thread's column: entry d at lds[d * kBlockThreads]
-	static constexpr int kBlockThreads = 256;
-	uint32_t spillRef[kStackSize - LDS_DEPTH];
-	float spillT[kStackSize - LDS_DEPTH];
-	int n;
-	uint32_t topRef;
-	float topT;
-	bool hasTop;
-	bool overflow;
-	__device__ __forceinline__ void reset() {
-		n = 0;
-		hasTop = false;
-		overflow = false;
-	}
-	__device__ __forceinline__ void push(uint32_t r, float t) {
-		if (hasTop) {
-			if (n < LDS_DEPTH) {
-				lds[n * kBlockThreads] = make_uint2(topRef, __float_as_uint(topT));
-				++n;
-			} else if (n < kStackSize - 1) {
-				spillRef[n - LDS_DEPTH] = topRef;
-				spillT[n - LDS_DEPTH] = topT;
-				++n;
-			} else {
-				overflow = true;
-			}
-		}
-		topRef = r;
-		topT = t;
-		hasTop = true;
-	}
-	__device__ __forceinline__ bool pop(uint32_t& r, float& t) {
-		if (hasTop) {
-			r = topRef;
-			t = topT;
-			hasTop = false;
-			return true;
-		}
-		if (n == 0)
-			return false;
-		--n;
-		if (n < LDS_DEPTH) {
+		if (LDS_DEPTH > 0 && n < LDS_DEPTH) {
 			const uint2 e = lds[n * kBlockThreads];
 			r = e.x;
 			t = __uint_as_float(e.y);
@@ -315,6 +284,77 @@ __device__ __forceinline__ PairTest test_pair_fast(const float4* __restrict__ no
 		p.farT = -__builtin_inff();
 	}
 	return p;
+}
+
+
+// ---- quad nodes (128 B): a node and both its children in one fetch -----------------------------
+// Layout: host/bvh_layout.cpp.  One step tests the four GRANDCHILD boxes (or a leaf child in slot 0 /
+// 2 of its group) instead of child, then grandchild: half the dependent memory round trips.
+//
+// Exactness.  Boxes are exact unions (min/max) and rounding is monotone, so a child's slab interval
+// [tMin, tMax] is nested in its parent's: if the child passes Bbox.h:38-62 for some bound, so does the
+// parent for any bound at least as large.  Skipping the intermediate node's test therefore never
+// changes WHICH leaves are reached; and the order in which they are reached is still the reference's
+// depth-first order: group of the near child first (dirIsNeg[axis of the node], bvh.h:146-152), then
+// inside each group its near slot first (dirIsNeg[axis of that child]).  Every reached box is
+// re-checked against the current distance when popped, as for pair nodes.
+struct QuadHits { // in visit order
+	uint32_t ref[4];
+	float t[4];
+	bool hit[4];
+};
+
+__device__ __forceinline__ bool slab_any(const RayConst& r, bool regular, float lox, float hix, float loy, float hiy, float loz, float hiz, float lowest, float& tOut) {
+	if (regular)
+		return slab_fast(r, lox, hix, loy, hiy, loz, hiz, lowest, tOut);
+	return slab_test(r, r.nx ? hix : lox, r.nx ? lox : hix, r.ny ? hiy : loy, r.ny ? loy : hiy, r.nz ? hiz : loz, r.nz ? loz : hiz, lowest, tOut);
+}
+
+__device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, uint32_t idx, const RayConst& r, bool regular, float dist) {
+	const float4* q = quads + 8 * idx;
+	const float4 x01 = q[0], x23 = q[1], y01 = q[2], y23 = q[3], z01 = q[4], z23 = q[5], rf = q[6], mt = q[7];
+	const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
+	const uint32_t meta = __float_as_uint(mt.x);
+	float t0, t1, t2, t3;
+	bool h0 = slab_any(r, regular, x01.x, x01.y, y01.x, y01.y, z01.x, z01.y, dist, t0);
+	bool h1 = slab_any(r, regular, x01.z, x01.w, y01.z, y01.w, z01.z, z01.w, dist, t1);
+	bool h2 = slab_any(r, regular, x23.x, x23.y, y23.x, y23.y, z23.x, z23.y, dist, t2);
+	bool h3 = slab_any(r, regular, x23.z, x23.w, y23.z, y23.w, z23.z, z23.w, dist, t3);
+	const bool synthetic = (meta & 64u) != 0; // consecutive chunks of one over-long leaf: no box tests, slot order (bvh.h:131)
+	if (synthetic) {
+		h0 = h1 = h2 = h3 = true;
+		t0 = t1 = t2 = t3 = -__builtin_inff();
+	}
+	h0 = h0 && (r0 != kRefDone); // unused slots
+	h1 = h1 && (r1 != kRefDone);
+	h2 = h2 && (r2 != kRefDone);
+	h3 = h3 && (r3 != kRefDone);
+	const uint32_t aT = meta & 3u, aL = (meta >> 2) & 3u, aR = (meta >> 4) & 3u;
+	const bool bT = !synthetic && ((aT == 0) ? r.nx : (aT == 1) ? r.ny : r.nz);
+	const bool bL = !synthetic && ((aL == 0) ? r.nx : (aL == 1) ? r.ny : r.nz);
+	const bool bR = !synthetic && ((aR == 0) ? r.nx : (aR == 1) ? r.ny : r.nz);
+	// near slot first inside each group
+	const uint32_t lr0 = bL ? r1 : r0, lr1 = bL ? r0 : r1;
+	const float lt0 = bL ? t1 : t0, lt1 = bL ? t0 : t1;
+	const bool lh0 = bL ? h1 : h0, lh1 = bL ? h0 : h1;
+	const uint32_t rr0 = bR ? r3 : r2, rr1 = bR ? r2 : r3;
+	const float rt0 = bR ? t3 : t2, rt1 = bR ? t2 : t3;
+	const bool rh0 = bR ? h3 : h2, rh1 = bR ? h2 : h3;
+	// near group first
+	QuadHits o;
+	o.ref[0] = bT ? rr0 : lr0;
+	o.ref[1] = bT ? rr1 : lr1;
+	o.ref[2] = bT ? lr0 : rr0;
+	o.ref[3] = bT ? lr1 : rr1;
+	o.t[0] = bT ? rt0 : lt0;
+	o.t[1] = bT ? rt1 : lt1;
+	o.t[2] = bT ? lt0 : rt0;
+	o.t[3] = bT ? lt1 : rt1;
+	o.hit[0] = bT ? rh0 : lh0;
+	o.hit[1] = bT ? rh1 : lh1;
+	o.hit[2] = bT ? lh0 : rh0;
+	o.hit[3] = bT ? lh1 : rh1;
+	return o;
 }
 
 struct VisitCount {

@@ -3,6 +3,7 @@
 // layout documented in hip/traverse.hpp (64-byte child-pair nodes, 48-byte triangles).
 // The tree itself -- which primitive is in which leaf, which child is "first", every box --
 // is unchanged, so the traversal visit order of bvh.h:118-161 is preserved.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -153,6 +154,135 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 	std::memcpy(L.rootMax, nodes[0].bbox.bounds[1], 12);
 	L.rootRef = child_ref(0);
 	L.nPairs = static_cast<uint32_t>(L.pairNodes.size() / 16);
+
+	// ---- quad nodes: a node together with both its children, 128 B ------------------------------
+	// Slots 0,1 = the children of the node's LEFT child (or the left child itself in slot 0 when it is
+	// a leaf), slots 2,3 = the same for the RIGHT child.  Visit order is decided by three split axes:
+	// the node's (which group first) and each interior child's (which slot of the group first).
+	//   q0 = {s0.min.x, s0.max.x, s1.min.x, s1.max.x}   q1 = {s2.., s3..}   q2,q3 = y   q4,q5 = z
+	//   q6 = {ref0, ref1, ref2, ref3}                   q7 = {axisTop | axisL << 2 | axisR << 4 | synthetic << 6, 0, 0, 0}
+	L.quadNodes.clear();
+	L.nQuads = 0;
+	L.quadRootRef = kRefDone;
+	constexpr uint32_t kEmptyRef = kRefDone; // an unused slot
+	if (nodes[0].primitiveCount > 0) {
+		L.quadRootRef = L.rootRef; // single-leaf tree: same leaf reference (or pair-node chain for a long leaf, see below)
+	}
+	std::vector<uint32_t> quadIndex(static_cast<size_t>(nNodes), 0xFFFFFFFFu);
+	if (nodes[0].primitiveCount == 0) {
+		// pass 1: quad roots = the root and every interior grandchild of a quad root
+		std::vector<uint8_t> isRoot(static_cast<size_t>(nNodes), 0);
+		std::vector<int32_t> work{ 0 };
+		while (!work.empty()) {
+			const int32_t pi = work.back();
+			work.pop_back();
+			isRoot[static_cast<size_t>(pi)] = 1;
+			const int32_t kids[2] = { pi + 1, nodes[pi].offset };
+			for (int32_t x : kids) {
+				if (nodes[x].primitiveCount > 0)
+					continue;
+				const int32_t gk[2] = { x + 1, nodes[x].offset };
+				for (int32_t y : gk)
+					if (nodes[y].primitiveCount == 0)
+						work.push_back(y);
+			}
+		}
+		uint32_t nq = 0;
+		for (int32_t i = 0; i < nNodes; ++i)
+			if (isRoot[static_cast<size_t>(i)])
+				quadIndex[static_cast<size_t>(i)] = nq++; // depth-first array order
+		L.quadNodes.assign(static_cast<size_t>(nq) * 32, 0.0f);
+	}
+	auto quad_write = [&](uint32_t qi, const tyr_bbox* boxes /*4*/, const uint32_t* refs /*4*/, uint32_t meta) {
+		if (L.quadNodes.size() < (static_cast<size_t>(qi) + 1) * 32)
+			L.quadNodes.resize((static_cast<size_t>(qi) + 1) * 32, 0.0f);
+		float* q = &L.quadNodes[static_cast<size_t>(qi) * 32];
+		for (int k = 0; k < 3; ++k) {
+			for (int sidx = 0; sidx < 4; ++sidx) {
+				q[8 * k + 2 * sidx + 0] = boxes[sidx].bounds[0][k];
+				q[8 * k + 2 * sidx + 1] = boxes[sidx].bounds[1][k];
+			}
+		}
+		for (int sidx = 0; sidx < 4; ++sidx)
+			q[24 + sidx] = bits(refs[sidx]);
+		q[28] = bits(meta);
+		q[29] = q[30] = q[31] = 0.0f;
+	};
+	// an empty slot: a finite box no ray can enter in the tests, and a reference that marks it unused
+	tyr_bbox emptyBox;
+	for (int k = 0; k < 3; ++k) {
+		emptyBox.bounds[0][k] = 1e30f;
+		emptyBox.bounds[1][k] = 1e30f;
+	}
+	// leaf reference in the quad layout; leaves longer than kMaxLeafPrims become synthetic quads
+	// (bit 6 of meta) whose slots are consecutive chunks, visited in slot order without box tests
+	auto quad_leaf_ref = [&](const tyr_bvh_node& c) -> uint32_t {
+		uint32_t off = static_cast<uint32_t>(c.offset), cnt = c.primitiveCount;
+		if (cnt <= kMaxLeafPrims)
+			return leaf_ref(off, cnt);
+		// chunks back to front: the last quad of the chain holds up to 4 chunks, earlier ones 3 chunks + a link
+		std::vector<uint32_t> chunkRefs;
+		for (uint32_t o = 0; o < cnt; o += kMaxLeafPrims)
+			chunkRefs.push_back(leaf_ref(off + o, std::min<uint32_t>(kMaxLeafPrims, cnt - o)));
+		uint32_t link = kEmptyRef;
+		bool haveLink = false;
+		size_t end = chunkRefs.size();
+		while (end > 0) {
+			const size_t room = haveLink ? 3 : 4;
+			const size_t begin = end > room ? end - room : 0;
+			uint32_t refs[4] = { kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef };
+			tyr_bbox boxes[4] = { emptyBox, emptyBox, emptyBox, emptyBox };
+			size_t k = 0;
+			for (size_t i = begin; i < end; ++i, ++k) {
+				refs[k] = chunkRefs[i];
+				boxes[k] = c.bbox;
+			}
+			if (haveLink) {
+				refs[k] = link;
+				boxes[k] = c.bbox;
+			}
+			const uint32_t qi = static_cast<uint32_t>(L.quadNodes.size() / 32);
+			quad_write(qi, boxes, refs, 1u << 6);
+			link = qi;
+			haveLink = true;
+			end = begin;
+		}
+		return link;
+	};
+	if (nodes[0].primitiveCount > 0) {
+		L.quadRootRef = quad_leaf_ref(nodes[0]);
+	} else {
+		const uint32_t nRealQuads = static_cast<uint32_t>(L.quadNodes.size() / 32);
+		(void)nRealQuads;
+		for (int32_t pi = 0; pi < nNodes; ++pi) {
+			const uint32_t qi = quadIndex[static_cast<size_t>(pi)];
+			if (qi == 0xFFFFFFFFu)
+				continue;
+			const tyr_bvh_node& P = nodes[pi];
+			uint32_t refs[4] = { kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef };
+			tyr_bbox boxes[4] = { emptyBox, emptyBox, emptyBox, emptyBox };
+			uint32_t axes[2] = { 0, 0 };
+			const int32_t kids[2] = { pi + 1, P.offset };
+			for (int g = 0; g < 2; ++g) {
+				const tyr_bvh_node& X = nodes[kids[g]];
+				if (X.primitiveCount > 0) {
+					refs[2 * g] = quad_leaf_ref(X);
+					boxes[2 * g] = X.bbox;
+				} else {
+					axes[g] = X.splitAxis;
+					const int32_t gk[2] = { kids[g] + 1, X.offset };
+					for (int h = 0; h < 2; ++h) {
+						const tyr_bvh_node& Y = nodes[gk[h]];
+						refs[2 * g + h] = Y.primitiveCount > 0 ? quad_leaf_ref(Y) : quadIndex[static_cast<size_t>(gk[h])];
+						boxes[2 * g + h] = Y.bbox;
+					}
+				}
+			}
+			quad_write(qi, boxes, refs, static_cast<uint32_t>(P.splitAxis) | (axes[0] << 2) | (axes[1] << 4));
+		}
+		L.quadRootRef = 0;
+	}
+	L.nQuads = static_cast<uint32_t>(L.quadNodes.size() / 32);
 	return TYR_OK;
 }
 

@@ -42,6 +42,7 @@ struct tyr_ctx {
 	bool ownBlit = false;
 
 	float4* dNodes = nullptr;
+	float4* dQuads = nullptr;
 	float4* dTris = nullptr;
 	DevScene scene{};
 	bool haveScene = false;
@@ -171,6 +172,7 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.refillMinIdle = static_cast<uint32_t>(std::min(std::max(c->tuning.refillMinIdle, 1), 64));
 	P.minTraversing = static_cast<uint32_t>(std::min(std::max(c->tuning.minTraversing, 1), 64));
 	P.ticketChunk = static_cast<uint32_t>(std::min(std::max(c->tuning.ticketChunk, 64), 65536));
+	P.raysPerBlock = static_cast<uint32_t>(std::min(std::max(c->tuning.raysPerBlock, 256), 65536));
 	return P;
 }
 
@@ -376,6 +378,7 @@ int tyr_destroy(tyr_ctx* c) {
 	dev_free(c->scanDesc);
 	dev_free(c->dK);
 	dev_free(c->dNodes);
+	dev_free(c->dQuads);
 	dev_free(c->dTris);
 	if (c->ownBlit)
 		dev_free(c->blit);
@@ -401,6 +404,7 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 		return rc;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	dev_free(c->dNodes);
+	dev_free(c->dQuads);
 	dev_free(c->dTris);
 	c->scene = DevScene{};
 	c->scene.rootRef = kRefDone;
@@ -408,11 +412,16 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	if (L.rootRef == kRefDone)
 		return TYR_OK; // Scene.cpp:49-52
 	// at least one element so the pointers are never null
-	const size_t nodeFloats = std::max<size_t>(L.pairNodes.size(), 16), triFloats = L.tris.size();
-	if ((rc = dev_alloc(c->dNodes, nodeFloats / 4)) || (rc = dev_alloc(c->dTris, triFloats / 4)))
+	const size_t nodeFloats = std::max<size_t>(L.pairNodes.size(), 16), quadFloats = std::max<size_t>(L.quadNodes.size(), 32), triFloats = L.tris.size();
+	if ((rc = dev_alloc(c->dNodes, nodeFloats / 4)) || (rc = dev_alloc(c->dQuads, quadFloats / 4)) || (rc = dev_alloc(c->dTris, triFloats / 4)))
 		return rc;
 	if (!L.pairNodes.empty())
 		HIPCHK(hipMemcpy(c->dNodes, L.pairNodes.data(), L.pairNodes.size() * sizeof(float), hipMemcpyHostToDevice));
+	if (!L.quadNodes.empty())
+		HIPCHK(hipMemcpy(c->dQuads, L.quadNodes.data(), L.quadNodes.size() * sizeof(float), hipMemcpyHostToDevice));
+	c->scene.quads = c->dQuads;
+	c->scene.quadRootRef = L.quadRootRef;
+	c->scene.nQuads = L.nQuads;
 	HIPCHK(hipMemcpy(c->dTris, L.tris.data(), triFloats * sizeof(float), hipMemcpyHostToDevice));
 	c->scene.nodes = c->dNodes;
 	c->scene.tris = c->dTris;
@@ -812,7 +821,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		return TYR_ERR_INVALID;
 	switch (key) {
 	case TYR_TUNE_TRAVERSAL_VARIANT:
-		if (value < 0 || value > 2)
+		if (value < 0 || value > 3)
 			return TYR_ERR_INVALID;
 		c->tuning.traversalVariant = value;
 		return TYR_OK;
@@ -830,6 +839,11 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		if (value < 1 || value > 64)
 			return TYR_ERR_INVALID;
 		c->tuning.minTraversing = value;
+		return TYR_OK;
+	case TYR_TUNE_RAYS_PER_BLOCK:
+		if (value < 256 || value > 65536)
+			return TYR_ERR_INVALID;
+		c->tuning.raysPerBlock = value;
 		return TYR_OK;
 	case TYR_TUNE_TICKET_CHUNK:
 		if (value < 64 || value > 65536)

@@ -22,6 +22,9 @@ void triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out);
 // host/bvh_layout.cpp -- flat reference nodes -> device pair nodes + 48-byte triangles
 struct DeviceLayout {
 	std::vector<float> pairNodes; // 16 floats per pair node
+	std::vector<float> quadNodes; // 32 floats per quad node (hip/traverse.hpp "QuadNode")
+	uint32_t quadRootRef = 0;
+	uint32_t nQuads = 0;
 	std::vector<float> tris;      // 12 floats per triangle
 	float rootMin[3], rootMax[3];
 	uint32_t rootRef;
