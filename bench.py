@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--queue", type=int, default=2097152, help="ray_queue_buffer_size (variables.h:44)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=3)
+    ap.add_argument("--tune", action="append", default=[], help="launch-shape knob of tyr_set_tuning, e.g. --tune shade_tiles=2 (never changes results)")
     args = ap.parse_args()
 
     import numpy as np
@@ -94,6 +95,9 @@ def main():
     torch.cuda.synchronize()  # the library launches on its own stream
     r = binding.Renderer(W, H, N, device=local_rank, flags=flags, blit_buffer=accum.data_ptr(), **shard)
     r.load_scene(sc, nodes, prims)
+    tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune)}
+    if tune:
+        r.set_tuning(**tune)
 
     def step():
         r.reset_accum()
@@ -180,6 +184,7 @@ def main():
                 "extend_Mrays/s": round(ext_all / dt_all / 1e6, 3),
                 "shadow_Mrays/s": round(shd_all / dt_all / 1e6, 3),
                 "host_bvh_build_s": round(t_build, 3),
+                **({"tuning": tune} if tune else {}),
             },
             "roofline": {
                 "kernel": "k_extend",

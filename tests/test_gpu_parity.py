@@ -263,3 +263,4 @@ def test_every_traversal_variant_is_bit_exact(orc, hip, variant, lds):
             so, sg = o.shadow_queue(nh), g.shadow_queue(nh)
             assert so.tobytes() == sg.tobytes()
         assert_accum_close(o.blit_buffer(), g.blit_buffer(), f"{name} variant {variant}")
+

@@ -250,6 +250,8 @@ struct ShadeOut {
 	uint32_t flags;
 	f3 sOrigin, sDir, sColor;      // shadow ray
 	float sClosest;
+	f3 color;                      // kernel.cu:622-625: contribution to the pixel, added at the end of the kernel
+	int newFrame;
 };
 
 // NEE toward spheres[6], kernel.cu:419-447 / 559-590 (common part)
@@ -491,8 +493,16 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 		new_frame++;
 	}
 
-	// kernel.cu:622-625; adding +0 leaves the pixel unchanged, so zero terms are skipped
-	float* px = reinterpret_cast<float*>(&P.blit[pixel]);
+	out.color = color;
+	out.newFrame = new_frame;
+}
+
+// kernel.cu:622-625.  Adding +0 leaves the pixel unchanged, so zero terms are skipped (the reference's
+// own TODO at kernel.cu:621).  Called as the LAST thing the kernel does: vmcnt retires loads, stores and
+// atomics in issue order and __syncthreads() waits for vmcnt(0), so atomics issued before the compaction
+// barrier made every wave sit out its own scattered atomics (~3000 cycles each under load).
+__device__ __forceinline__ void accumulate_pixel(float4* blit, int pixel, f3 color, int new_frame) {
+	float* px = reinterpret_cast<float*>(&blit[pixel]);
 	if (color.x != 0.0f)
 		atomicAdd(px + 0, color.x);
 	if (color.y != 0.0f)
@@ -510,105 +520,122 @@ __device__ __forceinline__ unsigned long long desc_pack(uint32_t s, uint32_t h) 
 __device__ __forceinline__ uint32_t desc_s(unsigned long long d) { return (uint32_t)((d >> 31) & 0x7fffffffull); }
 __device__ __forceinline__ uint32_t desc_h(unsigned long long d) { return (uint32_t)(d & 0x7fffffffull); }
 
-__global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P) {
+// Tile order without a ticket.  The stable compaction needs every tile's predecessors to be running
+// (or done) while it looks back.  The first version drew a virtual tile id from an atomic counter at
+// block start -- 8192 returning atomics on one word per launch, ~0.2 ms of a 0.3 ms kernel (one word
+// serves ~88 of them per microsecond; measured by replacing the ticket: 0.30 -> 0.096 ms per launch).
+// Now the grid is small enough to be entirely co-resident (at most 4 blocks of 256 threads per CU) and
+// block b shades tiles b, b + G, b + 2G, ...: the predecessor of any tile belongs to a block that is
+// resident, whatever order the hardware dispatched them in, so the look-back cannot starve.
+__global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t nTiles) {
 	__shared__ uint32_t sh[16];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u, wave = tid >> 6;
-
-	// virtual block id in ticket order: every lower id has already started, so the look-back
-	// below can never wait on a block that is not running
-	if (tid == 0)
-		sh[0] = atomicAdd(&P.k->shade_ticket, 1u);
-	__syncthreads();
-	const uint32_t vb = sh[0];
-	const uint32_t slot = vb * kBlock + tid;
 	const uint32_t nLive = P.k->n_live;
-
-	ShadeOut out = {};
-	uint32_t pixelBits = 0;
-	if (slot < nLive) {
-		pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
-		shade_ray(P, slot, out);
-	}
-
-	// ---- stable compaction of survivors and shadow rays -------------------------------
-	const unsigned long long bs = __ballot(out.survive);
-	const unsigned long long bh = __ballot(out.shadow);
 	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t rs = __popcll(bs & below), rh = __popcll(bh & below);
-	__syncthreads(); // sh[0] has been read by everyone
-	if (lane == 0) {
-		sh[4 + wave] = __popcll(bs);
-		sh[8 + wave] = __popcll(bh);
-	}
-	__syncthreads();
-	uint32_t ws = 0, wh = 0, totS = 0, totH = 0;
+
+	for (uint32_t vb = blockIdx.x; vb < nTiles; vb += gridDim.x) { // vb = tile id = queue order
+		const uint32_t slot = vb * kBlock + tid;
+		ShadeOut out = {};
+		uint32_t pixelBits = 0;
+		if (slot < nLive) {
+			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
+			shade_ray(P, slot, out);
+		}
+
+		// ---- stable compaction of survivors and shadow rays -------------------------------
+		const unsigned long long bs = __ballot(out.survive);
+		const unsigned long long bh = __ballot(out.shadow);
+		const uint32_t rs = __popcll(bs & below), rh = __popcll(bh & below);
+		if (lane == 0) {
+			sh[4 + wave] = __popcll(bs);
+			sh[8 + wave] = __popcll(bh);
+		}
+		__syncthreads();
+		uint32_t ws = 0, wh = 0, totS = 0, totH = 0;
 #pragma unroll
-	for (uint32_t w = 0; w < kBlock / 64; ++w) {
-		const uint32_t cs = sh[4 + w], ch = sh[8 + w];
-		if (w < wave) {
-			ws += cs;
-			wh += ch;
-		}
-		totS += cs;
-		totH += ch;
-	}
-	if (tid == 0) {
-		uint32_t es = 0, eh = 0; // exclusive prefix over lower virtual blocks
-		if (vb == 0) {
-			__hip_atomic_store(&P.scanDesc[0], kDescInclusive | desc_pack(totS, totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		} else {
-			__hip_atomic_store(&P.scanDesc[vb], kDescAggregate | desc_pack(totS, totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			int j = (int)vb - 1;
-			bool timeout = false;
-			while (j >= 0) {
-				unsigned long long d = 0;
-				uint32_t spins = 0;
-				for (;;) {
-					d = __hip_atomic_load(&P.scanDesc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if (d >> 62)
-						break;
-					if (++spins > (1u << 24)) {
-						timeout = true;
-						break;
-					}
-					__builtin_amdgcn_s_sleep(2);
-				}
-				if (timeout)
-					break;
-				es += desc_s(d);
-				eh += desc_h(d);
-				if ((d >> 62) == 2ull)
-					break;
-				--j;
+		for (uint32_t w = 0; w < kBlock / 64; ++w) {
+			const uint32_t cs = sh[4 + w], ch = sh[8 + w];
+			if (w < wave) {
+				ws += cs;
+				wh += ch;
 			}
-			if (timeout)
-				atomicOr(&P.k->device_error, kErrScanTimeout);
-			__hip_atomic_store(&P.scanDesc[vb], kDescInclusive | desc_pack(es + totS, eh + totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			totS += cs;
+			totH += ch;
 		}
-		sh[1] = es;
-		sh[2] = eh;
-		if (vb == gridDim.x - 1) {
-			// kernel.cu:607 / 416: the totals the next top-up and connect read
-			P.k->primary_ray_cnt = es + totS;
-			P.k->shadow_ray_cnt = eh + totH;
-			P.k->total_shadow_rays += eh + totH;
-			P.k->n_survive += es + totS;
+		// Decoupled look-back, one WAVE wide: lane i inspects the descriptor of tile vb-1-i, so one memory
+		// round trip covers 64 predecessors.  Descriptor = 8 bytes {status, survivors, shadows} written by one
+		// relaxed agent-scope store: payload and flag travel together, no fence needed.
+		if (wave == 0) {
+			uint32_t es = 0, eh = 0; // exclusive prefix over lower tiles
+			if (vb > 0) {
+				if (lane == 0)
+					__hip_atomic_store(&P.scanDesc[vb], kDescAggregate | desc_pack(totS, totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				int base = (int)vb - 1; // nearest predecessor of this window
+				bool timeout = false;
+				for (;;) {
+					const int idx = base - (int)lane;
+					unsigned long long d = kDescInclusive; // below tile 0: an inclusive prefix of zero
+					if (idx >= 0) {
+						uint32_t spins = 0;
+						for (;;) {
+							d = __hip_atomic_load(&P.scanDesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							if (d >> 62)
+								break;
+							if (++spins > (1u << 22)) { // every wait is bounded: report, never hang
+								timeout = true;
+								d = kDescInclusive;
+								break;
+							}
+							__builtin_amdgcn_s_sleep(1);
+						}
+					}
+					const unsigned long long inclMask = __ballot((d >> 62) == 2ull);
+					// lanes up to and including the nearest inclusive descriptor contribute
+					const uint32_t stop = inclMask ? (uint32_t)__ffsll((long long)inclMask) - 1u : 63u;
+					unsigned long long v = (lane <= stop) ? (d & ~(3ull << 62)) : 0ull;
+#pragma unroll
+					for (int o = 32; o > 0; o >>= 1)
+						v += __shfl_xor(v, o, 64);
+					es += desc_s(v);
+					eh += desc_h(v);
+					if (inclMask)
+						break;
+					base -= 64;
+				}
+				if (__ballot(timeout) != 0ull && lane == 0)
+					atomicOr(&P.k->device_error, kErrScanTimeout);
+			}
+			if (lane == 0) {
+				__hip_atomic_store(&P.scanDesc[vb], kDescInclusive | desc_pack(es + totS, eh + totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				sh[1] = es;
+				sh[2] = eh;
+				if (vb == nTiles - 1) {
+					// kernel.cu:607 / 416: the totals the next top-up and connect read
+					P.k->primary_ray_cnt = es + totS;
+					P.k->shadow_ray_cnt = eh + totH;
+					P.k->total_shadow_rays += eh + totH;
+					P.k->n_survive += es + totS;
+				}
+			}
 		}
-	}
-	__syncthreads();
-	if (out.survive) {
-		const uint32_t dst = sh[1] + ws + rs; // kernel.cu:607-608, in slot order
-		P.next.o_dx[dst] = make_float4(out.origin.x, out.origin.y, out.origin.z, out.direction.x);
-		P.next.dyz[dst] = make_float2(out.direction.y, out.direction.z);
-		P.next.direct_ix[dst] = make_float4(out.direct.x, out.direct.y, out.direct.z, __uint_as_float(pixelBits));
-		P.next.flags[dst] = out.flags;
-	}
-	if (out.shadow) {
-		const uint32_t dst = sh[2] + wh + rh; // kernel.cu:416-417 etc., in slot order
-		P.shadow.o_dx[dst] = make_float4(out.sOrigin.x, out.sOrigin.y, out.sOrigin.z, out.sDir.x);
-		P.shadow.dyz_cd_ix[dst] = make_float4(out.sDir.y, out.sDir.z, out.sClosest, __uint_as_float(pixelBits));
-		P.shadow.color[dst] = make_float4(out.sColor.x, out.sColor.y, out.sColor.z, 0.0f);
+		__syncthreads();
+		if (out.survive) {
+			const uint32_t dst = sh[1] + ws + rs; // kernel.cu:607-608, in slot order
+			P.next.o_dx[dst] = make_float4(out.origin.x, out.origin.y, out.origin.z, out.direction.x);
+			P.next.dyz[dst] = make_float2(out.direction.y, out.direction.z);
+			P.next.direct_ix[dst] = make_float4(out.direct.x, out.direct.y, out.direct.z, __uint_as_float(pixelBits));
+			P.next.flags[dst] = out.flags;
+		}
+		if (out.shadow) {
+			const uint32_t dst = sh[2] + wh + rh; // kernel.cu:416-417 etc., in slot order
+			P.shadow.o_dx[dst] = make_float4(out.sOrigin.x, out.sOrigin.y, out.sOrigin.z, out.sDir.x);
+			P.shadow.dyz_cd_ix[dst] = make_float4(out.sDir.y, out.sDir.z, out.sClosest, __uint_as_float(pixelBits));
+			P.shadow.color[dst] = make_float4(out.sColor.x, out.sColor.y, out.sColor.z, 0.0f);
+		}
+		if (slot < nLive)
+			accumulate_pixel(P.blit, (int)pixelBits, out.color, out.newFrame);
+		__syncthreads(); // sh[] is rewritten by the next tile
 	}
 }
 
@@ -1338,13 +1365,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 			if (!occluded) { // kernel.cu:640-644
 				const float4 c = P.shadow.color[index];
 				const float4 b = P.shadow.dyz_cd_ix[index];
-				float* px = reinterpret_cast<float*>(&P.blit[__float_as_int(b.w)]);
-				if (c.x != 0.0f)
-					atomicAdd(px + 0, c.x);
-				if (c.y != 0.0f)
-					atomicAdd(px + 1, c.y);
-				if (c.z != 0.0f)
-					atomicAdd(px + 2, c.z);
+				accumulate_pixel(P.blit, __float_as_int(b.w), mk3(c.x, c.y, c.z), 0);
 				visible += 1;
 			}
 			overflow = overflow || st.overflow;
@@ -1360,6 +1381,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 	}
 }
 #undef TYR_DBG
+
 
 // ======================================================================================
 // blit_onto_framebuffer, kernel.cu:648-662 -> linear RGBA32F
@@ -1433,11 +1455,12 @@ static void launch_connect_t(const FrameParams& P, uint32_t maxShadow, const Tun
 	}
 	hipLaunchKernelGGL(k_connect_spheres, dim3(blocks_for(maxShadow)), dim3(kBlock), 0, stream, P);
 	const uint32_t flatBlocks = (maxShadow + P.raysPerBlock - 1) / P.raysPerBlock;
-	if (t.traversalVariant == 3 && !COUNT)
-		hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, true>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
-	else if (t.traversalVariant >= 2)
-		hipLaunchKernelGGL((k_connect_flat<COUNT, STACK_LDS, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
-	else
+	if (t.traversalVariant >= 2) {
+		if (t.traversalVariant == 3 && !COUNT)
+			hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, true>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+		else
+			hipLaunchKernelGGL((k_connect_flat<COUNT, STACK_LDS, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+	} else
 		hipLaunchKernelGGL((k_connect_persistent<COUNT, STACK_LDS>), dim3(persistent_blocks(k_connect_persistent<COUNT, STACK_LDS>, maxShadow, t, numCUs)), dim3(kBlock), 0, stream, P);
 }
 
@@ -1460,10 +1483,14 @@ void launch_extend(const FrameParams& P, uint32_t maxLive, bool countVisits, con
 		TYR_DISPATCH_STACK(launch_extend_t, false, P, maxLive, t, numCUs, stream)
 	}
 }
-void launch_shade(const FrameParams& P, uint32_t maxLive, hipStream_t stream) {
+void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, hipStream_t stream) {
 	if (maxLive == 0)
 		return;
-	hipLaunchKernelGGL(k_shade, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
+	const uint32_t nTiles = blocks_for(maxLive);
+	// at most 4 blocks of 256 threads per CU: k_shade needs ~70 VGPRs and 64 B of LDS, so the hardware admits
+	// twice that; the whole grid is resident and the look-back never waits on a block that cannot start
+	const uint32_t resident = 4u * (uint32_t)numCUs;
+	hipLaunchKernelGGL(k_shade, dim3(nTiles < resident ? nTiles : resident), dim3(kBlock), 0, stream, P, nTiles);
 }
 void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream) {
 	if (maxShadow == 0)

@@ -100,7 +100,7 @@ constexpr int kBlock = 256; // 4 wave64 per workgroup
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream);
 void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream);
 void launch_extend(const FrameParams& P, uint32_t maxLive, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream);
-void launch_shade(const FrameParams& P, uint32_t maxLive, hipStream_t stream);
+void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, hipStream_t stream);
 void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream);
 void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream);
 

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -252,7 +253,7 @@ void enqueue_primary(tyr_ctx* c, const FrameParams& P, uint32_t nNew, uint32_t n
 		KernelTimer t(c, TYR_K_PRIMARY);
 		launch_primary(P, nNew, c->stream);
 	}
-	launch_globals(P, (nLive + kBlock - 1) / kBlock, c->stream);
+	launch_globals(P, std::min<uint32_t>(c->nDescCap, (nLive + kBlock - 1) / kBlock + 8), c->stream);
 }
 void enqueue_extend(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	KernelTimer t(c, TYR_K_EXTEND);
@@ -260,7 +261,7 @@ void enqueue_extend(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 }
 void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	KernelTimer t(c, TYR_K_SHADE);
-	launch_shade(P, nLive, c->stream);
+	launch_shade(P, nLive, c->numCUs, c->stream);
 }
 void enqueue_connect(tyr_ctx* c, const FrameParams& P, uint32_t maxShadow) {
 	KernelTimer t(c, TYR_K_CONNECT);
@@ -347,7 +348,7 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		return fail(rc);
 	if ((rc = dev_alloc(c->shadow.o_dx, N)) || (rc = dev_alloc(c->shadow.dyz_cd_ix, N)) || (rc = dev_alloc(c->shadow.color, N)))
 		return fail(rc);
-	c->nDescCap = static_cast<uint32_t>((N + kBlock - 1) / kBlock);
+	c->nDescCap = static_cast<uint32_t>((N + kBlock - 1) / kBlock) + 8; // k_shade rounds the tile count up to its group size
 	if ((rc = dev_alloc(c->scanDesc, c->nDescCap)) || (rc = dev_alloc(c->dK, 1)))
 		return fail(rc);
 	if (hipHostMalloc(reinterpret_cast<void**>(&c->hK), sizeof(DevCounters), hipHostMallocDefault) != hipSuccess)
