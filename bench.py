@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--queue", type=int, default=2097152, help="ray_queue_buffer_size (variables.h:44)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearse the multi-rank path with every rank on one GPU (the reduce then goes through host memory)")
     ap.add_argument("--tune", action="append", default=[], help="launch-shape knob of tyr_set_tuning, e.g. --tune shade_tiles=2 (never changes results)")
     args = ap.parse_args()
 
@@ -81,8 +82,10 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = 0  # rehearsal: all ranks share device 0
     torch.cuda.set_device(local_rank)
-    dist = tdist.init_process_group("nccl") if world > 1 else None
+    dist = tdist.init_process_group(args.backend) if world > 1 else None
 
     W, H, N = args.width, args.height, args.queue
     spp_total = args.spp * world
@@ -103,7 +106,13 @@ def main():
         r.reset_accum()
         it = r.render(spp_total)
         if world > 1:
-            tdist.reduce_accum(accum, dst=0)
+            if args.backend == "gloo":
+                host = accum.cpu()
+                tdist.reduce_accum(host, dst=0)
+                if rank == 0:
+                    accum.copy_(host)
+            else:
+                tdist.reduce_accum(accum, dst=0)
         return it
 
     def fence():
@@ -139,7 +148,7 @@ def main():
 
     ext = k1["total_extend_rays"] - k0["total_extend_rays"]
     shd = k1["total_shadow_rays"] - k0["total_shadow_rays"]
-    stats = torch.tensor([float(ext), float(shd), dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+    stats = torch.tensor([float(ext), float(shd), dt], dtype=torch.float64, device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
     if world > 1:
         tmax = stats[2:3].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

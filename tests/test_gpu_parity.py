@@ -264,3 +264,24 @@ def test_every_traversal_variant_is_bit_exact(orc, hip, variant, lds):
             assert so.tobytes() == sg.tobytes()
         assert_accum_close(o.blit_buffer(), g.blit_buffer(), f"{name} variant {variant}")
 
+
+
+def test_bench_two_ranks_on_one_gpu(hip):
+    """bench.py's N > 1 path end to end on hardware: two ranks (gloo, both on device 0), rows dealt y % 2 == rank,
+    16 spp in total, reduce onto rank 0 -- bench.py itself asserts that every pixel of the reduced frame holds
+    exactly spp_total completed paths"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo", "--workload", "c1", "--width", "320", "--height", "180", "--queue", "32768", "--spp", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["spp_total"] == 4 and d["scaling"] == "weak" and d["value"] > 0

@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="c2")
 ap.add_argument("--iters", type=int, default=6, help="wavefront iterations to run before freezing the queues")
 ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--configs", default="0:16:0:0:32:128,2:16:0:12:32:128,3:16:0:12:32:128,3:16:0:16:32:128,3:16:0:8:32:128,3:8:0:12:32:128,3:32:0:12:32:128,3:16:0:12:16:128,3:16:0:12:48:128,3:16:0:12:32:64", help="variant:refill_min_idle:waves_per_simd:stack_lds_depth:min_traversing:ticket_chunk:rays_per_block,...")
+ap.add_argument("--configs", default="0:16:0:0:32:128,2:16:0:12:32:128,3:16:0:12:32:128,3:16:0:16:32:128,3:16:0:8:32:128,3:8:0:12:32:128,3:32:0:12:32:128,3:16:0:12:16:128,3:16:0:12:48:128,3:16:0:12:32:64", help="variant:refill_min_idle:waves_per_simd:stack_lds_depth:min_traversing:ticket_chunk:rays_per_block:min_leaves,...")
 args = ap.parse_args()
 
 sc = {"c1": scenes.cornell_box, "c2": lambda: scenes.cornell_soup(10000), "c3": lambda: scenes.mesh_scene(706)}[args.workload]()
@@ -54,7 +54,7 @@ for rep in range(args.reps):
         r.stage("connect")  # adds to the pixels again each time: harmless here
         t = r.timings()
         res[c]["connect"].append(t["connect"]["ms"])
-print(f"{'variant:refill:waves:lds:mintrav:chunk:rpb':>40s} {'extend ms (min / med)':>24s} {'connect ms (min / med)':>24s}")
+print(f"{'variant:refill:waves:lds:mintrav:chunk:rpb:minleaf':>40s} {'extend ms (min / med)':>24s} {'connect ms (min / med)':>24s}")
 for c in configs:
     e, cn = np.array(res[c]["extend"]), np.array(res[c]["connect"])
     print(f"{':'.join(map(str, c)):>40s} {e.min():10.3f} / {np.median(e):8.3f}   {cn.min():10.3f} / {np.median(cn):8.3f}", flush=True)

@@ -1138,11 +1138,17 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
 			if (nTrav == 0)
 				break;
-			if (nTrav < P.minTraversing) {
-				const bool leafPending = __ballot(ref_is_leaf(ref)) != 0ull;
-				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
-				if (leafPending || canRefill)
+			{
+				// leave the descent when enough lanes hold a leaf for the triangle tests to run wide, or when few
+				// lanes are still descending and there is anything else to do (leaves, or a refill)
+				const uint32_t nLeaf = __popcll(__ballot(ref_is_leaf(ref)));
+				if (nLeaf >= P.minLeaves)
 					break;
+				if (nTrav < P.minTraversing) {
+					const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
+					if (nLeaf > 0 || canRefill)
+						break;
+				}
 			}
 			if (ref == kRefPop) {
 				TYR_DBG(2)
@@ -1293,11 +1299,17 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
 			if (nTrav == 0)
 				break;
-			if (nTrav < P.minTraversing) {
-				const bool leafPending = __ballot(ref_is_leaf(ref)) != 0ull;
-				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
-				if (leafPending || canRefill)
+			{
+				// leave the descent when enough lanes hold a leaf for the triangle tests to run wide, or when few
+				// lanes are still descending and there is anything else to do (leaves, or a refill)
+				const uint32_t nLeaf = __popcll(__ballot(ref_is_leaf(ref)));
+				if (nLeaf >= P.minLeaves)
 					break;
+				if (nTrav < P.minTraversing) {
+					const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
+					if (nLeaf > 0 || canRefill)
+						break;
+				}
 			}
 			if (ref == kRefPop) {
 				uint32_t pr;

@@ -80,6 +80,7 @@ struct FrameParams {
 	uint32_t minTraversing;       // flat traversal: leave the descent loop below this many descending lanes
 	uint32_t ticketChunk;         // variant 1: queue slots a wave takes per global atomic
 	uint32_t raysPerBlock;        // variants 2/3: queue slots owned by one 256-thread block
+	uint32_t minLeaves;           // variants 2/3: leave the descent loop once this many lanes hold a leaf
 };
 
 // traversal kernel structure (tyr_set_tuning)
@@ -88,6 +89,7 @@ struct Tuning {
 	int minTraversing = 32;
 	int ticketChunk = 128;
 	int raysPerBlock = 512;
+	int minLeaves = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
 	int stackLdsDepth = 12;   // traversal-stack entries per lane kept in LDS (0, 8, 12, 16, 24); the rest spill to scratch

@@ -144,6 +144,16 @@ int push_counters(tyr_ctx* c) {
 	return TYR_OK;
 }
 
+// rays owned by one block of the flat traversal kernels: the tuned value while that still gives every CU
+// several blocks, smaller (down to one wave-load per wave) for the thin queues of the drain iterations
+uint32_t rays_per_block_for(const tyr_ctx* c, uint32_t nRays) {
+	uint32_t rpb = static_cast<uint32_t>(std::min(std::max(c->tuning.raysPerBlock, 256), 65536));
+	const uint64_t wanted = static_cast<uint64_t>(c->numCUs) * 8; // blocks needed to keep every CU busy with latency hidden
+	while (rpb > 256 && (nRays + rpb - 1) / rpb < wanted)
+		rpb /= 2;
+	return std::max<uint32_t>(rpb, 256);
+}
+
 FrameParams make_params(const tyr_ctx* c) {
 	FrameParams P{};
 	P.W = c->cfg.width;
@@ -174,6 +184,7 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.minTraversing = static_cast<uint32_t>(std::min(std::max(c->tuning.minTraversing, 1), 64));
 	P.ticketChunk = static_cast<uint32_t>(std::min(std::max(c->tuning.ticketChunk, 64), 65536));
 	P.raysPerBlock = static_cast<uint32_t>(std::min(std::max(c->tuning.raysPerBlock, 256), 65536));
+	P.minLeaves = static_cast<uint32_t>(std::min(std::max(c->tuning.minLeaves, 1), 64));
 	return P;
 }
 
@@ -255,16 +266,20 @@ void enqueue_primary(tyr_ctx* c, const FrameParams& P, uint32_t nNew, uint32_t n
 	}
 	launch_globals(P, std::min<uint32_t>(c->nDescCap, (nLive + kBlock - 1) / kBlock + 8), c->stream);
 }
-void enqueue_extend(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
+void enqueue_extend(tyr_ctx* c, const FrameParams& P0, uint32_t nLive) {
 	KernelTimer t(c, TYR_K_EXTEND);
+	FrameParams P = P0;
+	P.raysPerBlock = rays_per_block_for(c, nLive);
 	launch_extend(P, nLive, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->stream);
 }
 void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	KernelTimer t(c, TYR_K_SHADE);
 	launch_shade(P, nLive, c->numCUs, c->stream);
 }
-void enqueue_connect(tyr_ctx* c, const FrameParams& P, uint32_t maxShadow) {
+void enqueue_connect(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow) {
 	KernelTimer t(c, TYR_K_CONNECT);
+	FrameParams P = P0;
+	P.raysPerBlock = rays_per_block_for(c, maxShadow);
 	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->stream);
 }
 
@@ -845,6 +860,11 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		if (value < 256 || value > 65536)
 			return TYR_ERR_INVALID;
 		c->tuning.raysPerBlock = value;
+		return TYR_OK;
+	case TYR_TUNE_MIN_LEAVES:
+		if (value < 1 || value > 64)
+			return TYR_ERR_INVALID;
+		c->tuning.minLeaves = value;
 		return TYR_OK;
 	case TYR_TUNE_TICKET_CHUNK:
 		if (value < 64 || value > 65536)
