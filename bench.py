@@ -11,6 +11,12 @@ before the timed region starts; nothing crosses PCIe inside it except 120-byte c
 Workloads (BASELINE.json configs):
     c2  Cornell box + 10,000 seeded random diffuse triangles, 1920x1080, 8 spp     (default: configs[1])
     c3  room + 706x706 height-field mesh (996,882 triangles), 30 % SPEC, 1920x1080, 8 spp
+Queue size: the reference's ray_queue_buffer_size (2,097,152, variables.h:44) was chosen for a small
+GPU and forces 20 thin wavefront iterations per 8-spp frame.  It is a runtime parameter here, and the
+headline run sizes it for the GPU -- spp x pixels slots (16.6 M, 2.5 GB of 288 GB), i.e. every primary of
+the render in flight at once and 6 fat iterations.  The same workload at the reference's queue size is
+measured too and reported under config.reference_queue_size.
+
 At N GPUs the frame is pixel-sharded (rows y % N == rank) and rendered at 8*N spp, so each
 GPU traces what one GPU traces at N = 1: weak scaling (N = 8 is BASELINE config C4's 64 spp).
 
@@ -62,7 +68,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel per GPU (total spp = spp * gpus)")
-    ap.add_argument("--queue", type=int, default=2097152, help="ray_queue_buffer_size (variables.h:44)")
+    ap.add_argument("--queue", type=int, default=0, help="ray_queue_buffer_size (variables.h:44); 0 = sized for the GPU: spp x local pixels, i.e. every primary ray of the render in flight at once (16.6 M slots = 2.5 GB of the 288 GB)")
+    ap.add_argument("--no-reference-queue", action="store_true", help="skip the second measurement at the reference's queue size (2,097,152)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=3)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearse the multi-rank path with every rank on one GPU (the reduce then goes through host memory)")
@@ -87,80 +94,94 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = tdist.init_process_group(args.backend) if world > 1 else None
 
-    W, H, N = args.width, args.height, args.queue
+    W, H = args.width, args.height
     spp_total = args.spp * world
+    N = args.queue if args.queue > 0 else min(args.spp * W * H, 1 << 25)
     sc, nodes, prims, label, t_build = build_workload(args.workload, binding, scenes)
     flags = binding.TYR_FLAG_PROFILE | (binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0)
     shard = tdist.shard_spec(rank, world, H)
 
-    # the caller owns blit_buffer (main.cpp:129-130); here it is a torch tensor so RCCL can reduce it in place
-    accum = torch.zeros(H * W * 4, dtype=torch.float32, device=f"cuda:{local_rank}")
-    torch.cuda.synchronize()  # the library launches on its own stream
-    r = binding.Renderer(W, H, N, device=local_rank, flags=flags, blit_buffer=accum.data_ptr(), **shard)
-    r.load_scene(sc, nodes, prims)
+    def measure(N, steps, warmup):
+        """one renderer at queue size N: untimed counting render, warm-up, `steps` timed renders"""
+        # the caller owns blit_buffer (main.cpp:129-130); here it is a torch tensor so RCCL can reduce it in place
+        accum = torch.zeros(H * W * 4, dtype=torch.float32, device=f"cuda:{local_rank}")
+        torch.cuda.synchronize()  # the library launches on its own stream
+        r = binding.Renderer(W, H, N, device=local_rank, flags=flags, blit_buffer=accum.data_ptr(), **shard)
+        r.load_scene(sc, nodes, prims)
+        if tune:
+            r.set_tuning(**tune)
+
+        def step():
+            r.reset_accum()
+            it = r.render(spp_total)
+            if world > 1:
+                if args.backend == "gloo":
+                    host = accum.cpu()
+                    tdist.reduce_accum(host, dst=0)
+                    if rank == 0:
+                        accum.copy_(host)
+                else:
+                    tdist.reduce_accum(accum, dst=0)
+            return it
+
+        def fence():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        # untimed: nodes / triangles per ray from the counting build of the same kernels (one render, this rank's shard)
+        rc = binding.Renderer(W, H, N, device=local_rank, flags=flags | binding.TYR_FLAG_COUNT_VISITS, **shard)
+        rc.load_scene(sc, nodes, prims)
+        rc.render(spp_total)
+        kc = rc.counters()
+        visits = {
+            "nodes_per_ext": kc["nodes_extend"] / max(kc["total_extend_rays"], 1),
+            "tris_per_ext": kc["tris_extend"] / max(kc["total_extend_rays"], 1),
+            "nodes_per_con": kc["nodes_connect"] / max(kc["total_shadow_rays"], 1),
+            "tris_per_con": kc["tris_connect"] / max(kc["total_shadow_rays"], 1),
+        }
+        rc.close()
+
+        for _ in range(warmup):
+            step()
+        fence()
+        k0 = r.counters()
+        r.timings(reset=True)
+        t0 = time.perf_counter()
+        iters = 0
+        for _ in range(steps):
+            iters += step()
+        fence()
+        dt = time.perf_counter() - t0
+        k1 = r.counters()
+        tm = r.timings()
+        assert k1["device_error"] == 0, k1
+        ext = k1["total_extend_rays"] - k0["total_extend_rays"]
+        shd = k1["total_shadow_rays"] - k0["total_shadow_rays"]
+        stats = torch.tensor([float(ext), float(shd), dt], dtype=torch.float64, device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
+        if world > 1:
+            tmax = stats[2:3].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(stats[0:2], op=dist.ReduceOp.SUM)
+            stats[2] = tmax[0]
+        ext_all, shd_all, dt_all = (float(x) for x in stats.tolist())
+        if rank == 0:
+            # sanity of the reduced frame: every pixel has exactly spp_total completed paths
+            a = accum.view(H * W, 4)[:, 3]
+            assert float(a.min()) == float(a.max()) == float(spp_total), (float(a.min()), float(a.max()), spp_total)
+        r.close()
+        return {"ext": ext, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, **visits}
+
     tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune)}
-    if tune:
-        r.set_tuning(**tune)
-
-    def step():
-        r.reset_accum()
-        it = r.render(spp_total)
-        if world > 1:
-            if args.backend == "gloo":
-                host = accum.cpu()
-                tdist.reduce_accum(host, dst=0)
-                if rank == 0:
-                    accum.copy_(host)
-            else:
-                tdist.reduce_accum(accum, dst=0)
-        return it
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # untimed: nodes / triangles per ray from the counting build of the same kernels (one render, rank 0's shard)
-    rc = binding.Renderer(W, H, N, device=local_rank, flags=flags | binding.TYR_FLAG_COUNT_VISITS, **shard)
-    rc.load_scene(sc, nodes, prims)
-    rc.render(spp_total)
-    kc = rc.counters()
-    nodes_per_ext = kc["nodes_extend"] / max(kc["total_extend_rays"], 1)
-    tris_per_ext = kc["tris_extend"] / max(kc["total_extend_rays"], 1)
-    nodes_per_con = kc["nodes_connect"] / max(kc["total_shadow_rays"], 1)
-    tris_per_con = kc["tris_connect"] / max(kc["total_shadow_rays"], 1)
-    rc.close()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    k0 = r.counters()
-    r.timings(reset=True)
-    t0 = time.perf_counter()
-    iters = 0
-    for _ in range(args.steps):
-        iters += step()
-    fence()
-    dt = time.perf_counter() - t0
-    k1 = r.counters()
-    tm = r.timings()
-    assert k1["device_error"] == 0, k1
-
-    ext = k1["total_extend_rays"] - k0["total_extend_rays"]
-    shd = k1["total_shadow_rays"] - k0["total_shadow_rays"]
-    stats = torch.tensor([float(ext), float(shd), dt], dtype=torch.float64, device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
-    if world > 1:
-        tmax = stats[2:3].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats[0:2], op=dist.ReduceOp.SUM)
-        stats[2] = tmax[0]
-    ext_all, shd_all, dt_all = (float(x) for x in stats.tolist())
+    m = measure(N, args.steps, args.warmup)
+    ext, ext_all, shd_all, dt_all, iters, tm = m["ext"], m["ext_all"], m["shd_all"], m["dt_all"], m["iters"], m["tm"]
+    nodes_per_ext, tris_per_ext, nodes_per_con, tris_per_con = m["nodes_per_ext"], m["tris_per_ext"], m["nodes_per_con"], m["tris_per_con"]
+    REF_N = 2097152  # variables.h:44
+    mref = None
+    if not args.no_reference_queue and N != REF_N:
+        mref = measure(REF_N, max(1, min(args.steps, 2)), 1)
 
     if rank == 0:
-        # sanity of the reduced frame: every pixel has exactly spp_total completed paths
-        a = accum.view(H * W, 4)[:, 3]
-        assert float(a.min()) == float(a.max()) == float(spp_total), (float(a.min()), float(a.max()), spp_total)
-
         mrays = (ext_all + shd_all) / dt_all / 1e6
         # roofline of the dominant kernel (extend), this rank's launches inside the timed region
         bytes_per_ext = 24 + 8 + 32 * nodes_per_ext + 36 * tris_per_ext
@@ -194,6 +215,18 @@ def main():
                 "shadow_Mrays/s": round(shd_all / dt_all / 1e6, 3),
                 "host_bvh_build_s": round(t_build, 3),
                 **({"tuning": tune} if tune else {}),
+                **(
+                    {
+                        "reference_queue_size": {
+                            "queue_size": REF_N,
+                            "Mrays/s": round((mref["ext_all"] + mref["shd_all"]) / mref["dt_all"] / 1e6, 3),
+                            "wavefront_iterations_per_step": mref["iters"] / max(1, min(args.steps, 2)),
+                            "extend_avg_launch_ms": round(mref["tm"]["extend"]["ms"] / max(mref["tm"]["extend"]["launches"], 1), 4),
+                        }
+                    }
+                    if mref
+                    else {}
+                ),
             },
             "roofline": {
                 "kernel": "k_extend",
@@ -214,9 +247,8 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, W, H, N, args.cpu_iterations, sc.triangle_materials)
+            out["cpu_baseline"] = cpu_baseline(sc, W, H, N, args.cpu_iterations if N <= 4 * REF_N else 1, sc.triangle_materials)
         print(json.dumps(out), flush=True)
-    r.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

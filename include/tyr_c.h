@@ -226,7 +226,7 @@ enum {
 	TYR_TUNE_MIN_TRAVERSING = 4,    /* variant 2: leave the descent loop when fewer lanes than this are descending and leaves / refills are pending (1..64, default 32) */
 	TYR_TUNE_TICKET_CHUNK = 5,      /* variant 1: queue slots a wave reserves per global atomic (64..65536, default 128) */
 	TYR_TUNE_MIN_LEAVES = 7,        /* variants 2/3: also leave the descent loop once this many lanes hold a leaf, so triangle tests run wide (1..64) */
-	TYR_TUNE_RAYS_PER_BLOCK = 6     /* variants 2/3: queue slots owned by one 256-thread block and handed to its free lanes through LDS (256..65536, default 512) */
+	TYR_TUNE_RAYS_PER_BLOCK = 6     /* variants 2/3: queue slots owned by one 256-thread block and handed to its free lanes through LDS (256..65536, default 1024; halved automatically for thin queues) */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);
 

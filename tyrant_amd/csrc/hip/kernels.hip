@@ -1072,7 +1072,8 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 	const uint32_t nLive = P.k->n_live;
 	const DevScene& sc = P.scene;
 	RayConst r = {};
-	bool regular = true;
+	bool regular = true;      // this lane's ray has a finite 1/d in all three components
+	bool allRegular = true;   // ... and so has every live ray of the wave (wave-uniform; refreshed at refills)
 	float dist = 0.0f;
 	uint32_t ref = kRefDone, slot = 0;
 	int prim = 0;
@@ -1133,6 +1134,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 				break;
 			continue;
 		}
+		allRegular = (__ballot(live && !regular) == 0ull);
 		// ---- descent: one pop attempt + one pair test per lane per trip ----
 		for (;;) {
 			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
@@ -1164,7 +1166,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 			if ((int)ref >= 0) {
 				TYR_DBG(0)
 				if (QUAD) {
-					const QuadHits q = test_quad(sc.quads, ref, r, regular, dist);
+					const QuadHits q = allRegular ? test_quad<true, true>(sc.quads, ref, r, dist) : test_quad<false, true>(sc.quads, ref, r, dist);
 					// the earliest hit in visit order is entered now, the later ones are pushed latest first
 					uint32_t cur = kRefPop;
 					float curT = 0.0f;
@@ -1179,7 +1181,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 					}
 					ref = cur;
 				} else {
-					const PairTest p = regular ? test_pair_fast(sc.nodes, ref, r, dist) : test_pair(sc.nodes, ref, r, dist);
+					const PairTest p = allRegular ? test_pair_fast(sc.nodes, ref, r, dist) : test_pair(sc.nodes, ref, r, dist);
 					if (COUNT && !p.synthetic)
 						vc.nodes += 2;
 					if (p.nearHit) {
@@ -1239,7 +1241,8 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 	const DevScene& sc = P.scene;
 	const bool haveBvh = (sc.rootRef != kRefDone);
 	RayConst r = {};
-	bool regular = true;
+	bool regular = true;      // this lane's ray has a finite 1/d in all three components
+	bool allRegular = true;   // ... and so has every live ray of the wave (wave-uniform; refreshed at refills)
 	float closest = 0.0f;
 	uint32_t ref = kRefDone, index = 0;
 	bool live = false, occluded = false, overflow = false;
@@ -1295,6 +1298,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 				break;
 			continue;
 		}
+		allRegular = (__ballot(live && !regular) == 0ull);
 		for (;;) {
 			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
 			if (nTrav == 0)
@@ -1325,7 +1329,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 			}
 			if ((int)ref >= 0) {
 				if (QUAD) {
-					const QuadHits q = test_quad(sc.quads, ref, r, regular, closest);
+					const QuadHits q = allRegular ? test_quad<true, false>(sc.quads, ref, r, closest) : test_quad<false, false>(sc.quads, ref, r, closest);
 					uint32_t cur = kRefPop;
 					float curT = 0.0f;
 #pragma unroll
@@ -1340,7 +1344,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 					ref = cur;
 					continue;
 				}
-				const PairTest p = regular ? test_pair_fast(sc.nodes, ref, r, closest) : test_pair(sc.nodes, ref, r, closest);
+				const PairTest p = allRegular ? test_pair_fast(sc.nodes, ref, r, closest) : test_pair(sc.nodes, ref, r, closest);
 				if (COUNT && !p.synthetic) {
 					vc.nodes += 1;
 					st.push(p.farRef, p.farHit ? p.farT : kFailed);

@@ -88,7 +88,7 @@ struct Tuning {
 	int traversalVariant = 3; // 0 = one thread per queue slot, 1 = persistent waves with lane refill, 2 = 1 + flat state machine, 3 = 2 on quad nodes
 	int minTraversing = 32;
 	int ticketChunk = 128;
-	int raysPerBlock = 512;
+	int raysPerBlock = 1024;
 	int minLeaves = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits

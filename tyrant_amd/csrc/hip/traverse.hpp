@@ -304,22 +304,27 @@ struct QuadHits { // in visit order
 	bool hit[4];
 };
 
-__device__ __forceinline__ bool slab_any(const RayConst& r, bool regular, float lox, float hix, float loy, float hiy, float loz, float hiz, float lowest, float& tOut) {
-	if (regular)
+template <bool FAST>
+__device__ __forceinline__ bool slab_any(const RayConst& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float lowest, float& tOut) {
+	if (FAST)
 		return slab_fast(r, lox, hix, loy, hiy, loz, hiz, lowest, tOut);
 	return slab_test(r, r.nx ? hix : lox, r.nx ? lox : hix, r.ny ? hiy : loy, r.ny ? loy : hiy, r.nz ? hiz : loz, r.nz ? loz : hiz, lowest, tOut);
 }
 
-__device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, uint32_t idx, const RayConst& r, bool regular, float dist) {
+// FAST: every lane of the wave has a finite 1/d (the caller decides once per wave, not per box: a
+// per-lane choice made the compiler emit both paths with exec juggling around each of the four tests).
+// ORDERED: closest-hit needs the reference's visit order; any-hit (bvh.h:213-256) does not depend on it.
+template <bool FAST, bool ORDERED>
+__device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, uint32_t idx, const RayConst& r, float dist) {
 	const float4* q = quads + 8 * idx;
 	const float4 x01 = q[0], x23 = q[1], y01 = q[2], y23 = q[3], z01 = q[4], z23 = q[5], rf = q[6], mt = q[7];
 	const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
 	const uint32_t meta = __float_as_uint(mt.x);
 	float t0, t1, t2, t3;
-	bool h0 = slab_any(r, regular, x01.x, x01.y, y01.x, y01.y, z01.x, z01.y, dist, t0);
-	bool h1 = slab_any(r, regular, x01.z, x01.w, y01.z, y01.w, z01.z, z01.w, dist, t1);
-	bool h2 = slab_any(r, regular, x23.x, x23.y, y23.x, y23.y, z23.x, z23.y, dist, t2);
-	bool h3 = slab_any(r, regular, x23.z, x23.w, y23.z, y23.w, z23.z, z23.w, dist, t3);
+	bool h0 = slab_any<FAST>(r, x01.x, x01.y, y01.x, y01.y, z01.x, z01.y, dist, t0);
+	bool h1 = slab_any<FAST>(r, x01.z, x01.w, y01.z, y01.w, z01.z, z01.w, dist, t1);
+	bool h2 = slab_any<FAST>(r, x23.x, x23.y, y23.x, y23.y, z23.x, z23.y, dist, t2);
+	bool h3 = slab_any<FAST>(r, x23.z, x23.w, y23.z, y23.w, z23.z, z23.w, dist, t3);
 	const bool synthetic = (meta & 64u) != 0; // consecutive chunks of one over-long leaf: no box tests, slot order (bvh.h:131)
 	if (synthetic) {
 		h0 = h1 = h2 = h3 = true;
@@ -329,6 +334,13 @@ __device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, 
 	h1 = h1 && (r1 != kRefDone);
 	h2 = h2 && (r2 != kRefDone);
 	h3 = h3 && (r3 != kRefDone);
+	if (!ORDERED) {
+		QuadHits o;
+		o.ref[0] = r0, o.ref[1] = r1, o.ref[2] = r2, o.ref[3] = r3;
+		o.t[0] = t0, o.t[1] = t1, o.t[2] = t2, o.t[3] = t3;
+		o.hit[0] = h0, o.hit[1] = h1, o.hit[2] = h2, o.hit[3] = h3;
+		return o;
+	}
 	const uint32_t aT = meta & 3u, aL = (meta >> 2) & 3u, aR = (meta >> 4) & 3u;
 	const bool bT = !synthetic && ((aT == 0) ? r.nx : (aT == 1) ? r.ny : r.nz);
 	const bool bL = !synthetic && ((aL == 0) ? r.nx : (aL == 1) ? r.ny : r.nz);
