@@ -188,6 +188,18 @@ def main():
         ext_ms, ext_launches = tm["extend"]["ms"], max(tm["extend"]["launches"], 1)
         bytes_per_launch = bytes_per_ext * ext / ext_launches
         achieved = (bytes_per_launch / (ext_ms / ext_launches * 1e-3)) / 1e9 if ext_ms > 0 else 0.0
+        # HBM bytes per extend launch from rocprofv3 PMC passes of this same command (tools/pmc_traffic.sh); bench.py
+        # cannot run under a profiler itself, so the committed measurement is attached when it matches the run
+        traffic, traffic_detail = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")) as f:
+                tj = json.load(f)
+            if tj["queue_size"] == N and world == 1:
+                # same unit as `achieved`: bytes per launch / average launch duration
+                traffic = round(tj["hbm_bytes_per_launch_corrected"] / (ext_ms / ext_launches * 1e-3) / 1e9, 2)
+                traffic_detail = {"hbm_bytes_per_launch": round(tj["hbm_bytes_per_launch_corrected"]), "algorithmic_bytes_per_launch": round(bytes_per_launch), "source": tj["source"]}
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "Mrays/s at 1080p 8spp",
             "value": round(mrays, 3),
@@ -235,7 +247,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_detail": traffic_detail,
                 "algorithmic_bytes_per_ray": round(bytes_per_ext, 1),
                 "nodes_per_ray": round(nodes_per_ext, 2),
                 "tris_per_ray": round(tris_per_ext, 3),
