@@ -239,6 +239,16 @@ int tyr_set_tuning(tyr_ctx* ctx, int key, int value);
 int tyr_bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo);
 /* Scene.cpp:22-33: per-face bounding boxes */
 int tyr_triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out);
+/* The import half of Scene::Load (Scene.cpp:3-47, static_mesh.cpp:3-32) for PLY files (ASCII or binary
+ * little-endian): first mesh, polygons triangulated as fans (aiProcess_Triangulate), one
+ * Triangle{vert, e1, e2} per face; the y/z exchange of static_mesh.cpp:17 and its undo at Scene.cpp:10 cancel.
+ * Returns the triangle count (>= 0) or a negative status; *prims_out is malloc'ed, release it with tyr_free. */
+int tyr_load_ply(const char* path, tyr_triangle** prims_out);
+void tyr_free(void* p);
+/* Export of the frame tyr_resolve produced (host copy, float4 per pixel), in place of the GL blit (interop.cpp:50):
+ * 8-bit binary PPM of the tonemapped colours, or a float PFM. */
+int tyr_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t height);
+int tyr_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height);
 /* Camera::update, camera.cpp:46-52 */
 int tyr_camera_update(double horizontal_angle, double vertical_angle, float direction_out[3]);
 /* the reference's hard-wired sphere table, kernel.cu:674-680 */

@@ -3,6 +3,8 @@
 // import of its first half is a "next" row, so triangles are handed in.
 #pragma once
 #include <iostream>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "bvh.h"
@@ -13,6 +15,25 @@ public:
 	struct GPUScene {
 		CachedBVH CUDACachedBVH; // the reference's member name, Scene.h:6
 	} gpuScene;
+
+	// Scene::Load(path), Scene.cpp:3: PLY files through tyr_load_ply (first mesh, fan triangulation)
+	void Load(tyr_ctx* ctx, const char path[]) {
+		std::cout << "Loading scene:" << path << "\n"; // Scene.cpp:7
+		tyr_triangle* t = nullptr;
+		const int n = tyr_load_ply(path, &t);
+		if (n < 0)
+			throw std::runtime_error(std::string("Scene::Load: ") + tyr_status_string(n));
+		std::vector<vec3> v;
+		v.reserve(static_cast<size_t>(n) * 3);
+		for (int i = 0; i < n; ++i) {
+			const vec3 a = { t[i].vert[0], t[i].vert[1], t[i].vert[2] };
+			v.push_back(a);
+			v.push_back({ a.x + t[i].e1[0], a.y + t[i].e1[1], a.z + t[i].e1[2] });
+			v.push_back({ a.x + t[i].e2[0], a.y + t[i].e2[1], a.z + t[i].e2[2] });
+		}
+		tyr_free(t);
+		Load(ctx, v);
+	}
 
 	// vertices are {v0, v1, v2} per face, as Scene.cpp:25-27 reads them from the mesh
 	void Load(tyr_ctx* ctx, const std::vector<vec3>& faceVertices) {

@@ -1,0 +1,116 @@
+"""PLY import with Scene::Load's conventions and image export.  CPU only."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+CUBE_PLY = """ply
+format ascii 1.0           { ascii/binary, format version number }
+comment made by anonymous  { comments are keyword specified }
+element vertex 8           { define "vertex" element, 8 in file }
+property float32 x         { vertex contains float "x" coordinate }
+property float32 y
+property float32 z
+element face 6             { there are 6 "face" elements in the file }
+property list uint8 int32 vertex_index
+                           { "vertex_indices" is a list of ints }
+end_header                 { delimits the end of the header }
+0 0 0                      { start of vertex list }
+0 0 1
+0 1 1
+0 1 0
+1 0 0
+1 0 1
+1 1 1
+1 1 0
+4 0 1 2 3                  { start of face list }
+4 7 6 5 4
+4 0 4 5 1
+4 1 5 6 2
+4 2 6 7 3
+4 3 7 4 0
+some trailing text
+after the face list
+"""
+
+
+def test_ascii_ply_with_annotations_quads_and_trailing_text(hip, tmp_path):
+    """the layout of the reference's Data/cube.ply: { } annotations in header AND data, quads, junk after the faces"""
+    p = tmp_path / "cube.ply"
+    p.write_text(CUBE_PLY)
+    t = hip.load_ply(str(p))
+    assert t.shape[0] == 12  # 6 quads -> fans of 2 (aiProcess_Triangulate, Scene.cpp:4-5)
+    v = np.array([[0, 0, 0], [0, 0, 1], [0, 1, 1], [0, 1, 0], [1, 0, 0], [1, 0, 1], [1, 1, 1], [1, 1, 0]], dtype=np.float32)
+    # first quad 0 1 2 3 -> (0,1,2), (0,2,3); Triangle = {v0, v1 - v0, v2 - v0} (Scene.cpp:39-45); y/z swaps cancel
+    assert np.array_equal(t["vert"][0], v[0]) and np.array_equal(t["e1"][0], v[1] - v[0]) and np.array_equal(t["e2"][0], v[2] - v[0])
+    assert np.array_equal(t["vert"][1], v[0]) and np.array_equal(t["e1"][1], v[2] - v[0]) and np.array_equal(t["e2"][1], v[3] - v[0])
+    assert np.all(t["materialType"] == 0)
+    # the loaded mesh goes straight into the builder
+    nodes, prims = hip.bvh_build(t)
+    assert nodes[nodes["primitiveCount"] > 0]["primitiveCount"].sum() == 12
+
+
+def test_binary_ply_with_extra_properties(hip, tmp_path):
+    """binary little-endian, normals + uv after the position (the property set of Data/dragon.ply), triangles"""
+    rng = np.random.default_rng(4)
+    nv, nf = 50, 80
+    verts = rng.uniform(-5, 5, size=(nv, 8)).astype(np.float32)
+    faces = rng.integers(0, nv, size=(nf, 3)).astype(np.uint32)
+    hdr = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % nv
+    hdr += "".join(f"property float {n}\n" for n in ("x", "y", "z", "nx", "ny", "nz", "s", "t"))
+    hdr += "element face %d\nproperty list uchar uint vertex_indices\nend_header\n" % nf
+    p = tmp_path / "mesh.ply"
+    with open(p, "wb") as f:
+        f.write(hdr.encode())
+        f.write(verts.tobytes())
+        for tri in faces:
+            f.write(struct.pack("<B3I", 3, *tri))
+    t = hip.load_ply(str(p))
+    assert t.shape[0] == nf
+    assert np.array_equal(t["vert"], verts[faces[:, 0], :3])
+    assert np.array_equal(t["e1"], verts[faces[:, 1], :3] - verts[faces[:, 0], :3])
+    assert np.array_equal(t["e2"], verts[faces[:, 2], :3] - verts[faces[:, 0], :3])
+
+
+def test_ply_errors(hip, tmp_path):
+    with pytest.raises(hip.TyrError):
+        hip.load_ply(str(tmp_path / "missing.ply"))
+    bad = tmp_path / "bad.ply"
+    bad.write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n3 0 1 2\n")
+    with pytest.raises(hip.TyrError):  # face index out of range
+        hip.load_ply(str(bad))
+    notply = tmp_path / "x.ply"
+    notply.write_text("solid\n")
+    with pytest.raises(hip.TyrError):
+        hip.load_ply(str(notply))
+
+
+def test_reference_dragon_if_present(hip):
+    """Data/dragon.ply of the reference checkout (only in the authoring container): 22,126 vertices, 37,986 triangles"""
+    path = "/root/reference/PathTracer/Data/dragon.ply"
+    if not os.path.exists(path):
+        pytest.skip("reference data not present on this machine")
+    t = hip.load_ply(path)
+    assert t.shape[0] == 37986 and np.all(np.isfinite(t["vert"]))
+    nodes, prims = hip.bvh_build(t)
+    assert nodes[nodes["primitiveCount"] > 0]["primitiveCount"].sum() == 37986
+
+
+def test_image_export(hip, tmp_path):
+    W, H = 5, 3
+    img = np.zeros((H * W, 4), dtype=np.float32)
+    img[:, 0] = np.linspace(0, 1, H * W)
+    img[:, 1] = 0.5
+    img[3, 2] = np.nan  # a pixel without a completed path resolves to NaN (0/0, kernel.cu:658)
+    hip.write_image(str(tmp_path / "a.ppm"), img, W, H)
+    raw = (tmp_path / "a.ppm").read_bytes()
+    assert raw.startswith(b"P6 5 3 255\n") and len(raw) == len(b"P6 5 3 255\n") + W * H * 3
+    px = np.frombuffer(raw[len(b"P6 5 3 255\n"):], dtype=np.uint8).reshape(H * W, 3)
+    assert px[0, 0] == 0 and px[-1, 0] == 255 and np.all(px[:, 1] == 128) and px[3, 2] == 0
+    hip.write_image(str(tmp_path / "a.pfm"), img, W, H)
+    raw = (tmp_path / "a.pfm").read_bytes()
+    head = b"PF\n5 3\n-1.0\n"
+    assert raw.startswith(head)
+    data = np.frombuffer(raw[len(head):], dtype="<f4").reshape(H, W, 3)
+    assert np.array_equal(data[::-1, :, 0].reshape(-1), img[:, 0])  # bottom-up rows

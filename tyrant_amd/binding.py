@@ -112,6 +112,10 @@ SYMBOLS = {
     "tyr_bvh_build": (C.c_int, [P, c_i32, P, P, c_i32]),
     "tyr_triangle_bboxes": (C.c_int, [P, c_i32, P]),
     "tyr_camera_update": (C.c_int, [C.c_double, C.c_double, C.POINTER(c_f)]),
+    "tyr_load_ply": (C.c_int, [C.c_char_p, C.POINTER(P)]),
+    "tyr_free": (None, [P]),
+    "tyr_write_ppm": (C.c_int, [C.c_char_p, P, c_u32, c_u32]),
+    "tyr_write_pfm": (C.c_int, [C.c_char_p, P, c_u32, c_u32]),
     "tyr_default_spheres": (C.c_int, [P]),
 }
 
@@ -166,6 +170,28 @@ def bvh_build(tris: np.ndarray, bboxes: np.ndarray | None = None, algo: int = 2)
     if nn < 0:
         raise TyrError(nn, "tyr_bvh_build")
     return nodes[:nn].copy(), prims
+
+
+def load_ply(path: str) -> np.ndarray:
+    """Scene::Load's import half for a PLY file: TRIANGLE_DTYPE array (Scene.cpp:3-47)"""
+    out = P()
+    n = lib().tyr_load_ply(os.fsencode(path), C.byref(out))
+    if n < 0:
+        raise TyrError(n, f"tyr_load_ply({path})")
+    try:
+        if n == 0:
+            return np.zeros(0, dtype=scenes.TRIANGLE_DTYPE)
+        buf = (C.c_char * (40 * n)).from_address(out.value)
+        return np.frombuffer(buf, dtype=scenes.TRIANGLE_DTYPE, count=n).copy()
+    finally:
+        lib().tyr_free(out)
+
+
+def write_image(path: str, rgba: np.ndarray, width: int, height: int):
+    """PPM (tonemapped 8-bit) or PFM (float) by extension"""
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    fn = lib().tyr_write_pfm if path.lower().endswith(".pfm") else lib().tyr_write_ppm
+    _check(fn(os.fsencode(path), _ptr(a), width, height), "tyr_write_image")
 
 
 def camera_update(horizontal_angle: float, vertical_angle: float) -> np.ndarray:

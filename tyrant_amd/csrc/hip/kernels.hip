@@ -190,7 +190,6 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 		k->n_live = cnt + nNew;
 		k->shadow_ray_cnt = 0;
 		k->primary_ray_cnt = 0;
-		k->shade_ticket = 0;
 		k->extend_ticket = 0;
 		k->connect_ticket = 0;
 		if (budget != ~0ull)
@@ -1503,9 +1502,18 @@ void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, hipStream_
 	if (maxLive == 0)
 		return;
 	const uint32_t nTiles = blocks_for(maxLive);
-	// at most 4 blocks of 256 threads per CU: k_shade needs ~70 VGPRs and 64 B of LDS, so the hardware admits
-	// twice that; the whole grid is resident and the look-back never waits on a block that cannot start
-	const uint32_t resident = 4u * (uint32_t)numCUs;
+	// The look-back needs every block of the grid resident at once.  k_shade is small (64 B of LDS, < 128 VGPRs),
+	// so the hardware admits at least 4 blocks of 256 threads per CU; ask it once, take one off because the
+	// occupancy API over-reports by a block per CU for SGPR-heavy kernels (MI355X_MICROARCH.md "Residency"),
+	// and never use more than 4.
+	static int perCU = 0;
+	if (perCU == 0) {
+		int q = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade, kBlock, 0) != hipSuccess || q < 2)
+			q = 2;
+		perCU = q - 1 > 4 ? 4 : q - 1;
+	}
+	const uint32_t resident = (uint32_t)perCU * (uint32_t)numCUs;
 	hipLaunchKernelGGL(k_shade, dim3(nTiles < resident ? nTiles : resident), dim3(kBlock), 0, stream, P, nTiles);
 }
 void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream) {

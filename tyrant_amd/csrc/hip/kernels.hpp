@@ -40,7 +40,7 @@ struct DevCounters {
 	uint32_t start_position;
 	uint32_t shadow_ray_cnt;
 	uint32_t n_live;
-	uint32_t shade_ticket;   // dynamic block id of the shade kernel (stable compaction)
+	uint32_t reserved0;      // (was the shade kernel's tile ticket; tiles are ordered without an atomic now)
 	uint32_t device_error;
 	uint32_t extend_ticket;  // next queue slot to hand to a free lane of the persistent extend kernel
 	uint32_t connect_ticket; // same for connect

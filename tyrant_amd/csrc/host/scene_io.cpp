@@ -1,0 +1,334 @@
+// scene_io.cpp -- the import half of Scene::Load for PLY files and image export of the resolved frame
+// (SURVEY.md section 8f-2).
+//
+// Reference: Scene::Load reads a file through assimp with aiProcess_Triangulate (Scene.cpp:4-5), keeps the
+// FIRST mesh only (static_mesh.cpp:6), copies its vertices with y and z exchanged (static_mesh.cpp:17), undoes
+// that exchange (Scene.cpp:10) -- the two cancel -- and emits one Triangle{vert, e1 = v1 - v0, e2 = v2 - v0}
+// per face (Scene.cpp:39-45).  assimp is not available here (Windows .lib only in the reference tree), so this
+// is a PLY reader with the same conventions: polygons are triangulated as fans, extra vertex properties
+// (normals, uv) are skipped, `{ ... }` annotations in the header and trailing text after the face list -- both
+// present in the reference's own Data/cube.ply -- are tolerated.
+//
+// Export replaces the GL blit (interop.cpp:50): the RGBA32F buffer written by tyr_resolve goes to a binary PPM
+// (8-bit, already tonemapped by kernel.cu:661's Reinhard + gamma) or a PFM (raw float, bottom-up rows).
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "host.hpp"
+
+namespace {
+
+enum class PlyFormat { Ascii, BinaryLE };
+
+struct PlyProperty {
+	std::string name;
+	std::string type;      // scalar type, or the item type of a list
+	std::string countType; // non-empty for list properties
+};
+struct PlyElement {
+	std::string name;
+	size_t count = 0;
+	std::vector<PlyProperty> props;
+};
+
+size_t type_size(const std::string& t) {
+	if (t == "char" || t == "uchar" || t == "int8" || t == "uint8")
+		return 1;
+	if (t == "short" || t == "ushort" || t == "int16" || t == "uint16")
+		return 2;
+	if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32")
+		return 4;
+	if (t == "double" || t == "float64")
+		return 8;
+	return 0;
+}
+
+// one binary little-endian scalar -> double
+bool read_binary(std::istream& in, const std::string& t, double& out) {
+	unsigned char b[8] = {};
+	const size_t n = type_size(t);
+	if (n == 0 || !in.read(reinterpret_cast<char*>(b), static_cast<std::streamsize>(n)))
+		return false;
+	if (t == "char" || t == "int8")
+		out = static_cast<signed char>(b[0]);
+	else if (t == "uchar" || t == "uint8")
+		out = b[0];
+	else if (t == "short" || t == "int16") {
+		int16_t v;
+		std::memcpy(&v, b, 2);
+		out = v;
+	} else if (t == "ushort" || t == "uint16") {
+		uint16_t v;
+		std::memcpy(&v, b, 2);
+		out = v;
+	} else if (t == "int" || t == "int32") {
+		int32_t v;
+		std::memcpy(&v, b, 4);
+		out = v;
+	} else if (t == "uint" || t == "uint32") {
+		uint32_t v;
+		std::memcpy(&v, b, 4);
+		out = v;
+	} else if (t == "float" || t == "float32") {
+		float v;
+		std::memcpy(&v, b, 4);
+		out = v;
+	} else {
+		double v;
+		std::memcpy(&v, b, 8);
+		out = v;
+	}
+	return true;
+}
+
+std::string strip_annotation(std::string line) {
+	const size_t brace = line.find('{');
+	if (brace != std::string::npos)
+		line.erase(brace);
+	while (!line.empty() && std::isspace(static_cast<unsigned char>(line.back())))
+		line.pop_back();
+	return line;
+}
+
+} // namespace
+
+extern "C" {
+
+void tyr_free(void* p) { std::free(p); }
+
+int tyr_load_ply(const char* path, tyr_triangle** prims_out) {
+	if (!path || !prims_out)
+		return TYR_ERR_INVALID;
+	*prims_out = nullptr;
+	std::ifstream in(path, std::ios::binary);
+	if (!in)
+		return TYR_ERR_INVALID;
+	std::string line;
+	if (!std::getline(in, line) || strip_annotation(line).rfind("ply", 0) != 0)
+		return TYR_ERR_INVALID;
+	PlyFormat fmt = PlyFormat::Ascii;
+	std::vector<PlyElement> elements;
+	bool headerDone = false;
+	while (std::getline(in, line)) {
+		line = strip_annotation(line);
+		if (line.empty())
+			continue;
+		std::istringstream ls(line);
+		std::string kw;
+		ls >> kw;
+		if (kw == "format") {
+			std::string f;
+			ls >> f;
+			if (f == "ascii")
+				fmt = PlyFormat::Ascii;
+			else if (f == "binary_little_endian")
+				fmt = PlyFormat::BinaryLE;
+			else
+				return TYR_ERR_UNSUPPORTED;
+		} else if (kw == "element") {
+			PlyElement e;
+			ls >> e.name >> e.count;
+			elements.push_back(e);
+		} else if (kw == "property" && !elements.empty()) {
+			PlyProperty p;
+			std::string t;
+			ls >> t;
+			if (t == "list") {
+				ls >> p.countType >> p.type >> p.name;
+			} else {
+				p.type = t;
+				ls >> p.name;
+			}
+			if (type_size(p.type) == 0 || (!p.countType.empty() && type_size(p.countType) == 0))
+				return TYR_ERR_UNSUPPORTED;
+			elements.back().props.push_back(p);
+		} else if (kw == "end_header") {
+			headerDone = true;
+			break;
+		} // comment, obj_info: ignored
+	}
+	if (!headerDone)
+		return TYR_ERR_INVALID;
+
+	std::vector<float> verts; // x y z per vertex
+	std::vector<tyr_triangle> tris;
+	// ASCII values: whitespace separated; `{ ... }` annotations may follow values on a data line too
+	// (the reference's Data/cube.ply: "0 0 0    { start of vertex list }")
+	auto next_ascii = [&](double& v) -> bool {
+		for (;;) {
+			int c = in.peek();
+			while (c != EOF && std::isspace(c)) {
+				in.get();
+				c = in.peek();
+			}
+			if (c == EOF)
+				return false;
+			if (c == '{') {
+				while (c != EOF && c != '}')
+					c = in.get();
+				continue;
+			}
+			break;
+		}
+		std::string tok;
+		for (int c = in.peek(); c != EOF && !std::isspace(c) && c != '{'; c = in.peek())
+			tok.push_back(static_cast<char>(in.get()));
+		char* end = nullptr;
+		v = std::strtod(tok.c_str(), &end);
+		return end != tok.c_str() && *end == '\0';
+	};
+	auto next_value = [&](const std::string& type, double& v) -> bool {
+		if (fmt == PlyFormat::Ascii)
+			return next_ascii(v);
+		return read_binary(in, type, v);
+	};
+	for (const PlyElement& e : elements) {
+		if (e.name == "vertex") {
+			int ix = -1, iy = -1, iz = -1;
+			for (size_t k = 0; k < e.props.size(); ++k) {
+				if (!e.props[k].countType.empty())
+					return TYR_ERR_UNSUPPORTED;
+				if (e.props[k].name == "x")
+					ix = static_cast<int>(k);
+				else if (e.props[k].name == "y")
+					iy = static_cast<int>(k);
+				else if (e.props[k].name == "z")
+					iz = static_cast<int>(k);
+			}
+			if (ix < 0 || iy < 0 || iz < 0)
+				return TYR_ERR_INVALID;
+			verts.resize(e.count * 3);
+			for (size_t i = 0; i < e.count; ++i) {
+				for (size_t k = 0; k < e.props.size(); ++k) {
+					double v;
+					if (!next_value(e.props[k].type, v))
+						return TYR_ERR_INVALID;
+					if (static_cast<int>(k) == ix)
+						verts[3 * i + 0] = static_cast<float>(v);
+					else if (static_cast<int>(k) == iy)
+						verts[3 * i + 1] = static_cast<float>(v);
+					else if (static_cast<int>(k) == iz)
+						verts[3 * i + 2] = static_cast<float>(v);
+				}
+			}
+		} else if (e.name == "face") {
+			const size_t nVerts = verts.size() / 3;
+			tris.reserve(e.count);
+			std::vector<uint32_t> idx;
+			for (size_t i = 0; i < e.count; ++i) {
+				for (const PlyProperty& p : e.props) {
+					double v;
+					if (p.countType.empty()) {
+						if (!next_value(p.type, v))
+							return TYR_ERR_INVALID;
+						continue;
+					}
+					if (!next_value(p.countType, v) || v < 0 || v > 255)
+						return TYR_ERR_INVALID;
+					const size_t n = static_cast<size_t>(v);
+					const bool isIndexList = (p.name == "vertex_indices" || p.name == "vertex_index");
+					idx.clear();
+					for (size_t k = 0; k < n; ++k) {
+						if (!next_value(p.type, v))
+							return TYR_ERR_INVALID;
+						if (isIndexList) {
+							if (v < 0 || static_cast<size_t>(v) >= nVerts)
+								return TYR_ERR_INVALID;
+							idx.push_back(static_cast<uint32_t>(v));
+						}
+					}
+					// aiProcess_Triangulate: a convex polygon becomes a fan around its first vertex
+					for (size_t k = 1; isIndexList && k + 1 < idx.size(); ++k) {
+						const float* a = &verts[3 * idx[0]];
+						const float* b = &verts[3 * idx[k]];
+						const float* c = &verts[3 * idx[k + 1]];
+						tyr_triangle t{};
+						for (int d = 0; d < 3; ++d) { // Scene.cpp:39-45
+							t.vert[d] = a[d];
+							t.e1[d] = b[d] - a[d];
+							t.e2[d] = c[d] - a[d];
+						}
+						tris.push_back(t);
+					}
+				}
+			}
+		} else {
+			// other elements (edge, material, ...): must still be consumed in order
+			for (size_t i = 0; i < e.count; ++i) {
+				for (const PlyProperty& p : e.props) {
+					double v;
+					if (p.countType.empty()) {
+						if (!next_value(p.type, v))
+							return TYR_ERR_INVALID;
+					} else {
+						if (!next_value(p.countType, v) || v < 0)
+							return TYR_ERR_INVALID;
+						for (size_t k = 0, n = static_cast<size_t>(v); k < n; ++k)
+							if (!next_value(p.type, v))
+								return TYR_ERR_INVALID;
+					}
+				}
+			}
+		}
+	}
+	if (tris.size() > static_cast<size_t>(INT32_MAX))
+		return TYR_ERR_UNSUPPORTED;
+	if (!tris.empty()) {
+		*prims_out = static_cast<tyr_triangle*>(std::malloc(tris.size() * sizeof(tyr_triangle)));
+		if (!*prims_out)
+			return TYR_ERR_OOM;
+		std::memcpy(*prims_out, tris.data(), tris.size() * sizeof(tyr_triangle));
+	}
+	return static_cast<int>(tris.size());
+}
+
+int tyr_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t height) {
+	if (!path || !rgba || width == 0 || height == 0)
+		return TYR_ERR_INVALID;
+	FILE* fp = std::fopen(path, "wb");
+	if (!fp)
+		return TYR_ERR_INVALID;
+	std::fprintf(fp, "P6 %u %u 255\n", width, height);
+	std::vector<unsigned char> row(static_cast<size_t>(width) * 3);
+	for (uint32_t y = 0; y < height; ++y) {
+		for (uint32_t x = 0; x < width; ++x) {
+			const float* p = &rgba[4 * (static_cast<size_t>(y) * width + x)];
+			for (int c = 0; c < 3; ++c) {
+				float v = p[c];
+				v = (v != v) ? 0.0f : std::min(std::max(v, 0.0f), 1.0f); // pixels without a completed path resolve to NaN (0/0, kernel.cu:658)
+				row[3 * x + c] = static_cast<unsigned char>(v * 255.0f + 0.5f);
+			}
+		}
+		std::fwrite(row.data(), 1, row.size(), fp);
+	}
+	std::fclose(fp);
+	return TYR_OK;
+}
+
+int tyr_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height) {
+	if (!path || !rgba || width == 0 || height == 0)
+		return TYR_ERR_INVALID;
+	FILE* fp = std::fopen(path, "wb");
+	if (!fp)
+		return TYR_ERR_INVALID;
+	std::fprintf(fp, "PF\n%u %u\n-1.0\n", width, height); // negative scale = little endian
+	std::vector<float> row(static_cast<size_t>(width) * 3);
+	for (uint32_t y = height; y-- > 0;) { // PFM rows run bottom to top
+		for (uint32_t x = 0; x < width; ++x)
+			for (int c = 0; c < 3; ++c)
+				row[3 * x + c] = rgba[4 * (static_cast<size_t>(y) * width + x) + c];
+		std::fwrite(row.data(), sizeof(float), row.size(), fp);
+	}
+	std::fclose(fp);
+	return TYR_OK;
+}
+
+} // extern "C"
