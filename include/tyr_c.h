@@ -237,6 +237,9 @@ int tyr_set_tuning(tyr_ctx* ctx, int key, int value);
  * nodes_out must hold 2*n-1 nodes.  algo: 1 = EqualCounts, 2 = SAH (bvh.h:45-47).
  * Returns the node count (>= 0) or a negative status. */
 int tyr_bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo);
+/* Threads tyr_bvh_build may use: the top of the tree fans out into tasks, the output is byte-identical
+ * to the serial build.  0 = automatic (env TYR_BUILD_THREADS, else min(16, cores)); 1 = the reference's serial behaviour. */
+int tyr_set_build_threads(int32_t threads);
 /* Scene.cpp:22-33: per-face bounding boxes */
 int tyr_triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out);
 /* The import half of Scene::Load (Scene.cpp:3-47, static_mesh.cpp:3-32) for PLY files (ASCII or binary

@@ -64,6 +64,29 @@ def test_product_builder_matches_oracle_bytes(hip, orc, name):
     assert prims_p.tobytes() == prims_o.tobytes()
 
 
+@pytest.mark.parametrize("threads", [1, 2, 3, 8])
+def test_parallel_builder_is_byte_identical(hip, orc, threads):
+    """the task-parallel build emits the serial builder's bytes for every thread count, both on a
+    scene large enough to fan out over several levels and on one below the task grain"""
+    from tyrant_amd import scenes
+
+    try:
+        for sc in (scenes.cornell_soup(60000, seed=5), scenes.mesh_scene(96), scenes.cornell_soup(3000, seed=2)):
+            bb = scenes.triangle_bboxes(sc.triangles)
+            nodes_o, prims_o = orc.bvh_build(sc.triangles, bb)
+            hip.set_build_threads(threads)
+            nodes_p, prims_p = hip.bvh_build(sc.triangles, bb)
+            assert nodes_p.tobytes() == nodes_o.tobytes() and prims_p.tobytes() == prims_o.tobytes()
+            nodes_e, prims_e = hip.bvh_build(sc.triangles, bb, algo=1)  # EqualCounts: same bytes as its own serial build
+            hip.set_build_threads(1)
+            nodes_s, prims_s = hip.bvh_build(sc.triangles, bb, algo=1)
+            assert nodes_e.tobytes() == nodes_s.tobytes() and prims_e.tobytes() == prims_s.tobytes()
+    finally:
+        hip.set_build_threads(0)
+    with pytest.raises(hip.TyrError):
+        hip.set_build_threads(-1)
+
+
 def test_builder_structure(hip):
     sc, nodes, prims = built_scene("cornell_soup2k")
     n = prims.shape[0]

@@ -111,6 +111,7 @@ SYMBOLS = {
     "tyr_set_tuning": (C.c_int, [P, C.c_int, C.c_int]),
     "tyr_bvh_build": (C.c_int, [P, c_i32, P, P, c_i32]),
     "tyr_triangle_bboxes": (C.c_int, [P, c_i32, P]),
+    "tyr_set_build_threads": (C.c_int, [c_i32]),
     "tyr_camera_update": (C.c_int, [C.c_double, C.c_double, C.POINTER(c_f)]),
     "tyr_load_ply": (C.c_int, [C.c_char_p, C.POINTER(P)]),
     "tyr_free": (None, [P]),
@@ -192,6 +193,10 @@ def write_image(path: str, rgba: np.ndarray, width: int, height: int):
     a = np.ascontiguousarray(rgba, dtype=np.float32)
     fn = lib().tyr_write_pfm if path.lower().endswith(".pfm") else lib().tyr_write_ppm
     _check(fn(os.fsencode(path), _ptr(a), width, height), "tyr_write_image")
+
+
+def set_build_threads(threads: int):
+    _check(lib().tyr_set_build_threads(threads), "tyr_set_build_threads")
 
 
 def camera_update(horizontal_angle: float, vertical_angle: float) -> np.ndarray:

@@ -893,6 +893,13 @@ int tyr_get_timings(tyr_ctx* c, tyr_timings* out, int reset) {
 // ---- host side of the hot path --------------------------------------------------------------
 int tyr_bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo) { return bvh_build(prims, n, bboxes, nodes_out, algo); }
 
+int tyr_set_build_threads(int32_t threads) {
+	if (threads < 0 || threads > 256)
+		return TYR_ERR_INVALID;
+	set_build_threads(threads);
+	return TYR_OK;
+}
+
 int tyr_triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out) {
 	if (n < 0 || (n > 0 && (!prims || !out)))
 		return TYR_ERR_INVALID;

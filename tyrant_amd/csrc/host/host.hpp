@@ -18,6 +18,7 @@ void sun_setup(float sun_x, float sun_y, SunParams& out);
 // host/bvh_build.cpp -- class BVH of the reference (bvh.h:49-108, bvh.cpp:3-225)
 int bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo);
 void triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out);
+void set_build_threads(int threads); // 0 = automatic (TYR_BUILD_THREADS or min(16, cores))
 
 // host/bvh_layout.cpp -- flat reference nodes -> device pair nodes + 48-byte triangles
 struct DeviceLayout {
