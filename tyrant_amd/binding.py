@@ -13,7 +13,8 @@ import numpy as np
 from . import scenes
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtyrant_hip.so")
+# TYRANT_HIP_LIBRARY: load another build of the same ABI (diagnostic builds made by tools/*.sh); never a CPU path
+LIB_PATH = os.environ.get("TYRANT_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libtyrant_hip.so")
 
 TYR_FLAG_TRIANGLE_MATERIALS = 1
 TYR_FLAG_PROFILE = 2

@@ -26,6 +26,12 @@ using namespace tyr;
 			return static_cast<int>(e_);   \
 	} while (0)
 
+#ifdef TYR_WHATIF_DOUBLE_NODE
+constexpr size_t kWhatIfQuadPad = size_t(8) << 20; // float4s: 1 Mi quad nodes
+#else
+constexpr size_t kWhatIfQuadPad = 0;
+#endif
+
 struct tyr_ctx {
 	tyr_config cfg{};
 	hipStream_t stream = nullptr;
@@ -429,12 +435,16 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 		return TYR_OK; // Scene.cpp:49-52
 	// at least one element so the pointers are never null
 	const size_t nodeFloats = std::max<size_t>(L.pairNodes.size(), 16), quadFloats = std::max<size_t>(L.quadNodes.size(), 32), triFloats = L.tris.size();
-	if ((rc = dev_alloc(c->dNodes, nodeFloats / 4)) || (rc = dev_alloc(c->dQuads, quadFloats / 4)) || (rc = dev_alloc(c->dTris, triFloats / 4)))
+	if ((rc = dev_alloc(c->dNodes, nodeFloats / 4)) || (rc = dev_alloc(c->dQuads, quadFloats / 4 + kWhatIfQuadPad)) || (rc = dev_alloc(c->dTris, triFloats / 4)))
 		return rc;
 	if (!L.pairNodes.empty())
 		HIPCHK(hipMemcpy(c->dNodes, L.pairNodes.data(), L.pairNodes.size() * sizeof(float), hipMemcpyHostToDevice));
 	if (!L.quadNodes.empty())
 		HIPCHK(hipMemcpy(c->dQuads, L.quadNodes.data(), L.quadNodes.size() * sizeof(float), hipMemcpyHostToDevice));
+#ifdef TYR_WHATIF_DOUBLE_NODE
+	if (!L.quadNodes.empty()) // second copy of the node array at a fixed distance: see tools/whatif_node_bytes.sh
+		HIPCHK(hipMemcpy(c->dQuads + kWhatIfQuadPad, L.quadNodes.data(), L.quadNodes.size() * sizeof(float), hipMemcpyHostToDevice));
+#endif
 	c->scene.quads = c->dQuads;
 	c->scene.quadRootRef = L.quadRootRef;
 	c->scene.nQuads = L.nQuads;
