@@ -49,6 +49,9 @@ def build_workload(name: str, binding, scenes):
     elif name == "c3":
         sc = scenes.mesh_scene(706)
         label = "C3: room + 706x706 height-field mesh (996,882 tris), 70% DIFF / 30% SPEC"
+    elif name == "c5":
+        sc = scenes.glass_dof_scene(2236)
+        label = "C5: room + 2236x2236 height-field mesh (9,999,402 tris), 65% DIFF / 30% SPEC / 5% REFR, thin lens 0.5, sun (0.3,0.2); quoted at --width 3840 --height 2160 --spp 16"
     elif name == "c1":
         sc = scenes.cornell_box()
         label = "C1: Cornell box (36 tris)"
@@ -64,7 +67,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel per GPU (total spp = spp * gpus)")

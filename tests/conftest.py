@@ -61,6 +61,7 @@ def built_scene(name: str):
         "mesh128": lambda: scenes.mesh_scene(128),
         "mesh706": lambda: scenes.mesh_scene(706),
         "tyrant_default": scenes.tyrant_default,
+        "glass_dof48": lambda: scenes.glass_dof_scene(48),
     }
     sc = makers[name]()
     nodes, prims = pyorc.bvh_build(sc.triangles, scenes.triangle_bboxes(sc.triangles))

@@ -39,7 +39,7 @@ def assert_accum_close(bo, bg, what):
     assert np.allclose(bg[:, :3], bo[:, :3], rtol=1e-5, atol=1e-6), f"{what}: max rel err {np.max(np.abs(bg[:, :3] - bo[:, :3]) / np.maximum(np.abs(bo[:, :3]), 1e-3))}"
 
 
-@pytest.mark.parametrize("name,W,H,N", [("cornell36", 64, 64, 6000), ("tyrant_default", 96, 64, 5000), ("cornell_soup2k", 80, 48, 4096), ("mesh32", 64, 64, 4096)])
+@pytest.mark.parametrize("name,W,H,N", [("cornell36", 64, 64, 6000), ("tyrant_default", 96, 64, 5000), ("cornell_soup2k", 80, 48, 4096), ("mesh32", 64, 64, 4096), ("glass_dof48", 96, 54, 4096)])
 def test_stage_by_stage_bit_parity(orc, hip, name, W, H, N):
     """every kernel of every iteration, fed by its predecessors on each side, matches the oracle bit for bit"""
     o, g = pair(orc, hip, name, W, H, N)
@@ -78,7 +78,7 @@ def test_stage_by_stage_bit_parity(orc, hip, name, W, H, N):
         o.stage("end"), g.stage("end")
 
 
-@pytest.mark.parametrize("name,W,H,N,spp", [("cornell36", 128, 128, 16384, 4), ("tyrant_default", 160, 96, 10000, 4), ("cornell_soup10k", 128, 72, 8192, 3), ("mesh128", 96, 96, 8192, 2)])
+@pytest.mark.parametrize("name,W,H,N,spp", [("cornell36", 128, 128, 16384, 4), ("tyrant_default", 160, 96, 10000, 4), ("cornell_soup10k", 128, 72, 8192, 3), ("mesh128", 96, 96, 8192, 2), ("glass_dof48", 128, 72, 8192, 3)])
 def test_render_matches_oracle(orc, hip, name, W, H, N, spp):
     """launch_kernels loop with a primary budget: same iteration count, same ray totals, radiance within 1e-5 rel"""
     o, g = pair(orc, hip, name, W, H, N)

@@ -754,6 +754,13 @@ __global__ void __launch_bounds__(kBlock) k_extend_persistent(const FrameParams 
 	bool hitTri = false, live = false, overflow = false;
 	VisitCount vc{ 0, 0 };
 	uint32_t dbg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // COUNT only
+// Register budget of the flat traversal kernels, as waves per SIMD.  Five (<= 96 VGPRs) measured 7-10 % faster in
+// extend than the four the allocator picks by itself (99 VGPRs); six (80 VGPRs) spills 32 registers in the descent
+// loop and is 40 % slower.  Deeper LDS stacks cap the occupancy below five anyway.
+#ifndef TYR_FLAT_WAVES_PER_EU
+#define TYR_FLAT_WAVES_PER_EU (STACK_LDS <= 12 ? 5 : STACK_LDS <= 16 ? 4 : 3)
+#endif
+
 #define TYR_DBG(i)                                                     \
 	if (COUNT) {                                                       \
 		const unsigned long long m_ = __ballot(1);                     \
@@ -1063,14 +1070,16 @@ __device__ __forceinline__ bool ref_is_traversing(uint32_t ref) { return ((int)r
 	}
 
 template <bool COUNT, int STACK_LDS, bool QUAD>
-__global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
+__global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(const FrameParams P) {
 	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
 	TYR_DECLARE_STACK(st)
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t nLive = P.k->n_live;
 	const DevScene& sc = P.scene;
-	RayConst r = {};
+	// the ray of this lane as plain scalars: kept as one RayConst object across the refill branch, its first 16
+	// bytes (origin + direction.x) stayed in a private-memory slot that every descent and leaf phase re-read
+	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f;
 	bool regular = true;      // this lane's ray has a finite 1/d in all three components
 	bool allRegular = true;   // ... and so has every live ray of the wave (wave-uniform; refreshed at refills)
 	float dist = 0.0f;
@@ -1113,14 +1122,15 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 					const float4 a = P.work.o_dx[s];
 					const float2 b = P.work.dyz[s];
 					const float2 h = P.work.hit[s];
-					r = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
-					regular = ray_is_regular(r);
+					const RayConst nr = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+					rox = nr.o.x, roy = nr.o.y, roz = nr.o.z, rdx = nr.d.x, rdy = nr.d.y, rdz = nr.d.z, rix = nr.inv.x, riy = nr.inv.y, riz = nr.inv.z;
+					regular = ray_is_regular(nr);
 					dist = h.x;
 					slot = s;
 					hitTri = false;
 					live = true;
 					st.reset();
-					ref = root_ref(sc, r, dist);
+					ref = root_ref(sc, nr, dist);
 					if (QUAD && ref != kRefDone)
 						ref = sc.quadRootRef;
 					if (COUNT)
@@ -1134,6 +1144,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 			continue;
 		}
 		allRegular = (__ballot(live && !regular) == 0ull);
+		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
 		// ---- descent: one pop attempt + one pair test per lane per trip ----
 		for (;;) {
 			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
@@ -1166,19 +1177,16 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 				TYR_DBG(0)
 				if (QUAD) {
 					const QuadHits q = allRegular ? test_quad<true, true>(sc.quads, ref, r, dist) : test_quad<false, true>(sc.quads, ref, r, dist);
-					// the earliest hit in visit order is entered now, the later ones are pushed latest first
-					uint32_t cur = kRefPop;
-					float curT = 0.0f;
-#pragma unroll
-					for (int k = 3; k >= 0; --k) {
-						if (q.hit[k]) {
-							if (cur != kRefPop)
-								st.push(cur, curT);
-							cur = q.ref[k];
-							curT = q.t[k];
-						}
-					}
-					ref = cur;
+					// the earliest hit in visit order is entered now, the later ones are pushed latest first:
+					// entry k is pushed iff it hit and an earlier entry hit too
+					const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
+					if (lane_in(q.hit[3] & any012))
+						st.push(q.ref[3], q.t[3]);
+					if (lane_in(q.hit[2] & any01))
+						st.push(q.ref[2], q.t[2]);
+					if (lane_in(q.hit[1] & q.hit[0]))
+						st.push(q.ref[1], q.t[1]);
+					ref = lane_in(q.hit[0]) ? q.ref[0] : lane_in(q.hit[1]) ? q.ref[1] : lane_in(q.hit[2]) ? q.ref[2] : lane_in(q.hit[3]) ? q.ref[3] : kRefPop;
 				} else {
 					const PairTest p = allRegular ? test_pair_fast(sc.nodes, ref, r, dist) : test_pair(sc.nodes, ref, r, dist);
 					if (COUNT && !p.synthetic)
@@ -1231,7 +1239,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_flat(const FrameParams P) {
 }
 
 template <bool COUNT, int STACK_LDS, bool QUAD>
-__global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
+__global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(const FrameParams P) {
 	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
 	TYR_DECLARE_STACK(st)
 	const uint32_t lane = lane_id();
@@ -1239,7 +1247,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 	const uint32_t nRays = P.k->shadow_ray_cnt;
 	const DevScene& sc = P.scene;
 	const bool haveBvh = (sc.rootRef != kRefDone);
-	RayConst r = {};
+	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f; // see k_extend_flat
 	bool regular = true;      // this lane's ray has a finite 1/d in all three components
 	bool allRegular = true;   // ... and so has every live ray of the wave (wave-uniform; refreshed at refills)
 	float closest = 0.0f;
@@ -1281,9 +1289,10 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 					st.reset();
 					ref = kRefDone;
 					if (haveBvh && (COUNT || !occluded)) {
-						r = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
-						regular = ray_is_regular(r);
-						ref = root_ref(sc, r, closest);
+						const RayConst nr = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+						rox = nr.o.x, roy = nr.o.y, roz = nr.o.z, rdx = nr.d.x, rdy = nr.d.y, rdz = nr.d.z, rix = nr.inv.x, riy = nr.inv.y, riz = nr.inv.z;
+						regular = ray_is_regular(nr);
+						ref = root_ref(sc, nr, closest);
 						if (QUAD && ref != kRefDone)
 							ref = sc.quadRootRef;
 						if (COUNT)
@@ -1298,6 +1307,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 			continue;
 		}
 		allRegular = (__ballot(live && !regular) == 0ull);
+		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
 		for (;;) {
 			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
 			if (nTrav == 0)
@@ -1329,18 +1339,14 @@ __global__ void __launch_bounds__(kBlock) k_connect_flat(const FrameParams P) {
 			if ((int)ref >= 0) {
 				if (QUAD) {
 					const QuadHits q = allRegular ? test_quad<true, false>(sc.quads, ref, r, closest) : test_quad<false, false>(sc.quads, ref, r, closest);
-					uint32_t cur = kRefPop;
-					float curT = 0.0f;
-#pragma unroll
-					for (int k = 3; k >= 0; --k) {
-						if (q.hit[k]) {
-							if (cur != kRefPop)
-								st.push(cur, curT);
-							cur = q.ref[k];
-							curT = q.t[k];
-						}
-					}
-					ref = cur;
+					const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
+					if (lane_in(q.hit[3] & any012))
+						st.push(q.ref[3], q.t[3]);
+					if (lane_in(q.hit[2] & any01))
+						st.push(q.ref[2], q.t[2]);
+					if (lane_in(q.hit[1] & q.hit[0]))
+						st.push(q.ref[1], q.t[1]);
+					ref = lane_in(q.hit[0]) ? q.ref[0] : lane_in(q.hit[1]) ? q.ref[1] : lane_in(q.hit[2]) ? q.ref[2] : lane_in(q.hit[3]) ? q.ref[3] : kRefPop;
 					continue;
 				}
 				const PairTest p = allRegular ? test_pair_fast(sc.nodes, ref, r, closest) : test_pair(sc.nodes, ref, r, closest);

@@ -45,6 +45,9 @@ constexpr uint32_t kRefPop = 0xFFFFFFFEu;  // flat state machine: this lane must
 constexpr int kStackSize = 64;             // bvh.h:124 nodesToVisit[64]
 constexpr uint32_t kMaxLeafPrims = 31; // count-1 <= 30 keeps 0xFFFFFFFE / 0xFFFFFFFF out of the leaf encoding
 constexpr uint32_t kMaxPrimOffset = 1u << 26;
+// interior reference of the quad layout: node index in bits 0..24, the node's visit-order bits in 25..30
+constexpr uint32_t kQuadOrderShift = 25;
+constexpr uint32_t kQuadIndexMask = (1u << kQuadOrderShift) - 1u;
 
 struct DevScene {
 	const float4* quads; // QuadNode array, 8 float4 each (the production traversal)
@@ -247,12 +250,17 @@ __device__ __forceinline__ PairTest test_pair(const float4* __restrict__ nodes, 
 // (all nine near_i <= far_j comparisons of the reference collapse to max(near) <= min(far)).
 // That is ~25 VALU per box instead of ~45.  Rays with a zero direction component (inv = inf)
 // keep the generic path above.
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool slab_fast(const RayConst& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float lowest, float& tMinOut) {
-	const float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
-	const float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
-	const float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
-	const float tMin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-	const float tMax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+	// both planes of an axis in one packed operation (v_pk_add_f32 / v_pk_mul_f32: two IEEE binary32 results per
+	// instruction, each rounded exactly like the scalar form -- contraction is off for the whole file)
+	const float ox = r.o.x, oy = r.o.y, oz = r.o.z, ix = r.inv.x, iy = r.inv.y, iz = r.inv.z;
+	v2f x = { lox, hix }, y = { loy, hiy }, z = { loz, hiz };
+	x = (x - ox) * ix;
+	y = (y - oy) * iy;
+	z = (z - oz) * iz;
+	const float tMin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x.x, x.y), __builtin_fminf(y.x, y.y)), __builtin_fminf(z.x, z.y));
+	const float tMax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x.x, x.y), __builtin_fmaxf(y.x, y.y)), __builtin_fmaxf(z.x, z.y));
 	tMinOut = tMin;
 	return (tMin <= tMax) && (tMin < lowest) && (tMax > 0);
 }
@@ -298,10 +306,18 @@ __device__ __forceinline__ PairTest test_pair_fast(const float4* __restrict__ no
 // depth-first order: group of the near child first (dirIsNeg[axis of the node], bvh.h:146-152), then
 // inside each group its near slot first (dirIsNeg[axis of that child]).  Every reached box is
 // re-checked against the current distance when popped, as for pair nodes.
+// Hit flags travel as WAVE-WIDE lane masks (the ballot of the per-lane flag, a scalar register pair): as `bool`s
+// they met in a phi where the finite-1/d and the generic box tests rejoin and were materialised as 0/1 vector
+// registers, re-compared before every use; as masks the near/far reordering is scalar and/or work.
+typedef unsigned long long lanemask;
+__device__ __forceinline__ lanemask lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lane_in(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ lanemask mask_select(lanemask sel, lanemask a, lanemask b) { return (sel & a) | (~sel & b); }
+
 struct QuadHits { // in visit order
 	uint32_t ref[4];
 	float t[4];
-	bool hit[4];
+	lanemask hit[4];
 };
 
 template <bool FAST>
@@ -315,51 +331,51 @@ __device__ __forceinline__ bool slab_any(const RayConst& r, float lox, float hix
 // per-lane choice made the compiler emit both paths with exec juggling around each of the four tests).
 // ORDERED: closest-hit needs the reference's visit order; any-hit (bvh.h:213-256) does not depend on it.
 template <bool FAST, bool ORDERED>
-__device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, uint32_t idx, const RayConst& r, float dist) {
-	const float4* q = quads + 8 * idx;
+__device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, uint32_t ref, const RayConst& r, float dist) {
+	const float4* q = quads + 8 * (ref & kQuadIndexMask);
+	const uint32_t meta = ref >> kQuadOrderShift; // bit 31 of an interior reference is clear
 #ifdef TYR_WHATIF_DOUBLE_NODE
 	// diagnostic build only: every node is fetched twice, from two copies 128 MiB apart, and merged with min()
 	// (equal values, so the traversal is unchanged) -- measures how much of the kernel's time is node bytes
 	const float4* q2 = q + (size_t(8) << 20);
 	auto mg = [](float4 a, float4 b) { return make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)); };
-	const float4 x01 = mg(q[0], q2[0]), x23 = mg(q[1], q2[1]), y01 = mg(q[2], q2[2]), y23 = mg(q[3], q2[3]), z01 = mg(q[4], q2[4]), z23 = mg(q[5], q2[5]), rf = q[6], mt = q[7];
+	const float4 x01 = mg(q[0], q2[0]), x23 = mg(q[1], q2[1]), y01 = mg(q[2], q2[2]), y23 = mg(q[3], q2[3]), z01 = mg(q[4], q2[4]), z23 = mg(q[5], q2[5]), rf = q[6];
 #else
-	const float4 x01 = q[0], x23 = q[1], y01 = q[2], y23 = q[3], z01 = q[4], z23 = q[5], rf = q[6], mt = q[7];
+	const float4 x01 = q[0], x23 = q[1], y01 = q[2], y23 = q[3], z01 = q[4], z23 = q[5], rf = q[6];
 #endif
 	const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
-	const uint32_t meta = __float_as_uint(mt.x);
 	float t0, t1, t2, t3;
 	bool h0 = slab_any<FAST>(r, x01.x, x01.y, y01.x, y01.y, z01.x, z01.y, dist, t0);
 	bool h1 = slab_any<FAST>(r, x01.z, x01.w, y01.z, y01.w, z01.z, z01.w, dist, t1);
 	bool h2 = slab_any<FAST>(r, x23.x, x23.y, y23.x, y23.y, z23.x, z23.y, dist, t2);
 	bool h3 = slab_any<FAST>(r, x23.z, x23.w, y23.z, y23.w, z23.z, z23.w, dist, t3);
-	const bool synthetic = (meta & 64u) != 0; // consecutive chunks of one over-long leaf: no box tests, slot order (bvh.h:131)
+	const bool synthetic = (meta & 3u) == 3u; // consecutive chunks of one over-long leaf: no box tests, slot order (bvh.h:131)
 	if (synthetic) {
 		h0 = h1 = h2 = h3 = true;
 		t0 = t1 = t2 = t3 = -__builtin_inff();
 	}
-	h0 = h0 && (r0 != kRefDone); // unused slots
-	h1 = h1 && (r1 != kRefDone);
-	h2 = h2 && (r2 != kRefDone);
-	h3 = h3 && (r3 != kRefDone);
+	// unused slots never hit
+	const lanemask H0 = lanes_where(h0 && (r0 != kRefDone)), H1 = lanes_where(h1 && (r1 != kRefDone));
+	const lanemask H2 = lanes_where(h2 && (r2 != kRefDone)), H3 = lanes_where(h3 && (r3 != kRefDone));
 	if (!ORDERED) {
 		QuadHits o;
 		o.ref[0] = r0, o.ref[1] = r1, o.ref[2] = r2, o.ref[3] = r3;
 		o.t[0] = t0, o.t[1] = t1, o.t[2] = t2, o.t[3] = t3;
-		o.hit[0] = h0, o.hit[1] = h1, o.hit[2] = h2, o.hit[3] = h3;
+		o.hit[0] = H0, o.hit[1] = H1, o.hit[2] = H2, o.hit[3] = H3;
 		return o;
 	}
 	const uint32_t aT = meta & 3u, aL = (meta >> 2) & 3u, aR = (meta >> 4) & 3u;
 	const bool bT = !synthetic && ((aT == 0) ? r.nx : (aT == 1) ? r.ny : r.nz);
 	const bool bL = !synthetic && ((aL == 0) ? r.nx : (aL == 1) ? r.ny : r.nz);
 	const bool bR = !synthetic && ((aR == 0) ? r.nx : (aR == 1) ? r.ny : r.nz);
+	const lanemask BT = lanes_where(bT), BL = lanes_where(bL), BR = lanes_where(bR);
 	// near slot first inside each group
 	const uint32_t lr0 = bL ? r1 : r0, lr1 = bL ? r0 : r1;
 	const float lt0 = bL ? t1 : t0, lt1 = bL ? t0 : t1;
-	const bool lh0 = bL ? h1 : h0, lh1 = bL ? h0 : h1;
+	const lanemask LH0 = mask_select(BL, H1, H0), LH1 = mask_select(BL, H0, H1);
 	const uint32_t rr0 = bR ? r3 : r2, rr1 = bR ? r2 : r3;
 	const float rt0 = bR ? t3 : t2, rt1 = bR ? t2 : t3;
-	const bool rh0 = bR ? h3 : h2, rh1 = bR ? h2 : h3;
+	const lanemask RH0 = mask_select(BR, H3, H2), RH1 = mask_select(BR, H2, H3);
 	// near group first
 	QuadHits o;
 	o.ref[0] = bT ? rr0 : lr0;
@@ -370,10 +386,10 @@ __device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, 
 	o.t[1] = bT ? rt1 : lt1;
 	o.t[2] = bT ? lt0 : rt0;
 	o.t[3] = bT ? lt1 : rt1;
-	o.hit[0] = bT ? rh0 : lh0;
-	o.hit[1] = bT ? rh1 : lh1;
-	o.hit[2] = bT ? lh0 : rh0;
-	o.hit[3] = bT ? lh1 : rh1;
+	o.hit[0] = mask_select(BT, RH0, LH0);
+	o.hit[1] = mask_select(BT, RH1, LH1);
+	o.hit[2] = mask_select(BT, LH0, RH0);
+	o.hit[3] = mask_select(BT, LH1, RH1);
 	return o;
 }
 

@@ -161,6 +161,7 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 	// the node's (which group first) and each interior child's (which slot of the group first).
 	//   q0 = {s0.min.x, s0.max.x, s1.min.x, s1.max.x}   q1 = {s2.., s3..}   q2,q3 = y   q4,q5 = z
 	//   q6 = {ref0, ref1, ref2, ref3}                   q7 = {axisTop | axisL << 2 | axisR << 4 | synthetic << 6, 0, 0, 0}
+	// (q7 is not fetched by the kernels: the same bits ride in every reference TO this node, see the end of this function)
 	L.quadNodes.clear();
 	L.nQuads = 0;
 	L.quadRootRef = kRefDone;
@@ -283,6 +284,28 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 		L.quadRootRef = 0;
 	}
 	L.nQuads = static_cast<uint32_t>(L.quadNodes.size() / 32);
+	// An interior reference carries the visit-order bits of the node it points to in bits 25..30 (axisTop | axisL << 2 |
+	// axisR << 4, axisTop == 3 for a synthetic chain), so the kernel knows them before the node arrives and fetches
+	// seven vectors per node instead of eight.
+	if (L.nQuads > kQuadIndexMask)
+		return TYR_ERR_INVALID;
+	auto with_order_bits = [&](uint32_t ref) -> uint32_t {
+		if (static_cast<int32_t>(ref) < 0)
+			return ref; // leaf, unused slot
+		uint32_t meta;
+		std::memcpy(&meta, &L.quadNodes[static_cast<size_t>(ref) * 32 + 28], 4);
+		const uint32_t order = (meta & 64u) ? 3u : (meta & 63u);
+		return ref | (order << kQuadOrderShift);
+	};
+	for (uint32_t qi = 0; qi < L.nQuads; ++qi) {
+		for (int sidx = 0; sidx < 4; ++sidx) {
+			uint32_t ref;
+			std::memcpy(&ref, &L.quadNodes[static_cast<size_t>(qi) * 32 + 24 + sidx], 4);
+			ref = with_order_bits(ref);
+			std::memcpy(&L.quadNodes[static_cast<size_t>(qi) * 32 + 24 + sidx], &ref, 4);
+		}
+	}
+	L.quadRootRef = with_order_bits(L.quadRootRef);
 	return TYR_OK;
 }
 

@@ -251,6 +251,14 @@ def mesh_scene(cells: int = 706, seed: int = 12345, spec_fraction: float = 0.3, 
     return SceneData(f"room+heightfield{cells}", tris, cornell_spheres(), CORNELL_CAMERA, triangle_materials=True)
 
 
+def glass_dof_scene(cells: int = 2236, seed: int = 12345) -> SceneData:
+    """C5: the C3 generator with 5 % REFR triangles, a thin lens (lensRadius 0.5) focused on the
+    height field from the Cornell camera (kernel.cu:286-293 multiplies focalDistance by 3), and a high sun."""
+    sc = mesh_scene(cells, seed, spec_fraction=0.3, refr_fraction=0.05)
+    cam = Camera(position=CORNELL_CAMERA.position, direction=CORNELL_CAMERA.direction, up=CORNELL_CAMERA.up, focalDistance=60.0, lensRadius=0.5)
+    return SceneData(f"glass+dof{cells}", sc.triangles, sc.spheres, cam, sun_position=(0.3, 0.2), triangle_materials=True)  # sun (0.25,-0.77,0.59): shines in through the open side
+
+
 def tyrant_default(cells: int = 24, seed: int = 7) -> SceneData:
     """The reference's own sphere table (all five materials) over a small height-field
     placed near the spheres: exercises every branch of shade (kernel.cu:404-597)."""
