@@ -245,7 +245,7 @@ def test_cpp_host_api_example(hip):
     assert os.path.getsize(out) > 640 * 360 * 3
 
 
-@pytest.mark.parametrize("variant,lds", [(0, 0), (0, 8), (1, 0), (1, 16), (2, 12), (2, 0), (3, 12), (3, 0), (3, 24)])
+@pytest.mark.parametrize("variant,lds", [(0, 0), (0, 8), (1, 0), (1, 16), (2, 12), (2, 0), (3, 12), (3, 0), (3, 24), (4, 12), (4, 0), (4, 8)])
 def test_every_traversal_variant_is_bit_exact(orc, hip, variant, lds):
     """launch shape / node layout / stack placement never change results: each traversal variant reproduces
     the oracle's queues bit for bit over several iterations (bounce rays included)"""

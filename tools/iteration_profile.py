@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tyrant_amd import binding, scenes  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
+tune = {k: int(v) for k, v in (a.split("=") for a in sys.argv[2:])}  # e.g. traversal_variant=3
 sc = {"c1": scenes.cornell_box, "c2": lambda: scenes.cornell_soup(10000), "c3": lambda: scenes.mesh_scene(706)}[wl]()
 nodes, prims = binding.bvh_build(sc.triangles)
 base = binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0
@@ -17,6 +18,8 @@ rows = {}
 for counting in (True, False):
     r = binding.Renderer(W, H, W * H * SPP, flags=base | (binding.TYR_FLAG_COUNT_VISITS if counting else binding.TYR_FLAG_PROFILE))
     r.load_scene(sc, nodes, prims)
+    if tune:
+        r.set_tuning(**tune)
     for rep in range(2 if not counting else 1):  # production: second pass is the warm one
         r.reset_accum()
         r.set_budget(W * H * SPP)
@@ -46,7 +49,7 @@ for counting in (True, False):
             if n_ext == 0 or it > 64:
                 break
     r.close()
-print(f"{wl}: {W}x{H} {SPP} spp, queue {W*H*SPP}")
+print(f"{wl}: {W}x{H} {SPP} spp, queue {W*H*SPP}, tuning {tune}")
 print(" it      rays   nodes/ray tris/ray  extend ms  ps/ray  ps/node |   shadow  nodes/ray connect ms  ps/ray  ps/node | shade ms")
 for it in sorted(rows):
     x = rows[it]

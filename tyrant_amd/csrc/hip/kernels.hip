@@ -180,6 +180,10 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i < nDesc)
 		P.scanDesc[i] = 0ull;
+	if (i < kTicketWords) {
+		P.k->extend_chunks[i * 32] = 0;
+		P.k->connect_chunks[i * 32] = 0;
+	}
 	if (i == 0) {
 		DevCounters* k = P.k;
 		const uint32_t cnt = k->primary_ray_cnt;
@@ -1069,7 +1073,68 @@ __device__ __forceinline__ bool ref_is_traversing(uint32_t ref) { return ((int)r
 		}                                                              \
 	}
 
-template <bool COUNT, int STACK_LDS, bool QUAD>
+// Variant 4 work distribution: a PERSISTENT grid (as many blocks as stay resident) whose waves each own a private
+// range of queue slots and draw the next chunk from one of kTicketWords device-wide tickets when it runs out.
+// Chunk c of the queue belongs to ticket word c % kTicketWords; a wave starts at word blockIdx % kTicketWords
+// (its XCD under round-robin placement) and moves on to the next word when one is used up, so the last chunks
+// are shared by whoever is free.  Compared with block-owned ranges (variant 3) there is no per-block tail: the
+// four waves of a block never wait for the block's longest ray, only the end of the launch has partly filled waves.
+struct ChunkFeed {
+	uint32_t next, end;   // this wave's private range of queue slots (wave-uniform)
+	uint32_t word, tried; // ticket word in use, words found empty so far
+	uint32_t chunk;       // slots per draw
+	__device__ __forceinline__ void init(uint32_t nItems, uint32_t chunkWanted) {
+		next = end = 0;
+		word = blockIdx.x % kTicketWords;
+		tried = 0;
+		// thin queues: smaller chunks, so that the rays spread over more CUs (never below one wave's worth).
+		// What the sweeps said (profiles/r01_chunk_feed_sweep.txt): a draw must be ONE round trip -- with a look
+		// at the word before every atomic, launches of short rays (the primary rays) were 30-60 % slower than
+		// block-owned ranges; with that gone, 64- and 128-slot chunks beat larger ones by 2-4 %.  Guided
+		// (shrinking) draws over 64-slot granules lost to fixed chunks.
+		const uint32_t waves = gridDim.x * (kBlock / 64);
+		chunk = chunkWanted;
+		while (chunk > 64 && (unsigned long long)waves * chunk > nItems)
+			chunk >>= 1;
+	}
+	// true when [next, end) is non-empty afterwards
+	__device__ __forceinline__ bool refill(uint32_t* tickets, uint32_t nItems, uint32_t lane) {
+		while (next == end && tried < kTicketWords) {
+			uint32_t t = 0;
+			if (lane == 0) {
+				uint32_t* w = tickets + word * 32;
+				// once a word has been found empty, look before drawing: at the end of a launch every wave walks all the
+				// words, and plain reads are served in parallel (an atomic on one word is not).  Before that, draw
+				// straight away -- a look first would double the round trip of every draw.
+				bool draw = true;
+				if (tried != 0) {
+					t = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					draw = (unsigned long long)(t * kTicketWords + word) * chunk < nItems;
+				}
+				if (draw)
+					t = atomicAdd(w, 1u);
+			}
+			t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+			const unsigned long long start = (unsigned long long)(t * kTicketWords + word) * chunk;
+			if (start < nItems) {
+				next = (uint32_t)start;
+				end = (start + chunk < nItems) ? (uint32_t)(start + chunk) : nItems;
+			} else {
+				word = (word + 1) % kTicketWords;
+				++tried;
+			}
+		}
+		return next != end;
+	}
+};
+
+// slots of the queue that each block of a persistent grid owns outright (a multiple of 64; 0 for thin queues)
+__device__ __forceinline__ uint32_t static_range(uint32_t nItems, uint32_t sixteenths) {
+	const unsigned long long share = (unsigned long long)nItems * sixteenths / 16ull;
+	return (uint32_t)(share / gridDim.x) & ~63u;
+}
+
+template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
 __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(const FrameParams P) {
 	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
 	TYR_DECLARE_STACK(st)
@@ -1095,29 +1160,72 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 	// microsecond (MI355X_MICROARCH.md "dequeue"), and with >= 2 pulls per wave that alone was a
 	// 0.26 ms floor per launch, whatever the traversal cost.
 	__shared__ uint32_t blockNext;
-	const uint32_t blockBegin = blockIdx.x * P.raysPerBlock;
-	const uint32_t blockEnd = (blockBegin + P.raysPerBlock) < nLive ? (blockBegin + P.raysPerBlock) : nLive;
+	// variant 4 (PERSIST): the first staticShare/16 of the queue is dealt to the blocks as fixed ranges, handed out
+	// through LDS exactly like variant 3 (no device-wide atomic: a launch of short rays -- the primary rays --
+	// would spend a third of its time on ticket round trips); the rest goes out in ticketed chunks to whoever is
+	// free, which evens out the blocks and leaves no block waiting for its longest ray.
+	const uint32_t perBlock = PERSIST ? static_range(nLive, P.staticShare) : P.raysPerBlock;
+	const uint32_t dynBase = PERSIST ? perBlock * gridDim.x : 0u;
+	const uint32_t blockBegin = blockIdx.x * perBlock;
+	const uint32_t blockEnd = PERSIST ? blockBegin + perBlock : ((blockBegin + perBlock) < nLive ? (blockBegin + perBlock) : nLive);
+	ChunkFeed feed;
+	feed.init(nLive - dynBase, P.ticketChunk);
+	bool staticDone = (perBlock == 0); // wave-uniform
 	if (threadIdx.x == 0)
 		blockNext = blockBegin;
 	__syncthreads();
-	bool exhausted = (sc.rootRef == kRefDone) || (blockBegin >= nLive);
+	bool exhausted = (sc.rootRef == kRefDone) || (PERSIST ? nLive == 0 : blockBegin >= nLive);
 
 	for (;;) {
 		// ---- refill free lanes from the queue ----
 		const unsigned long long idleMask = __ballot(!live);
 		const uint32_t nIdle = __popcll(idleMask);
 		if (!exhausted && nIdle >= P.refillMinIdle) {
-			uint32_t base = 0;
-			if (lane == 0)
-				base = atomicAdd(&blockNext, nIdle); // LDS
-			base = __shfl(base, 0, 64);
-			const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
-			const uint32_t take = avail < nIdle ? avail : nIdle;
-			exhausted = (base + nIdle >= blockEnd);
-			if (!live) {
-				const uint32_t rank = __popcll(idleMask & below);
-				const uint32_t s = base + rank;
-				if (rank < take) {
+			const uint32_t rank = __popcll(idleMask & below);
+			uint32_t s = 0;
+			bool fed = false;
+			if (PERSIST) {
+				uint32_t got = 0; // idle lanes served so far; one refill may take from the fixed range and from two chunks
+				if (!staticDone) {
+					uint32_t base = 0;
+					if (lane == 0)
+						base = atomicAdd(&blockNext, nIdle); // LDS
+					base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, 0, 64));
+					const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+					got = avail < nIdle ? avail : nIdle;
+					if (!live && rank < got) {
+						s = base + rank;
+						fed = true;
+					}
+					staticDone = (base + nIdle >= blockEnd);
+				}
+				while (staticDone && got < nIdle) {
+					if (!feed.refill(P.k->extend_chunks, nLive - dynBase, lane)) {
+						exhausted = true;
+						break;
+					}
+					const uint32_t avail = feed.end - feed.next, room = nIdle - got;
+					const uint32_t take = avail < room ? avail : room;
+					if (!live && rank >= got && rank < got + take) {
+						s = dynBase + feed.next + (rank - got);
+						fed = true;
+					}
+					feed.next += take;
+					got += take;
+				}
+			} else {
+				uint32_t base = 0;
+				if (lane == 0)
+					base = atomicAdd(&blockNext, nIdle); // LDS
+				base = __shfl(base, 0, 64);
+				const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+				const uint32_t take = avail < nIdle ? avail : nIdle;
+				exhausted = (base + nIdle >= blockEnd);
+				s = base + rank;
+				fed = !live && rank < take;
+			}
+			{
+				if (fed) {
 					TYR_DBG(6)
 					const float4 a = P.work.o_dx[s];
 					const float2 b = P.work.dyz[s];
@@ -1238,7 +1346,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 	}
 }
 
-template <bool COUNT, int STACK_LDS, bool QUAD>
+template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
 __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(const FrameParams P) {
 	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
 	TYR_DECLARE_STACK(st)
@@ -1256,29 +1364,68 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 	VisitCount vc{ 0, 0 };
 	uint32_t visible = 0;
 	__shared__ uint32_t blockNext;
-	const uint32_t blockBegin = blockIdx.x * P.raysPerBlock;
-	const uint32_t blockEnd = (blockBegin + P.raysPerBlock) < nRays ? (blockBegin + P.raysPerBlock) : nRays;
+	const uint32_t perBlock = PERSIST ? static_range(nRays, P.staticShare) : P.raysPerBlock; // see k_extend_flat
+	const uint32_t dynBase = PERSIST ? perBlock * gridDim.x : 0u;
+	const uint32_t blockBegin = blockIdx.x * perBlock;
+	const uint32_t blockEnd = PERSIST ? blockBegin + perBlock : ((blockBegin + perBlock) < nRays ? (blockBegin + perBlock) : nRays);
+	ChunkFeed feed;
+	feed.init(nRays - dynBase, P.ticketChunk);
+	bool staticDone = (perBlock == 0); // wave-uniform
 	if (threadIdx.x == 0)
 		blockNext = blockBegin;
 	__syncthreads();
-	bool exhausted = (blockBegin >= nRays);
+	bool exhausted = PERSIST ? nRays == 0 : (blockBegin >= nRays);
 	const float kFailed = __builtin_inff();
 
 	for (;;) {
 		const unsigned long long idleMask = __ballot(!live);
 		const uint32_t nIdle = __popcll(idleMask);
 		if (!exhausted && nIdle >= P.refillMinIdle) {
-			uint32_t base = 0;
-			if (lane == 0)
-				base = atomicAdd(&blockNext, nIdle); // LDS
-			base = __shfl(base, 0, 64);
-			const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
-			const uint32_t take = avail < nIdle ? avail : nIdle;
-			exhausted = (base + nIdle >= blockEnd);
-			if (!live) {
-				const uint32_t rank = __popcll(idleMask & below);
-				const uint32_t s = base + rank;
-				if (rank < take) {
+			const uint32_t rank = __popcll(idleMask & below);
+			uint32_t s = 0;
+			bool fed = false;
+			if (PERSIST) {
+				uint32_t got = 0;
+				if (!staticDone) {
+					uint32_t base = 0;
+					if (lane == 0)
+						base = atomicAdd(&blockNext, nIdle); // LDS
+					base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, 0, 64));
+					const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+					got = avail < nIdle ? avail : nIdle;
+					if (!live && rank < got) {
+						s = base + rank;
+						fed = true;
+					}
+					staticDone = (base + nIdle >= blockEnd);
+				}
+				while (staticDone && got < nIdle) {
+					if (!feed.refill(P.k->connect_chunks, nRays - dynBase, lane)) {
+						exhausted = true;
+						break;
+					}
+					const uint32_t avail = feed.end - feed.next, room = nIdle - got;
+					const uint32_t take = avail < room ? avail : room;
+					if (!live && rank >= got && rank < got + take) {
+						s = dynBase + feed.next + (rank - got);
+						fed = true;
+					}
+					feed.next += take;
+					got += take;
+				}
+			} else {
+				uint32_t base = 0;
+				if (lane == 0)
+					base = atomicAdd(&blockNext, nIdle); // LDS
+				base = __shfl(base, 0, 64);
+				const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+				const uint32_t take = avail < nIdle ? avail : nIdle;
+				exhausted = (base + nIdle >= blockEnd);
+				s = base + rank;
+				fed = !live && rank < take;
+			}
+			{
+				if (fed) {
 					const float4 a = P.shadow.o_dx[s];
 					const float4 b = P.shadow.dyz_cd_ix[s];
 					const float sphereOccluded = reinterpret_cast<const float*>(&P.shadow.color[s])[3];
@@ -1461,10 +1608,12 @@ static void launch_extend_t(const FrameParams& P, uint32_t maxLive, const Tuning
 	}
 	hipLaunchKernelGGL(k_extend_spheres, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
 	const uint32_t flatBlocks = (maxLive + P.raysPerBlock - 1) / P.raysPerBlock;
-	if (t.traversalVariant == 3 && !COUNT)
-		hipLaunchKernelGGL((k_extend_flat<false, STACK_LDS, true>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+	if (t.traversalVariant == 4 && !COUNT)
+		hipLaunchKernelGGL((k_extend_flat<false, STACK_LDS, true, true>), dim3(persistent_blocks(k_extend_flat<false, STACK_LDS, true, true>, maxLive, t, numCUs)), dim3(kBlock), 0, stream, P);
+	else if (t.traversalVariant == 3 && !COUNT)
+		hipLaunchKernelGGL((k_extend_flat<false, STACK_LDS, true, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
 	else if (t.traversalVariant >= 2)
-		hipLaunchKernelGGL((k_extend_flat<COUNT, STACK_LDS, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+		hipLaunchKernelGGL((k_extend_flat<COUNT, STACK_LDS, false, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
 	else
 		hipLaunchKernelGGL((k_extend_persistent<COUNT, STACK_LDS>), dim3(persistent_blocks(k_extend_persistent<COUNT, STACK_LDS>, maxLive, t, numCUs)), dim3(kBlock), 0, stream, P);
 }
@@ -1477,10 +1626,12 @@ static void launch_connect_t(const FrameParams& P, uint32_t maxShadow, const Tun
 	hipLaunchKernelGGL(k_connect_spheres, dim3(blocks_for(maxShadow)), dim3(kBlock), 0, stream, P);
 	const uint32_t flatBlocks = (maxShadow + P.raysPerBlock - 1) / P.raysPerBlock;
 	if (t.traversalVariant >= 2) {
-		if (t.traversalVariant == 3 && !COUNT)
-			hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, true>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+		if (t.traversalVariant == 4 && !COUNT)
+			hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, true, true>), dim3(persistent_blocks(k_connect_flat<false, STACK_LDS, true, true>, maxShadow, t, numCUs)), dim3(kBlock), 0, stream, P);
+		else if (t.traversalVariant == 3 && !COUNT)
+			hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, true, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
 		else
-			hipLaunchKernelGGL((k_connect_flat<COUNT, STACK_LDS, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+			hipLaunchKernelGGL((k_connect_flat<COUNT, STACK_LDS, false, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
 	} else
 		hipLaunchKernelGGL((k_connect_persistent<COUNT, STACK_LDS>), dim3(persistent_blocks(k_connect_persistent<COUNT, STACK_LDS>, maxShadow, t, numCUs)), dim3(kBlock), 0, stream, P);
 }

@@ -35,6 +35,7 @@ struct ShadowQ {
 };
 
 // kernel.cu:211-224 device counters + the extensions (budget, totals, visit counters)
+constexpr uint32_t kTicketWords = 8; // = XCDs: block b draws from word b % 8 first (round-robin block placement)
 struct DevCounters {
 	uint32_t primary_ray_cnt;
 	uint32_t start_position;
@@ -55,6 +56,10 @@ struct DevCounters {
 	// [0]/[1] node-test loop: wave iterations / lane iterations; [2]/[3] pop loop; [4]/[5] triangle loop;
 	// [6]/[7] refills / lanes refilled
 	unsigned long long debug[8];
+	// variant 4: chunk tickets of the persistent traversal kernels, one word per 128 bytes so that the eight words
+	// are eight L2 lines (a single word serves only ~88 returning atomics per microsecond)
+	uint32_t extend_chunks[kTicketWords * 32];
+	uint32_t connect_chunks[kTicketWords * 32];
 };
 constexpr uint32_t kErrStackOverflow = 1u;
 constexpr uint32_t kErrScanTimeout = 2u;
@@ -80,16 +85,18 @@ struct FrameParams {
 	uint32_t minTraversing;       // flat traversal: leave the descent loop below this many descending lanes
 	uint32_t ticketChunk;         // variant 1: queue slots a wave takes per global atomic
 	uint32_t raysPerBlock;        // variants 2/3: queue slots owned by one 256-thread block
+	uint32_t staticShare;         // variant 4: sixteenths of the queue handed out as fixed per-block ranges
 	uint32_t minLeaves;           // variants 2/3: leave the descent loop once this many lanes hold a leaf
 };
 
 // traversal kernel structure (tyr_set_tuning)
 struct Tuning {
-	int traversalVariant = 3; // 0 = one thread per queue slot, 1 = persistent waves with lane refill, 2 = 1 + flat state machine, 3 = 2 on quad nodes
+	int traversalVariant = 4; // 0 = one thread per queue slot, 1 = persistent waves with lane refill, 2 = 1 + flat state machine, 3 = 2 on quad nodes
 	int minTraversing = 32;
-	int ticketChunk = 128;
+	int ticketChunk = 64;
 	int raysPerBlock = 1024;
 	int minLeaves = 64;
+	int staticShare = 4;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
 	int stackLdsDepth = 12;   // traversal-stack entries per lane kept in LDS (0, 8, 12, 16, 24); the rest spill to scratch

@@ -191,6 +191,7 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.ticketChunk = static_cast<uint32_t>(std::min(std::max(c->tuning.ticketChunk, 64), 65536));
 	P.raysPerBlock = static_cast<uint32_t>(std::min(std::max(c->tuning.raysPerBlock, 256), 65536));
 	P.minLeaves = static_cast<uint32_t>(std::min(std::max(c->tuning.minLeaves, 1), 64));
+	P.staticShare = static_cast<uint32_t>(std::min(std::max(c->tuning.staticShare, 0), 15));
 	return P;
 }
 
@@ -847,7 +848,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		return TYR_ERR_INVALID;
 	switch (key) {
 	case TYR_TUNE_TRAVERSAL_VARIANT:
-		if (value < 0 || value > 3)
+		if (value < 0 || value > 4)
 			return TYR_ERR_INVALID;
 		c->tuning.traversalVariant = value;
 		return TYR_OK;
@@ -875,6 +876,11 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		if (value < 1 || value > 64)
 			return TYR_ERR_INVALID;
 		c->tuning.minLeaves = value;
+		return TYR_OK;
+	case TYR_TUNE_STATIC_SHARE:
+		if (value < 0 || value > 15)
+			return TYR_ERR_INVALID;
+		c->tuning.staticShare = value;
 		return TYR_OK;
 	case TYR_TUNE_TICKET_CHUNK:
 		if (value < 64 || value > 65536)
