@@ -1138,6 +1138,16 @@ template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
 __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(const FrameParams P) {
 	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
 	TYR_DECLARE_STACK(st)
+	// variant 4: the top of the tree lives in LDS for the lifetime of the (persistent) block
+	__shared__ float4 stagedNodes[PERSIST ? 7 * kStagedNodes : 1];
+	const uint32_t nStaged = (PERSIST && QUAD) ? P.scene.nStaged : 0u;
+	if (PERSIST && QUAD) {
+		for (uint32_t i = threadIdx.x; i < 7 * nStaged; i += kBlock) {
+			const uint32_t v = i / nStaged, n = i - v * nStaged;
+			stagedNodes[v * kStagedNodes + n] = P.scene.quads[8 * n + v];
+		}
+		// visible to the block after the __syncthreads() that precedes the main loop
+	}
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t nLive = P.k->n_live;
@@ -1284,7 +1294,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 			if ((int)ref >= 0) {
 				TYR_DBG(0)
 				if (QUAD) {
-					const QuadHits q = allRegular ? test_quad<true, true>(sc.quads, ref, r, dist) : test_quad<false, true>(sc.quads, ref, r, dist);
+					const QuadHits q = allRegular ? test_quad<true, true, PERSIST>(sc.quads, ref, r, dist, stagedNodes, nStaged) : test_quad<false, true, PERSIST>(sc.quads, ref, r, dist, stagedNodes, nStaged);
 					// the earliest hit in visit order is entered now, the later ones are pushed latest first:
 					// entry k is pushed iff it hit and an earlier entry hit too
 					const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
@@ -1350,6 +1360,16 @@ template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
 __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(const FrameParams P) {
 	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
 	TYR_DECLARE_STACK(st)
+	// variant 4: the top of the tree lives in LDS for the lifetime of the (persistent) block
+	__shared__ float4 stagedNodes[PERSIST ? 7 * kStagedNodes : 1];
+	const uint32_t nStaged = (PERSIST && QUAD) ? P.scene.nStaged : 0u;
+	if (PERSIST && QUAD) {
+		for (uint32_t i = threadIdx.x; i < 7 * nStaged; i += kBlock) {
+			const uint32_t v = i / nStaged, n = i - v * nStaged;
+			stagedNodes[v * kStagedNodes + n] = P.scene.quads[8 * n + v];
+		}
+		// visible to the block after the __syncthreads() that precedes the main loop
+	}
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const uint32_t nRays = P.k->shadow_ray_cnt;
@@ -1485,7 +1505,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 			}
 			if ((int)ref >= 0) {
 				if (QUAD) {
-					const QuadHits q = allRegular ? test_quad<true, false>(sc.quads, ref, r, closest) : test_quad<false, false>(sc.quads, ref, r, closest);
+					const QuadHits q = allRegular ? test_quad<true, false, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged) : test_quad<false, false, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged);
 					const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
 					if (lane_in(q.hit[3] & any012))
 						st.push(q.ref[3], q.t[3]);
@@ -1641,6 +1661,7 @@ static void launch_connect_t(const FrameParams& P, uint32_t maxShadow, const Tun
 	switch (t.stackLdsDepth) {                      \
 	case 0: FN<COUNT, 0>(__VA_ARGS__); break;       \
 	case 8: FN<COUNT, 8>(__VA_ARGS__); break;       \
+	case 10: FN<COUNT, 10>(__VA_ARGS__); break;     \
 	case 12: FN<COUNT, 12>(__VA_ARGS__); break;     \
 	case 24: FN<COUNT, 24>(__VA_ARGS__); break;     \
 	default: FN<COUNT, 16>(__VA_ARGS__); break;     \

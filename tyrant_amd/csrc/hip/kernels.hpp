@@ -97,6 +97,7 @@ struct Tuning {
 	int raysPerBlock = 1024;
 	int minLeaves = 64;
 	int staticShare = 4;
+	int stagedNodes = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
 	int stackLdsDepth = 12;   // traversal-stack entries per lane kept in LDS (0, 8, 12, 16, 24); the rest spill to scratch

@@ -46,6 +46,11 @@ constexpr int kStackSize = 64;             // bvh.h:124 nodesToVisit[64]
 constexpr uint32_t kMaxLeafPrims = 31; // count-1 <= 30 keeps 0xFFFFFFFE / 0xFFFFFFFF out of the leaf encoding
 constexpr uint32_t kMaxPrimOffset = 1u << 26;
 // interior reference of the quad layout: node index in bits 0..24, the node's visit-order bits in 25..30
+// Top of the tree staged in LDS by the persistent traversal kernels (variant 4): the first kStagedNodes records
+// of the quad array are the tree's top levels in breadth-first order (host/bvh_layout.cpp).  In LDS they are kept
+// vector-major -- vector v of node n at [v][n] -- so that lanes reading different nodes spread over 16 bank
+// groups (node-major, every node would start on bank 0 or 32); lanes reading the same node are a broadcast.
+constexpr uint32_t kStagedNodes = 64;
 constexpr uint32_t kQuadOrderShift = 25;
 constexpr uint32_t kQuadIndexMask = (1u << kQuadOrderShift) - 1u;
 
@@ -53,6 +58,7 @@ struct DevScene {
 	const float4* quads; // QuadNode array, 8 float4 each (the production traversal)
 	uint32_t quadRootRef;
 	uint32_t nQuads;
+	uint32_t nStaged;    // the first nStaged quad nodes are the top of the tree in breadth-first order (<= kStagedNodes)
 	const float4* nodes; // PairNode array, 4 float4 each (the counting build and variants 0/1)
 	const float4* tris;  // 3 float4 each
 	float rootMin[3];
@@ -330,18 +336,36 @@ __device__ __forceinline__ bool slab_any(const RayConst& r, float lox, float hix
 // FAST: every lane of the wave has a finite 1/d (the caller decides once per wave, not per box: a
 // per-lane choice made the compiler emit both paths with exec juggling around each of the four tests).
 // ORDERED: closest-hit needs the reference's visit order; any-hit (bvh.h:213-256) does not depend on it.
-template <bool FAST, bool ORDERED>
-__device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, uint32_t ref, const RayConst& r, float dist) {
-	const float4* q = quads + 8 * (ref & kQuadIndexMask);
+template <bool FAST, bool ORDERED, bool STAGED = false>
+__device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, uint32_t ref, const RayConst& r, float dist, const float4* staged = nullptr, uint32_t nStaged = 0) {
+	const uint32_t idx = ref & kQuadIndexMask;
+	const float4* q = quads + 8 * idx;
 	const uint32_t meta = ref >> kQuadOrderShift; // bit 31 of an interior reference is clear
+	float4 x01, x23, y01, y23, z01, z23, rf;
 #ifdef TYR_WHATIF_DOUBLE_NODE
 	// diagnostic build only: every node is fetched twice, from two copies 128 MiB apart, and merged with min()
 	// (equal values, so the traversal is unchanged) -- measures how much of the kernel's time is node bytes
 	const float4* q2 = q + (size_t(8) << 20);
 	auto mg = [](float4 a, float4 b) { return make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)); };
-	const float4 x01 = mg(q[0], q2[0]), x23 = mg(q[1], q2[1]), y01 = mg(q[2], q2[2]), y23 = mg(q[3], q2[3]), z01 = mg(q[4], q2[4]), z23 = mg(q[5], q2[5]), rf = q[6];
+	x01 = mg(q[0], q2[0]), x23 = mg(q[1], q2[1]), y01 = mg(q[2], q2[2]), y23 = mg(q[3], q2[3]), z01 = mg(q[4], q2[4]), z23 = mg(q[5], q2[5]), rf = q[6];
 #else
-	const float4 x01 = q[0], x23 = q[1], y01 = q[2], y23 = q[3], z01 = q[4], z23 = q[5], rf = q[6];
+	if (STAGED && idx < nStaged) {
+		// an explicit LDS pointer: as a generic pointer the compiler selected between the two bases and issued
+		// 28 flat_load_dword per node
+#if defined(__HIP_DEVICE_COMPILE__)
+		typedef __attribute__((address_space(3))) const float4* lds_f4;
+		const lds_f4 c = (lds_f4)staged + idx;
+#else
+		const float4* c = staged + idx; // host pass of the same source: never executed
+#endif
+		x01 = c[0 * kStagedNodes], x23 = c[1 * kStagedNodes], y01 = c[2 * kStagedNodes], y23 = c[3 * kStagedNodes];
+		z01 = c[4 * kStagedNodes], z23 = c[5 * kStagedNodes], rf = c[6 * kStagedNodes];
+		// keeps this tail different from the global branch's: otherwise the two sets of loads are merged into
+		// loads through one generic pointer (flat_load_dword x 28)
+		__asm__ volatile("" : "+v"(rf.x));
+	} else {
+		x01 = q[0], x23 = q[1], y01 = q[2], y23 = q[3], z01 = q[4], z23 = q[5], rf = q[6];
+	}
 #endif
 	const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
 	float t0, t1, t2, t3;

@@ -284,6 +284,46 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 		L.quadRootRef = 0;
 	}
 	L.nQuads = static_cast<uint32_t>(L.quadNodes.size() / 32);
+	// The top of the tree moves to the front of the array in breadth-first order: the persistent kernels keep the
+	// first kStagedNodes records in LDS (hip/traverse.hpp).  Everything else keeps its depth-first order.
+	L.nStaged = 0;
+	if (L.nQuads > 0 && static_cast<int32_t>(L.quadRootRef) >= 0) {
+		auto ref_at = [&](uint32_t qi, int sidx) {
+			uint32_t r;
+			std::memcpy(&r, &L.quadNodes[static_cast<size_t>(qi) * 32 + 24 + sidx], 4);
+			return r;
+		};
+		std::vector<uint32_t> top{ L.quadRootRef };
+		for (size_t head = 0; head < top.size() && top.size() < kStagedNodes; ++head)
+			for (int sidx = 0; sidx < 4 && top.size() < kStagedNodes; ++sidx) {
+				const uint32_t r = ref_at(top[head], sidx);
+				if (static_cast<int32_t>(r) >= 0)
+					top.push_back(r);
+			}
+		std::vector<uint32_t> newIndex(L.nQuads, 0xFFFFFFFFu);
+		for (size_t i = 0; i < top.size(); ++i)
+			newIndex[top[i]] = static_cast<uint32_t>(i);
+		uint32_t next = static_cast<uint32_t>(top.size());
+		for (uint32_t qi = 0; qi < L.nQuads; ++qi)
+			if (newIndex[qi] == 0xFFFFFFFFu)
+				newIndex[qi] = next++;
+		std::vector<float> moved(L.quadNodes.size());
+		for (uint32_t qi = 0; qi < L.nQuads; ++qi) {
+			float* dst = &moved[static_cast<size_t>(newIndex[qi]) * 32];
+			std::memcpy(dst, &L.quadNodes[static_cast<size_t>(qi) * 32], 32 * sizeof(float));
+			for (int sidx = 0; sidx < 4; ++sidx) {
+				uint32_t r;
+				std::memcpy(&r, dst + 24 + sidx, 4);
+				if (static_cast<int32_t>(r) >= 0) {
+					r = newIndex[r];
+					std::memcpy(dst + 24 + sidx, &r, 4);
+				}
+			}
+		}
+		L.quadNodes.swap(moved);
+		L.quadRootRef = newIndex[L.quadRootRef];
+		L.nStaged = static_cast<uint32_t>(top.size());
+	}
 	// An interior reference carries the visit-order bits of the node it points to in bits 25..30 (axisTop | axisL << 2 |
 	// axisR << 4, axisTop == 3 for a synthetic chain), so the kernel knows them before the node arrives and fetches
 	// seven vectors per node instead of eight.

@@ -180,6 +180,7 @@ FrameParams make_params(const tyr_ctx* c) {
 	std::memcpy(P.spheres, c->spheres, sizeof(P.spheres));
 	P.sun = c->sun;
 	P.scene = c->scene;
+	P.scene.nStaged = std::min(c->scene.nStaged, static_cast<uint32_t>(std::max(c->tuning.stagedNodes, 0)));
 	P.work = c->q[c->cur];
 	P.next = c->q[c->cur ^ 1];
 	P.shadow = c->shadow;
@@ -449,6 +450,7 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	c->scene.quads = c->dQuads;
 	c->scene.quadRootRef = L.quadRootRef;
 	c->scene.nQuads = L.nQuads;
+	c->scene.nStaged = L.nStaged;
 	HIPCHK(hipMemcpy(c->dTris, L.tris.data(), triFloats * sizeof(float), hipMemcpyHostToDevice));
 	c->scene.nodes = c->dNodes;
 	c->scene.tris = c->dTris;
@@ -877,6 +879,11 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 			return TYR_ERR_INVALID;
 		c->tuning.minLeaves = value;
 		return TYR_OK;
+	case TYR_TUNE_STAGED_NODES:
+		if (value < 0 || value > static_cast<int>(kStagedNodes))
+			return TYR_ERR_INVALID;
+		c->tuning.stagedNodes = value;
+		return TYR_OK;
 	case TYR_TUNE_STATIC_SHARE:
 		if (value < 0 || value > 15)
 			return TYR_ERR_INVALID;
@@ -888,7 +895,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		c->tuning.ticketChunk = value;
 		return TYR_OK;
 	case TYR_TUNE_STACK_LDS_DEPTH:
-		if (value != 0 && value != 8 && value != 12 && value != 16 && value != 24)
+		if (value != 0 && value != 8 && value != 10 && value != 12 && value != 16 && value != 24)
 			return TYR_ERR_INVALID;
 		c->tuning.stackLdsDepth = value;
 		return TYR_OK;

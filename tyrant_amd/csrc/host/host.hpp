@@ -26,6 +26,7 @@ struct DeviceLayout {
 	std::vector<float> quadNodes; // 32 floats per quad node (hip/traverse.hpp "QuadNode")
 	uint32_t quadRootRef = 0;
 	uint32_t nQuads = 0;
+	uint32_t nStaged = 0; // leading records that are the top of the tree in breadth-first order
 	std::vector<float> tris;      // 12 floats per triangle
 	float rootMin[3], rootMax[3];
 	uint32_t rootRef;
