@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 	if (i < kTicketWords) {
 		P.k->extend_chunks[i * 32] = 0;
 		P.k->connect_chunks[i * 32] = 0;
+		P.k->shade_tiles[i * 32] = 0;
 	}
 	if (i == 0) {
 		DevCounters* k = P.k;
@@ -530,14 +531,194 @@ __device__ __forceinline__ uint32_t desc_h(unsigned long long d) { return (uint3
 // Now the grid is small enough to be entirely co-resident (at most 4 blocks of 256 threads per CU) and
 // block b shades tiles b, b + G, b + 2G, ...: the predecessor of any tile belongs to a block that is
 // resident, whatever order the hardware dispatched them in, so the look-back cannot starve.
+//
+// Deferred look-back.  With "shade tile i, look back for tile i, write tile i" every block waited, tile after
+// tile, for the SLOWEST of its predecessors to publish an aggregate (all resident blocks shade the same
+// generation of tiles at the same time and shading time has a long tail): an s_memtime build showed two thirds
+// of a tile's time inside the look-back, and fetching more descriptors per round trip did not help.  Now the
+// tile's compacted records wait in LDS (survivors and shadow rays at their rank inside the tile) and the
+// look-back for tile i runs AFTER tile i+G has been shaded: by then every predecessor has long published, the
+// look-back is pure round trips (kWindows x 64 descriptors each), and the records leave LDS as coalesced stores
+// (thread t writes record t).
+struct ShadeStage { // one tile's compacted output, 23 KB
+	float4 sv_o_dx[kBlock];
+	float2 sv_dyz[kBlock];
+	float4 sv_direct_ix[kBlock];
+	uint32_t sv_flags[kBlock];
+	float4 sh_o_dx[kBlock];
+	float4 sh_dyz_cd_ix[kBlock];
+	float4 sh_color[kBlock];
+};
+
+// Exclusive prefix of tile vb over all lower tiles, computed by the whole block; publishes the tile's inclusive
+// prefix.  Wave w inspects descriptors vb-1-512w ... vb-512(w+1) (kWindows x 64, lane i of window k reads one), so
+// one memory round trip covers 2048 predecessors -- more than the distance to the nearest inclusive prefix, which
+// is one to two generations of resident tiles (<= 1024 each) because the look-back is deferred by one tile.
+// With wave 0 alone and 512 descriptors per step it took three steps, 36 % of a tile's time.
+__device__ __forceinline__ void shade_lookback(const FrameParams& P, uint32_t vb, uint32_t totS, uint32_t totH, uint32_t tid, uint32_t nTiles, uint32_t* sh, uint32_t& esOut, uint32_t& ehOut) {
+	constexpr int kWindows = 2;
+	constexpr int kPerWave = 64 * kWindows, kPerStep = kPerWave * (int)(kBlock / 64);
+	const uint32_t lane = tid & 63u, wave = tid >> 6;
+	uint32_t es = 0, eh = 0;
+	if (vb > 0) { // block-uniform
+		int base = (int)vb - 1; // nearest predecessor of this step
+		for (;;) {
+			const int first = base - kPerWave * (int)wave; // nearest descriptor of this wave's share
+			unsigned long long d[kWindows];
+#pragma unroll
+			for (int k = 0; k < kWindows; ++k) {
+				const int idx = first - 64 * k - (int)lane;
+				d[k] = kDescInclusive; // below tile 0: an inclusive prefix of zero
+				if (idx >= 0)
+					d[k] = __hip_atomic_load(&P.scanDesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			bool found = false, timeout = false;
+			uint32_t ps = 0, ph = 0;
+#pragma unroll
+			for (int k = 0; k < kWindows; ++k) {
+				if (found)
+					continue; // (wave-uniform) an inclusive prefix was found in a nearer window
+				const int idx = first - 64 * k - (int)lane;
+				uint32_t spins = 0;
+				const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();
+				while (!(d[k] >> 62)) { // not published yet: poll this one
+					if (++spins > (1u << 25)) { // every wait is bounded (~4 s): report, never hang
+						timeout = true;
+						d[k] = kDescInclusive;
+						// what timed out, for TYR_VERBOSE's report (host/driver.cpp check_device_error)
+						P.k->debug[0] = vb;
+						P.k->debug[1] = (unsigned long long)idx;
+						P.k->debug[2] = blockIdx.x;
+						P.k->debug[3] = gridDim.x;
+						P.k->debug[4] = __builtin_amdgcn_s_memrealtime() - t0_; // 100 MHz ticks
+						break;
+					}
+					__builtin_amdgcn_s_sleep(1);
+					d[k] = __hip_atomic_load(&P.scanDesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				const unsigned long long inclMask = __ballot((d[k] >> 62) == 2ull);
+				// lanes up to and including the nearest inclusive descriptor contribute
+				const uint32_t stop = inclMask ? (uint32_t)__ffsll((long long)inclMask) - 1u : 63u;
+				unsigned long long v = (lane <= stop) ? (d[k] & ~(3ull << 62)) : 0ull;
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1)
+					v += __shfl_xor(v, o, 64);
+				ps += desc_s(v);
+				ph += desc_h(v);
+				found = (inclMask != 0ull);
+			}
+			if (__ballot(timeout) != 0ull && lane == 0)
+				atomicOr(&P.k->device_error, kErrScanTimeout);
+			if (lane == 0) {
+				sh[16 + 3 * wave + 0] = ps;
+				sh[16 + 3 * wave + 1] = ph;
+				sh[16 + 3 * wave + 2] = found ? 1u : 0u;
+			}
+			__syncthreads();
+			bool any = false;
+#pragma unroll
+			for (uint32_t w = 0; w < kBlock / 64; ++w) {
+				if (!any) {
+					es += sh[16 + 3 * w + 0];
+					eh += sh[16 + 3 * w + 1];
+					any = sh[16 + 3 * w + 2] != 0u;
+				}
+			}
+			__syncthreads(); // sh[16..] may be rewritten by another step
+			if (any)
+				break;
+			base -= kPerStep;
+		}
+	}
+	if (tid == 0) {
+		__hip_atomic_store(&P.scanDesc[vb], kDescInclusive | desc_pack(es + totS, eh + totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (vb == nTiles - 1) {
+			// kernel.cu:607 / 416: the totals the next top-up and connect read
+			P.k->primary_ray_cnt = es + totS;
+			P.k->shadow_ray_cnt = eh + totH;
+			P.k->total_shadow_rays += eh + totH;
+			P.k->n_survive += es + totS;
+		}
+	}
+	esOut = es;
+	ehOut = eh;
+}
+
 __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t nTiles) {
-	__shared__ uint32_t sh[16];
+	__shared__ uint32_t sh[32];
+	__shared__ ShadeStage stage;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u, wave = tid >> 6;
 	const uint32_t nLive = P.k->n_live;
 	const unsigned long long below = (1ull << lane) - 1ull;
+#ifdef TYR_SHADE_TIMING
+	// diagnostic build: where a tile's time goes, in s_memtime ticks summed over this block's tiles (thread 0;
+	// debug[0] shade, [1] ranks + barrier, [2] look-back, [3] barrier after it, [4] copy out + barrier, [5] stage +
+	// pixel atomics, [7] tiles)
+	unsigned long long tacc_[6] = { 0, 0, 0, 0, 0, 0 }, t_ = __builtin_amdgcn_s_memtime(), ntiles_ = 0;
+#define TYR_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc_[i] += now_ - t_; t_ = now_; }
+#else
+#define TYR_STAMP(i)
+#endif
+	bool havePrev = false;            // a shaded tile whose records wait in `stage`
+	uint32_t prevVb = 0, prevS = 0, prevH = 0;
 
-	for (uint32_t vb = blockIdx.x; vb < nTiles; vb += gridDim.x) { // vb = tile id = queue order
+	// finish the waiting tile: look back, then move its records from LDS to their slots (kernel.cu:607-608, 416-417)
+	auto flush_prev = [&]() {
+		uint32_t es, eh;
+		shade_lookback(P, prevVb, prevS, prevH, tid, nTiles, sh, es, eh);
+		TYR_STAMP(2)
+		// one array at a time (the compiler barrier keeps it from loading all seven records first): this copy is where
+		// the kernel's register count peaks, and 96 VGPRs = one more resident block per CU than 97
+		if (tid < prevS) {
+			P.next.o_dx[es + tid] = stage.sv_o_dx[tid];
+			__asm__ volatile("" ::: "memory");
+			P.next.direct_ix[es + tid] = stage.sv_direct_ix[tid];
+			__asm__ volatile("" ::: "memory");
+			P.next.dyz[es + tid] = stage.sv_dyz[tid];
+			P.next.flags[es + tid] = stage.sv_flags[tid];
+		}
+		__asm__ volatile("" ::: "memory");
+		if (tid < prevH) {
+			P.shadow.o_dx[eh + tid] = stage.sh_o_dx[tid];
+			__asm__ volatile("" ::: "memory");
+			P.shadow.dyz_cd_ix[eh + tid] = stage.sh_dyz_cd_ix[tid];
+			__asm__ volatile("" ::: "memory");
+			P.shadow.color[eh + tid] = stage.sh_color[tid];
+		}
+		__syncthreads(); // `stage` and sh[] are free again
+		TYR_STAMP(4)
+	};
+
+	// Tiles are drawn from eight tickets (word w hands out tiles w, w + 8, ...; a block starts at word
+	// blockIdx % 8 and moves on when a word is used up).  A tile is only ever started after every lower tile of
+	// its word, and the lowest tile not yet started always belongs to a word whose running tiles are lower still,
+	// so every tile a look-back waits for is being shaded by some block: no starvation, whatever the grid size.
+	// Unlike the fixed assignment b, b + G, ... a slow block simply shades fewer tiles instead of holding up every
+	// look-back of its generation; one word per tile id would be a single ticket again (88 draws/us: 0.74 ms for
+	// the 64.8 k tiles of a full queue).
+	uint32_t word = blockIdx.x % kTicketWords, tried = 0;
+	auto draw_tile = [&]() -> uint32_t { // block-uniform; nTiles when nothing is left
+		uint32_t vbNext = nTiles;
+		if (tid == 0) {
+			while (tried < kTicketWords) {
+				const uint32_t t = atomicAdd(&P.k->shade_tiles[word * 32], 1u);
+				const unsigned long long cand = (unsigned long long)t * kTicketWords + word;
+				if (cand < nTiles) {
+					vbNext = (uint32_t)cand;
+					break;
+				}
+				word = (word + 1) % kTicketWords;
+				++tried;
+			}
+			sh[3] = vbNext;
+		}
+		__syncthreads();
+		vbNext = sh[3];
+		__syncthreads();
+		return vbNext;
+	};
+	for (uint32_t vb = draw_tile(); vb < nTiles; vb = draw_tile()) { // vb = tile id = queue order
 		const uint32_t slot = vb * kBlock + tid;
 		ShadeOut out = {};
 		uint32_t pixelBits = 0;
@@ -545,8 +726,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t 
 			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
 			shade_ray(P, slot, out);
 		}
+		TYR_STAMP(0)
 
-		// ---- stable compaction of survivors and shadow rays -------------------------------
+		// ---- stable compaction of survivors and shadow rays: ranks inside the tile ----
 		const unsigned long long bs = __ballot(out.survive);
 		const unsigned long long bh = __ballot(out.shadow);
 		const uint32_t rs = __popcll(bs & below), rh = __popcll(bh & below);
@@ -566,80 +748,56 @@ __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t 
 			totS += cs;
 			totH += ch;
 		}
-		// Decoupled look-back, one WAVE wide: lane i inspects the descriptor of tile vb-1-i, so one memory
-		// round trip covers 64 predecessors.  Descriptor = 8 bytes {status, survivors, shadows} written by one
-		// relaxed agent-scope store: payload and flag travel together, no fence needed.
-		if (wave == 0) {
-			uint32_t es = 0, eh = 0; // exclusive prefix over lower tiles
-			if (vb > 0) {
-				if (lane == 0)
-					__hip_atomic_store(&P.scanDesc[vb], kDescAggregate | desc_pack(totS, totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				int base = (int)vb - 1; // nearest predecessor of this window
-				bool timeout = false;
-				for (;;) {
-					const int idx = base - (int)lane;
-					unsigned long long d = kDescInclusive; // below tile 0: an inclusive prefix of zero
-					if (idx >= 0) {
-						uint32_t spins = 0;
-						for (;;) {
-							d = __hip_atomic_load(&P.scanDesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-							if (d >> 62)
-								break;
-							if (++spins > (1u << 22)) { // every wait is bounded: report, never hang
-								timeout = true;
-								d = kDescInclusive;
-								break;
-							}
-							__builtin_amdgcn_s_sleep(1);
-						}
-					}
-					const unsigned long long inclMask = __ballot((d >> 62) == 2ull);
-					// lanes up to and including the nearest inclusive descriptor contribute
-					const uint32_t stop = inclMask ? (uint32_t)__ffsll((long long)inclMask) - 1u : 63u;
-					unsigned long long v = (lane <= stop) ? (d & ~(3ull << 62)) : 0ull;
-#pragma unroll
-					for (int o = 32; o > 0; o >>= 1)
-						v += __shfl_xor(v, o, 64);
-					es += desc_s(v);
-					eh += desc_h(v);
-					if (inclMask)
-						break;
-					base -= 64;
-				}
-				if (__ballot(timeout) != 0ull && lane == 0)
-					atomicOr(&P.k->device_error, kErrScanTimeout);
-			}
-			if (lane == 0) {
-				__hip_atomic_store(&P.scanDesc[vb], kDescInclusive | desc_pack(es + totS, eh + totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				sh[1] = es;
-				sh[2] = eh;
-				if (vb == nTiles - 1) {
-					// kernel.cu:607 / 416: the totals the next top-up and connect read
-					P.k->primary_ray_cnt = es + totS;
-					P.k->shadow_ray_cnt = eh + totH;
-					P.k->total_shadow_rays += eh + totH;
-					P.k->n_survive += es + totS;
-				}
-			}
-		}
-		__syncthreads();
+		totS = (uint32_t)__builtin_amdgcn_readfirstlane((int)totS); // block-uniform: keep them out of the vector registers
+		totH = (uint32_t)__builtin_amdgcn_readfirstlane((int)totH);
+		// the aggregate goes out at once: later tiles can add it up long before this tile knows its own prefix.
+		// Descriptor = 8 bytes {status, survivors, shadows} written by one relaxed agent-scope store: payload and
+		// flag travel together, no fence needed.  Tile 0 publishes one too: its inclusive prefix only appears when its
+		// deferred look-back runs, and every look-back of the first generation would sit waiting for it.
+		if (tid == 0)
+			__hip_atomic_store(&P.scanDesc[vb], kDescAggregate | desc_pack(totS, totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		TYR_STAMP(1)
+		if (havePrev)
+			flush_prev(); // ends with a barrier: sh[4..11] have been read by every thread
+		else
+			__syncthreads();
 		if (out.survive) {
-			const uint32_t dst = sh[1] + ws + rs; // kernel.cu:607-608, in slot order
-			P.next.o_dx[dst] = make_float4(out.origin.x, out.origin.y, out.origin.z, out.direction.x);
-			P.next.dyz[dst] = make_float2(out.direction.y, out.direction.z);
-			P.next.direct_ix[dst] = make_float4(out.direct.x, out.direct.y, out.direct.z, __uint_as_float(pixelBits));
-			P.next.flags[dst] = out.flags;
+			const uint32_t k = ws + rs;
+			stage.sv_o_dx[k] = make_float4(out.origin.x, out.origin.y, out.origin.z, out.direction.x);
+			stage.sv_dyz[k] = make_float2(out.direction.y, out.direction.z);
+			stage.sv_direct_ix[k] = make_float4(out.direct.x, out.direct.y, out.direct.z, __uint_as_float(pixelBits));
+			stage.sv_flags[k] = out.flags;
 		}
 		if (out.shadow) {
-			const uint32_t dst = sh[2] + wh + rh; // kernel.cu:416-417 etc., in slot order
-			P.shadow.o_dx[dst] = make_float4(out.sOrigin.x, out.sOrigin.y, out.sOrigin.z, out.sDir.x);
-			P.shadow.dyz_cd_ix[dst] = make_float4(out.sDir.y, out.sDir.z, out.sClosest, __uint_as_float(pixelBits));
-			P.shadow.color[dst] = make_float4(out.sColor.x, out.sColor.y, out.sColor.z, 0.0f);
+			const uint32_t k = wh + rh;
+			stage.sh_o_dx[k] = make_float4(out.sOrigin.x, out.sOrigin.y, out.sOrigin.z, out.sDir.x);
+			stage.sh_dyz_cd_ix[k] = make_float4(out.sDir.y, out.sDir.z, out.sClosest, __uint_as_float(pixelBits));
+			stage.sh_color[k] = make_float4(out.sColor.x, out.sColor.y, out.sColor.z, 0.0f);
 		}
+		havePrev = true;
+		prevVb = vb;
+		prevS = totS;
+		prevH = totH;
 		if (slot < nLive)
 			accumulate_pixel(P.blit, (int)pixelBits, out.color, out.newFrame);
-		__syncthreads(); // sh[] is rewritten by the next tile
+		// no barrier here: the next tile's first barrier orders these LDS writes before flush_prev reads them
+		TYR_STAMP(5)
+#ifdef TYR_SHADE_TIMING
+		++ntiles_;
+#endif
 	}
+	if (havePrev) {
+		__syncthreads();
+		flush_prev();
+	}
+#ifdef TYR_SHADE_TIMING
+	if (tid == 0) {
+		for (int i = 0; i < 6; ++i)
+			atomicAdd(&P.k->debug[i], tacc_[i]);
+		atomicAdd(&P.k->debug[7], ntiles_);
+	}
+#endif
+#undef TYR_STAMP
 }
 
 // ======================================================================================
@@ -1680,16 +1838,14 @@ void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, hipStream_
 	if (maxLive == 0)
 		return;
 	const uint32_t nTiles = blocks_for(maxLive);
-	// The look-back needs every block of the grid resident at once.  k_shade is small (64 B of LDS, < 128 VGPRs),
-	// so the hardware admits at least 4 blocks of 256 threads per CU; ask it once, take one off because the
-	// occupancy API over-reports by a block per CU for SGPR-heavy kernels (MI355X_MICROARCH.md "Residency"),
-	// and never use more than 4.
+	// A persistent grid: as many blocks as stay resident (more would only wait for a slot and then find no tile
+	// left; the tile tickets make any grid size safe).  Asked once: the occupancy query is a slow host call.
 	static int perCU = 0;
 	if (perCU == 0) {
 		int q = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade, kBlock, 0) != hipSuccess || q < 2)
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade, kBlock, 0) != hipSuccess || q < 1)
 			q = 2;
-		perCU = q - 1 > 4 ? 4 : q - 1;
+		perCU = q > 6 ? 6 : q;
 	}
 	const uint32_t resident = (uint32_t)perCU * (uint32_t)numCUs;
 	hipLaunchKernelGGL(k_shade, dim3(nTiles < resident ? nTiles : resident), dim3(kBlock), 0, stream, P, nTiles);

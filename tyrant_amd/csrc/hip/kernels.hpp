@@ -60,6 +60,7 @@ struct DevCounters {
 	// are eight L2 lines (a single word serves only ~88 returning atomics per microsecond)
 	uint32_t extend_chunks[kTicketWords * 32];
 	uint32_t connect_chunks[kTicketWords * 32];
+	uint32_t shade_tiles[kTicketWords * 32]; // k_shade: word w hands out tiles w, w + 8, w + 16, ...
 };
 constexpr uint32_t kErrStackOverflow = 1u;
 constexpr uint32_t kErrScanTimeout = 2u;

@@ -303,7 +303,34 @@ void stage_end(tyr_ctx* c) {
 	c->cur ^= 1; // main.cpp:169
 }
 
-int check_device_error(const tyr_ctx* c) { return c->hK->device_error ? TYR_ERR_DEVICE : TYR_OK; }
+int check_device_error(const tyr_ctx* c) {
+	if (!c->hK->device_error)
+		return TYR_OK;
+	if (std::getenv("TYR_VERBOSE")) {
+		std::fprintf(stderr, "[tyrant] device_error bits 0x%x (1 = traversal stack overflow, 2 = compaction look-back timeout); n_live %u\n", c->hK->device_error, c->hK->n_live);
+		// state of the compaction descriptors of the failed launch
+		std::vector<unsigned long long> d(c->nDescCap);
+		DevCounters k;
+		if (hipMemcpy(d.data(), c->scanDesc, d.size() * 8, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(&k, c->dK, sizeof k, hipMemcpyDeviceToHost) == hipSuccess) {
+			const uint32_t nTiles = (c->hK->n_live + kBlock - 1) / kBlock;
+			uint32_t cnt[4] = { 0, 0, 0, 0 };
+			int firstEmpty = -1, firstAgg = -1;
+			for (uint32_t i = 0; i < nTiles && i < d.size(); ++i) {
+				const uint32_t st = static_cast<uint32_t>(d[i] >> 62);
+				++cnt[st];
+				if (st == 0 && firstEmpty < 0)
+					firstEmpty = static_cast<int>(i);
+				if (st == 1 && firstAgg < 0)
+					firstAgg = static_cast<int>(i);
+			}
+			std::fprintf(stderr, "[tyrant] %u tiles: %u unpublished, %u aggregate only, %u inclusive; first unpublished %d, first aggregate-only %d; tile tickets", nTiles, cnt[0], cnt[1], cnt[2], firstEmpty, firstAgg);
+			for (uint32_t w = 0; w < kTicketWords; ++w)
+				std::fprintf(stderr, " %u", k.shade_tiles[w * 32]);
+			std::fprintf(stderr, "\n[tyrant] last timed-out wait: tile %llu waited for tile %llu (block %llu of %llu) for %.3f ms\n", k.debug[0], k.debug[1], k.debug[2], k.debug[3], k.debug[4] / 1e5);
+		}
+	}
+	return TYR_ERR_DEVICE;
+}
 
 } // namespace
 
