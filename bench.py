@@ -125,6 +125,9 @@ def main():
                         accum.copy_(host)
                 else:
                     tdist.reduce_accum(accum, dst=0)
+                    # the collective is enqueued on torch's stream, the library renders on its own: the next step's
+                    # tyr_reset_accum must not zero the buffer while RCCL still reads it
+                    torch.cuda.current_stream().synchronize()
             return it
 
         def fence():

@@ -919,6 +919,9 @@ __global__ void __launch_bounds__(kBlock) k_extend_persistent(const FrameParams 
 // Register budget of the flat traversal kernels, as waves per SIMD.  Five (<= 96 VGPRs) measured 7-10 % faster in
 // extend than the four the allocator picks by itself (99 VGPRs); six (80 VGPRs) spills 32 registers in the descent
 // loop and is 40 % slower.  Deeper LDS stacks cap the occupancy below five anyway.
+#ifndef TYR_CONNECT_ORDERED
+#define TYR_CONNECT_ORDERED false
+#endif
 #ifndef TYR_FLAT_WAVES_PER_EU
 #define TYR_FLAT_WAVES_PER_EU (STACK_LDS <= 12 ? 5 : STACK_LDS <= 16 ? 4 : 3)
 #endif
@@ -1663,7 +1666,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 			}
 			if ((int)ref >= 0) {
 				if (QUAD) {
-					const QuadHits q = allRegular ? test_quad<true, false, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged) : test_quad<false, false, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged);
+					const QuadHits q = allRegular ? test_quad<true, TYR_CONNECT_ORDERED, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged) : test_quad<false, TYR_CONNECT_ORDERED, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged);
 					const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
 					if (lane_in(q.hit[3] & any012))
 						st.push(q.ref[3], q.t[3]);
