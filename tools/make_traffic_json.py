@@ -9,6 +9,7 @@ import re
 import sys
 
 wl, path = sys.argv[1], sys.argv[2]
+queue = int(sys.argv[3]) if len(sys.argv) > 3 else 1920 * 1080 * 8  # bench.py's default queue at 1080p, 8 spp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 kernel, vals = None, {}
 cur = None
@@ -27,6 +28,7 @@ write, _ = vals["WRITE_SIZE"]
 name = f"r01_pmc_traffic_bench_{wl}_final.txt"
 out = {
     "workload": wl,
+    "queue_size": queue,
     "kernel": kernel,
     "launches": n,
     "FETCH_SIZE_KB_per_launch": fetch,

@@ -923,7 +923,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_persistent(const FrameParams 
 #define TYR_CONNECT_ORDERED false
 #endif
 #ifndef TYR_FLAT_WAVES_PER_EU
-#define TYR_FLAT_WAVES_PER_EU (STACK_LDS <= 12 ? 5 : STACK_LDS <= 16 ? 4 : 3)
+#define TYR_FLAT_WAVES_PER_EU (STACK_LDS <= 12 ? 5 : STACK_LDS <= 16 ? 3 : 2)
 #endif
 
 #define TYR_DBG(i)                                                     \
