@@ -266,6 +266,30 @@ def test_every_traversal_variant_is_bit_exact(orc, hip, variant, lds):
 
 
 
+@pytest.mark.parametrize("knobs", [
+    dict(static_share=0, ticket_chunk=64), dict(static_share=15, ticket_chunk=4096), dict(static_share=8, ticket_chunk=256, staged_nodes=0),
+    dict(staged_nodes=1), dict(staged_nodes=21, stack_lds_depth=10), dict(refill_min_idle=1, min_traversing=1), dict(refill_min_idle=64, min_traversing=64, min_leaves=1),
+    dict(traversal_variant=3, rays_per_block=256), dict(traversal_variant=3, rays_per_block=65536),
+])
+def test_work_distribution_knobs_never_change_results(orc, hip, knobs):
+    """every launch-shape knob of tyr_set_tuning -- how queue slots reach the waves, how much of the tree sits in LDS,
+    when the descent loop is left -- at its extremes: queues stay bit-identical to the oracle's, on a scene whose
+    tree is deeper than the LDS stack and on a queue that is not a multiple of anything"""
+    for name, W, H, N in (("mesh128", 72, 40, 2999), ("cornell_soup2k", 50, 30, 777)):
+        o, g = pair(orc, hip, name, W, H, N)
+        g.set_tuning(**knobs)
+        for it in range(3):
+            o.launch_kernels(), g.launch_kernels()
+            ko, kg = o.counters(), g.counters()
+            assert kg["device_error"] == 0
+            for f in ("primary_ray_cnt", "shadow_ray_cnt", "n_shadow_visible", "total_shadow_rays", "n_survive"):
+                assert ko[f] == kg[f], (name, knobs, it, f)
+            ns, nh = ko["primary_ray_cnt"], ko["shadow_ray_cnt"]
+            assert_state_equal(o.ray_queue(0, ns), g.ray_queue(0, ns), f"{name} {knobs} iteration {it}")
+            assert o.shadow_queue(nh).tobytes() == g.shadow_queue(nh).tobytes()
+        assert_accum_close(o.blit_buffer(), g.blit_buffer(), f"{name} {knobs}")
+
+
 def test_bench_two_ranks_on_one_gpu(hip):
     """bench.py's N > 1 path end to end on hardware: two ranks (gloo, both on device 0), rows dealt y % 2 == rank,
     16 spp in total, reduce onto rank 0 -- bench.py itself asserts that every pixel of the reduced frame holds
