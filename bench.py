@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=3)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearse the multi-rank path with every rank on one GPU (the reduce then goes through host memory)")
+    ap.add_argument("--combine", default="gather", choices=["gather", "reduce"], help="N > 1: how rank 0 gets the frame -- gather of the rows each rank owns (1/N of the frame per rank; falls back to the reduce if a probe of dist.gather fails on any rank) or sum-reduce of the full buffers")
     ap.add_argument("--tune", action="append", default=[], help="launch-shape knob of tyr_set_tuning, e.g. --tune shade_tiles=2 (never changes results)")
     args = ap.parse_args()
 
@@ -103,6 +104,10 @@ def main():
     sc, nodes, prims, label, t_build = build_workload(args.workload, binding, scenes)
     flags = binding.TYR_FLAG_PROFILE | (binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0)
     shard = tdist.shard_spec(rank, world, H)
+    # how rank 0 gets the frame: the ranks' own rows by point-to-point gather when that works everywhere, else the sum
+    use_gather = False
+    if world > 1 and args.combine == "gather":
+        use_gather = tdist.agree_gather_works("cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
 
     def measure(N, steps, warmup):
         """one renderer at queue size N: untimed counting render, warm-up, `steps` timed renders"""
@@ -118,13 +123,14 @@ def main():
             r.reset_accum()
             it = r.render(spp_total)
             if world > 1:
+                combine = (lambda t: tdist.gather_rows(t, H, W, rank, world, dst=0)) if use_gather else (lambda t: tdist.reduce_accum(t, dst=0))
                 if args.backend == "gloo":
                     host = accum.cpu()
-                    tdist.reduce_accum(host, dst=0)
+                    combine(host)
                     if rank == 0:
                         accum.copy_(host)
                 else:
-                    tdist.reduce_accum(accum, dst=0)
+                    combine(accum)
                     # the collective is enqueued on torch's stream, the library renders on its own: the next step's
                     # tyr_reset_accum must not zero the buffer while RCCL still reads it
                     torch.cuda.current_stream().synchronize()
@@ -227,7 +233,7 @@ def main():
                 "queue_size": N,
                 "triangles": int(prims.shape[0]),
                 "bvh_nodes": int(nodes.shape[0]),
-                "sharding": f"rows y % {world} == rank, RCCL reduce of the accumulation buffer" if world > 1 else "none",
+                "sharding": (f"rows y % {world} == rank, " + ("RCCL gather of each rank's rows onto rank 0" if use_gather else "RCCL reduce of the accumulation buffer")) if world > 1 else "none",
                 "wavefront_iterations_per_step": iters / args.steps,
                 "extend_Mrays/s": round(ext_all / dt_all / 1e6, 3),
                 "shadow_Mrays/s": round(shd_all / dt_all / 1e6, 3),

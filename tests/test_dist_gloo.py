@@ -39,9 +39,13 @@ def _worker(rank, world, port, out_dir):
     mine = o.blit_buffer()
     np.save(os.path.join(out_dir, f"shard{rank}.npy"), mine)
     accum = torch.from_numpy(mine.copy()).reshape(-1)
+    gathered = accum.clone()
     tdist.reduce_accum(accum, dst=0)
+    assert tdist.agree_gather_works("cpu")
+    tdist.gather_rows(gathered, H, W, rank, world, dst=0)
     if rank == 0:
         np.save(os.path.join(out_dir, "reduced.npy"), accum.numpy().reshape(-1, 4))
+        np.save(os.path.join(out_dir, "gathered.npy"), gathered.numpy().reshape(-1, 4))
     import torch.distributed as dist
 
     dist.barrier()
@@ -62,6 +66,8 @@ def test_two_rank_gloo_reduce(tmp_path):
     # the reduce is the frame: every pixel has exactly SPP completed paths, values are the shards'
     assert np.array_equal(red, s0 + s1)
     assert np.all(red[:, :, 3] == SPP)
+    # the cheaper way to the same frame: gather of the rows each rank owns
+    assert np.array_equal(np.load(tmp_path / "gathered.npy").reshape(H, W, 4), red)
 
 
 def test_shard_spec_and_rows():
