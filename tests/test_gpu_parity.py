@@ -226,6 +226,36 @@ def test_full_size_properties(hip, orc):
     assert_state_equal(o.ray_queue(0), g3.ray_queue(0), "1080p primary rays")
 
 
+def test_full_size_first_wavefront_on_the_million_triangle_scene(hip, orc):
+    """BASELINE config C3 (996,882 triangles) at 1080p and the reference's queue size: the first wavefront -- 2 Mi
+    primary rays through the 1.1 M-node tree, shaded -- is bit-exact against the oracle; the rest of the render is
+    checked through ray conservation and exact sample counts"""
+    W, H, N, spp = 1920, 1080, 2097152, 1
+    sc, nodes, prims = built_scene("mesh706")
+    o = orc.Oracle(W, H, N, flags=1)
+    g = hip.Renderer(W, H, N, flags=1)
+    o.load_scene(sc, nodes, prims), g.load_scene(sc, nodes, prims)
+    for r in (o, g):
+        r.stage("begin"), r.stage("primary"), r.stage("extend")
+    qo, qg = o.ray_queue(0), g.ray_queue(0)
+    assert np.array_equal(bits(qo["distance"]), bits(qg["distance"]))
+    hit = qo["distance"] < 1e20
+    assert hit.mean() > 0.25 and np.array_equal(qo["identifier"][hit], qg["identifier"][hit]) and np.array_equal(qo["geometry_type"][hit], qg["geometry_type"][hit])
+    o.stage("shade"), g.stage("shade")
+    ko, kg = o.counters(), g.counters()
+    assert kg["device_error"] == 0 and ko["primary_ray_cnt"] == kg["primary_ray_cnt"] and ko["shadow_ray_cnt"] == kg["shadow_ray_cnt"]
+    assert_state_equal(o.ray_queue(1, ko["primary_ray_cnt"]), g.ray_queue(1, kg["primary_ray_cnt"]), "C3 survivors of the first wavefront")
+    assert o.shadow_queue(ko["shadow_ray_cnt"]).tobytes() == g.shadow_queue(kg["shadow_ray_cnt"]).tobytes()
+    # a whole render at the GPU-sized queue: conservation and sample counts
+    g2 = hip.Renderer(W, H, W * H * 2, flags=1)
+    g2.load_scene(sc, nodes, prims)
+    g2.render(2)
+    k = g2.counters()
+    assert k["device_error"] == 0 and k["total_primary_rays"] == 2 * W * H and k["total_extend_rays"] == k["total_primary_rays"] + k["n_survive"]
+    b = g2.blit_buffer()
+    assert np.all(b[:, 3] == 2) and np.all(np.isfinite(b)) and np.all(b[:, :3] >= 0)
+
+
 def test_cpp_host_api_example(hip):
     """examples/render_main.cpp -- the reference's main.cpp loop written against include/tyrant/*.h -- runs
     (BVH build, upload, 24 frames of launch_kernels + the caller's swap, resolve, PPM)"""
