@@ -114,6 +114,15 @@ __device__ __forceinline__ float sphere_intersect(const tyr_sphere& sp, f3 origi
 	st.bind(smem_ + threadIdx.x, spillRef_, spillT_);                                \
 	st.reset();
 
+// the flat kernels' stack (hip/traverse.hpp LdsStack), same storage
+#define TYR_DECLARE_FLAT_STACK(st)                                                   \
+	__shared__ uint2 smem_[STACK_LDS ? STACK_LDS * kBlock : 1];                      \
+	uint32_t spillRef_[kStackSize - STACK_LDS];                                      \
+	float spillT_[kStackSize - STACK_LDS];                                           \
+	LdsStack<STACK_LDS> st;                                                          \
+	st.bind(smem_ + threadIdx.x, spillRef_, spillT_);                                \
+	st.reset();
+
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // wave-aggregated 64-bit counter add (one atomic per wave)
@@ -1298,7 +1307,7 @@ __device__ __forceinline__ uint32_t static_range(uint32_t nItems, uint32_t sixte
 template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
 __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(const FrameParams P) {
 	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
-	TYR_DECLARE_STACK(st)
+	TYR_DECLARE_FLAT_STACK(st)
 	// variant 4: the top of the tree lives in LDS for the lifetime of the (persistent) block
 	__shared__ float4 stagedNodes[PERSIST ? 7 * kStagedNodes : 1];
 	const uint32_t nStaged = (PERSIST && QUAD) ? P.scene.nStaged : 0u;
@@ -1459,12 +1468,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 					// the earliest hit in visit order is entered now, the later ones are pushed latest first:
 					// entry k is pushed iff it hit and an earlier entry hit too
 					const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
-					if (lane_in(q.hit[3] & any012))
-						st.push(q.ref[3], q.t[3]);
-					if (lane_in(q.hit[2] & any01))
-						st.push(q.ref[2], q.t[2]);
-					if (lane_in(q.hit[1] & q.hit[0]))
-						st.push(q.ref[1], q.t[1]);
+					st.push3(q.hit[3] & any012, q.ref[3], q.t[3], q.hit[2] & any01, q.ref[2], q.t[2], q.hit[1] & q.hit[0], q.ref[1], q.t[1]);
 					ref = lane_in(q.hit[0]) ? q.ref[0] : lane_in(q.hit[1]) ? q.ref[1] : lane_in(q.hit[2]) ? q.ref[2] : lane_in(q.hit[3]) ? q.ref[3] : kRefPop;
 				} else {
 					const PairTest p = allRegular ? test_pair_fast(sc.nodes, ref, r, dist) : test_pair(sc.nodes, ref, r, dist);
@@ -1520,7 +1524,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
 __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(const FrameParams P) {
 	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
-	TYR_DECLARE_STACK(st)
+	TYR_DECLARE_FLAT_STACK(st)
 	// variant 4: the top of the tree lives in LDS for the lifetime of the (persistent) block
 	__shared__ float4 stagedNodes[PERSIST ? 7 * kStagedNodes : 1];
 	const uint32_t nStaged = (PERSIST && QUAD) ? P.scene.nStaged : 0u;
@@ -1668,12 +1672,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 				if (QUAD) {
 					const QuadHits q = allRegular ? test_quad<true, TYR_CONNECT_ORDERED, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged) : test_quad<false, TYR_CONNECT_ORDERED, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged);
 					const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
-					if (lane_in(q.hit[3] & any012))
-						st.push(q.ref[3], q.t[3]);
-					if (lane_in(q.hit[2] & any01))
-						st.push(q.ref[2], q.t[2]);
-					if (lane_in(q.hit[1] & q.hit[0]))
-						st.push(q.ref[1], q.t[1]);
+					st.push3(q.hit[3] & any012, q.ref[3], q.t[3], q.hit[2] & any01, q.ref[2], q.t[2], q.hit[1] & q.hit[0], q.ref[1], q.t[1]);
 					ref = lane_in(q.hit[0]) ? q.ref[0] : lane_in(q.hit[1]) ? q.ref[1] : lane_in(q.hit[2]) ? q.ref[2] : lane_in(q.hit[3]) ? q.ref[3] : kRefPop;
 					continue;
 				}
