@@ -225,7 +225,7 @@ enum {
 	TYR_TUNE_STACK_LDS_DEPTH = 3,   /* traversal-stack entries per lane held in LDS: 0, 8, 12 (default), 16 or 24; deeper entries spill to scratch */
 	TYR_TUNE_MIN_TRAVERSING = 4,    /* variant 2: leave the descent loop when fewer lanes than this are descending and leaves / refills are pending (1..64, default 32) */
 	TYR_TUNE_TICKET_CHUNK = 5,      /* variants 1/4: queue slots a wave reserves per global atomic (64..65536, default 64) */
-	TYR_TUNE_MIN_LEAVES = 7,        /* variants 2/3: also leave the descent loop once this many lanes hold a leaf, so triangle tests run wide (1..64) */
+	TYR_TUNE_MIN_LEAVES = 7,        /* retired (leaving the descent loop once this many lanes hold a leaf never paid): accepted, no effect */
 	TYR_TUNE_STATIC_SHARE = 8,      /* variant 4: sixteenths of the queue dealt to the blocks as fixed ranges before the ticketed chunks start (0..15, default 4) */
 	TYR_TUNE_STAGED_NODES = 9,      /* variant 4: top-of-tree quad nodes each block keeps in LDS (0..64, default 64) */
 	TYR_TUNE_RAYS_PER_BLOCK = 6     /* variants 2/3: queue slots owned by one 256-thread block and handed to its free lanes through LDS (256..65536, default 1024; halved automatically for thin queues) */

@@ -1438,17 +1438,14 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
 			if (nTrav == 0)
 				break;
-			{
-				// leave the descent when enough lanes hold a leaf for the triangle tests to run wide, or when few
-				// lanes are still descending and there is anything else to do (leaves, or a refill)
-				const uint32_t nLeaf = __popcll(__ballot(ref_is_leaf(ref)));
-				if (nLeaf >= P.minLeaves)
+			// leave the descent when few lanes are still descending and there is anything else to do (leaves, or a
+			// refill).  (Also leaving once many lanes hold a leaf, so that triangle tests run wide, was measured at
+			// every threshold and never paid; the test cost eight instructions per trip.)
+			if (nTrav < P.minTraversing) {
+				const bool anyLeaf = __ballot(ref_is_leaf(ref)) != 0ull;
+				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
+				if (anyLeaf || canRefill)
 					break;
-				if (nTrav < P.minTraversing) {
-					const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
-					if (nLeaf > 0 || canRefill)
-						break;
-				}
 			}
 			if (ref == kRefPop) {
 				TYR_DBG(2)
@@ -1644,17 +1641,14 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
 			if (nTrav == 0)
 				break;
-			{
-				// leave the descent when enough lanes hold a leaf for the triangle tests to run wide, or when few
-				// lanes are still descending and there is anything else to do (leaves, or a refill)
-				const uint32_t nLeaf = __popcll(__ballot(ref_is_leaf(ref)));
-				if (nLeaf >= P.minLeaves)
+			// leave the descent when few lanes are still descending and there is anything else to do (leaves, or a
+			// refill).  (Also leaving once many lanes hold a leaf, so that triangle tests run wide, was measured at
+			// every threshold and never paid; the test cost eight instructions per trip.)
+			if (nTrav < P.minTraversing) {
+				const bool anyLeaf = __ballot(ref_is_leaf(ref)) != 0ull;
+				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
+				if (anyLeaf || canRefill)
 					break;
-				if (nTrav < P.minTraversing) {
-					const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
-					if (nLeaf > 0 || canRefill)
-						break;
-				}
 			}
 			if (ref == kRefPop) {
 				uint32_t pr;

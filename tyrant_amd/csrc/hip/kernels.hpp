@@ -87,7 +87,6 @@ struct FrameParams {
 	uint32_t ticketChunk;         // variant 1: queue slots a wave takes per global atomic
 	uint32_t raysPerBlock;        // variants 2/3: queue slots owned by one 256-thread block
 	uint32_t staticShare;         // variant 4: sixteenths of the queue handed out as fixed per-block ranges
-	uint32_t minLeaves;           // variants 2/3: leave the descent loop once this many lanes hold a leaf
 };
 
 // traversal kernel structure (tyr_set_tuning)
@@ -96,7 +95,6 @@ struct Tuning {
 	int minTraversing = 32;
 	int ticketChunk = 64;
 	int raysPerBlock = 1024;
-	int minLeaves = 64;
 	int staticShare = 4;
 	int stagedNodes = 64;
 	int refillMinIdle = 16;

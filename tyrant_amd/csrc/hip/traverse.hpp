@@ -458,12 +458,11 @@ __device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, 
 	bool h3 = slab_any<FAST>(r, x23.z, x23.w, y23.z, y23.w, z23.z, z23.w, dist, t3);
 	const bool synthetic = (meta & 3u) == 3u; // consecutive chunks of one over-long leaf: no box tests, slot order (bvh.h:131)
 	if (synthetic) {
-		h0 = h1 = h2 = h3 = true;
+		h0 = (r0 != kRefDone), h1 = (r1 != kRefDone), h2 = (r2 != kRefDone), h3 = (r3 != kRefDone); // every used slot
 		t0 = t1 = t2 = t3 = -__builtin_inff();
 	}
-	// unused slots never hit
-	const lanemask H0 = lanes_where(h0 && (r0 != kRefDone)), H1 = lanes_where(h1 && (r1 != kRefDone));
-	const lanemask H2 = lanes_where(h2 && (r2 != kRefDone)), H3 = lanes_where(h3 && (r3 != kRefDone));
+	// unused slots of ordinary nodes never hit: their box is at +infinity (host/bvh_layout.cpp "an empty slot")
+	const lanemask H0 = lanes_where(h0), H1 = lanes_where(h1), H2 = lanes_where(h2), H3 = lanes_where(h3);
 	if (!ORDERED) {
 		QuadHits o;
 		o.ref[0] = r0, o.ref[1] = r1, o.ref[2] = r2, o.ref[3] = r3;

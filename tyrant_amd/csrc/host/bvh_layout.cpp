@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include "host.hpp"
@@ -209,11 +210,14 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 		q[28] = bits(meta);
 		q[29] = q[30] = q[31] = 0.0f;
 	};
-	// an empty slot: a finite box no ray can enter in the tests, and a reference that marks it unused
+	// an empty slot: both planes of every axis at +infinity, and a reference that marks it unused.  No ray passes the
+	// box tests on it (hip/traverse.hpp): a positive 1/d makes the entry distance +inf (never < the bound), a
+	// negative one makes the exit distance -inf (never > 0), infinite 1/d likewise, and inf * x is never NaN for
+	// x != 0 -- so the kernels do not spend four compares per node on "is this slot used".
 	tyr_bbox emptyBox;
 	for (int k = 0; k < 3; ++k) {
-		emptyBox.bounds[0][k] = 1e30f;
-		emptyBox.bounds[1][k] = 1e30f;
+		emptyBox.bounds[0][k] = std::numeric_limits<float>::infinity();
+		emptyBox.bounds[1][k] = std::numeric_limits<float>::infinity();
 	}
 	// leaf reference in the quad layout; leaves longer than kMaxLeafPrims become synthetic quads
 	// (bit 6 of meta) whose slots are consecutive chunks, visited in slot order without box tests

@@ -191,7 +191,6 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.minTraversing = static_cast<uint32_t>(std::min(std::max(c->tuning.minTraversing, 1), 64));
 	P.ticketChunk = static_cast<uint32_t>(std::min(std::max(c->tuning.ticketChunk, 64), 65536));
 	P.raysPerBlock = static_cast<uint32_t>(std::min(std::max(c->tuning.raysPerBlock, 256), 65536));
-	P.minLeaves = static_cast<uint32_t>(std::min(std::max(c->tuning.minLeaves, 1), 64));
 	P.staticShare = static_cast<uint32_t>(std::min(std::max(c->tuning.staticShare, 0), 15));
 	return P;
 }
@@ -902,10 +901,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		c->tuning.raysPerBlock = value;
 		return TYR_OK;
 	case TYR_TUNE_MIN_LEAVES:
-		if (value < 1 || value > 64)
-			return TYR_ERR_INVALID;
-		c->tuning.minLeaves = value;
-		return TYR_OK;
+		return (value < 1 || value > 64) ? TYR_ERR_INVALID : TYR_OK; // retired knob: accepted, no effect
 	case TYR_TUNE_STAGED_NODES:
 		if (value < 0 || value > static_cast<int>(kStagedNodes))
 			return TYR_ERR_INVALID;
