@@ -1487,9 +1487,14 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 		if (ref_is_leaf(ref)) {
 			const uint32_t off = ref & (kMaxPrimOffset - 1);
 			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+			TriData tri = triangle_load(sc.tris, off);
 			for (uint32_t i = 0; i < cnt; ++i) {
 				TYR_DBG(4)
-				const float t = triangle_test(sc.tris, off + i, r);
+				// the next primitive of the leaf is on its way while this one is tested (a leaf is 1..4 consecutive records)
+				const TriData cur = tri;
+				if (i + 1 < cnt)
+					tri = triangle_load(sc.tris, off + i + 1);
+				const float t = triangle_test(cur, r);
 				if (COUNT)
 					vc.tris += 1;
 				if (t > kEpsilon && t < dist && ((dist - t) > kEpsilon)) {
@@ -1690,8 +1695,12 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 			const uint32_t off = ref & (kMaxPrimOffset - 1);
 			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
 			bool found = false;
+			TriData tri = triangle_load(sc.tris, off);
 			for (uint32_t i = 0; i < cnt && !found; ++i) {
-				const float t = triangle_test(sc.tris, off + i, r);
+				const TriData cur = tri; // next record in flight while this one is tested
+				if (i + 1 < cnt)
+					tri = triangle_load(sc.tris, off + i + 1);
+				const float t = triangle_test(cur, r);
 				if (COUNT)
 					vc.tris += 1;
 				found = (t > kEpsilon && ((closest - t) > kEpsilon)); // bvh.h:232-236

@@ -111,10 +111,20 @@ __device__ __forceinline__ bool slab_test(const RayConst& r, float lox, float hi
 }
 
 // loader.h:21-46: Moller-Trumbore, back faces culled (det < 1e-7), 0 = miss
-__device__ __forceinline__ float triangle_test(const float4* __restrict__ tris, uint32_t prim, const RayConst& r) {
-	const float4 a = tris[3 * prim + 0];
-	const float4 b = tris[3 * prim + 1];
-	const float4 c = tris[3 * prim + 2];
+struct TriData {
+	float4 a, b, c; // vert.xyz e1.x | e1.yz e2.xy | e2.z material pad pad
+};
+__device__ __forceinline__ TriData triangle_load(const float4* __restrict__ tris, uint32_t prim) {
+	TriData d;
+	d.a = tris[3 * prim + 0];
+	d.b = tris[3 * prim + 1];
+	d.c = tris[3 * prim + 2];
+	return d;
+}
+__device__ __forceinline__ float triangle_test(const TriData& d, const RayConst& r);
+__device__ __forceinline__ float triangle_test(const float4* __restrict__ tris, uint32_t prim, const RayConst& r) { return triangle_test(triangle_load(tris, prim), r); }
+__device__ __forceinline__ float triangle_test(const TriData& d, const RayConst& r) {
+	const float4 a = d.a, b = d.b, c = d.c;
 	const f3 vert = mk3(a.x, a.y, a.z);
 	const f3 e1 = mk3(a.w, b.x, b.y);
 	const f3 e2 = mk3(b.z, b.w, c.x);
