@@ -932,7 +932,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_persistent(const FrameParams 
 #define TYR_CONNECT_ORDERED false
 #endif
 #ifndef TYR_FLAT_WAVES_PER_EU
-#define TYR_FLAT_WAVES_PER_EU (STACK_LDS <= 12 ? 5 : STACK_LDS <= 16 ? 3 : 2)
+#define TYR_FLAT_WAVES_PER_EU (STACK_LDS <= 8 ? 6 : STACK_LDS <= 12 ? 5 : STACK_LDS <= 16 ? 3 : 2)
 #endif
 
 #define TYR_DBG(i)                                                     \
@@ -1416,15 +1416,21 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 					dist = h.x;
 					slot = s;
 					hitTri = false;
-					live = true;
 					st.reset();
 					ref = root_ref(sc, nr, dist);
 					if (QUAD && ref != kRefDone)
 						ref = sc.quadRootRef;
+					// a ray that misses the root box (or is already stopped short of it by a sphere) is finished here:
+					// the pre-pass's answer stands, nothing to write, the lane stays free
+					live = (ref != kRefDone);
 					if (COUNT)
 						vc.nodes += 1;
 				}
 			}
+			// Primary rays mostly end right there (three in four on C3): top the wave up again rather than run
+			// the descent loop a quarter full.  Every pass consumes queue slots, so this terminates.
+			if (!exhausted && (uint32_t)__popcll(__ballot(live)) < P.minTraversing)
+				continue;
 		}
 		if (__ballot(live) == 0ull) {
 			if (exhausted)
