@@ -115,11 +115,11 @@ __device__ __forceinline__ float sphere_intersect(const tyr_sphere& sp, f3 origi
 	st.reset();
 
 // the flat kernels' stack (hip/traverse.hpp LdsStack), same storage
-#define TYR_DECLARE_FLAT_STACK(st)                                                   \
-	__shared__ uint2 smem_[STACK_LDS ? STACK_LDS * kBlock : 1];                      \
+#define TYR_DECLARE_FLAT_STACK(st, WITH_T)                                           \
+	__shared__ typename LdsStack<STACK_LDS, WITH_T>::entry_t smem_[STACK_LDS ? STACK_LDS * kBlock : 1]; \
 	uint32_t spillRef_[kStackSize - STACK_LDS];                                      \
-	float spillT_[kStackSize - STACK_LDS];                                           \
-	LdsStack<STACK_LDS> st;                                                          \
+	float spillT_[(WITH_T) ? kStackSize - STACK_LDS : 1];                            \
+	LdsStack<STACK_LDS, WITH_T> st;                                                  \
 	st.bind(smem_ + threadIdx.x, spillRef_, spillT_);                                \
 	st.reset();
 
@@ -1307,7 +1307,7 @@ __device__ __forceinline__ uint32_t static_range(uint32_t nItems, uint32_t sixte
 template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
 __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(const FrameParams P) {
 	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
-	TYR_DECLARE_FLAT_STACK(st)
+	TYR_DECLARE_FLAT_STACK(st, true)
 	// variant 4: the top of the tree lives in LDS for the lifetime of the (persistent) block
 	__shared__ float4 stagedNodes[PERSIST ? 7 * kStagedNodes : 1];
 	const uint32_t nStaged = (PERSIST && QUAD) ? P.scene.nStaged : 0u;
@@ -1532,7 +1532,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
 __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(const FrameParams P) {
 	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
-	TYR_DECLARE_FLAT_STACK(st)
+	constexpr bool kKeepT = !(QUAD && !COUNT); // the pair / counting path marks failed boxes through the entry distance
+	TYR_DECLARE_FLAT_STACK(st, kKeepT)
 	// variant 4: the top of the tree lives in LDS for the lifetime of the (persistent) block
 	__shared__ float4 stagedNodes[PERSIST ? 7 * kStagedNodes : 1];
 	const uint32_t nStaged = (PERSIST && QUAD) ? P.scene.nStaged : 0u;

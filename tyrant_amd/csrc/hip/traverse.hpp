@@ -33,6 +33,8 @@
 // bvh.h:134 -- is identical.
 #pragma once
 
+#include <type_traits>
+
 #include <hip/hip_runtime.h>
 
 #include "vecmath.hpp"
@@ -225,15 +227,19 @@ struct TravStack {
 // three pushes of a quad step: each push nested "is there a cached top", "LDS or private", "full?".  Here a wave
 // first asks once whether ANY of its lanes could leave the LDS part during this step; if not (the common case) a
 // push is one predicated ds_write_b64 and a pop one ds_read_b64.
-template <int LDS_DEPTH>
+template <int LDS_DEPTH, bool WITH_T = true>
 struct LdsStack {
+	// WITH_T = false: entries are the reference alone (4 bytes).  Any-hit traversal tests boxes against a bound that
+	// never shrinks, so the pop-time "entry distance < bound" re-check of the closest-hit traversal is always true
+	// and the entry distance need not be kept: half the LDS per lane and ds_*_b32 instead of ds_*_b64.
 	static constexpr int kBlockThreads = 256;
-	uint2* lds;          // this thread's column: entry d at lds[d * kBlockThreads]
+	typedef typename std::conditional<WITH_T, uint2, uint32_t>::type entry_t;
+	entry_t* lds;        // this thread's column: entry d at lds[d * kBlockThreads]
 	uint32_t* spillRef;  // kStackSize - LDS_DEPTH entries
 	float* spillT;
 	int n;
 	bool overflow;
-	__device__ __forceinline__ void bind(uint2* ldsColumn, uint32_t* refs, float* ts) {
+	__device__ __forceinline__ void bind(entry_t* ldsColumn, uint32_t* refs, float* ts) {
 		lds = ldsColumn;
 		spillRef = refs;
 		spillT = ts;
@@ -242,13 +248,30 @@ struct LdsStack {
 		n = 0;
 		overflow = false;
 	}
+	__device__ __forceinline__ void lds_put(int d, uint32_t r, float t) {
+		if constexpr (WITH_T)
+			lds[d * kBlockThreads] = make_uint2(r, __float_as_uint(t));
+		else
+			lds[d * kBlockThreads] = r;
+	}
+	__device__ __forceinline__ void lds_get(int d, uint32_t& r, float& t) {
+		if constexpr (WITH_T) {
+			const uint2 e = lds[d * kBlockThreads];
+			r = e.x;
+			t = __uint_as_float(e.y);
+		} else {
+			r = lds[d * kBlockThreads];
+			t = -__builtin_inff();
+		}
+	}
 	__device__ __forceinline__ void push(uint32_t r, float t) {
 		if (LDS_DEPTH > 0 && n < LDS_DEPTH) {
-			lds[n * kBlockThreads] = make_uint2(r, __float_as_uint(t));
+			lds_put(n, r, t);
 			++n;
 		} else if (n < kStackSize) {
 			spillRef[n - LDS_DEPTH] = r;
-			spillT[n - LDS_DEPTH] = t;
+			if (WITH_T)
+				spillT[n - LDS_DEPTH] = t;
 			++n;
 		} else {
 			overflow = true; // the reference's 64-entry array would be overrun here (bvh.h:124)
@@ -260,19 +283,15 @@ struct LdsStack {
 		// wave-level: does any popping lane sit in the private part?
 		if (LDS_DEPTH > 0 && __builtin_amdgcn_ballot_w64(n > LDS_DEPTH) == 0ull) {
 			--n;
-			const uint2 e = lds[n * kBlockThreads];
-			r = e.x;
-			t = __uint_as_float(e.y);
+			lds_get(n, r, t);
 			return true;
 		}
 		--n;
 		if (LDS_DEPTH > 0 && n < LDS_DEPTH) {
-			const uint2 e = lds[n * kBlockThreads];
-			r = e.x;
-			t = __uint_as_float(e.y);
+			lds_get(n, r, t);
 		} else {
 			r = spillRef[n - LDS_DEPTH];
-			t = spillT[n - LDS_DEPTH];
+			t = WITH_T ? spillT[n - LDS_DEPTH] : -__builtin_inff();
 		}
 		return true;
 	}
@@ -280,15 +299,15 @@ struct LdsStack {
 	__device__ __forceinline__ void push3(unsigned long long ma, uint32_t ra, float ta, unsigned long long mb, uint32_t rb, float tb, unsigned long long mc, uint32_t rc, float tc) {
 		if (LDS_DEPTH >= 3 && __builtin_amdgcn_ballot_w64(n > LDS_DEPTH - 3) == 0ull) {
 			if (__builtin_amdgcn_inverse_ballot_w64(ma)) {
-				lds[n * kBlockThreads] = make_uint2(ra, __float_as_uint(ta));
+				lds_put(n, ra, ta);
 				++n;
 			}
 			if (__builtin_amdgcn_inverse_ballot_w64(mb)) {
-				lds[n * kBlockThreads] = make_uint2(rb, __float_as_uint(tb));
+				lds_put(n, rb, tb);
 				++n;
 			}
 			if (__builtin_amdgcn_inverse_ballot_w64(mc)) {
-				lds[n * kBlockThreads] = make_uint2(rc, __float_as_uint(tc));
+				lds_put(n, rc, tc);
 				++n;
 			}
 			return;
