@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""tools/fuzz_parity.py [n] [seed] -- randomised end-to-end parity: random scenes (triangle soups and height-field meshes of
+random size, with and without per-triangle materials), random resolutions, queue sizes, cameras and launch-shape knobs;
+each render is compared with the oracle's: identical iteration and ray counts, queues of the last iteration bit-exact,
+radiance within 1e-5 relative.  Not part of the test suite (run time grows with n); prints one line per case."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pyorc  # noqa: E402
+from tyrant_amd import binding, scenes  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for case in range(n_cases):
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        sc = scenes.cornell_soup(int(rng.integers(50, 6000)), seed=int(rng.integers(1, 1 << 30)))
+    elif kind == 1:
+        sc = scenes.mesh_scene(int(rng.integers(4, 90)), seed=int(rng.integers(1, 1 << 30)), spec_fraction=float(rng.uniform(0, 0.5)), refr_fraction=float(rng.uniform(0, 0.2)))
+    else:
+        sc = scenes.tyrant_default(int(rng.integers(4, 40)), seed=int(rng.integers(1, 1 << 30)))
+    W, H = int(rng.integers(17, 140)), int(rng.integers(11, 90))
+    N = int(rng.integers(65, 9000))
+    spp = int(rng.integers(1, 4))
+    cam = scenes.Camera(position=tuple(np.array(sc.camera.position) + rng.normal(0, 3, 3)), direction=sc.camera.direction, up=sc.camera.up,
+                        focalDistance=float(rng.uniform(1, 80)), lensRadius=float(rng.choice([0.0, 0.0, rng.uniform(0.1, 3.0)])))
+    knobs = dict(traversal_variant=int(rng.choice([4, 4, 4, 3, 2, 1, 0])), stack_lds_depth=int(rng.choice([0, 8, 10, 12, 16, 24])), refill_min_idle=int(rng.integers(1, 65)),
+                 min_traversing=int(rng.integers(1, 65)), ticket_chunk=int(rng.choice([64, 128, 1024])), static_share=int(rng.integers(0, 16)), staged_nodes=int(rng.integers(0, 65)),
+                 rays_per_block=int(rng.choice([256, 1024, 4096])))
+    flags = 1 if sc.triangle_materials else 0
+    bb = scenes.triangle_bboxes(sc.triangles)
+    nodes, prims = pyorc.bvh_build(sc.triangles, bb)
+    o = pyorc.Oracle(W, H, N, flags=flags)
+    g = binding.Renderer(W, H, N, flags=flags)
+    for r in (o, g):
+        r.load_scene(sc, nodes, prims)
+        r.set_camera(cam)
+    sun = (float(rng.uniform(0, 1)), float(rng.uniform(0.05, 0.49)))
+    o.set_sun_position(*sun), g.set_sun_position(*sun)
+    g.set_tuning(**knobs)
+    ok, why = True, ""
+    try:
+        io, ig = o.render(spp), g.render(spp)
+        ko, kg = o.counters(), g.counters()
+        if io != ig or kg["device_error"]:
+            ok, why = False, f"iterations {io} vs {ig}, device_error {kg['device_error']}"
+        for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible", "start_position", "frame"):
+            if ko[f] != kg[f]:
+                ok, why = False, why + f" {f}: {ko[f]} vs {kg[f]}"
+        bo, bg = o.blit_buffer(), g.blit_buffer()
+        if not (np.array_equal(bo[:, 3], bg[:, 3]) and np.allclose(bg[:, :3], bo[:, :3], rtol=1e-5, atol=1e-6)):
+            ok, why = False, why + " radiance differs"
+        # one more iteration, stage by stage, queues bit for bit
+        for st in ("begin", "primary", "extend", "shade"):
+            o.stage(st), g.stage(st)
+        ko, kg = o.counters(), g.counters()
+        ns, nh = ko["primary_ray_cnt"], ko["shadow_ray_cnt"]
+        qo, qg = o.ray_queue(1, ns), g.ray_queue(1, kg["primary_ray_cnt"])
+        same = (ns, nh) == (kg["primary_ray_cnt"], kg["shadow_ray_cnt"]) and all(np.ascontiguousarray(qo[f]).tobytes() == np.ascontiguousarray(qg[f]).tobytes() for f in ("origin", "direction", "direct", "index", "bounces", "lastSpecular"))
+        if not (same and o.shadow_queue(nh).tobytes() == g.shadow_queue(nh).tobytes()):
+            ok, why = False, why + " queues differ"
+    except Exception as e:  # noqa: BLE001
+        ok, why = False, repr(e)
+    bad += not ok
+    print(f"case {case:3d} {sc.name:26s} {len(sc.triangles):7d} tris {W:3d}x{H:<3d} N={N:5d} spp={spp} lens={cam.lensRadius:.2f} {knobs} -> {'ok' if ok else 'FAIL ' + why}", flush=True)
+    g.close()
+print("failures:", bad)
+sys.exit(1 if bad else 0)
