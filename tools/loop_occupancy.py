@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""tools/loop_occupancy.py -- SIMD occupancy of the extend kernel's loops from the counting build
-(tyr_counters.debug): lanes doing work / 64 in the node-test, pop and triangle loops."""
+"""tools/loop_occupancy.py [c2|c3] [knob=value ...] -- SIMD lane occupancy of the extend kernel's loops from
+tyr_counters.debug: lanes doing work / 64 in the node-test, pop and triangle loops and in the refills.
+With the standard library this is the counting build (pair nodes, variant 2); with a diagnostic build
+(make ... EXTRA_HIPFLAGS=-DTYR_QUAD_STATS, loaded through TYRANT_HIP_LIBRARY) and `production=1` it is the production
+quad kernel, iteration by iteration."""
 import os
 import sys
 
@@ -8,19 +11,28 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tyrant_amd import binding, scenes  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
+kv = dict(a.split("=") for a in sys.argv[2:])
+production = int(kv.pop("production", 0))
+tune = {k: int(v) for k, v in kv.items()}
 sc = {"c1": scenes.cornell_box, "c2": lambda: scenes.cornell_soup(10000), "c3": lambda: scenes.mesh_scene(706)}[wl]()
 nodes, prims = binding.bvh_build(sc.triangles)
-flags = binding.TYR_FLAG_COUNT_VISITS | (binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0)
-for variant, refill, mintrav in ((1, 16, 32), (2, 16, 16), (2, 16, 32), (2, 16, 48), (2, 4, 32)):
-    r = binding.Renderer(1920, 1080, 2097152, flags=flags)
-    r.load_scene(sc, nodes, prims)
-    r.set_tuning(traversal_variant=variant, refill_min_idle=refill, min_traversing=mintrav)
-    r.render(2)
+W, H, SPP = 1920, 1080, 8
+flags = (0 if production else binding.TYR_FLAG_COUNT_VISITS) | (binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0)
+r = binding.Renderer(W, H, W * H * SPP, flags=flags)
+r.load_scene(sc, nodes, prims)
+if tune:
+    r.set_tuning(**tune)
+r.set_budget(W * H * SPP)
+prev = r.counters()
+print(f"{wl} {'production quad kernel' if production else 'counting build (pair nodes)'} {tune}")
+print(" it      rays | node trips/64 rays  lanes | pop trips  lanes | triangle trips  lanes | refills  lanes")
+for it in range(6):
+    r.launch_kernels()
     k = r.counters()
-    d = k["debug"]
-    rays = k["total_extend_rays"]
-    print(f"{wl} variant {variant} refill>={refill} minTrav {mintrav}: rays {rays}  nodes/ray {k['nodes_extend']/rays:.1f} tris/ray {k['tris_extend']/rays:.2f}")
-    for name, i in (("node tests", 0), ("stack pops", 2), ("triangle tests", 4), ("refills", 6)):
-        w, l = d[i], d[i + 1]
-        print(f"   {name:15s} wave-iterations/ray {w/rays*64:8.2f} (per 64 rays)  lane-iterations/ray {l/rays:7.2f}  occupancy {l/max(w,1)/64*100:5.1f} %")
-    r.close()
+    d = [k["debug"][i] - prev["debug"][i] for i in range(8)]
+    rays = k["total_extend_rays"] - prev["total_extend_rays"]
+    prev = k
+    if rays == 0:
+        break
+    f = lambda i: f"{d[i] / rays * 64:9.2f} {d[i + 1] / max(d[i], 1) / 64 * 100:5.1f}%"  # noqa: E731
+    print(f"{it:3d} {rays:9d} | {f(0)}        | {f(2)} | {f(4)}      | {f(6)}")

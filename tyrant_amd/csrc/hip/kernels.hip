@@ -1234,8 +1234,13 @@ __global__ void __launch_bounds__(kBlock) k_connect_persistent(const FrameParams
 __device__ __forceinline__ bool ref_is_leaf(uint32_t ref) { return (ref & kRefLeaf) && ref < kRefPop; }
 __device__ __forceinline__ bool ref_is_traversing(uint32_t ref) { return ((int)ref >= 0) || ref == kRefPop; }
 
+#ifdef TYR_QUAD_STATS
+constexpr bool kLoopStats = true; // diagnostic build: the production (quad) kernel fills tyr_counters.debug too, tools/loop_occupancy.py
+#else
+constexpr bool kLoopStats = false;
+#endif
 #define TYR_DBG(i)                                                     \
-	if (COUNT) {                                                       \
+	if (COUNT || kLoopStats) {                                         \
 		const unsigned long long m_ = __ballot(1);                     \
 		if (lane == (uint32_t)__ffsll((long long)m_) - 1) {            \
 			dbg[i] += 1;                                               \
@@ -1524,6 +1529,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 	if (COUNT) {
 		wave_add_u64(&P.k->nodes_extend, vc.nodes);
 		wave_add_u64(&P.k->tris_extend, vc.tris);
+	}
+	if (COUNT || kLoopStats) {
 		for (int i = 0; i < 8; ++i)
 			wave_add_u64(&P.k->debug[i], dbg[i]);
 	}
