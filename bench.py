@@ -272,7 +272,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, W, H, N, args.cpu_iterations if N <= 4 * REF_N else 1, sc.triangle_materials)
+            out["cpu_baseline"] = cpu_baseline(sc, W, H, N, args.cpu_iterations if N <= 4 * REF_N else 2, sc.triangle_materials)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
