@@ -272,14 +272,14 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, W, H, N, args.cpu_iterations if N <= 4 * REF_N else 2, sc.triangle_materials)
+            out["cpu_baseline"] = cpu_baseline(sc, W, H, N, args.cpu_iterations if N <= 4 * REF_N else 2, sc.triangle_materials, spp_total)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(sc, W, H, N, iterations, tri_materials):
+def cpu_baseline(sc, W, H, N, iterations, tri_materials, spp):
     """the oracle (a serial CPU port of the reference's loop) on the first `iterations` wavefront
     iterations of the same workload: same scene, resolution, queue size, seeds; 1 core"""
     from oracle import pyorc
@@ -290,6 +290,7 @@ def cpu_baseline(sc, W, H, N, iterations, tri_materials):
     t_build = time.perf_counter() - t0
     o = pyorc.Oracle(W, H, N, flags=1 if tri_materials else 0)
     o.load_scene(sc, nodes, prims)
+    o.set_budget(spp * W * H)  # the same primary-ray budget as the timed render: no top-up once it is spent
     t0 = time.perf_counter()
     for _ in range(iterations):
         o.launch_kernels()
