@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""tools/fuzz_parity.py [n] [seed] -- randomised end-to-end parity: random scenes (triangle soups and height-field meshes of
+"""tests/fuzz_parity.py [n] [seed] -- randomised end-to-end parity: random scenes (triangle soups and height-field meshes of
 random size, with and without per-triangle materials), random resolutions, queue sizes, cameras and launch-shape knobs;
 each render is compared with the oracle's: identical iteration and ray counts, queues of the last iteration bit-exact,
-radiance within 1e-5 relative.  Not part of the test suite (run time grows with n); prints one line per case."""
+radiance within 1e-5 relative.  A checker like the tests (it is the only other place that drives the oracle), not collected by pytest (run time grows with n); prints one line per case."""
 import os
 import sys
 
