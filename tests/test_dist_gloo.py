@@ -70,6 +70,43 @@ def test_two_rank_gloo_reduce(tmp_path):
     assert np.array_equal(np.load(tmp_path / "gathered.npy").reshape(H, W, 4), red)
 
 
+def _gather_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+
+    from tyrant_amd import dist as tdist
+
+    tdist.init_process_group("gloo")
+    h, w = 24, 5
+    frame = torch.zeros(h * w * 4)
+    view = frame.view(h, w, 4)
+    for y in tdist.owned_rows(rank, world, h):
+        view[y] = float(100 * rank + y)  # what this rank "rendered" into its rows
+    summed = frame.clone()
+    assert tdist.agree_gather_works("cpu")
+    tdist.gather_rows(frame, h, w, rank, world, dst=0)
+    tdist.reduce_accum(summed, dst=0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "g.npy"), frame.numpy())
+        np.save(os.path.join(out_dir, "s.npy"), summed.numpy())
+    import torch.distributed as dist
+
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_gather_equals_reduce(tmp_path):
+    """the two ways of combining the frame agree for R = 4 (rows y % 4 == rank), on synthetic row contents"""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_gather_worker, args=(4, _free_port(), str(tmp_path)), nprocs=4, join=True)
+    g = np.load(tmp_path / "g.npy").reshape(24, 5, 4)
+    assert np.array_equal(g, np.load(tmp_path / "s.npy").reshape(24, 5, 4))
+    for y in range(24):
+        assert np.all(g[y] == 100 * (y % 4) + y)
+
+
 def test_shard_spec_and_rows():
     sys.path.insert(0, ROOT)
     from tyrant_amd import dist as tdist
