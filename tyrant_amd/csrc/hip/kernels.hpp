@@ -84,14 +84,15 @@ struct FrameParams {
 	unsigned long long* scanDesc; // one look-back descriptor per shade block
 	uint32_t refillMinIdle;       // persistent traversal: refill a wave once this many lanes are free
 	uint32_t minTraversing;       // flat traversal: leave the descent loop below this many descending lanes
-	uint32_t ticketChunk;         // variant 1: queue slots a wave takes per global atomic
-	uint32_t raysPerBlock;        // variants 2/3: queue slots owned by one 256-thread block
+	uint32_t ticketChunk;         // variants 1 / 4: queue slots a wave takes per draw from a device-wide ticket
+	uint32_t raysPerBlock;        // variants 2 / 3: queue slots owned by one 256-thread block
 	uint32_t staticShare;         // variant 4: sixteenths of the queue handed out as fixed per-block ranges
 };
 
 // traversal kernel structure (tyr_set_tuning)
 struct Tuning {
-	int traversalVariant = 4; // 0 = one thread per queue slot, 1 = persistent waves with lane refill, 2 = 1 + flat state machine, 3 = 2 on quad nodes
+	int traversalVariant = 4; // 0 = one thread per queue slot, 1 = persistent waves with lane refill, 2 = 1 + flat state machine, 3 = 2 on quad nodes,
+	                          // 4 = 3 on a persistent grid fed by block-owned ranges + ticketed chunks, top of the tree in LDS (production)
 	int minTraversing = 32;
 	int ticketChunk = 64;
 	int raysPerBlock = 1024;
@@ -99,7 +100,7 @@ struct Tuning {
 	int stagedNodes = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
-	int stackLdsDepth = 12;   // traversal-stack entries per lane kept in LDS (0, 8, 12, 16, 24); the rest spill to scratch
+	int stackLdsDepth = 12;   // traversal-stack entries per lane kept in LDS (0, 8, 10, 12, 16, 24); the rest spill to scratch
 };
 
 constexpr int kBlock = 256; // 4 wave64 per workgroup
