@@ -220,10 +220,10 @@ int tyr_get_timings(tyr_ctx* ctx, tyr_timings* out, int reset);
  * `sm_cores * 8, 128` at kernel.cu:719-726).  They never change results. */
 enum {
 	TYR_TUNE_TRAVERSAL_VARIANT = 0, /* 0 = one thread per queue slot; 1 = persistent waves, finished lanes take new rays; 2 = 1 as a flat per-lane state machine; 3 = 2 on 128-byte quad nodes, each block owning a range of queue slots; 4 = 3 as a persistent grid whose waves draw chunks of slots from eight tickets (the counting build always uses 2) */
-	TYR_TUNE_REFILL_MIN_IDLE = 1,   /* variant 1: refill a wave when at least this many of its 64 lanes are free (1..64, default 16) */
-	TYR_TUNE_WAVES_PER_SIMD = 2,    /* variant 1: resident waves per SIMD; 0 (default) = the occupancy query's answer */
+	TYR_TUNE_REFILL_MIN_IDLE = 1,   /* variants 1-4: refill a wave when at least this many of its 64 lanes are free (1..64, default 16) */
+	TYR_TUNE_WAVES_PER_SIMD = 2,    /* variants 1 and 4 (persistent grids): resident 256-thread blocks per CU = waves per SIMD; 0 (default) = the occupancy query's answer */
 	TYR_TUNE_STACK_LDS_DEPTH = 3,   /* traversal-stack entries per lane held in LDS: 0, 8, 10, 12 (default), 16 or 24; deeper entries spill to scratch */
-	TYR_TUNE_MIN_TRAVERSING = 4,    /* variant 2: leave the descent loop when fewer lanes than this are descending and leaves / refills are pending (1..64, default 32) */
+	TYR_TUNE_MIN_TRAVERSING = 4,    /* variants 2-4: leave the descent loop when fewer lanes than this are descending and leaves / refills are pending (1..64, default 32) */
 	TYR_TUNE_TICKET_CHUNK = 5,      /* variants 1/4: queue slots a wave reserves per global atomic (64..65536, default 64) */
 	TYR_TUNE_MIN_LEAVES = 7,        /* retired (leaving the descent loop once this many lanes hold a leaf never paid): accepted, no effect */
 	TYR_TUNE_STATIC_SHARE = 8,      /* variant 4: sixteenths of the queue dealt to the blocks as fixed ranges before the ticketed chunks start (0..15, default 4) */
