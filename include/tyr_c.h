@@ -254,6 +254,8 @@ void tyr_free(void* p);
  * 8-bit binary PPM of the tonemapped colours, or a float PFM. */
 int tyr_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t height);
 int tyr_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height);
+/* the same 8-bit frame as tyr_write_ppm in a PNG container (stored deflate blocks, no zlib needed) */
+int tyr_write_png(const char* path, const float* rgba, uint32_t width, uint32_t height);
 /* Camera::update, camera.cpp:46-52 */
 int tyr_camera_update(double horizontal_angle, double vertical_angle, float direction_out[3]);
 /* the reference's hard-wired sphere table, kernel.cu:674-680 */

@@ -114,3 +114,28 @@ def test_image_export(hip, tmp_path):
     assert raw.startswith(head)
     data = np.frombuffer(raw[len(head):], dtype="<f4").reshape(H, W, 3)
     assert np.array_equal(data[::-1, :, 0].reshape(-1), img[:, 0])  # bottom-up rows
+    # PNG: decoded independently (zlib + the PNG chunk layout), also for an image wider than one 64 KiB stored block
+    import struct
+    import zlib
+
+    def decode_png(raw):
+        assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, chunks = 8, []
+        while pos < len(raw):
+            n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+            body = raw[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+            chunks.append((typ, body))
+            pos += 12 + n
+        assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+        w, h, depth, ctype = struct.unpack(">IIBB", chunks[0][1][:10])
+        assert (depth, ctype) == (8, 2)
+        rows = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(h, w * 3 + 1)
+        assert np.all(rows[:, 0] == 0)
+        return rows[:, 1:].reshape(h * w, 3)
+
+    hip.write_image(str(tmp_path / "a.png"), img, W, H)
+    assert np.array_equal(decode_png((tmp_path / "a.png").read_bytes()), px)
+    big = np.random.default_rng(1).random((40 * 700, 4)).astype(np.float32)
+    hip.write_image(str(tmp_path / "b.png"), big, 700, 40)
+    assert np.array_equal(decode_png((tmp_path / "b.png").read_bytes()), (np.clip(big[:, :3], 0, 1) * 255.0 + 0.5).astype(np.uint8))

@@ -118,6 +118,7 @@ SYMBOLS = {
     "tyr_free": (None, [P]),
     "tyr_write_ppm": (C.c_int, [C.c_char_p, P, c_u32, c_u32]),
     "tyr_write_pfm": (C.c_int, [C.c_char_p, P, c_u32, c_u32]),
+    "tyr_write_png": (C.c_int, [C.c_char_p, P, c_u32, c_u32]),
     "tyr_default_spheres": (C.c_int, [P]),
 }
 
@@ -192,7 +193,8 @@ def load_ply(path: str) -> np.ndarray:
 def write_image(path: str, rgba: np.ndarray, width: int, height: int):
     """PPM (tonemapped 8-bit) or PFM (float) by extension"""
     a = np.ascontiguousarray(rgba, dtype=np.float32)
-    fn = lib().tyr_write_pfm if path.lower().endswith(".pfm") else lib().tyr_write_ppm
+    low = path.lower()
+    fn = lib().tyr_write_pfm if low.endswith(".pfm") else lib().tyr_write_png if low.endswith(".png") else lib().tyr_write_ppm
     _check(fn(os.fsencode(path), _ptr(a), width, height), "tyr_write_image")
 
 

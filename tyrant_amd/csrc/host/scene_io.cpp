@@ -313,6 +313,103 @@ int tyr_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t 
 	return TYR_OK;
 }
 
+// PNG, 8-bit RGB, "stored" deflate blocks (no compression: the file is W*H*3 bytes plus a few per row block), so that the
+// resolved frame opens in any viewer without a dependency on zlib
+namespace {
+struct Crc32 {
+	uint32_t table[256];
+	Crc32() {
+		for (uint32_t n = 0; n < 256; ++n) {
+			uint32_t c = n;
+			for (int k = 0; k < 8; ++k)
+				c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+			table[n] = c;
+		}
+	}
+	uint32_t run(uint32_t crc, const unsigned char* p, size_t n) const {
+		for (size_t i = 0; i < n; ++i)
+			crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+		return crc;
+	}
+};
+void put_be32(std::vector<unsigned char>& v, uint32_t x) {
+	v.push_back(static_cast<unsigned char>(x >> 24));
+	v.push_back(static_cast<unsigned char>(x >> 16));
+	v.push_back(static_cast<unsigned char>(x >> 8));
+	v.push_back(static_cast<unsigned char>(x));
+}
+void write_chunk(FILE* fp, const Crc32& crc, const char type[4], const std::vector<unsigned char>& data) {
+	std::vector<unsigned char> head;
+	put_be32(head, static_cast<uint32_t>(data.size()));
+	std::fwrite(head.data(), 1, 4, fp);
+	std::fwrite(type, 1, 4, fp);
+	if (!data.empty())
+		std::fwrite(data.data(), 1, data.size(), fp);
+	uint32_t c = crc.run(0xFFFFFFFFu, reinterpret_cast<const unsigned char*>(type), 4);
+	c = crc.run(c, data.data(), data.size()) ^ 0xFFFFFFFFu;
+	std::vector<unsigned char> tail;
+	put_be32(tail, c);
+	std::fwrite(tail.data(), 1, 4, fp);
+}
+} // namespace
+
+int tyr_write_png(const char* path, const float* rgba, uint32_t width, uint32_t height) {
+	if (!path || !rgba || width == 0 || height == 0 || static_cast<uint64_t>(width) * height > (1ull << 28))
+		return TYR_ERR_INVALID;
+	FILE* fp = std::fopen(path, "wb");
+	if (!fp)
+		return TYR_ERR_INVALID;
+	static const Crc32 crc;
+	static const unsigned char magic[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n' };
+	std::fwrite(magic, 1, 8, fp);
+	std::vector<unsigned char> ihdr;
+	put_be32(ihdr, width);
+	put_be32(ihdr, height);
+	const unsigned char rest[5] = { 8, 2, 0, 0, 0 }; // 8 bits, colour type 2 (RGB), deflate, adaptive filtering, no interlace
+	ihdr.insert(ihdr.end(), rest, rest + 5);
+	write_chunk(fp, crc, "IHDR", ihdr);
+	// raw image: per scan line one filter byte (0 = none) + RGB
+	const size_t stride = static_cast<size_t>(width) * 3 + 1;
+	std::vector<unsigned char> raw(stride * height);
+	for (uint32_t y = 0; y < height; ++y) {
+		unsigned char* row = &raw[stride * y];
+		row[0] = 0;
+		for (uint32_t x = 0; x < width; ++x) {
+			const float* p = &rgba[4 * (static_cast<size_t>(y) * width + x)];
+			for (int c = 0; c < 3; ++c) {
+				float v = p[c];
+				v = (v != v) ? 0.0f : std::min(std::max(v, 0.0f), 1.0f);
+				row[1 + 3 * x + c] = static_cast<unsigned char>(v * 255.0f + 0.5f);
+			}
+		}
+	}
+	// zlib stream of stored blocks (at most 65535 bytes each) + Adler-32 of the raw bytes
+	std::vector<unsigned char> z;
+	z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+	z.push_back(0x78);
+	z.push_back(0x01);
+	uint32_t a = 1, b = 0;
+	for (size_t off = 0; off < raw.size();) {
+		const size_t n = std::min<size_t>(65535, raw.size() - off);
+		z.push_back(off + n == raw.size() ? 1 : 0);
+		z.push_back(static_cast<unsigned char>(n & 0xff));
+		z.push_back(static_cast<unsigned char>(n >> 8));
+		z.push_back(static_cast<unsigned char>(~n & 0xff));
+		z.push_back(static_cast<unsigned char>((~n >> 8) & 0xff));
+		z.insert(z.end(), raw.begin() + static_cast<std::ptrdiff_t>(off), raw.begin() + static_cast<std::ptrdiff_t>(off + n));
+		for (size_t i = 0; i < n; ++i) {
+			a = (a + raw[off + i]) % 65521u;
+			b = (b + a) % 65521u;
+		}
+		off += n;
+	}
+	put_be32(z, (b << 16) | a);
+	write_chunk(fp, crc, "IDAT", z);
+	write_chunk(fp, crc, "IEND", {});
+	std::fclose(fp);
+	return TYR_OK;
+}
+
 int tyr_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height) {
 	if (!path || !rgba || width == 0 || height == 0)
 		return TYR_ERR_INVALID;
