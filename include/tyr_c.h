@@ -125,6 +125,9 @@ typedef struct tyr_config {
 #define TYR_FLAG_TRIANGLE_MATERIALS 1u /* shade switch driven by Triangle::materialType (loader.h:16) instead of hard-wired DIFF (kernel.cu:380-383) */
 #define TYR_FLAG_PROFILE 2u            /* bracket every kernel with hipEvents on the ctx stream (tyr_get_timings) */
 #define TYR_FLAG_COUNT_VISITS 4u       /* counting build of extend/connect: nodes visited / triangles tested (bvh.h:164-209) */
+#define TYR_FLAG_LIGHT_LIST 8u         /* with TRIANGLE_MATERIALS: triangles of materialType LIGHT emit and are sampled by next-event
+                                        * estimation next to spheres[6] -- the light array kernel.cu:420 / 560 leave as a TODO.  Off = the
+                                        * reference's behaviour and random sequence. */
 
 typedef struct tyr_ctx tyr_ctx;
 
@@ -138,6 +141,8 @@ int tyr_scene_upload(tyr_ctx* ctx, const tyr_bvh_node* nodes, int32_t nNodes, co
 
 /* kernel.cu:674-681: the __constant__ sphere table (7 entries, light = slot 6). NULL = the reference's table. */
 int tyr_set_spheres(tyr_ctx* ctx, const tyr_sphere* spheres);
+/* TYR_FLAG_LIGHT_LIST: the emission of every LIGHT triangle, float[3]; default (3,3,3), the reference light's (kernel.cu:680) */
+int tyr_set_triangle_emission(tyr_ctx* ctx, const float* rgb);
 /* the global `camera` (camera.h:24) read at kernel.cu:699-702, 719 */
 int tyr_set_camera(tyr_ctx* ctx, const tyr_camera* cam);
 /* sun_position / sun_position_changed (variables.h:16-17, kernel.cu:704-710) */

@@ -14,6 +14,9 @@
  *     spp * pixels primaries and drain; then n_live < N in the last iterations;
  *   - pixel sharding (rank, nranks): rank r owns image rows y with y % nranks == r;
  *   - ORC_FLAG_TRIANGLE_MATERIALS: triangles use Triangle::materialType
+ *   - ORC_FLAG_LIGHT_LIST (with the former): triangles of materialType LIGHT emit (one emission colour for all of
+ *     them, default the reference light's (3,3,3), kernel.cu:680) and are sampled by next-event estimation next to
+ *     spheres[6] -- the reference's own TODO "Use light array" (kernel.cu:420, 560).  Defined in orc.h.
  *     instead of the hard-wired DIFF (kernel.cu:380-383).
  */
 #include <stdlib.h>
@@ -26,6 +29,10 @@ struct orc_ctx {
 	orc_node* nodes;
 	orc_triangle* prims;
 	int nNodes, nPrims;
+	/* ORC_FLAG_LIGHT_LIST (extension): triangles whose materialType is LIGHT, in array order */
+	uint32_t* lights;
+	int nLights;
+	float tri_emission[3];
 	orc_sphere spheres[ORC_NUM_SPHERES];
 	orc_camera camera;
 	float sun_position[2];
@@ -63,6 +70,8 @@ void orc_default_spheres(orc_sphere s[ORC_NUM_SPHERES]) {
 orc_ctx* orc_create(uint32_t W, uint32_t H, uint32_t N, uint32_t rank, uint32_t nranks, uint32_t flags) {
 	if (W == 0 || H == 0 || N == 0 || nranks == 0 || rank >= nranks || (H % nranks) != 0)
 		return NULL;
+	if ((flags & ORC_FLAG_LIGHT_LIST) && !(flags & ORC_FLAG_TRIANGLE_MATERIALS))
+		return NULL;
 	orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
 	if (!c)
 		return NULL;
@@ -81,6 +90,7 @@ orc_ctx* orc_create(uint32_t W, uint32_t H, uint32_t N, uint32_t rank, uint32_t 
 	c->sun_position[1] = 0.3f;
 	c->sun_position_changed = 1; /* variables.cpp:4 */
 	c->first_time = 1;
+	c->tri_emission[0] = c->tri_emission[1] = c->tri_emission[2] = 3.0f; /* kernel.cu:680 */
 	c->frame = 1;
 	c->last_focaldistance = 1.0f;
 	c->last_lensradius = 0.02f;
@@ -102,6 +112,7 @@ void orc_destroy(orc_ctx* c) {
 		return;
 	free(c->nodes);
 	free(c->prims);
+	free(c->lights);
 	free(c->ray_buffer);
 	free(c->ray_buffer_next);
 	free(c->shadow_queue);
@@ -112,10 +123,13 @@ void orc_destroy(orc_ctx* c) {
 int orc_scene_upload(orc_ctx* c, const orc_node* nodes, int nNodes, const orc_triangle* prims, int nPrims) {
 	free(c->nodes);
 	free(c->prims);
+	free(c->lights);
 	c->nodes = NULL;
 	c->prims = NULL;
+	c->lights = NULL;
 	c->nNodes = 0;
 	c->nPrims = 0;
+	c->nLights = 0;
 	if (nPrims <= 0 || nNodes <= 0)
 		return 0; /* Scene.cpp:49-52: empty scene, no BVH */
 	c->nodes = (orc_node*)malloc(sizeof(orc_node) * (size_t)nNodes);
@@ -126,8 +140,21 @@ int orc_scene_upload(orc_ctx* c, const orc_node* nodes, int nNodes, const orc_tr
 	memcpy(c->prims, prims, sizeof(orc_triangle) * (size_t)nPrims);
 	c->nNodes = nNodes;
 	c->nPrims = nPrims;
+	free(c->lights);
+	c->lights = NULL;
+	c->nLights = 0;
+	if (c->flags & ORC_FLAG_LIGHT_LIST) {
+		c->lights = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)nPrims);
+		if (!c->lights)
+			return -1;
+		for (int i = 0; i < nPrims; ++i)
+			if (c->prims[i].materialType == ORC_LIGHT)
+				c->lights[c->nLights++] = (uint32_t)i;
+	}
 	return 0;
 }
+
+void orc_set_triangle_emission(orc_ctx* c, const float rgb[3]) { memcpy(c->tri_emission, rgb, 12); }
 
 void orc_set_spheres(orc_ctx* c, const orc_sphere s[ORC_NUM_SPHERES]) { memcpy(c->spheres, s, sizeof(c->spheres)); }
 void orc_set_camera(orc_ctx* c, const orc_camera* cam) { c->camera = *cam; }
@@ -336,6 +363,46 @@ static int sample_sphere_light(const orc_ctx* c, uint32_t* seed, v3 origin, v3 n
 	return *cosSurfaceToLight > 0 && *cosLightToSurface > 0;
 }
 
+/* The emitter a next-event sample goes to (ORC_FLAG_LIGHT_LIST; without it, or without emissive triangles, this is
+ * spheres[6] and draws nothing extra, so the reference's random sequence is untouched):
+ *   k = RandomIntBetween0AndMax(seed, nLights) (kernel.cu:39-41, range [0, nLights]); k == nLights -> spheres[6];
+ *   otherwise triangle lights[k], a point p = vert + e1*b1 + e2*b2 with b1 = sqrt(u1)*(1-u2), b2 = sqrt(u1)*u2 (uniform
+ *   over the triangle), emitting from its front side (normal e1 x e2, loader.h:28).
+ * Returns 1 if a shadow ray is due; *weight = emission * area-measure factors that replace "emission, 4 pi r^2" of the
+ * sphere formulas (kernel.cu:436-442), including the 1/(pick probability) = nLights + 1. */
+static int sample_light(const orc_ctx* c, uint32_t* seed, v3 origin, v3 normal, v3* lightDir, float* cosSurfaceToLight, float* cosLightToSurface, v3* lightVector, v3* emission, float* area) {
+	const orc_sphere* ls = &c->spheres[6];
+	if (!(c->flags & ORC_FLAG_LIGHT_LIST) || c->nLights == 0) {
+		*emission = v3load(ls->emmission);
+		*area = 4 * ORC_PI * ls->radius * ls->radius;
+		return sample_sphere_light(c, seed, origin, normal, lightDir, cosSurfaceToLight, cosLightToSurface, lightVector);
+	}
+	const int k = rng_int_0_max(seed, c->nLights);
+	const float pick = (float)(c->nLights + 1);
+	if (k >= c->nLights) {
+		*emission = v3scale(v3load(ls->emmission), pick);
+		*area = 4 * ORC_PI * ls->radius * ls->radius;
+		return sample_sphere_light(c, seed, origin, normal, lightDir, cosSurfaceToLight, cosLightToSurface, lightVector);
+	}
+	const orc_triangle* t = &c->prims[c->lights[k]];
+	const float u1 = rng_float(seed);
+	const float u2 = rng_float(seed);
+	const float su = sqrtf(u1);
+	const float b1 = su * (1.0f - u2);
+	const float b2 = su * u2;
+	const v3 e1 = v3load(t->e1), e2 = v3load(t->e2);
+	const v3 p = v3add(v3add(v3load(t->vert), v3scale(e1, b1)), v3scale(e2, b2));
+	const v3 cr = v3cross(e1, e2);
+	*lightVector = v3sub(p, origin);
+	const v3 nL = v3normalize(cr);
+	*lightDir = v3normalize(*lightVector);
+	*cosSurfaceToLight = v3dot(normal, *lightDir);
+	*cosLightToSurface = v3dot(nL, v3neg(*lightDir));
+	*emission = v3scale(v3load(c->tri_emission), pick);
+	*area = 0.5f * v3length(cr);
+	return *cosSurfaceToLight > 0 && *cosLightToSurface > 0;
+}
+
 static void push_shadow(orc_ctx* c, v3 origin, v3 dir, v3 color, int index, float closest) {
 	orc_shadow* s = &c->shadow_queue[c->k.shadow_ray_cnt++];
 	v3store(s->origin, origin);
@@ -377,8 +444,9 @@ void orc_stage_shade(orc_ctx* c) {
 				reflection_type = ORC_DIFF;
 				object_color = v3make(1.f, 1.f, 1.f);
 				if (c->flags & ORC_FLAG_TRIANGLE_MATERIALS) {
-					/* extension: LIGHT is not available on triangles */
-					reflection_type = triangle->materialType <= ORC_PHONG ? triangle->materialType : ORC_DIFF;
+					/* extension: LIGHT on a triangle needs ORC_FLAG_LIGHT_LIST */
+					const int highest = (c->flags & ORC_FLAG_LIGHT_LIST) ? ORC_LIGHT : ORC_PHONG;
+					reflection_type = triangle->materialType <= highest ? triangle->materialType : ORC_DIFF;
 				}
 			}
 
@@ -388,7 +456,7 @@ void orc_stage_shade(orc_ctx* c) {
 
 			if (reflection_type == ORC_LIGHT) {
 				if (ray.lastSpecular) {
-					color = v3mul(direct, v3load(c->spheres[ray.identifier].emmission));
+					color = v3mul(direct, ray.geometry_type == 0 ? v3load(c->spheres[ray.identifier].emmission) : v3load(c->tri_emission));
 				} else {
 					color = v3make(0.f, 0.f, 0.f);
 					direct = v3make(0.f, 0.f, 0.f);
@@ -411,14 +479,12 @@ void orc_stage_shade(orc_ctx* c) {
 						push_shadow(c, origin, sunSampleDir, col, ray.index, 1e20f);
 					}
 				} else {
-					v3 lightDir, lightVector;
-					float cosS, cosL;
-					if (sample_sphere_light(c, &seed, origin, normal, &lightDir, &cosS, &cosL, &lightVector)) {
-						const orc_sphere* ls = &c->spheres[6];
+					v3 lightDir, lightVector, emission;
+					float cosS, cosL, area;
+					if (sample_light(c, &seed, origin, normal, &lightDir, &cosS, &cosL, &lightVector, &emission, &area)) {
 						float closestAllowed = v3length(lightVector);
-						float area = 4 * ORC_PI * ls->radius * ls->radius;
 						float solidAngle = (cosL * area) / v3dot(lightVector, lightVector);
-						v3 shadowColor = v3scale(v3scale(v3scale(v3mul(v3scale(v3load(ls->emmission), 2.0f), direct), solidAngle), ORC_INV_PI), cosS);
+						v3 shadowColor = v3scale(v3scale(v3scale(v3mul(v3scale(emission, 2.0f), direct), solidAngle), ORC_INV_PI), cosS);
 						push_shadow(c, origin, lightDir, shadowColor, ray.index, closestAllowed);
 					}
 				}
@@ -503,17 +569,15 @@ void orc_stage_shade(orc_ctx* c) {
 						}
 					}
 				} else {
-					v3 lightDir, lightVector;
-					float cosS, cosL;
-					if (sample_sphere_light(c, &seed, origin, normal, &lightDir, &cosS, &cosL, &lightVector)) {
+					v3 lightDir, lightVector, emission;
+					float cosS, cosL, area;
+					if (sample_light(c, &seed, origin, normal, &lightDir, &cosS, &cosL, &lightVector, &emission, &area)) {
 						float phongCos = v3dot(lightDir, w);
 						if (phongCos > ORC_EPSILON) {
-							const orc_sphere* ls = &c->spheres[6];
 							phongCos = dm_powf(phongCos, phongexponent);
 							float closestAllowed = v3length(lightVector);
-							float area = 4.0f * ORC_PI * ls->radius * ls->radius;
 							float solidAngle = (cosL * area) / v3dot(lightVector, lightVector);
-							v3 sc = v3mul(v3scale(v3load(ls->emmission), 2.0f), direct);
+							v3 sc = v3mul(v3scale(emission, 2.0f), direct);
 							sc = v3scale(sc, solidAngle);
 							sc = v3scale(sc, (phongexponent + 2));
 							sc = v3scale(sc, 0.5f);

@@ -125,6 +125,7 @@ def lib() -> C.CDLL:
         L.orc_scene_upload.restype = c_i
         L.orc_scene_upload.argtypes = [P, P, c_i, P, c_i]
         L.orc_set_spheres.argtypes = [P, P]
+        L.orc_set_triangle_emission.argtypes = [P, fp]
         L.orc_default_spheres.argtypes = [P]
         L.orc_set_camera.argtypes = [P, C.POINTER(CameraC)]
         L.orc_set_sun_position.argtypes = [P, c_f, c_f]
@@ -258,6 +259,9 @@ class Oracle:
         assert s.nbytes == 7 * 44
         self.L.orc_set_spheres(self.h, _ptr(s))
 
+    def set_triangle_emission(self, rgb):
+        self.L.orc_set_triangle_emission(self.h, (C.c_float * 3)(*[float(v) for v in rgb]))
+
     def set_camera(self, cam):
         c = CameraC(f3(cam.position), f3(cam.direction), f3(cam.up), cam.focalDistance, cam.lensRadius)
         self.L.orc_set_camera(self.h, C.byref(c))
@@ -273,6 +277,7 @@ class Oracle:
         self.set_spheres(scene.spheres)
         self.set_camera(scene.camera)
         self.set_sun_position(*scene.sun_position)
+        self.set_triangle_emission(getattr(scene, "triangle_emission", (3.0, 3.0, 3.0)))
 
     def launch_kernels(self):
         return self.L.orc_launch_kernels(self.h)

@@ -62,6 +62,7 @@ def built_scene(name: str):
         "mesh706": lambda: scenes.mesh_scene(706),
         "tyrant_default": scenes.tyrant_default,
         "glass_dof48": lambda: scenes.glass_dof_scene(48),
+        "cornell_area_light": scenes.cornell_area_light,
     }
     sc = makers[name]()
     nodes, prims = pyorc.bvh_build(sc.triangles, scenes.triangle_bboxes(sc.triangles))

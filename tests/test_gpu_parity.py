@@ -20,7 +20,9 @@ def pair(orc, hip, name, W, H, N, flags=0, rank=0, nranks=1):
     sc, nodes, prims = built_scene(name)
     if sc.triangle_materials:
         flags |= 1
-    o = orc.Oracle(W, H, N, rank=rank, nranks=nranks, flags=flags & 1)
+    if sc.light_list:
+        flags |= 8
+    o = orc.Oracle(W, H, N, rank=rank, nranks=nranks, flags=flags & 9)
     o.load_scene(sc, nodes, prims)
     g = hip.Renderer(W, H, N, rank=rank, nranks=nranks, flags=flags)
     g.load_scene(sc, nodes, prims)
@@ -39,7 +41,7 @@ def assert_accum_close(bo, bg, what):
     assert np.allclose(bg[:, :3], bo[:, :3], rtol=1e-5, atol=1e-6), f"{what}: max rel err {np.max(np.abs(bg[:, :3] - bo[:, :3]) / np.maximum(np.abs(bo[:, :3]), 1e-3))}"
 
 
-@pytest.mark.parametrize("name,W,H,N", [("cornell36", 64, 64, 6000), ("tyrant_default", 96, 64, 5000), ("cornell_soup2k", 80, 48, 4096), ("mesh32", 64, 64, 4096), ("glass_dof48", 96, 54, 4096)])
+@pytest.mark.parametrize("name,W,H,N", [("cornell36", 64, 64, 6000), ("tyrant_default", 96, 64, 5000), ("cornell_soup2k", 80, 48, 4096), ("mesh32", 64, 64, 4096), ("glass_dof48", 96, 54, 4096), ("cornell_area_light", 96, 64, 5000)])
 def test_stage_by_stage_bit_parity(orc, hip, name, W, H, N):
     """every kernel of every iteration, fed by its predecessors on each side, matches the oracle bit for bit"""
     o, g = pair(orc, hip, name, W, H, N)
@@ -78,7 +80,7 @@ def test_stage_by_stage_bit_parity(orc, hip, name, W, H, N):
         o.stage("end"), g.stage("end")
 
 
-@pytest.mark.parametrize("name,W,H,N,spp", [("cornell36", 128, 128, 16384, 4), ("tyrant_default", 160, 96, 10000, 4), ("cornell_soup10k", 128, 72, 8192, 3), ("mesh128", 96, 96, 8192, 2), ("glass_dof48", 128, 72, 8192, 3)])
+@pytest.mark.parametrize("name,W,H,N,spp", [("cornell36", 128, 128, 16384, 4), ("tyrant_default", 160, 96, 10000, 4), ("cornell_soup10k", 128, 72, 8192, 3), ("mesh128", 96, 96, 8192, 2), ("glass_dof48", 128, 72, 8192, 3), ("cornell_area_light", 128, 96, 8192, 4)])
 def test_render_matches_oracle(orc, hip, name, W, H, N, spp):
     """launch_kernels loop with a primary budget: same iteration count, same ray totals, radiance within 1e-5 rel"""
     o, g = pair(orc, hip, name, W, H, N)
@@ -182,6 +184,18 @@ def test_edge_cases(orc, hip):
         r.load_scene(sc, nodes, prims), r.set_camera(cam)
     o.stage("begin"), g.stage("begin"), o.stage("primary"), g.stage("primary")
     assert_state_equal(o.ray_queue(0), g.ray_queue(0), "thin lens")
+    # TYR_FLAG_LIGHT_LIST: needs TRIANGLE_MATERIALS; with no emissive triangle in the scene it changes nothing
+    with pytest.raises(Exception):
+        hip.Renderer(32, 32, 1024, flags=8)
+    sc, nodes, prims = built_scene("mesh32")
+    acc = []
+    for flags in (1, 9):
+        g = hip.Renderer(64, 48, 3072, flags=flags)
+        g.load_scene(sc, nodes, prims)
+        g.render(2)
+        acc.append((g.counters(), g.blit_buffer()))
+    assert acc[0][0]["total_shadow_rays"] == acc[1][0]["total_shadow_rays"] and acc[0][0]["total_extend_rays"] == acc[1][0]["total_extend_rays"]
+    assert np.array_equal(acc[0][1][:, 3], acc[1][1][:, 3]) and np.allclose(acc[0][1], acc[1][1], rtol=1e-5, atol=1e-6)
 
 
 def test_sharded_ranks_match_oracle(orc, hip):

@@ -163,6 +163,56 @@ def test_triangle_material_flag(orc):
     assert res[1][0] < res[0][0]  # SPEC emits no NEE shadow rays
 
 
+def test_light_list_flag(orc):
+    """extension: with ORC_FLAG_LIGHT_LIST, LIGHT triangles emit and take part in next-event
+    estimation; without emissive triangles the flag changes nothing, random sequence included"""
+    from oracle.pyorc import Oracle
+    from tyrant_amd import scenes
+
+    with pytest.raises(ValueError):
+        Oracle(32, 32, 1024, flags=8)  # an emissive triangle is a triangle material: needs flag 1
+
+    # no LIGHT triangle in the scene: bit-identical to the run without the flag
+    sc, nodes, prims = built_scene("mesh32")
+    img = {}
+    for flags in (1, 9):
+        o = Oracle(48, 48, 2304, flags=flags)
+        o.load_scene(sc, nodes, prims)
+        o.render(3)
+        img[flags] = o.blit_buffer()
+    assert np.array_equal(img[1].view(np.uint32), img[9].view(np.uint32))
+
+    sc, nodes, prims = built_scene("cornell_area_light")
+    W, H, N = 96, 64, 96 * 64
+    emission = np.array(sc.triangle_emission, dtype=np.float32)
+    lit = prims["materialType"] == scenes.LIGHT
+    assert lit.sum() == 3
+    res = {}
+    for flags in (1, 9):
+        o = Oracle(W, H, N, flags=flags)
+        o.load_scene(sc, nodes, prims)
+        o.stage("begin"), o.stage("primary"), o.stage("extend")
+        q = o.ray_queue(0)
+        on_light = (q["distance"] < 1e20) & (q["geometry_type"] == 1) & lit[np.where(q["geometry_type"] == 1, q["identifier"], 0)]
+        assert on_light.sum() >= 8  # the ceiling patch (seen at a grazing angle) and the wall panel are in view
+        o.stage("shade")
+        b = o.blit_buffer()
+        k = o.counters()
+        res[flags] = (b[q["index"][on_light], :3], k["shadow_ray_cnt"], o.shadow_queue(k["shadow_ray_cnt"]))
+    # seen directly (primary rays count as specular, variables.h:33) an emissive triangle shows its emission ...
+    assert np.array_equal(res[9][0], np.broadcast_to(emission, res[9][0].shape))
+    # ... and without the flag it is a white diffuse triangle: nothing reaches the pixel at this bounce
+    assert np.all(res[1][0] == 0)
+    # NEE: the sample goes to one of 3 triangles + the sphere, so some shadow rays end on the emissive triangles
+    sh = res[9][2]
+    end = sh["origin"] + sh["direction"] * sh["closestDistance"][:, None]
+    on_patch = (np.abs(end[:, 2] - 99.5) < 1e-2) & (np.abs(end[:, 0]) <= 12.01) & (np.abs(end[:, 1]) <= 12.01)
+    on_panel = np.abs(end[:, 0] + 49.5) < 1e-2
+    finite = sh["closestDistance"] < 1e19
+    assert on_patch.sum() > 0.2 * finite.sum() and on_panel.sum() > 0.05 * finite.sum()
+    assert (finite & ~on_patch & ~on_panel).sum() > 0.05 * finite.sum()  # the sphere light still gets its share
+
+
 def test_resolve_tonemap(orc):
     """blit_onto_framebuffer, kernel.cu:648-662: rgb/a -> c/(c+1) -> ^(1/2.2)"""
     o = make(orc, "cornell36", 32, 32, 1024)

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("TYRANT_HIP_LIBRARY") or os.path.join(_HERE, "lib", "l
 TYR_FLAG_TRIANGLE_MATERIALS = 1
 TYR_FLAG_PROFILE = 2
 TYR_FLAG_COUNT_VISITS = 4
+TYR_FLAG_LIGHT_LIST = 8
 TYR_ERR_NO_DEVICE = -2
 KERNEL_NAMES = ("primary", "extend", "shade", "connect", "resolve")
 
@@ -87,6 +88,7 @@ SYMBOLS = {
     "tyr_destroy": (C.c_int, [P]),
     "tyr_scene_upload": (C.c_int, [P, P, c_i32, P, c_i32]),
     "tyr_set_spheres": (C.c_int, [P, P]),
+    "tyr_set_triangle_emission": (C.c_int, [P, P]),
     "tyr_set_camera": (C.c_int, [P, C.POINTER(CameraC)]),
     "tyr_set_sun_position": (C.c_int, [P, c_f, c_f]),
     "tyr_set_blit_buffer": (C.c_int, [P, P]),
@@ -266,6 +268,10 @@ class Renderer:
         self.set_spheres(scene.spheres)
         self.set_camera(scene.camera)
         self.set_sun_position(*scene.sun_position)
+        self.set_triangle_emission(getattr(scene, "triangle_emission", (3.0, 3.0, 3.0)))
+
+    def set_triangle_emission(self, rgb):
+        _check(self.L.tyr_set_triangle_emission(self.h, (C.c_float * 3)(*[float(v) for v in rgb])), "tyr_set_triangle_emission")
 
     def set_budget(self, n):
         _check(self.L.tyr_set_budget(self.h, n), "tyr_set_budget")

@@ -293,6 +293,56 @@ __device__ __forceinline__ LightSample sample_sphere_light(const tyr_sphere& ls,
 	return L;
 }
 
+// The emitter a next-event sample goes to.  LIGHTS = TYR_FLAG_LIGHT_LIST (extension, SURVEY.md 8f-3: the reference's
+// "TODO Use light array", kernel.cu:420 / 560): with emissive triangles in the scene one of nLights + 1 emitters is
+// picked uniformly -- k == nLights is spheres[6], otherwise triangle lights[k], sampled uniformly over its area and
+// emitting from its front side (e1 x e2, loader.h:28).  `emission` carries the 1/(pick probability), `area` is what
+// the solid-angle term of kernel.cu:438-440 multiplies.  Without LIGHTS (a separate instantiation of the shade
+// kernel), or with no emissive triangle, this is the sphere sample and draws nothing extra.
+struct EmitterSample {
+	LightSample L;
+	f3 emission;
+	float area;
+};
+template <bool LIGHTS>
+__device__ __forceinline__ EmitterSample sample_emitter(const FrameParams& P, uint32_t& seed, f3 origin, f3 normal) {
+	const tyr_sphere& ls = P.spheres[6]; // kernel.cu:421, 561
+	EmitterSample E;
+	float pick = 1.0f;
+	if (LIGHTS && P.nLights != 0) {
+		const int k = rng_int_0_max(seed, (int)P.nLights);
+		pick = (float)(P.nLights + 1u);
+		if (k < (int)P.nLights) {
+			const uint32_t id = P.lights[k];
+			const float4 t0 = P.scene.tris[3 * id + 0];
+			const float4 t1 = P.scene.tris[3 * id + 1];
+			const float4 t2 = P.scene.tris[3 * id + 2];
+			const float u1 = rng_float(seed);
+			const float u2 = rng_float(seed);
+			const float su = sqrtf(u1);
+			const float b1 = su * (1.0f - u2);
+			const float b2 = su * u2;
+			const f3 e1 = mk3(t0.w, t1.x, t1.y), e2 = mk3(t1.z, t1.w, t2.x);
+			const f3 p = (mk3(t0.x, t0.y, t0.z) + e1 * b1) + e2 * b2;
+			const f3 cr = cross(e1, e2);
+			E.L.lightVector = p - origin;
+			const f3 nL = normalize(cr);
+			E.L.lightDir = normalize(E.L.lightVector);
+			E.L.cosSurfaceToLight = dot(normal, E.L.lightDir);
+			E.L.cosLightToSurface = dot(nL, -E.L.lightDir);
+			E.L.valid = E.L.cosSurfaceToLight > 0 && E.L.cosLightToSurface > 0;
+			E.emission = mk3(P.triEmission[0], P.triEmission[1], P.triEmission[2]) * pick;
+			E.area = 0.5f * length(cr);
+			return E;
+		}
+	}
+	E.L = sample_sphere_light(ls, seed, origin, normal);
+	E.emission = (LIGHTS && P.nLights != 0) ? ld3(ls.emmission) * pick : ld3(ls.emmission);
+	E.area = 4 * kPi * ls.radius * ls.radius;
+	return E;
+}
+
+template <bool LIGHTS>
 __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, ShadeOut& out) {
 	const float4 a = P.work.o_dx[slot];
 	const float2 b = P.work.dyz[slot];
@@ -335,7 +385,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 			object_color = mk3(1.f, 1.f, 1.f);
 			if (P.flags & TYR_FLAG_TRIANGLE_MATERIALS) {
 				const uint32_t m = __float_as_uint(t2.y);
-				reflection_type = m <= (uint32_t)TYR_PHONG ? (int)m : TYR_DIFF;
+				reflection_type = m <= (uint32_t)(LIGHTS ? TYR_LIGHT : TYR_PHONG) ? (int)m : TYR_DIFF;
 			}
 		}
 		const bool outside = dot(normal, direction) < 0;
@@ -344,7 +394,10 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 
 		if (reflection_type == TYR_LIGHT) {
 			if (lastSpecular) {
-				color = direct * ld3(P.spheres[ident & 7u].emmission);
+				if (LIGHTS && !(ident & kHitSphere))
+					color = direct * mk3(P.triEmission[0], P.triEmission[1], P.triEmission[2]);
+				else
+					color = direct * ld3(P.spheres[ident & 7u].emmission);
 			} else {
 				color = mk3(0.f, 0.f, 0.f);
 				direct = mk3(0.f, 0.f, 0.f);
@@ -352,7 +405,6 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 		}
 		lastSpecular = false;
 		constexpr float phongexponent = 40.0f;
-		const tyr_sphere& lightsource = P.spheres[6]; // kernel.cu:421, 561
 		switch (reflection_type) {
 		case TYR_LIGHT:
 			break;
@@ -368,15 +420,15 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 					out.sClosest = 1e20f; // variables.h:41
 				}
 			} else {
-				const LightSample L = sample_sphere_light(lightsource, seed, origin, normal);
+				const EmitterSample E = sample_emitter<LIGHTS>(P, seed, origin, normal);
+				const LightSample& L = E.L;
 				if (L.valid) {
 					const float closestAllowed = length(L.lightVector);
-					const float area = 4 * kPi * lightsource.radius * lightsource.radius;
-					const float solidAngle = (L.cosLightToSurface * area) / dot(L.lightVector, L.lightVector);
+					const float solidAngle = (L.cosLightToSurface * E.area) / dot(L.lightVector, L.lightVector);
 					out.shadow = true;
 					out.sOrigin = origin;
 					out.sDir = L.lightDir;
-					out.sColor = ((((ld3(lightsource.emmission) * 2.0f) * direct) * solidAngle) * kInvPi) * L.cosSurfaceToLight;
+					out.sColor = ((((E.emission * 2.0f) * direct) * solidAngle) * kInvPi) * L.cosSurfaceToLight;
 					out.sClosest = closestAllowed;
 				}
 			}
@@ -458,15 +510,15 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 					}
 				}
 			} else {
-				const LightSample L = sample_sphere_light(lightsource, seed, origin, normal);
+				const EmitterSample E = sample_emitter<LIGHTS>(P, seed, origin, normal);
+				const LightSample& L = E.L;
 				if (L.valid) {
 					float phongCos = dot(L.lightDir, w);
 					if (phongCos > kEpsilon) {
 						phongCos = dm::powf_det(phongCos, phongexponent);
 						const float closestAllowed = length(L.lightVector);
-						const float area = 4.0f * kPi * lightsource.radius * lightsource.radius;
-						const float solidAngle = (L.cosLightToSurface * area) / dot(L.lightVector, L.lightVector);
-						f3 sc = (ld3(lightsource.emmission) * 2.0f) * direct;
+						const float solidAngle = (L.cosLightToSurface * E.area) / dot(L.lightVector, L.lightVector);
+						f3 sc = (E.emission * 2.0f) * direct;
 						sc = sc * solidAngle;
 						sc = sc * (phongexponent + 2);
 						sc = sc * 0.5f;
@@ -653,6 +705,7 @@ __device__ __forceinline__ void shade_lookback(const FrameParams& P, uint32_t vb
 	ehOut = eh;
 }
 
+template <bool LIGHTS>
 __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t nTiles) {
 	__shared__ uint32_t sh[32];
 	__shared__ ShadeStage stage;
@@ -733,7 +786,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t 
 		uint32_t pixelBits = 0;
 		if (slot < nLive) {
 			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
-			shade_ray(P, slot, out);
+			shade_ray<LIGHTS>(P, slot, out);
 		}
 		TYR_STAMP(0)
 
@@ -1859,15 +1912,21 @@ void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, hipStream_
 	const uint32_t nTiles = blocks_for(maxLive);
 	// A persistent grid: as many blocks as stay resident (more would only wait for a slot and then find no tile
 	// left; the tile tickets make any grid size safe).  Asked once: the occupancy query is a slow host call.
-	static int perCU = 0;
-	if (perCU == 0) {
+	const bool lights = (P.flags & TYR_FLAG_LIGHT_LIST) != 0; // its own instantiation: the default kernel keeps its registers
+	static int perCU[2] = { 0, 0 };
+	if (perCU[lights] == 0) {
 		int q = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade, kBlock, 0) != hipSuccess || q < 1)
+		const hipError_t e = lights ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<true>, kBlock, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<false>, kBlock, 0);
+		if (e != hipSuccess || q < 1)
 			q = 2;
-		perCU = q > 6 ? 6 : q;
+		perCU[lights] = q > 6 ? 6 : q;
 	}
-	const uint32_t resident = (uint32_t)perCU * (uint32_t)numCUs;
-	hipLaunchKernelGGL(k_shade, dim3(nTiles < resident ? nTiles : resident), dim3(kBlock), 0, stream, P, nTiles);
+	const uint32_t resident = (uint32_t)perCU[lights] * (uint32_t)numCUs;
+	const dim3 grid(nTiles < resident ? nTiles : resident);
+	if (lights)
+		hipLaunchKernelGGL(k_shade<true>, grid, dim3(kBlock), 0, stream, P, nTiles);
+	else
+		hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), 0, stream, P, nTiles);
 }
 void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream) {
 	if (maxShadow == 0)

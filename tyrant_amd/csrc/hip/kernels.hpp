@@ -87,6 +87,10 @@ struct FrameParams {
 	uint32_t ticketChunk;         // variants 1 / 4: queue slots a wave takes per draw from a device-wide ticket
 	uint32_t raysPerBlock;        // variants 2 / 3: queue slots owned by one 256-thread block
 	uint32_t staticShare;         // variant 4: sixteenths of the queue handed out as fixed per-block ranges
+	// TYR_FLAG_LIGHT_LIST (extension): emissive triangles, as indices into scene.tris in array order
+	const uint32_t* lights;
+	uint32_t nLights;
+	float triEmission[3];
 };
 
 // traversal kernel structure (tyr_set_tuning)

@@ -51,6 +51,9 @@ struct tyr_ctx {
 	float4* dNodes = nullptr;
 	float4* dQuads = nullptr;
 	float4* dTris = nullptr;
+	uint32_t* dLights = nullptr; // TYR_FLAG_LIGHT_LIST: emissive triangles, array order
+	uint32_t nLights = 0;
+	float triEmission[3] = { 3.0f, 3.0f, 3.0f }; // kernel.cu:680
 	DevScene scene{};
 	bool haveScene = false;
 
@@ -192,6 +195,9 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.ticketChunk = static_cast<uint32_t>(std::min(std::max(c->tuning.ticketChunk, 64), 65536));
 	P.raysPerBlock = static_cast<uint32_t>(std::min(std::max(c->tuning.raysPerBlock, 256), 65536));
 	P.staticShare = static_cast<uint32_t>(std::min(std::max(c->tuning.staticShare, 0), 15));
+	P.lights = c->dLights;
+	P.nLights = c->nLights;
+	std::memcpy(P.triEmission, c->triEmission, 12);
 	return P;
 }
 
@@ -359,6 +365,8 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		return TYR_ERR_INVALID;
 	if (static_cast<uint64_t>(cfg->width) * cfg->height >= (1ull << 31) || cfg->queue_size >= (1u << 31))
 		return TYR_ERR_INVALID;
+	if ((cfg->flags & TYR_FLAG_LIGHT_LIST) && !(cfg->flags & TYR_FLAG_TRIANGLE_MATERIALS))
+		return TYR_ERR_INVALID; // an emissive triangle is a triangle material
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
 		return TYR_ERR_NO_DEVICE;
@@ -430,6 +438,7 @@ int tyr_destroy(tyr_ctx* c) {
 	dev_free(c->dNodes);
 	dev_free(c->dQuads);
 	dev_free(c->dTris);
+	dev_free(c->dLights);
 	if (c->ownBlit)
 		dev_free(c->blit);
 	if (c->hK)
@@ -456,6 +465,8 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	dev_free(c->dNodes);
 	dev_free(c->dQuads);
 	dev_free(c->dTris);
+	dev_free(c->dLights);
+	c->nLights = 0;
 	c->scene = DevScene{};
 	c->scene.rootRef = kRefDone;
 	c->haveScene = true;
@@ -485,6 +496,26 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	c->scene.rootRef = L.rootRef;
 	c->scene.nPairs = L.nPairs;
 	c->scene.nPrims = static_cast<uint32_t>(nPrims);
+	if (c->cfg.flags & TYR_FLAG_LIGHT_LIST) {
+		// the light array the reference leaves as a TODO (kernel.cu:420): LIGHT triangles in (reordered) array order
+		std::vector<uint32_t> lights;
+		for (int32_t i = 0; i < nPrims; ++i)
+			if (prims[i].materialType == TYR_LIGHT)
+				lights.push_back(static_cast<uint32_t>(i));
+		if (!lights.empty()) {
+			if ((rc = dev_alloc(c->dLights, lights.size())))
+				return rc;
+			HIPCHK(hipMemcpy(c->dLights, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+			c->nLights = static_cast<uint32_t>(lights.size());
+		}
+	}
+	return TYR_OK;
+}
+
+int tyr_set_triangle_emission(tyr_ctx* c, const float* rgb) {
+	if (!c || !rgb || !finite_n(rgb, 3))
+		return TYR_ERR_INVALID;
+	std::memcpy(c->triEmission, rgb, 12);
 	return TYR_OK;
 }
 

@@ -79,6 +79,8 @@ class SceneData:
     camera: Camera
     sun_position: tuple = (0.05, 0.3)  # variables.cpp:3
     triangle_materials: bool = False  # extension flag
+    light_list: bool = False  # extension flag: LIGHT triangles emit and are sampled by NEE
+    triangle_emission: tuple = (3.0, 3.0, 3.0)  # with light_list; the reference light's value (kernel.cu:680)
 
 
 def hash_u32(index: np.ndarray, seed: int) -> np.ndarray:
@@ -193,6 +195,22 @@ def cornell_box() -> SceneData:
     )
     assert tris.shape[0] == 36
     return SceneData("cornell36", tris, cornell_spheres(), CORNELL_CAMERA)
+
+
+def cornell_area_light() -> SceneData:
+    """Cornell box lit by emissive triangles (extension): the ceiling patch and a small panel on the
+    left wall are materialType LIGHT, the short box is a mirror, the tall box Phong; spheres[6] stays a light too, so
+    next-event estimation picks among three emitters of two kinds."""
+    short = _box(18.0, -12.0, 15.0, 15.0, 0.0, 30.0, -0.3)
+    short["materialType"] = SPEC
+    tall = _box(-16.0, 14.0, 15.0, 15.0, 0.0, 60.0, 0.3)
+    tall["materialType"] = PHONG
+    patch = _quad((-12, -12, 99.5), (-12, 12, 99.5), (12, 12, 99.5), (12, -12, 99.5), (0, 0, -1))
+    patch["materialType"] = LIGHT
+    panel = make_triangles([(-49.5, -10.0, 40.0)], [(-49.5, 10.0, 40.0)], [(-49.5, 0.0, 60.0)], LIGHT)
+    assert np.cross(panel["e1"][0], panel["e2"][0])[0] > 0  # faces +x, into the room
+    tris = np.concatenate([room_walls(), short, tall, patch, panel])
+    return SceneData("cornell_area_light", tris, cornell_spheres(light_z=70.0), CORNELL_CAMERA, triangle_materials=True, light_list=True, triangle_emission=(4.0, 3.5, 3.0))
 
 
 def random_soup(n: int, seed: int = 12345, lo=(-48.0, -48.0, 2.0), hi=(48.0, 48.0, 98.0), edge: float = 1.5) -> np.ndarray:
