@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tests/fuzz_parity.py [n] [seed] -- randomised end-to-end parity: random scenes (triangle soups and height-field meshes of
-random size, with and without per-triangle materials), random resolutions, queue sizes, cameras and launch-shape knobs;
+random size, with and without per-triangle materials and emissive triangles), random resolutions, queue sizes, cameras and launch-shape knobs;
 each render is compared with the oracle's: identical iteration and ray counts, queues of the last iteration bit-exact,
 radiance within 1e-5 relative.  A checker like the tests (it is the only other place that drives the oracle), not collected by pytest (run time grows with n); prints one line per case."""
 import os
@@ -31,7 +31,12 @@ for case in range(n_cases):
     knobs = dict(traversal_variant=int(rng.choice([4, 4, 4, 3, 2, 1, 0])), stack_lds_depth=int(rng.choice([0, 8, 10, 12, 16, 24])), refill_min_idle=int(rng.integers(1, 65)),
                  min_traversing=int(rng.integers(1, 65)), ticket_chunk=int(rng.choice([64, 128, 1024])), static_share=int(rng.integers(0, 16)), staged_nodes=int(rng.integers(0, 65)),
                  rays_per_block=int(rng.choice([256, 1024, 4096])))
-    flags = 1 if sc.triangle_materials else 0
+    if sc.triangle_materials and rng.random() < 0.5:  # emissive triangles + light list (TYR_FLAG_LIGHT_LIST)
+        lit = rng.choice(len(sc.triangles), size=int(rng.integers(1, min(40, len(sc.triangles)))), replace=False)
+        sc.triangles["materialType"][lit] = scenes.LIGHT
+        sc.light_list, sc.triangle_emission = True, tuple(float(v) for v in rng.uniform(0.5, 6.0, 3))
+        sc.name += "+lights"
+    flags = (1 if sc.triangle_materials else 0) | (8 if sc.light_list else 0)
     bb = scenes.triangle_bboxes(sc.triangles)
     nodes, prims = pyorc.bvh_build(sc.triangles, bb)
     o = pyorc.Oracle(W, H, N, flags=flags)
