@@ -334,6 +334,37 @@ def test_work_distribution_knobs_never_change_results(orc, hip, knobs):
         assert_accum_close(o.blit_buffer(), g.blit_buffer(), f"{name} {knobs}")
 
 
+@pytest.mark.parametrize("name,W,H,N,spp", [("cornell_soup2k", 160, 90, 9000, 5), ("mesh128", 128, 72, 20000, 3), ("cornell_area_light", 96, 64, 3000, 4)])
+def test_render_with_and_without_the_deferred_connect(orc, hip, name, W, H, N, spp):
+    """tyr_render can run connect(i) on a second stream next to primary / extend of iteration i + 1
+    (TYR_TUNE_OVERLAP_CONNECT): same iteration count, same counters -- connect's included, which arrive with the final join -- and the same
+    radiance as the one-stream order and as the oracle; a render, a camera move (reset of the accumulation buffer while
+    nothing may be in flight) and a second render back to back"""
+    o, g1 = pair(orc, hip, name, W, H, N)
+    _, g0 = pair(orc, hip, name, W, H, N)
+    g0.set_tuning(overlap_connect=0)
+    g1.set_tuning(overlap_connect=1)
+    from tyrant_amd import scenes
+
+    sc, _, _ = built_scene(name)
+    moved = scenes.Camera(position=tuple(np.array(sc.camera.position) + np.array([3.0, 2.0, -1.0])), direction=sc.camera.direction, up=sc.camera.up)
+    for cam in (sc.camera, moved):
+        for r in (o, g0, g1):
+            r.set_camera(cam)
+        io, i0, i1 = o.render(spp), g0.render(spp), g1.render(spp)
+        assert io == i0 == i1
+        ko, k0, k1 = o.counters(), g0.counters(), g1.counters()
+        assert k0["device_error"] == 0 and k1["device_error"] == 0
+        for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible", "start_position", "frame"):
+            assert ko[f] == k0[f] == k1[f], (name, f)
+        assert_accum_close(o.blit_buffer(), g0.blit_buffer(), name + " one stream")
+        assert_accum_close(o.blit_buffer(), g1.blit_buffer(), name + " deferred connect")
+    # stage by stage right after a render with deferred connects: nothing is left in flight
+    for st in ("begin", "primary", "extend", "shade", "connect", "end"):
+        o.stage(st), g1.stage(st)
+    assert_accum_close(o.blit_buffer(), g1.blit_buffer(), name + " staged iteration after the render")
+
+
 def test_bench_two_ranks_on_one_gpu(hip):
     """bench.py's N > 1 path end to end on hardware: two ranks (gloo, both on device 0), rows dealt y % 2 == rank,
     16 spp in total, reduce onto rank 0 -- bench.py itself asserts that every pixel of the reduced frame holds

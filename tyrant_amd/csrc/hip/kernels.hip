@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 		P.scanDesc[i] = 0ull;
 	if (i < kTicketWords) {
 		P.k->extend_chunks[i * 32] = 0;
-		P.k->connect_chunks[i * 32] = 0;
+		P.kc->chunks[i * 32] = 0;
 		P.k->shade_tiles[i * 32] = 0;
 	}
 	if (i == 0) {
@@ -205,7 +205,8 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 		k->shadow_ray_cnt = 0;
 		k->primary_ray_cnt = 0;
 		k->extend_ticket = 0;
-		k->connect_ticket = 0;
+		P.kc->ticket = 0;
+		P.kc->shadow_cnt = 0;
 		if (budget != ~0ull)
 			k->budget_remaining = budget - nNew;
 		k->total_primary_rays += nNew;
@@ -697,6 +698,7 @@ __device__ __forceinline__ void shade_lookback(const FrameParams& P, uint32_t vb
 			// kernel.cu:607 / 416: the totals the next top-up and connect read
 			P.k->primary_ray_cnt = es + totS;
 			P.k->shadow_ray_cnt = eh + totH;
+			P.kc->shadow_cnt = eh + totH;
 			P.k->total_shadow_rays += eh + totH;
 			P.k->n_survive += es + totS;
 		}
@@ -869,7 +871,7 @@ template <bool COUNT, int STACK_LDS>
 __global__ void __launch_bounds__(kBlock) k_connect(const FrameParams P) {
 	TYR_DECLARE_STACK(st)
 	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
-	const uint32_t n = P.k->shadow_ray_cnt;
+	const uint32_t n = P.kc->shadow_cnt;
 	VisitCount vc{ 0, 0 };
 	bool overflow = false;
 	uint32_t visible = 0;
@@ -1117,8 +1119,8 @@ __global__ void __launch_bounds__(kBlock) k_extend_persistent(const FrameParams 
 __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P) {
 	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
 	if (index == 0)
-		P.k->connect_ticket = 0;
-	if (index >= P.k->shadow_ray_cnt)
+		P.kc->ticket = 0;
+	if (index >= P.kc->shadow_cnt)
 		return;
 	const float4 a = P.shadow.o_dx[index];
 	const float4 b = P.shadow.dyz_cd_ix[index];
@@ -1138,7 +1140,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_persistent(const FrameParams
 	TYR_DECLARE_STACK(st)
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t nRays = P.k->shadow_ray_cnt;
+	const uint32_t nRays = P.kc->shadow_cnt;
 	const DevScene& sc = P.scene;
 	const bool haveBvh = (sc.rootRef != kRefDone);
 	RayConst r = {};
@@ -1157,7 +1159,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_persistent(const FrameParams
 			const uint32_t leader = __ffsll((long long)idleMask) - 1;
 			uint32_t base = 0;
 			if (lane == leader)
-				base = atomicAdd(&P.k->connect_ticket, nIdle);
+				base = atomicAdd(&P.kc->ticket, nIdle);
 			base = __shfl(base, leader, 64);
 			exhausted = (base + nIdle >= nRays);
 			if (!live) {
@@ -1606,7 +1608,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 	}
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t nRays = P.k->shadow_ray_cnt;
+	const uint32_t nRays = P.kc->shadow_cnt;
 	const DevScene& sc = P.scene;
 	const bool haveBvh = (sc.rootRef != kRefDone);
 	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f; // see k_extend_flat
@@ -1654,7 +1656,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 					staticDone = (base + nIdle >= blockEnd);
 				}
 				while (staticDone && got < nIdle) {
-					if (!feed.refill(P.k->connect_chunks, nRays - dynBase, lane)) {
+					if (!feed.refill(P.kc->chunks, nRays - dynBase, lane)) {
 						exhausted = true;
 						break;
 					}

@@ -44,7 +44,7 @@ struct DevCounters {
 	uint32_t reserved0;      // (was the shade kernel's tile ticket; tiles are ordered without an atomic now)
 	uint32_t device_error;
 	uint32_t extend_ticket;  // next queue slot to hand to a free lane of the persistent extend kernel
-	uint32_t connect_ticket; // same for connect
+	uint32_t reserved1;      // (connect's ticket lives in ConnectCounters)
 	unsigned long long budget_remaining;
 	unsigned long long total_extend_rays;
 	unsigned long long total_shadow_rays;
@@ -59,8 +59,17 @@ struct DevCounters {
 	// variant 4: chunk tickets of the persistent traversal kernels, one word per 128 bytes so that the eight words
 	// are eight L2 lines (a single word serves only ~88 returning atomics per microsecond)
 	uint32_t extend_chunks[kTicketWords * 32];
-	uint32_t connect_chunks[kTicketWords * 32];
+	uint32_t reserved2[kTicketWords * 32]; // (connect's chunk tickets live in ConnectCounters)
 	uint32_t shade_tiles[kTicketWords * 32]; // k_shade: word w hands out tiles w, w + 8, w + 16, ...
+};
+// What connect reads and draws from, apart from the shadow queue.  Two of them, used by alternate iterations:
+// inside tyr_render connect(i) runs on a second stream next to primary / extend of iteration i + 1, whose
+// set_wavefront_globals resets ITS set and leaves the one connect(i) is working on alone.
+struct ConnectCounters {
+	uint32_t shadow_cnt;                // = shadow_ray_cnt of the iteration (kernel.cu:416-417), written by shade's last tile
+	uint32_t ticket;                    // variant 1: next shadow-queue slot
+	uint32_t pad[30];
+	uint32_t chunks[kTicketWords * 32]; // variant 4: chunk tickets, one word per 128 bytes like extend_chunks
 };
 constexpr uint32_t kErrStackOverflow = 1u;
 constexpr uint32_t kErrScanTimeout = 2u;
@@ -81,6 +90,7 @@ struct FrameParams {
 	ShadowQ shadow;
 	float4* blit;            // main.cpp:129-130
 	DevCounters* k;
+	ConnectCounters* kc;     // this iteration's set
 	unsigned long long* scanDesc; // one look-back descriptor per shade block
 	uint32_t refillMinIdle;       // persistent traversal: refill a wave once this many lanes are free
 	uint32_t minTraversing;       // flat traversal: leave the descent loop below this many descending lanes
@@ -104,6 +114,7 @@ struct Tuning {
 	int stagedNodes = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
+	int overlapConnect = 0;   // tyr_render: connect(i) on a second stream next to primary / extend of iteration i + 1 (measured: no gain)
 	int stackLdsDepth = 12;   // traversal-stack entries per lane kept in LDS (0, 8, 10, 12, 16, 24); the rest spill to scratch
 };
 

@@ -43,6 +43,16 @@ struct tyr_ctx {
 	ShadowQ shadow{};
 	DevCounters* dK = nullptr;
 	DevCounters* hK = nullptr; // pinned host mirror
+	ConnectCounters* dKc = nullptr; // two sets, iteration i uses set i & 1
+	uint32_t iter = 0;
+
+	// tyr_render only: connect(i) runs on `side` while the host already reads shade(i)'s counts and `stream` runs
+	// primary / extend of iteration i + 1; shade(i + 1) waits for it (it rewrites the shadow queue)
+	hipStream_t side = nullptr;
+	hipEvent_t evShadeDone = nullptr, evConnectDone = nullptr;
+	bool connectPending = false;
+	hipEvent_t evSide[2][2]{}; // TYR_FLAG_PROFILE: connect's start / stop on `side`, per set
+	bool evSideUsed[2]{};
 	unsigned long long* scanDesc = nullptr;
 	uint32_t nDescCap = 0;
 	float4* blit = nullptr;
@@ -189,6 +199,7 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.shadow = c->shadow;
 	P.blit = c->blit;
 	P.k = c->dK;
+	P.kc = c->dKc + (c->iter & 1u);
 	P.scanDesc = c->scanDesc;
 	P.refillMinIdle = static_cast<uint32_t>(std::min(std::max(c->tuning.refillMinIdle, 1), 64));
 	P.minTraversing = static_cast<uint32_t>(std::min(std::max(c->tuning.minTraversing, 1), 64));
@@ -232,6 +243,33 @@ void collect_timings(tyr_ctx* c) {
 	}
 }
 
+// connect launches timed on the side stream: fold the pairs that have finished (all of them when `wait`)
+void collect_side_timings(tyr_ctx* c, bool wait) {
+	for (int p = 0; p < 2; ++p) {
+		if (!c->evSideUsed[p])
+			continue;
+		if (wait)
+			(void)hipEventSynchronize(c->evSide[p][1]);
+		else if (hipEventQuery(c->evSide[p][1]) != hipSuccess)
+			continue;
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, c->evSide[p][0], c->evSide[p][1]) == hipSuccess) {
+			c->timings.ms[TYR_K_CONNECT] += ms;
+			c->timings.launches[TYR_K_CONNECT] += 1;
+		}
+		c->evSideUsed[p] = false;
+	}
+}
+
+// `stream` takes over again: whatever follows on it sees the deferred connect's results
+int join_connect(tyr_ctx* c) {
+	if (c->connectPending) {
+		HIPCHK(hipStreamWaitEvent(c->stream, c->evConnectDone, 0));
+		c->connectPending = false;
+	}
+	return TYR_OK;
+}
+
 uint32_t planned_new(const tyr_ctx* c) {
 	const uint64_t room = c->cfg.queue_size - c->hK->primary_ray_cnt;
 	const uint64_t budget = c->hK->budget_remaining;
@@ -264,6 +302,9 @@ int stage_begin(tyr_ctx* c) {
 		sun_setup(c->sunPos[0], c->sunPos[1], c->sun);
 	}
 	if (reset) { // kernel.cu:712-718
+		int rcj = join_connect(c);
+		if (rcj)
+			return rcj;
 		HIPCHK(hipMemsetAsync(c->blit, 0, sizeof(float4) * static_cast<size_t>(c->cfg.width) * c->cfg.height, c->stream));
 		c->hK->primary_ray_cnt = 0;
 		HIPCHK(hipMemcpyAsync(&c->dK->primary_ray_cnt, &c->hK->primary_ray_cnt, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -295,6 +336,28 @@ void enqueue_connect(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow) {
 	P.raysPerBlock = rays_per_block_for(c, maxShadow);
 	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->stream);
 }
+// the same on the side stream, after shade(i) and without holding up `stream`
+int enqueue_connect_deferred(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow) {
+	HIPCHK(hipEventRecord(c->evShadeDone, c->stream));
+	HIPCHK(hipStreamWaitEvent(c->side, c->evShadeDone, 0));
+	const bool timed = (c->cfg.flags & TYR_FLAG_PROFILE) != 0;
+	const int set = static_cast<int>(c->iter & 1u);
+	if (timed) {
+		if (c->evSideUsed[set]) // connect(i - 2): shade(i - 1) waited for it and the host waited for shade(i - 1)
+			collect_side_timings(c, true);
+		HIPCHK(hipEventRecord(c->evSide[set][0], c->side));
+	}
+	FrameParams P = P0;
+	P.raysPerBlock = rays_per_block_for(c, maxShadow);
+	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->side);
+	if (timed) {
+		HIPCHK(hipEventRecord(c->evSide[set][1], c->side));
+		c->evSideUsed[set] = true;
+	}
+	HIPCHK(hipEventRecord(c->evConnectDone, c->side));
+	c->connectPending = true;
+	return TYR_OK;
+}
 
 void stage_end(tyr_ctx* c) {
 	// kernel.cu:735-745
@@ -306,6 +369,7 @@ void stage_end(tyr_ctx* c) {
 	c->lastFocal = c->cam.focalDistance;
 	c->lastLens = c->cam.lensRadius;
 	c->cur ^= 1; // main.cpp:169
+	c->iter++;
 }
 
 int check_device_error(const tyr_ctx* c) {
@@ -406,8 +470,18 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 	if ((rc = dev_alloc(c->shadow.o_dx, N)) || (rc = dev_alloc(c->shadow.dyz_cd_ix, N)) || (rc = dev_alloc(c->shadow.color, N)))
 		return fail(rc);
 	c->nDescCap = static_cast<uint32_t>((N + kBlock - 1) / kBlock) + 8; // k_shade rounds the tile count up to its group size
-	if ((rc = dev_alloc(c->scanDesc, c->nDescCap)) || (rc = dev_alloc(c->dK, 1)))
+	if ((rc = dev_alloc(c->scanDesc, c->nDescCap)) || (rc = dev_alloc(c->dK, 1)) || (rc = dev_alloc(c->dKc, 2)))
 		return fail(rc);
+	if (hipMemset(c->dKc, 0, 2 * sizeof(ConnectCounters)) != hipSuccess)
+		return fail(TYR_ERR_NO_DEVICE);
+	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess)
+		return fail(TYR_ERR_NO_DEVICE);
+	if (hipEventCreateWithFlags(&c->evShadeDone, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evConnectDone, hipEventDisableTiming) != hipSuccess)
+		return fail(TYR_ERR_NO_DEVICE);
+	for (auto& pair : c->evSide)
+		for (auto& e : pair)
+			if (hipEventCreate(&e) != hipSuccess)
+				return fail(TYR_ERR_NO_DEVICE);
 	if (hipHostMalloc(reinterpret_cast<void**>(&c->hK), sizeof(DevCounters), hipHostMallocDefault) != hipSuccess)
 		return fail(TYR_ERR_OOM);
 	std::memset(c->hK, 0, sizeof(DevCounters));
@@ -426,6 +500,8 @@ int tyr_destroy(tyr_ctx* c) {
 	if (!c)
 		return TYR_OK;
 	(void)hipSetDevice(c->cfg.device);
+	if (c->side)
+		(void)hipStreamSynchronize(c->side);
 	if (c->stream)
 		(void)hipStreamSynchronize(c->stream);
 	free_rayq(c->q[0]);
@@ -435,6 +511,7 @@ int tyr_destroy(tyr_ctx* c) {
 	dev_free(c->shadow.color);
 	dev_free(c->scanDesc);
 	dev_free(c->dK);
+	dev_free(c->dKc);
 	dev_free(c->dNodes);
 	dev_free(c->dQuads);
 	dev_free(c->dTris);
@@ -446,6 +523,16 @@ int tyr_destroy(tyr_ctx* c) {
 	for (auto& e : c->ev)
 		if (e)
 			(void)hipEventDestroy(e);
+	for (auto& pair : c->evSide)
+		for (auto& e : pair)
+			if (e)
+				(void)hipEventDestroy(e);
+	if (c->evShadeDone)
+		(void)hipEventDestroy(c->evShadeDone);
+	if (c->evConnectDone)
+		(void)hipEventDestroy(c->evConnectDone);
+	if (c->side)
+		(void)hipStreamDestroy(c->side);
 	if (c->ownStream && c->stream)
 		(void)hipStreamDestroy(c->stream);
 	delete c;
@@ -704,6 +791,35 @@ int tyr_sync(tyr_ctx* c) {
 }
 
 // ---- the per-frame entry point --------------------------------------------------------------
+// One wavefront iteration.  deferConnect = false is launch_kernels as the reference has it: everything on one
+// stream, done when it returns (kernel.cu:733).  deferConnect = true (inside tyr_render): connect goes to the side
+// stream and the call returns as soon as shade's counts are on the host, so that the next iteration's primary and
+// extend -- and the host's work to launch them -- overlap connect's tail; the caller joins at the end.
+static int launch_iteration(tyr_ctx* c, bool deferConnect) {
+	// hK is current: every entry point that enqueues work ends with sync_counters
+	int rc = stage_begin(c);
+	if (rc)
+		return rc;
+	const uint32_t nNew = planned_new(c), nLive = c->hK->primary_ray_cnt + nNew;
+	const FrameParams P = make_params(c);
+	enqueue_primary(c, P, nNew, nLive);
+	enqueue_extend(c, P, nLive);
+	if ((rc = join_connect(c))) // shade rewrites the shadow queue connect(i - 1) reads
+		return rc;
+	enqueue_shade(c, P, nLive);
+	if (deferConnect) {
+		if ((rc = enqueue_connect_deferred(c, P, nLive)))
+			return rc;
+	} else {
+		enqueue_connect(c, P, nLive); // at most one shadow ray per live ray
+	}
+	HIPCHK(hipGetLastError());
+	rc = sync_counters(c); // kernel.cu:733 cudaDeviceSynchronize (deferred: up to and including shade)
+	collect_timings(c);
+	stage_end(c);
+	return rc ? rc : check_device_error(c);
+}
+
 int tyr_launch_kernels(tyr_ctx* c) {
 	if (!c)
 		return TYR_ERR_INVALID;
@@ -712,20 +828,7 @@ int tyr_launch_kernels(tyr_ctx* c) {
 	int rc = use_device(c);
 	if (rc)
 		return rc;
-	// hK is current: every entry point that enqueues work ends with sync_counters
-	if ((rc = stage_begin(c)))
-		return rc;
-	const uint32_t nNew = planned_new(c), nLive = c->hK->primary_ray_cnt + nNew;
-	const FrameParams P = make_params(c);
-	enqueue_primary(c, P, nNew, nLive);
-	enqueue_extend(c, P, nLive);
-	enqueue_shade(c, P, nLive);
-	enqueue_connect(c, P, nLive); // at most one shadow ray per live ray
-	HIPCHK(hipGetLastError());
-	rc = sync_counters(c); // kernel.cu:733 cudaDeviceSynchronize
-	collect_timings(c);
-	stage_end(c);
-	return rc ? rc : check_device_error(c);
+	return launch_iteration(c, false);
 }
 
 int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iterations_out) {
@@ -734,13 +837,25 @@ int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iter
 	int rc = tyr_set_budget(c, static_cast<uint64_t>(spp) * c->localPixels);
 	if (rc)
 		return rc;
+	if (!c->haveScene)
+		return TYR_ERR_NO_SCENE;
+	const bool defer = c->tuning.overlapConnect != 0;
 	uint32_t it = 0;
 	while (it < max_iterations) {
-		if ((rc = tyr_launch_kernels(c)))
+		if ((rc = launch_iteration(c, defer)))
 			break;
 		++it;
 		if (c->hK->budget_remaining == 0 && c->hK->primary_ray_cnt == 0)
 			break;
+	}
+	if (defer) {
+		// the last connect: back onto `stream`, counters refreshed, nothing in flight when this returns
+		int rcj = join_connect(c);
+		if (!rcj)
+			rcj = sync_counters(c);
+		collect_side_timings(c, true);
+		if (!rc)
+			rc = rcj ? rcj : check_device_error(c);
 	}
 	if (iterations_out)
 		*iterations_out = it;
@@ -947,6 +1062,11 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		if (value < 64 || value > 65536)
 			return TYR_ERR_INVALID;
 		c->tuning.ticketChunk = value;
+		return TYR_OK;
+	case TYR_TUNE_OVERLAP_CONNECT:
+		if (value != 0 && value != 1)
+			return TYR_ERR_INVALID;
+		c->tuning.overlapConnect = value;
 		return TYR_OK;
 	case TYR_TUNE_STACK_LDS_DEPTH:
 		if (value != 0 && value != 8 && value != 10 && value != 12 && value != 16 && value != 24)
