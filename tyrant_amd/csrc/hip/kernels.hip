@@ -366,7 +366,11 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 	out.survive = false;
 	out.shadow = false;
 
-	if (distance < kVeryFar) {
+	enum { kAtmoNone = 0, kAtmoSun, kAtmoSky, kAtmoSunSky };
+	int atmo = kAtmoNone;   // what this ray wants from the atmosphere model, evaluated once for the whole wave below
+	float atmoScale = 0.0f;
+	const bool hit = distance < kVeryFar;
+	if (hit) {
 		origin = origin + direction * distance;
 		f3 normal;
 		if (ident & kHitSphere) {
@@ -417,7 +421,9 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 					out.shadow = true;
 					out.sOrigin = origin;
 					out.sDir = sunSampleDir;
-					out.sColor = (2.0f * direct) * ((sun_radiance(P.sun, sunSampleDir) * sunLight) * 1E-5f);
+					out.sColor = 2.0f * direct; // x ((sun(sunSampleDir) * sunLight) * 1E-5f) below, kernel.cu:414
+					atmo = kAtmoSun;
+					atmoScale = sunLight;
 					out.sClosest = 1e20f; // variables.h:41
 				}
 			} else {
@@ -506,7 +512,9 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 						out.shadow = true;
 						out.sOrigin = origin;
 						out.sDir = sunSampleDir;
-						out.sColor = ((2.0f * direct) * ((phongexponent + 2) * 0.5f * kInvPi)) * ((sun_radiance(P.sun, sunSampleDir) * sunLight) * 1E-5f);
+						out.sColor = (2.0f * direct) * ((phongexponent + 2) * 0.5f * kInvPi); // x ((sun(..) * sunLight) * 1E-5f) below
+						atmo = kAtmoSun;
+						atmoScale = sunLight;
 						out.sClosest = 1e20f;
 					}
 				}
@@ -540,6 +548,30 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 		}
 		}
 
+	} else {
+		atmo = lastSpecular ? kAtmoSunSky : kAtmoSky; // kernel.cu:613-617: nothing hit
+	}
+
+	// The atmosphere (sunsky.cu) is the most expensive thing a ray can ask for here, and three kinds of lanes ask:
+	// a diffuse or Phong hit whose next-event sample went to the sun (sun(sunSampleDir), kernel.cu:414 / 553), and a
+	// miss (sky / sunsky(direction), kernel.cu:613-617).  A ray asks at most once, nothing random is drawn in
+	// between, so all of them evaluate it HERE, in one pass of the wave, instead of one pass per place of call; every
+	// lane still performs exactly the operations the reference's order of evaluation prescribes.
+	if (atmo != kAtmoNone) {
+		const bool miss = !hit;
+		const f3 viewDir = miss ? direction : out.sDir;
+		if (atmo == kAtmoSunSky && P.sun.sunAngularDiameterCos == 1.0f) {
+			color = color + direct * mk3(1.0f, 0.0f, 0.0f); // sunsky.cu:118-119
+		} else {
+			const Atmosphere a = atmosphere(P.sun, viewDir);
+			if (atmo == kAtmoSun)
+				out.sColor = out.sColor * ((sun_radiance(P.sun, a) * atmoScale) * 1E-5f);
+			else
+				color = color + (atmo == kAtmoSky ? direct * sky_radiance(a) : direct * sunsky_radiance(P.sun, a));
+		}
+	}
+
+	if (hit) {
 		// Russian roulette, kernel.cu:599-611
 		const float p = gmin(1.0f, gmax(direct.z, gmax(direct.x, direct.y)));
 		if (bounces < kMaxBounces && p > (0 + kEpsilon) && rng_float(seed) <= p) {
@@ -554,8 +586,6 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 			new_frame++;
 		}
 	} else {
-		// kernel.cu:613-617: nothing hit
-		color = color + (lastSpecular == false ? direct * sky_radiance(P.sun, direction) : direct * sunsky_radiance(P.sun, direction));
 		new_frame++;
 	}
 

@@ -80,25 +80,19 @@ __device__ __forceinline__ Atmosphere atmosphere(const SunParams& S, f3 viewDir)
 }
 
 // sunsky.cu:32-74.  Line 70's `adc < (cos ? 1.0 : 0.0)` precedence quirk is kept: the
-// disk term is 1 for every non-zero cosine.
-__device__ __forceinline__ f3 sun_radiance(const SunParams& S, f3 viewDir) {
-	const Atmosphere a = atmosphere(S, viewDir);
+// disk term is 1 for every non-zero cosine.  (These take the shared block as an argument: k_shade evaluates it once
+// per ray, for whichever of the three a ray needs.)
+__device__ __forceinline__ f3 sun_radiance(const SunParams& S, const Atmosphere& a) {
 	const float sundisk = ((double)S.sunAngularDiameterCos < (a.cosViewSunAngle ? 1.0 : 0.0)) ? 1.0f : 0.0f;
 	const f3 sun = ((S.sunE * 19000.0f) * a.Fex) * sundisk;
 	return 0.01f * sun;
 }
 
 // sunsky.cu:76-114
-__device__ __forceinline__ f3 sky_radiance(const SunParams& S, f3 viewDir) {
-	const Atmosphere a = atmosphere(S, viewDir);
-	return (1.f * 0.01f) * a.sky;
-}
+__device__ __forceinline__ f3 sky_radiance(const Atmosphere& a) { return (1.f * 0.01f) * a.sky; }
 
-// sunsky.cu:116-161
-__device__ __forceinline__ f3 sunsky_radiance(const SunParams& S, f3 viewDir) {
-	if (S.sunAngularDiameterCos == 1.0f)
-		return mk3(1.0f, 0.0f, 0.0f);
-	const Atmosphere a = atmosphere(S, viewDir);
+// sunsky.cu:116-161; the caller handles the early return of sunsky.cu:118-119 (sunAngularDiameterCos == 1)
+__device__ __forceinline__ f3 sunsky_radiance(const SunParams& S, const Atmosphere& a) {
 	const float e0 = S.sunAngularDiameterCos;
 	const float e1 = S.sunAngularDiameterCos + 0.00002f;
 	const float t = gclamp((a.cosViewSunAngle - e0) / (e1 - e0), 0.0f, 1.0f); // smoothstep, func_common.inl:257-265
