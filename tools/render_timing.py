@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""tools/render_timing.py -- per-kernel milliseconds per render (1080p, 8 spp, queue sized for the GPU) on C2 and C3,
+through whichever library TYRANT_HIP_LIBRARY names: the quick A/B for what-if builds, e.g.
+  hipcc ... -DTYR_WHATIF_NO_ATOMICS -c hip/kernels.hip   (pixel atomics left out: wrong picture, right timing)
+No oracle, no assertions on the picture."""
+import sys, os
+sys.path.insert(0, os.getcwd())
+from tyrant_amd import binding, scenes
+import numpy as np
+W,H,spp=1920,1080,8
+for name, sc in (("c2", scenes.cornell_soup(10000)), ("c3", scenes.mesh_scene(706))):
+    bb=scenes.triangle_bboxes(sc.triangles)
+    nodes, prims = binding.bvh_build(sc.triangles, bb)
+    flags = binding.TYR_FLAG_PROFILE | (1 if sc.triangle_materials else 0)
+    r = binding.Renderer(W,H,W*H*spp, flags=flags)
+    r.load_scene(sc,nodes,prims)
+    r.render(spp)
+    r.reset_accum(); r.timings(reset=True)
+    import time
+    t0=time.perf_counter()
+    for _ in range(3):
+        r.reset_accum(); r.render(spp)
+    dt=(time.perf_counter()-t0)/3
+    tm=r.timings()
+    print(os.environ.get("TYRANT_HIP_LIBRARY","default"), name, "ms/render %.3f"%(dt*1e3), {k:round(v["ms"]/3,3) for k,v in tm.items() if v["launches"]})

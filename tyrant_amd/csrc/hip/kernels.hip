@@ -343,13 +343,23 @@ __device__ __forceinline__ EmitterSample sample_emitter(const FrameParams& P, ui
 	return E;
 }
 
-template <bool LIGHTS>
-__device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, ShadeOut& out) {
-	const float4 a = P.work.o_dx[slot];
-	const float2 b = P.work.dyz[slot];
-	const float2 h = P.work.hit[slot];
-	const float4 dq = P.work.direct_ix[slot];
-	const uint32_t fl = P.work.flags[slot];
+// `afterLoads` runs once, for every lane, at the point where this ray's last vector load has been consumed and
+// only arithmetic follows: the place to issue memory traffic nobody waits for (k_shade: the pixel atomics of the tile
+// before).
+// Lanes past the end of the queue come along with valid = false (they load nothing and produce nothing) so that
+// afterLoads is reached by the whole wave.
+template <bool LIGHTS, class AfterLoads>
+__device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, bool valid, ShadeOut& out, AfterLoads&& afterLoads) {
+	float4 a = make_float4(0.f, 0.f, 0.f, 0.f), dq = a;
+	float2 b = make_float2(0.f, 0.f), h = make_float2(kVeryFar, 0.f);
+	uint32_t fl = 0;
+	if (valid) {
+		a = P.work.o_dx[slot];
+		b = P.work.dyz[slot];
+		h = P.work.hit[slot];
+		dq = P.work.direct_ix[slot];
+		fl = P.work.flags[slot];
+	}
 
 	f3 origin = mk3(a.x, a.y, a.z), direction = mk3(a.w, b.x, b.y), direct = mk3(dq.x, dq.y, dq.z);
 	const int pixel = __float_as_int(dq.w);
@@ -369,10 +379,10 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 	enum { kAtmoNone = 0, kAtmoSun, kAtmoSky, kAtmoSunSky };
 	int atmo = kAtmoNone;   // what this ray wants from the atmosphere model, evaluated once for the whole wave below
 	float atmoScale = 0.0f;
-	const bool hit = distance < kVeryFar;
+	const bool hit = valid && distance < kVeryFar;
+	f3 normal = mk3(0.f, 0.f, 0.f);
 	if (hit) {
 		origin = origin + direction * distance;
-		f3 normal;
 		if (ident & kHitSphere) {
 			const tyr_sphere& object = P.spheres[ident & 7u];
 			normal = (origin - ld3(object.position)) / object.radius;
@@ -393,6 +403,9 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 				reflection_type = m <= (uint32_t)(LIGHTS ? TYR_LIGHT : TYR_PHONG) ? (int)m : TYR_DIFF;
 			}
 		}
+	}
+	afterLoads();
+	if (hit) {
 		const bool outside = dot(normal, direction) < 0;
 		normal = outside ? normal : normal * -1.f;
 		origin = origin + normal * kEpsilon;
@@ -548,7 +561,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 		}
 		}
 
-	} else {
+	} else if (valid) {
 		atmo = lastSpecular ? kAtmoSunSky : kAtmoSky; // kernel.cu:613-617: nothing hit
 	}
 
@@ -585,7 +598,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 		} else {
 			new_frame++;
 		}
-	} else {
+	} else if (valid) {
 		new_frame++;
 	}
 
@@ -599,6 +612,10 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, S
 // barrier made every wave sit out its own scattered atomics (~3000 cycles each under load).
 __device__ __forceinline__ void accumulate_pixel(float4* blit, int pixel, f3 color, int new_frame) {
 	float* px = reinterpret_cast<float*>(&blit[pixel]);
+#ifdef TYR_WHATIF_NO_ATOMICS
+	if (pixel != 12345)
+		return;
+#endif
 	if (color.x != 0.0f)
 		atomicAdd(px + 0, color.x);
 	if (color.y != 0.0f)
@@ -607,6 +624,27 @@ __device__ __forceinline__ void accumulate_pixel(float4* blit, int pixel, f3 col
 		atomicAdd(px + 2, color.z);
 	if (new_frame)
 		atomicAdd(px + 3, (float)new_frame);
+}
+
+// The same for a whole wave at once (every lane must call it; lanes without a contribution pass zeros).  A pixel is
+// 16 bytes, so "lane l adds its red" spreads one instruction over 64 pixels = eight 128-byte lines with four useful
+// bytes in sixteen, four times over for r, g, b and the count.  Here the wave transposes first: instruction j covers
+// the pixels of lanes 16j .. 16j + 15, lane l adding component l % 4 of lane 16j + l / 4 -- consecutive queue slots are
+// (mostly) consecutive pixels, so an instruction now touches two lines instead of eight.  Same sums, same skipping
+// of zero terms.
+__device__ __forceinline__ void accumulate_pixels_wave(float4* blit, int pixel, f3 color, int new_frame) {
+	const uint32_t lane = lane_id();
+	const uint32_t c = lane & 3u;
+	const float w = (float)new_frame;
+#pragma unroll
+	for (uint32_t j = 0; j < 4; ++j) {
+		const int src = (int)(16u * j + (lane >> 2));
+		const float x = __shfl(color.x, src, 64), y = __shfl(color.y, src, 64), z = __shfl(color.z, src, 64), n = __shfl(w, src, 64);
+		const int px = __shfl(pixel, src, 64);
+		const float v = c == 0u ? x : (c == 1u ? y : (c == 2u ? z : n));
+		if (v != 0.0f)
+			atomicAdd(reinterpret_cast<float*>(&blit[px]) + c, v);
+	}
 }
 
 // look-back descriptor: [63:62] status, [61:31] survivors, [30:0] shadow rays
@@ -755,6 +793,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t 
 #define TYR_STAMP(i)
 #endif
 	bool havePrev = false;            // a shaded tile whose records wait in `stage`
+	uint32_t pendPixel = 0;           // this lane's pixel contribution of that tile, not yet added
+	int pendNew = 0;
+	f3 pendColor = mk3(0.f, 0.f, 0.f);
 	uint32_t prevVb = 0, prevS = 0, prevH = 0;
 
 	// finish the waiting tile: look back, then move its records from LDS to their slots (kernel.cu:607-608, 416-417)
@@ -816,10 +857,20 @@ __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t 
 		const uint32_t slot = vb * kBlock + tid;
 		ShadeOut out = {};
 		uint32_t pixelBits = 0;
-		if (slot < nLive) {
+		// kernel.cu:622-625 for the tile BEFORE this one.  vmcnt retires loads and atomics in issue order, and an
+		// atomic that has to reach the memory side takes thousands of cycles under load: issued at the end of a
+		// tile they sat in front of the next tile's ray loads (0.34 ms of a render's 1.77 ms of shade, measured by
+		// leaving them out).  Issued here -- this tile's loads are back, ~1000 instructions of arithmetic follow --
+		// nobody waits for them.
+		auto flush_pixels = [&]() { // reached by every lane of every wave: lanes with nothing pending add nothing
+			accumulate_pixels_wave(P.blit, (int)pendPixel, pendColor, pendNew);
+			pendColor = mk3(0.f, 0.f, 0.f);
+			pendNew = 0;
+		};
+		const bool valid = slot < nLive;
+		if (valid)
 			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
-			shade_ray<LIGHTS>(P, slot, out);
-		}
+		shade_ray<LIGHTS>(P, slot, valid, out, flush_pixels);
 		TYR_STAMP(0)
 
 		// ---- stable compaction of survivors and shadow rays: ranks inside the tile ----
@@ -872,14 +923,17 @@ __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t 
 		prevVb = vb;
 		prevS = totS;
 		prevH = totH;
-		if (slot < nLive)
-			accumulate_pixel(P.blit, (int)pixelBits, out.color, out.newFrame);
+		// goes to the pixel under the next tile's arithmetic (or after the loop); zeros for lanes past the end
+		pendPixel = pixelBits;
+		pendColor = out.color;
+		pendNew = out.newFrame;
 		// no barrier here: the next tile's first barrier orders these LDS writes before flush_prev reads them
 		TYR_STAMP(5)
 #ifdef TYR_SHADE_TIMING
 		++ntiles_;
 #endif
 	}
+	accumulate_pixels_wave(P.blit, (int)pendPixel, pendColor, pendNew);
 	if (havePrev) {
 		__syncthreads();
 		flush_prev();
@@ -1601,7 +1655,9 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 			}
 			ref = kRefPop;
 		}
-		// ---- finished rays: a triangle hit replaces the sphere answer of the pre-pass (kernel.cu:138-140) ----
+		// ---- finished rays: a triangle hit replaces the sphere answer of the pre-pass (kernel.cu:138-140).
+		// (Holding the record back until the wave's next refill, one store for all lanes that finished in between,
+		// was measured: +1 %.) ----
 		if (live && ref == kRefDone) {
 			if (hitTri)
 				P.work.hit[slot] = make_float2(dist, __uint_as_float((uint32_t)prim));
@@ -1649,6 +1705,22 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 	bool live = false, occluded = false, overflow = false;
 	VisitCount vc{ 0, 0 };
 	uint32_t visible = 0;
+	// kernel.cu:640-644, deferred: a lane whose ray came through unoccluded notes the slot and goes idle; the wave
+	// adds all such colours to their pixels at its next refill (and once after the loop), loads batched with the new
+	// rays' loads and the atomics transposed (accumulate_pixels_wave) -- instead of two dependent loads and three
+	// scattered atomics in the middle of the descent every time some lane finishes.
+	constexpr uint32_t kNoPending = 0xffffffffu;
+	uint32_t pendIdx = kNoPending;
+	auto flush_visible = [&]() {
+		float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+		int px = 0;
+		if (pendIdx != kNoPending) {
+			c = P.shadow.color[pendIdx];
+			px = __float_as_int(P.shadow.dyz_cd_ix[pendIdx].w);
+		}
+		accumulate_pixels_wave(P.blit, px, mk3(c.x, c.y, c.z), 0);
+		pendIdx = kNoPending;
+	};
 	__shared__ uint32_t blockNext;
 	const uint32_t perBlock = PERSIST ? static_range(nRays, P.staticShare) : P.raysPerBlock; // see k_extend_flat
 	const uint32_t dynBase = PERSIST ? perBlock * gridDim.x : 0u;
@@ -1710,6 +1782,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 				s = base + rank;
 				fed = !live && rank < take;
 			}
+			if (__ballot(pendIdx != kNoPending) != 0ull)
+				flush_visible();
 			{
 				if (fed) {
 					const float4 a = P.shadow.o_dx[s];
@@ -1812,16 +1886,15 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 			}
 		}
 		if (live && ref == kRefDone) {
-			if (!occluded) { // kernel.cu:640-644
-				const float4 c = P.shadow.color[index];
-				const float4 b = P.shadow.dyz_cd_ix[index];
-				accumulate_pixel(P.blit, __float_as_int(b.w), mk3(c.x, c.y, c.z), 0);
+			if (!occluded) {
+				pendIdx = index;
 				visible += 1;
 			}
 			overflow = overflow || st.overflow;
 			live = false;
 		}
 	}
+	flush_visible();
 	if (overflow)
 		atomicOr(&P.k->device_error, kErrStackOverflow);
 	wave_add_u64(&P.k->n_shadow_visible, visible);
