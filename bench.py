@@ -297,7 +297,7 @@ def cpu_baseline(sc, W, H, N, iterations, tri_materials, spp):
     dt = time.perf_counter() - t0
     k = o.counters()
     rays = k["total_extend_rays"] + k["total_shadow_rays"]
-    return {
+    out = {
         "value": round(rays / dt / 1e6, 4),
         "unit": "Mrays/s",
         "cores": 1,
@@ -306,6 +306,32 @@ def cpu_baseline(sc, W, H, N, iterations, tri_materials, spp):
         "bvh_build_s": round(t_build, 3),
         "host_cpus": os.cpu_count(),
     }
+    # The reference's own traversal, where it can be had: oracle/_ref/libref_traverse.so is CachedBVH::intersect
+    # (bvh.h:118-161) compiled from the reference's header in the authoring container (the builder and the kernels
+    # cannot be built there).  Timed on the rays the next iteration would trace, through the same BVH, 1 core.
+    R = pyorc.ref()
+    if R is not None:
+        import ctypes
+
+        import numpy as np
+
+        o.stage("begin"), o.stage("primary")
+        n = min(o.counters()["n_live"], 1 << 21)
+        q = np.ascontiguousarray(o.ray_queue(0, n))
+        q["distance"] = 1e20  # VERY_FAR, variables.h:13: extend starts every ray there
+        hit = np.zeros(n, dtype=np.int32)
+        nd, pr = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
+        t0 = time.perf_counter()
+        R.ref_bvh_intersect(nd.ctypes.data_as(ctypes.c_void_p), pr.ctypes.data_as(ctypes.c_void_p), q.ctypes.data_as(ctypes.c_void_p), n, hit.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), None)
+        dtr = time.perf_counter() - t0
+        out["reference_trace"] = {
+            "value": round(n / dtr / 1e6, 4),
+            "unit": "Mrays/s",
+            "cores": 1,
+            "kind": "reference",
+            "sample": f"CachedBVH::intersect of the reference's bvh.h over the first {n} rays of iteration {iterations + 1}'s queue (BVH only, no spheres, no shading) in {dtr:.1f} s; {int(hit.sum())} hits",
+        }
+    return out
 
 
 if __name__ == "__main__":
