@@ -114,7 +114,7 @@ struct Tuning {
 	int stagedNodes = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
-	int overlapConnect = 0;   // tyr_render: connect(i) on a second stream next to primary / extend of iteration i + 1 (measured: no gain)
+	int overlapConnect = 2;   // tyr_render: connect(i) on a second stream next to primary / extend of iteration i + 1: 0 never, 1 always, 2 for thin wavefronts
 	int stackLdsDepth = 12;   // traversal-stack entries per lane kept in LDS (0, 8, 10, 12, 16, 24); the rest spill to scratch
 };
 

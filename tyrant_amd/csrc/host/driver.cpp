@@ -173,6 +173,8 @@ uint32_t rays_per_block_for(const tyr_ctx* c, uint32_t nRays) {
 	return std::max<uint32_t>(rpb, 256);
 }
 
+constexpr uint32_t kOverlapMaxLive = 6u << 20; // TYR_TUNE_OVERLAP_CONNECT = 2: queues of up to this many slots run connect on the side stream
+
 FrameParams make_params(const tyr_ctx* c) {
 	FrameParams P{};
 	P.W = c->cfg.width;
@@ -795,19 +797,31 @@ int tyr_sync(tyr_ctx* c) {
 // stream, done when it returns (kernel.cu:733).  deferConnect = true (inside tyr_render): connect goes to the side
 // stream and the call returns as soon as shade's counts are on the host, so that the next iteration's primary and
 // extend -- and the host's work to launch them -- overlap connect's tail; the caller joins at the end.
-static int launch_iteration(tyr_ctx* c, bool deferConnect) {
+static int launch_iteration(tyr_ctx* c, int overlap) {
 	// hK is current: every entry point that enqueues work ends with sync_counters
 	int rc = stage_begin(c);
 	if (rc)
 		return rc;
 	const uint32_t nNew = planned_new(c), nLive = c->hK->primary_ray_cnt + nNew;
-	const FrameParams P = make_params(c);
+	// overlap 2 = by queue size: a thin wavefront is mostly ramp and tail on a 256-CU part, and that is what the
+	// neighbouring kernel fills (N = 2 Mi: +8 % C2, +13 % C3; from ~8 M rays up the two grids only stretch each other;
+	// deciding per iteration by nLive instead was neutral on a 16.6 M queue: profiles/r01_deferred_connect_ab.txt)
+	const bool deferConnect = overlap == 1 || (overlap == 2 && c->cfg.queue_size <= kOverlapMaxLive);
+	FrameParams P = make_params(c);
 	enqueue_primary(c, P, nNew, nLive);
-	enqueue_extend(c, P, nLive);
+	{
+		// next to a connect that is still running, blocks become resident late: no fixed per-block ranges then
+		FrameParams Pe = P;
+		if (overlap == 2 && c->connectPending)
+			Pe.staticShare = 0;
+		enqueue_extend(c, Pe, nLive);
+	}
 	if ((rc = join_connect(c))) // shade rewrites the shadow queue connect(i - 1) reads
 		return rc;
 	enqueue_shade(c, P, nLive);
 	if (deferConnect) {
+		if (overlap == 2)
+			P.staticShare = 0;
 		if ((rc = enqueue_connect_deferred(c, P, nLive)))
 			return rc;
 	} else {
@@ -828,7 +842,7 @@ int tyr_launch_kernels(tyr_ctx* c) {
 	int rc = use_device(c);
 	if (rc)
 		return rc;
-	return launch_iteration(c, false);
+	return launch_iteration(c, 0);
 }
 
 int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iterations_out) {
@@ -839,10 +853,11 @@ int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iter
 		return rc;
 	if (!c->haveScene)
 		return TYR_ERR_NO_SCENE;
-	const bool defer = c->tuning.overlapConnect != 0;
+	const int overlap = c->tuning.overlapConnect;
+	const bool defer = overlap != 0;
 	uint32_t it = 0;
 	while (it < max_iterations) {
-		if ((rc = launch_iteration(c, defer)))
+		if ((rc = launch_iteration(c, overlap)))
 			break;
 		++it;
 		if (c->hK->budget_remaining == 0 && c->hK->primary_ray_cnt == 0)
@@ -1064,7 +1079,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		c->tuning.ticketChunk = value;
 		return TYR_OK;
 	case TYR_TUNE_OVERLAP_CONNECT:
-		if (value != 0 && value != 1)
+		if (value < 0 || value > 2)
 			return TYR_ERR_INVALID;
 		c->tuning.overlapConnect = value;
 		return TYR_OK;
