@@ -607,9 +607,10 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 }
 
 // kernel.cu:622-625.  Adding +0 leaves the pixel unchanged, so zero terms are skipped (the reference's
-// own TODO at kernel.cu:621).  Called as the LAST thing the kernel does: vmcnt retires loads, stores and
-// atomics in issue order and __syncthreads() waits for vmcnt(0), so atomics issued before the compaction
-// barrier made every wave sit out its own scattered atomics (~3000 cycles each under load).
+// own TODO at kernel.cu:621).  One lane, one pixel: used by the per-slot and first persistent kernels (variants
+// 0-1); the production kernels add a whole wave's contributions at once (accumulate_pixels_wave below).  vmcnt
+// retires loads, stores and atomics in issue order and __syncthreads() waits for vmcnt(0), so where these are
+// issued matters: in front of a barrier every wave sits out its own scattered atomics (~3000 cycles under load).
 __device__ __forceinline__ void accumulate_pixel(float4* blit, int pixel, f3 color, int new_frame) {
 	float* px = reinterpret_cast<float*>(&blit[pixel]);
 #ifdef TYR_WHATIF_NO_ATOMICS
@@ -804,7 +805,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t 
 		shade_lookback(P, prevVb, prevS, prevH, tid, nTiles, sh, es, eh);
 		TYR_STAMP(2)
 		// one array at a time (the compiler barrier keeps it from loading all seven records first): this copy is where
-		// the kernel's register count peaks, and 96 VGPRs = one more resident block per CU than 97
+		// the kernel's register count peaks
 		if (tid < prevS) {
 			P.next.o_dx[es + tid] = stage.sv_o_dx[tid];
 			__asm__ volatile("" ::: "memory");
