@@ -253,7 +253,7 @@ def main():
                 ),
             },
             "roofline": {
-                "kernel": "k_extend",
+                "kernel": "extend stage = k_extend_spheres (sphere pre-pass) + k_extend_flat, one hipEvent pair around both",
                 "bound": "hbm",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
