@@ -234,6 +234,7 @@ enum {
 	TYR_TUNE_STATIC_SHARE = 8,      /* variant 4: sixteenths of the queue dealt to the blocks as fixed ranges before the ticketed chunks start (0..15, default 4) */
 	TYR_TUNE_STAGED_NODES = 9,      /* variant 4: top-of-tree quad nodes each block keeps in LDS (0..64, default 64) */
 	TYR_TUNE_OVERLAP_CONNECT = 10,  /* tyr_render: connect(i) on a second stream while the first already does primary / extend of iteration i + 1 (shade(i + 1) waits for it): 0 = never (one stream, kernel after kernel), 1 = always, 2 (default) = when queue_size is at most 6 Mi slots, where ramp and tail dominate a launch and the neighbour fills them; fixed per-block ranges are switched off beside a running connect.  tyr_launch_kernels is always one stream. */
+	TYR_TUNE_PROFILE_MASK = 11,     /* with TYR_FLAG_PROFILE: bit TYR_K_* set = that stage is bracketed by a hipEvent pair (default 31 = all five).  An event between two kernels costs ~10 us of idle GPU, ~2 % of a 1080p render with all of them on. */
 	TYR_TUNE_RAYS_PER_BLOCK = 6     /* variants 2/3: queue slots owned by one 256-thread block and handed to its free lanes through LDS (256..65536, default 1024; halved automatically for thin queues) */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);

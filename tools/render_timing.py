@@ -12,7 +12,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else W*H*spp  # queue size; 2097152 = 
 for name, sc in (("c2", scenes.cornell_soup(10000)), ("c3", scenes.mesh_scene(706))):
     bb=scenes.triangle_bboxes(sc.triangles)
     nodes, prims = binding.bvh_build(sc.triangles, bb)
-    flags = binding.TYR_FLAG_PROFILE | (1 if sc.triangle_materials else 0)
+    flags = (0 if os.environ.get('NOPROFILE') else binding.TYR_FLAG_PROFILE) | (1 if sc.triangle_materials else 0)
     r = binding.Renderer(W,H,N, flags=flags)
     r.load_scene(sc,nodes,prims)
     r.render(spp)
@@ -23,4 +23,4 @@ for name, sc in (("c2", scenes.cornell_soup(10000)), ("c3", scenes.mesh_scene(70
         r.reset_accum(); r.render(spp)
     dt=(time.perf_counter()-t0)/3
     tm=r.timings()
-    print(os.environ.get("TYRANT_HIP_LIBRARY","default"), name, "N", N, "ms/render %.3f"%(dt*1e3), {k:round(v["ms"]/3,3) for k,v in tm.items() if v["launches"]}, "launches/render", tm["extend"]["launches"]//3)
+    print(os.environ.get("TYRANT_HIP_LIBRARY","default"), name, "N", N, "ms/render %.3f"%(dt*1e3), {k:round(v["ms"]/3,3) for k,v in tm.items() if v["launches"]}, "launches/render", tm["extend"]["launches"]//3, "(no per-kernel events)" if os.environ.get("NOPROFILE") else "")

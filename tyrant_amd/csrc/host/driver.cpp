@@ -49,7 +49,7 @@ struct tyr_ctx {
 	// tyr_render only: connect(i) runs on `side` while the host already reads shade(i)'s counts and `stream` runs
 	// primary / extend of iteration i + 1; shade(i + 1) waits for it (it rewrites the shadow queue)
 	hipStream_t side = nullptr;
-	hipEvent_t evShadeDone = nullptr, evConnectDone = nullptr;
+	hipEvent_t evShadeDone = nullptr, evConnectDone = nullptr, evSnapshot = nullptr;
 	bool connectPending = false;
 	hipEvent_t evSide[2][2]{}; // TYR_FLAG_PROFILE: connect's start / stop on `side`, per set
 	bool evSideUsed[2]{};
@@ -218,7 +218,7 @@ struct KernelTimer {
 	tyr_ctx* c;
 	int k;
 	bool on;
-	KernelTimer(tyr_ctx* c_, int k_) : c(c_), k(k_), on((c_->cfg.flags & TYR_FLAG_PROFILE) != 0) {
+	KernelTimer(tyr_ctx* c_, int k_) : c(c_), k(k_), on((c_->cfg.flags & TYR_FLAG_PROFILE) != 0 && ((c_->tuning.profileMask >> k_) & 1) != 0) {
 		if (on)
 			(void)hipEventRecord(c->ev[2 * k], c->stream);
 	}
@@ -338,26 +338,35 @@ void enqueue_connect(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow) {
 	P.raysPerBlock = rays_per_block_for(c, maxShadow);
 	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->stream);
 }
-// the same on the side stream, after shade(i) and without holding up `stream`
-int enqueue_connect_deferred(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow) {
-	HIPCHK(hipEventRecord(c->evShadeDone, c->stream));
-	HIPCHK(hipStreamWaitEvent(c->side, c->evShadeDone, 0));
-	const bool timed = (c->cfg.flags & TYR_FLAG_PROFILE) != 0;
+// Inside tyr_render the host does not wait for connect: shade's counts are all it needs to launch the next
+// iteration (connect only adds to pixels), so connect goes out either on the side stream (onSide: beside the next
+// iteration's primary / extend) or on `stream` behind a snapshot of the counters -- the host reads the snapshot and
+// queues iteration i + 1 while connect(i) runs, and the stream never runs dry (45 us per iteration otherwise).
+// Its hipEvent pair alternates between two sets, folded into the timings once they have completed.
+int enqueue_connect_unwaited(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow, bool onSide) {
+	hipStream_t s = onSide ? c->side : c->stream;
+	if (onSide) {
+		HIPCHK(hipEventRecord(c->evShadeDone, c->stream));
+		HIPCHK(hipStreamWaitEvent(c->side, c->evShadeDone, 0));
+	}
+	const bool timed = (c->cfg.flags & TYR_FLAG_PROFILE) != 0 && ((c->tuning.profileMask >> TYR_K_CONNECT) & 1) != 0;
 	const int set = static_cast<int>(c->iter & 1u);
 	if (timed) {
-		if (c->evSideUsed[set]) // connect(i - 2): shade(i - 1) waited for it and the host waited for shade(i - 1)
+		if (c->evSideUsed[set]) // connect(i - 2): shade(i - 1) ran after it and the host has seen shade(i - 1)'s counts
 			collect_side_timings(c, true);
-		HIPCHK(hipEventRecord(c->evSide[set][0], c->side));
+		HIPCHK(hipEventRecord(c->evSide[set][0], s));
 	}
 	FrameParams P = P0;
 	P.raysPerBlock = rays_per_block_for(c, maxShadow);
-	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->side);
+	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, s);
 	if (timed) {
-		HIPCHK(hipEventRecord(c->evSide[set][1], c->side));
+		HIPCHK(hipEventRecord(c->evSide[set][1], s));
 		c->evSideUsed[set] = true;
 	}
-	HIPCHK(hipEventRecord(c->evConnectDone, c->side));
-	c->connectPending = true;
+	if (onSide) {
+		HIPCHK(hipEventRecord(c->evConnectDone, c->side));
+		c->connectPending = true;
+	}
 	return TYR_OK;
 }
 
@@ -478,7 +487,8 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		return fail(TYR_ERR_NO_DEVICE);
 	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
-	if (hipEventCreateWithFlags(&c->evShadeDone, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evConnectDone, hipEventDisableTiming) != hipSuccess)
+	if (hipEventCreateWithFlags(&c->evShadeDone, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evConnectDone, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->evSnapshot, hipEventDisableTiming) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
 	for (auto& pair : c->evSide)
 		for (auto& e : pair)
@@ -533,6 +543,8 @@ int tyr_destroy(tyr_ctx* c) {
 		(void)hipEventDestroy(c->evShadeDone);
 	if (c->evConnectDone)
 		(void)hipEventDestroy(c->evConnectDone);
+	if (c->evSnapshot)
+		(void)hipEventDestroy(c->evSnapshot);
 	if (c->side)
 		(void)hipStreamDestroy(c->side);
 	if (c->ownStream && c->stream)
@@ -793,11 +805,11 @@ int tyr_sync(tyr_ctx* c) {
 }
 
 // ---- the per-frame entry point --------------------------------------------------------------
-// One wavefront iteration.  deferConnect = false is launch_kernels as the reference has it: everything on one
-// stream, done when it returns (kernel.cu:733).  deferConnect = true (inside tyr_render): connect goes to the side
-// stream and the call returns as soon as shade's counts are on the host, so that the next iteration's primary and
-// extend -- and the host's work to launch them -- overlap connect's tail; the caller joins at the end.
-static int launch_iteration(tyr_ctx* c, int overlap) {
+// One wavefront iteration.  overlap = 0, pipelined = false is launch_kernels as the reference has it: everything on
+// one stream, done when it returns (kernel.cu:733).  Inside tyr_render (pipelined) the call returns as soon as shade's
+// counts are on the host, with connect still queued or running -- on `stream`, or on the side stream beside the
+// next iteration's primary and extend (overlap); the caller syncs at the end.
+static int launch_iteration(tyr_ctx* c, int overlap, bool pipelined) {
 	// hK is current: every entry point that enqueues work ends with sync_counters
 	int rc = stage_begin(c);
 	if (rc)
@@ -819,16 +831,21 @@ static int launch_iteration(tyr_ctx* c, int overlap) {
 	if ((rc = join_connect(c))) // shade rewrites the shadow queue connect(i - 1) reads
 		return rc;
 	enqueue_shade(c, P, nLive);
-	if (deferConnect) {
-		if (overlap == 2)
+	if (deferConnect || pipelined) {
+		if (deferConnect && overlap == 2)
 			P.staticShare = 0;
-		if ((rc = enqueue_connect_deferred(c, P, nLive)))
+		// the counters as shade left them, on their way to the host before connect starts
+		HIPCHK(hipMemcpyAsync(c->hK, c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipEventRecord(c->evSnapshot, c->stream));
+		if ((rc = enqueue_connect_unwaited(c, P, nLive, deferConnect)))
 			return rc;
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventSynchronize(c->evSnapshot));
 	} else {
 		enqueue_connect(c, P, nLive); // at most one shadow ray per live ray
+		HIPCHK(hipGetLastError());
+		rc = sync_counters(c); // kernel.cu:733 cudaDeviceSynchronize
 	}
-	HIPCHK(hipGetLastError());
-	rc = sync_counters(c); // kernel.cu:733 cudaDeviceSynchronize (deferred: up to and including shade)
 	collect_timings(c);
 	stage_end(c);
 	return rc ? rc : check_device_error(c);
@@ -842,7 +859,7 @@ int tyr_launch_kernels(tyr_ctx* c) {
 	int rc = use_device(c);
 	if (rc)
 		return rc;
-	return launch_iteration(c, 0);
+	return launch_iteration(c, 0, false);
 }
 
 int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iterations_out) {
@@ -854,17 +871,17 @@ int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iter
 	if (!c->haveScene)
 		return TYR_ERR_NO_SCENE;
 	const int overlap = c->tuning.overlapConnect;
-	const bool defer = overlap != 0;
 	uint32_t it = 0;
 	while (it < max_iterations) {
-		if ((rc = launch_iteration(c, overlap)))
+		if ((rc = launch_iteration(c, overlap, true)))
 			break;
 		++it;
 		if (c->hK->budget_remaining == 0 && c->hK->primary_ray_cnt == 0)
 			break;
 	}
-	if (defer) {
-		// the last connect: back onto `stream`, counters refreshed, nothing in flight when this returns
+	{
+		// the last connect: back onto `stream` if it ran beside it, counters refreshed (connect's included),
+		// nothing in flight when this returns
 		int rcj = join_connect(c);
 		if (!rcj)
 			rcj = sync_counters(c);
@@ -1077,6 +1094,11 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		if (value < 64 || value > 65536)
 			return TYR_ERR_INVALID;
 		c->tuning.ticketChunk = value;
+		return TYR_OK;
+	case TYR_TUNE_PROFILE_MASK:
+		if (value < 0 || value >= (1 << TYR_K_COUNT))
+			return TYR_ERR_INVALID;
+		c->tuning.profileMask = value;
 		return TYR_OK;
 	case TYR_TUNE_OVERLAP_CONNECT:
 		if (value < 0 || value > 2)
