@@ -138,6 +138,21 @@ __device__ __forceinline__ void wave_add_u64(unsigned long long* p, uint32_t v) 
 // ======================================================================================
 // primary_rays, kernel.cu:247-297.  One thread per new queue slot.
 // ======================================================================================
+// the sphere half of intersect_scene (kernel.cu:127-136): closest of the seven spheres, or VERY_FAR
+__device__ __forceinline__ float2 sphere_hit_record(const FrameParams& P, f3 o, f3 d) {
+	float dist = kVeryFar;
+	uint32_t id = 0;
+#pragma unroll
+	for (int i = TYR_NUM_SPHERES; i--;) {
+		const float t = sphere_intersect(P.spheres[i], o, d);
+		if (t && t < dist) {
+			dist = t;
+			id = kHitSphere | (uint32_t)i;
+		}
+	}
+	return make_float2(dist, __uint_as_float(id));
+}
+
 __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t cnt = P.k->primary_ray_cnt; // survivors already in the buffer (kernel.cu:253)
@@ -180,6 +195,9 @@ __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 	P.work.dyz[slot] = make_float2(direction.y, direction.z);
 	P.work.direct_ix[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(y * (int)P.W + x));
 	P.work.flags[slot] = 0u | (1u << 8);
+	// extend's sphere pre-pass for this ray, while it is in registers (k_extend_spheres then only has the
+	// survivors of the last iteration to do: nothing at all in a render's first, largest wavefront)
+	P.work.hit[slot] = sphere_hit_record(P, newOrigin, direction);
 }
 
 // ======================================================================================
@@ -202,6 +220,7 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 		const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
 		k->start_position = (uint32_t)(((unsigned long long)k->start_position + nNew) % P.localPixels);
 		k->n_live = cnt + nNew;
+		k->first_fresh = cnt;
 		k->shadow_ray_cnt = 0;
 		k->primary_ray_cnt = 0;
 		k->extend_ticket = 0;
@@ -1026,22 +1045,11 @@ __global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) 
 	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
 	if (slot == 0)
 		P.k->extend_ticket = 0; // the persistent kernel that follows on the stream starts from slot 0
-	if (slot >= P.k->n_live)
+	if (slot >= P.k->first_fresh) // slots from there to n_live are this iteration's primary rays: k_primary has done them
 		return;
 	const float4 a = P.work.o_dx[slot];
 	const float2 b = P.work.dyz[slot];
-	const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
-	float dist = kVeryFar;
-	uint32_t id = 0;
-#pragma unroll
-	for (int i = TYR_NUM_SPHERES; i--;) {
-		const float t = sphere_intersect(P.spheres[i], o, d);
-		if (t && t < dist) {
-			dist = t;
-			id = kHitSphere | (uint32_t)i;
-		}
-	}
-	P.work.hit[slot] = make_float2(dist, __uint_as_float(id));
+	P.work.hit[slot] = sphere_hit_record(P, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
 }
 
 __device__ __forceinline__ uint32_t root_ref(const DevScene& sc, const RayConst& r, float bound) {
@@ -1957,12 +1965,13 @@ static uint32_t persistent_blocks(K kernel, uint32_t nItems, const Tuning& t, in
 }
 
 template <bool COUNT, int STACK_LDS>
-static void launch_extend_t(const FrameParams& P, uint32_t maxLive, const Tuning& t, int numCUs, hipStream_t stream) {
+static void launch_extend_t(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, const Tuning& t, int numCUs, hipStream_t stream) {
 	if (t.traversalVariant == 0) {
 		hipLaunchKernelGGL((k_extend<COUNT, STACK_LDS>), dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
 		return;
 	}
-	hipLaunchKernelGGL(k_extend_spheres, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
+	if (nSurvivors != 0)
+		hipLaunchKernelGGL(k_extend_spheres, dim3(blocks_for(nSurvivors)), dim3(kBlock), 0, stream, P);
 	const uint32_t flatBlocks = (maxLive + P.raysPerBlock - 1) / P.raysPerBlock;
 	if (t.traversalVariant == 4 && !COUNT)
 		hipLaunchKernelGGL((k_extend_flat<false, STACK_LDS, true, true>), dim3(persistent_blocks(k_extend_flat<false, STACK_LDS, true, true>, maxLive, t, numCUs)), dim3(kBlock), 0, stream, P);
@@ -2003,13 +2012,13 @@ static void launch_connect_t(const FrameParams& P, uint32_t maxShadow, const Tun
 	default: FN<COUNT, 16>(__VA_ARGS__); break;     \
 	}
 
-void launch_extend(const FrameParams& P, uint32_t maxLive, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream) {
+void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream) {
 	if (maxLive == 0)
 		return;
 	if (countVisits) {
-		TYR_DISPATCH_STACK(launch_extend_t, true, P, maxLive, t, numCUs, stream)
+		TYR_DISPATCH_STACK(launch_extend_t, true, P, maxLive, nSurvivors, t, numCUs, stream)
 	} else {
-		TYR_DISPATCH_STACK(launch_extend_t, false, P, maxLive, t, numCUs, stream)
+		TYR_DISPATCH_STACK(launch_extend_t, false, P, maxLive, nSurvivors, t, numCUs, stream)
 	}
 }
 void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, hipStream_t stream) {

@@ -41,7 +41,7 @@ struct DevCounters {
 	uint32_t start_position;
 	uint32_t shadow_ray_cnt;
 	uint32_t n_live;
-	uint32_t reserved0;      // (was the shade kernel's tile ticket; tiles are ordered without an atomic now)
+	uint32_t first_fresh;    // first slot of this iteration's primary rays = survivors in front of them
 	uint32_t device_error;
 	uint32_t extend_ticket;  // next queue slot to hand to a free lane of the persistent extend kernel
 	uint32_t reserved1;      // (connect's ticket lives in ConnectCounters)
@@ -125,7 +125,8 @@ constexpr int kBlock = 256; // 4 wave64 per workgroup
 // against the device counters
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream);
 void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream);
-void launch_extend(const FrameParams& P, uint32_t maxLive, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream);
+// nSurvivors: upper bound of the slots the sphere pre-pass still has to do (primary rays get theirs in k_primary)
+void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream);
 void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, hipStream_t stream);
 void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream);
 void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream);

@@ -322,11 +322,13 @@ void enqueue_primary(tyr_ctx* c, const FrameParams& P, uint32_t nNew, uint32_t n
 	}
 	launch_globals(P, std::min<uint32_t>(c->nDescCap, (nLive + kBlock - 1) / kBlock + 8), c->stream);
 }
-void enqueue_extend(tyr_ctx* c, const FrameParams& P0, uint32_t nLive) {
+// nSurvivors: how many of the nLive slots were in the queue before this iteration's primary rays (they still need
+// their sphere pre-pass; an upper bound is fine, the kernel checks against the device's count)
+void enqueue_extend(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t nSurvivors) {
 	KernelTimer t(c, TYR_K_EXTEND);
 	FrameParams P = P0;
 	P.raysPerBlock = rays_per_block_for(c, nLive);
-	launch_extend(P, nLive, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->stream);
+	launch_extend(P, nLive, nSurvivors, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->stream);
 }
 void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	KernelTimer t(c, TYR_K_SHADE);
@@ -755,7 +757,7 @@ int tyr_stage_extend(tyr_ctx* c) {
 		return rc;
 	if ((rc = sync_counters(c)))
 		return rc;
-	enqueue_extend(c, make_params(c), c->hK->n_live);
+	enqueue_extend(c, make_params(c), c->hK->n_live, c->hK->n_live); // the host mirror no longer has the survivor count: upper bound
 	HIPCHK(hipGetLastError());
 	rc = sync_counters(c);
 	collect_timings(c);
@@ -826,7 +828,7 @@ static int launch_iteration(tyr_ctx* c, int overlap, bool pipelined) {
 		FrameParams Pe = P;
 		if (overlap == 2 && c->connectPending)
 			Pe.staticShare = 0;
-		enqueue_extend(c, Pe, nLive);
+		enqueue_extend(c, Pe, nLive, nLive - nNew);
 	}
 	if ((rc = join_connect(c))) // shade rewrites the shadow queue connect(i - 1) reads
 		return rc;
