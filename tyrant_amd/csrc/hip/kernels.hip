@@ -1402,6 +1402,19 @@ constexpr bool kLoopStats = false;
 // (its XCD under round-robin placement) and moves on to the next word when one is used up, so the last chunks
 // are shared by whoever is free.  Compared with block-owned ranges (variant 3) there is no per-block tail: the
 // four waves of a block never wait for the block's longest ray, only the end of the launch has partly filled waves.
+// -DTYR_GUARD_PASSES (make EXTRA_HIPFLAGS=...): an exit condition every wave of the flat traversal kernels reaches
+// whatever the feed logic does -- an outer pass (refill + descent + leaves) takes at least ~0.1 us and a launch a
+// few milliseconds, so 2^24 passes are never seen by a working build; a wave that gets there gives up and reports
+// kErrNoProgress instead of holding the GPU.  For work on the refill / exit logic (one mistake there is a hung GPU);
+// off in the shipped build, where the counter and its branch cost 2 % of extend (measured), and the logic is what
+// the soak and fuzz runs of profiles/ exercised.
+#ifdef TYR_GUARD_PASSES
+constexpr bool kGuardPasses = true;
+#else
+constexpr bool kGuardPasses = false;
+#endif
+constexpr uint32_t kMaxPasses = 1u << 24;
+
 struct ChunkFeed {
 	uint32_t next, end;   // this wave's private range of queue slots (wave-uniform)
 	uint32_t word, tried; // ticket word in use, words found empty so far
@@ -1508,8 +1521,11 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 		blockNext = blockBegin;
 	__syncthreads();
 	bool exhausted = (sc.rootRef == kRefDone) || (PERSIST ? nLive == 0 : blockBegin >= nLive);
+	uint32_t passes = 0; // see kMaxPasses
 
 	for (;;) {
+		if (kGuardPasses && ++passes > kMaxPasses)
+			break;
 		// ---- refill free lanes from the queue ----
 		const unsigned long long idleMask = __ballot(!live);
 		const uint32_t nIdle = __popcll(idleMask);
@@ -1676,6 +1692,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 	}
 	if (overflow)
 		atomicOr(&P.k->device_error, kErrStackOverflow);
+	if (kGuardPasses && passes > kMaxPasses)
+		atomicOr(&P.k->device_error, kErrNoProgress);
 	if (COUNT) {
 		wave_add_u64(&P.k->nodes_extend, vc.nodes);
 		wave_add_u64(&P.k->tris_extend, vc.tris);
@@ -1743,8 +1761,11 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 	__syncthreads();
 	bool exhausted = PERSIST ? nRays == 0 : (blockBegin >= nRays);
 	const float kFailed = __builtin_inff();
+	uint32_t passes = 0; // see kMaxPasses
 
 	for (;;) {
+		if (kGuardPasses && ++passes > kMaxPasses)
+			break;
 		const unsigned long long idleMask = __ballot(!live);
 		const uint32_t nIdle = __popcll(idleMask);
 		if (!exhausted && nIdle >= P.refillMinIdle) {
@@ -1906,6 +1927,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 	flush_visible();
 	if (overflow)
 		atomicOr(&P.k->device_error, kErrStackOverflow);
+	if (kGuardPasses && passes > kMaxPasses)
+		atomicOr(&P.k->device_error, kErrNoProgress);
 	wave_add_u64(&P.k->n_shadow_visible, visible);
 	if (COUNT) {
 		wave_add_u64(&P.k->nodes_connect, vc.nodes);

@@ -73,6 +73,7 @@ struct ConnectCounters {
 };
 constexpr uint32_t kErrStackOverflow = 1u;
 constexpr uint32_t kErrScanTimeout = 2u;
+constexpr uint32_t kErrNoProgress = 4u; // -DTYR_GUARD_PASSES builds: a wave of a flat traversal kernel ran out of passes (kMaxPasses)
 
 struct FrameParams {
 	uint32_t W, H, N;

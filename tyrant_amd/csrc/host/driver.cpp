@@ -389,7 +389,7 @@ int check_device_error(const tyr_ctx* c) {
 	if (!c->hK->device_error)
 		return TYR_OK;
 	if (std::getenv("TYR_VERBOSE")) {
-		std::fprintf(stderr, "[tyrant] device_error bits 0x%x (1 = traversal stack overflow, 2 = compaction look-back timeout); n_live %u\n", c->hK->device_error, c->hK->n_live);
+		std::fprintf(stderr, "[tyrant] device_error bits 0x%x (1 = traversal stack overflow, 2 = compaction look-back timeout, 4 = a traversal wave made no progress); n_live %u\n", c->hK->device_error, c->hK->n_live);
 		// state of the compaction descriptors of the failed launch
 		std::vector<unsigned long long> d(c->nDescCap);
 		DevCounters k;
@@ -426,7 +426,7 @@ const char* tyr_status_string(int status) {
 	case TYR_ERR_NO_SCENE: return "no scene uploaded";
 	case TYR_ERR_NO_BUFFER: return "no blit_buffer bound";
 	case TYR_ERR_OOM: return "out of device memory";
-	case TYR_ERR_DEVICE: return "device-side error (traversal stack overflow or compaction timeout)";
+	case TYR_ERR_DEVICE: return "device-side error (traversal stack overflow, compaction timeout or a stuck traversal wave)";
 	case TYR_ERR_UNSUPPORTED: return "unsupported";
 	default: return status > 0 ? hipGetErrorString(static_cast<hipError_t>(status)) : "unknown status";
 	}
