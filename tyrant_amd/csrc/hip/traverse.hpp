@@ -481,16 +481,13 @@ __device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, 
 #endif
 	const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
 	float t0, t1, t2, t3;
-	bool h0 = slab_any<FAST>(r, x01.x, x01.y, y01.x, y01.y, z01.x, z01.y, dist, t0);
-	bool h1 = slab_any<FAST>(r, x01.z, x01.w, y01.z, y01.w, z01.z, z01.w, dist, t1);
-	bool h2 = slab_any<FAST>(r, x23.x, x23.y, y23.x, y23.y, z23.x, z23.y, dist, t2);
-	bool h3 = slab_any<FAST>(r, x23.z, x23.w, y23.z, y23.w, z23.z, z23.w, dist, t3);
-	const bool synthetic = (meta & 3u) == 3u; // consecutive chunks of one over-long leaf: no box tests, slot order (bvh.h:131)
-	if (synthetic) {
-		h0 = (r0 != kRefDone), h1 = (r1 != kRefDone), h2 = (r2 != kRefDone), h3 = (r3 != kRefDone); // every used slot
-		t0 = t1 = t2 = t3 = -__builtin_inff();
-	}
-	// unused slots of ordinary nodes never hit: their box is at +infinity (host/bvh_layout.cpp "an empty slot")
+	const bool h0 = slab_any<FAST>(r, x01.x, x01.y, y01.x, y01.y, z01.x, z01.y, dist, t0);
+	const bool h1 = slab_any<FAST>(r, x01.z, x01.w, y01.z, y01.w, z01.z, z01.w, dist, t1);
+	const bool h2 = slab_any<FAST>(r, x23.x, x23.y, y23.x, y23.y, z23.x, z23.y, dist, t2);
+	const bool h3 = slab_any<FAST>(r, x23.z, x23.w, y23.z, y23.w, z23.z, z23.w, dist, t3);
+	// No special cases: an unused slot's box is at +infinity and never hit, and the slots of a synthetic node (the
+	// consecutive chunks of one over-long leaf, bvh.h:131) have boxes from -inf to +inf that every ray enters at
+	// -inf, with order bits that swap nothing (host/bvh_layout.cpp).
 	const lanemask H0 = lanes_where(h0), H1 = lanes_where(h1), H2 = lanes_where(h2), H3 = lanes_where(h3);
 	if (!ORDERED) {
 		QuadHits o;
@@ -499,10 +496,15 @@ __device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, 
 		o.hit[0] = H0, o.hit[1] = H1, o.hit[2] = H2, o.hit[3] = H3;
 		return o;
 	}
+	// "is the ray's direction negative along this split axis": a bit extract from the three sign bits (constant for
+	// the ray, so hoisted out of the descent loop).  Written as `axis == 0 ? nx : axis == 1 ? ny : nz` the compiler
+	// built each of the three answers from nested exec-mask branches -- 75 scalar instructions and a dozen
+	// mask -> VGPR -> mask copies per trip, in a loop whose scalar pipe is as busy as its vector pipe.
+	const uint32_t signBits = (r.nx ? 1u : 0u) | (r.ny ? 2u : 0u) | (r.nz ? 4u : 0u);
 	const uint32_t aT = meta & 3u, aL = (meta >> 2) & 3u, aR = (meta >> 4) & 3u;
-	const bool bT = !synthetic && ((aT == 0) ? r.nx : (aT == 1) ? r.ny : r.nz);
-	const bool bL = !synthetic && ((aL == 0) ? r.nx : (aL == 1) ? r.ny : r.nz);
-	const bool bR = !synthetic && ((aR == 0) ? r.nx : (aR == 1) ? r.ny : r.nz);
+	const bool bT = ((signBits >> aT) & 1u) != 0u; // axis code 3 (synthetic nodes): bit 3 is clear, nothing is swapped
+	const bool bL = ((signBits >> aL) & 1u) != 0u;
+	const bool bR = ((signBits >> aR) & 1u) != 0u;
 	const lanemask BT = lanes_where(bT), BL = lanes_where(bL), BR = lanes_where(bR);
 	// near slot first inside each group
 	const uint32_t lr0 = bL ? r1 : r0, lr1 = bL ? r0 : r1;

@@ -220,7 +220,16 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 		emptyBox.bounds[1][k] = std::numeric_limits<float>::infinity();
 	}
 	// leaf reference in the quad layout; leaves longer than kMaxLeafPrims become synthetic quads
-	// (bit 6 of meta) whose slots are consecutive chunks, visited in slot order without box tests
+	// (bit 6 of meta) whose slots are consecutive chunks, visited in slot order (bvh.h:131: the reference tests a
+	// leaf's box once, at its parent, and then every primitive).  The kernel has no special case for them: a used
+	// slot's box is (-inf, +inf) on every axis, which every ray passes with entry distance -inf (inf * x is never NaN
+	// for the 1/d the kernel allows, see the empty slot above), and the order bits say "no swap" (axis code 3 three
+	// times: bit 3 of a ray's sign bits is clear).
+	tyr_bbox everythingBox;
+	for (int k = 0; k < 3; ++k) {
+		everythingBox.bounds[0][k] = -std::numeric_limits<float>::infinity();
+		everythingBox.bounds[1][k] = std::numeric_limits<float>::infinity();
+	}
 	auto quad_leaf_ref = [&](const tyr_bvh_node& c) -> uint32_t {
 		uint32_t off = static_cast<uint32_t>(c.offset), cnt = c.primitiveCount;
 		if (cnt <= kMaxLeafPrims)
@@ -240,11 +249,11 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 			size_t k = 0;
 			for (size_t i = begin; i < end; ++i, ++k) {
 				refs[k] = chunkRefs[i];
-				boxes[k] = c.bbox;
+				boxes[k] = everythingBox;
 			}
 			if (haveLink) {
 				refs[k] = link;
-				boxes[k] = c.bbox;
+				boxes[k] = everythingBox;
 			}
 			const uint32_t qi = static_cast<uint32_t>(L.quadNodes.size() / 32);
 			quad_write(qi, boxes, refs, 1u << 6);
@@ -329,7 +338,7 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 		L.nStaged = static_cast<uint32_t>(top.size());
 	}
 	// An interior reference carries the visit-order bits of the node it points to in bits 25..30 (axisTop | axisL << 2 |
-	// axisR << 4, axisTop == 3 for a synthetic chain), so the kernel knows them before the node arrives and fetches
+	// axisR << 4, all three 3 for a synthetic chain), so the kernel knows them before the node arrives and fetches
 	// seven vectors per node instead of eight.
 	if (L.nQuads > kQuadIndexMask)
 		return TYR_ERR_INVALID;
@@ -338,7 +347,7 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 			return ref; // leaf, unused slot
 		uint32_t meta;
 		std::memcpy(&meta, &L.quadNodes[static_cast<size_t>(ref) * 32 + 28], 4);
-		const uint32_t order = (meta & 64u) ? 3u : (meta & 63u);
+		const uint32_t order = (meta & 64u) ? 63u : (meta & 63u);
 		return ref | (order << kQuadOrderShift);
 	};
 	for (uint32_t qi = 0; qi < L.nQuads; ++qi) {
