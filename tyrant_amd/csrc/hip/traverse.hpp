@@ -382,6 +382,21 @@ __device__ __forceinline__ bool slab_fast(const RayConst& r, float lox, float hi
 	tMinOut = tMin;
 	return (tMin <= tMax) && (tMin < lowest) && (tMax > 0);
 }
+// the same test with its answer as a wave-wide lane mask: the ballot of each comparison IS that comparison's
+// result register, and the three are combined by scalar ands -- ballot(a && b && c) made the compiler turn the
+// combined mask into a 0/1 VGPR and compare that against zero again, for each of the four boxes of every node
+typedef unsigned long long lanemask;
+__device__ __forceinline__ lanemask slab_fast_mask(const RayConst& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float lowest, float& tMinOut) {
+	const float ox = r.o.x, oy = r.o.y, oz = r.o.z, ix = r.inv.x, iy = r.inv.y, iz = r.inv.z;
+	v2f x = { lox, hix }, y = { loy, hiy }, z = { loz, hiz };
+	x = (x - ox) * ix;
+	y = (y - oy) * iy;
+	z = (z - oz) * iz;
+	const float tMin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x.x, x.y), __builtin_fminf(y.x, y.y)), __builtin_fminf(z.x, z.y));
+	const float tMax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x.x, x.y), __builtin_fmaxf(y.x, y.y)), __builtin_fmaxf(z.x, z.y));
+	tMinOut = tMin;
+	return __builtin_amdgcn_ballot_w64(tMin <= tMax) & __builtin_amdgcn_ballot_w64(tMin < lowest) & __builtin_amdgcn_ballot_w64(tMax > 0);
+}
 __device__ __forceinline__ bool ray_is_regular(const RayConst& r) {
 	// |inv| < inf for all three components (also false for NaN)
 	return (fabsf(r.inv.x) < __builtin_inff()) && (fabsf(r.inv.y) < __builtin_inff()) && (fabsf(r.inv.z) < __builtin_inff());
@@ -427,7 +442,6 @@ __device__ __forceinline__ PairTest test_pair_fast(const float4* __restrict__ no
 // Hit flags travel as WAVE-WIDE lane masks (the ballot of the per-lane flag, a scalar register pair): as `bool`s
 // they met in a phi where the finite-1/d and the generic box tests rejoin and were materialised as 0/1 vector
 // registers, re-compared before every use; as masks the near/far reordering is scalar and/or work.
-typedef unsigned long long lanemask;
 __device__ __forceinline__ lanemask lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool lane_in(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 __device__ __forceinline__ lanemask mask_select(lanemask sel, lanemask a, lanemask b) { return (sel & a) | (~sel & b); }
@@ -439,10 +453,10 @@ struct QuadHits { // in visit order
 };
 
 template <bool FAST>
-__device__ __forceinline__ bool slab_any(const RayConst& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float lowest, float& tOut) {
+__device__ __forceinline__ lanemask slab_any(const RayConst& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float lowest, float& tOut) {
 	if (FAST)
-		return slab_fast(r, lox, hix, loy, hiy, loz, hiz, lowest, tOut);
-	return slab_test(r, r.nx ? hix : lox, r.nx ? lox : hix, r.ny ? hiy : loy, r.ny ? loy : hiy, r.nz ? hiz : loz, r.nz ? loz : hiz, lowest, tOut);
+		return slab_fast_mask(r, lox, hix, loy, hiy, loz, hiz, lowest, tOut);
+	return lanes_where(slab_test(r, r.nx ? hix : lox, r.nx ? lox : hix, r.ny ? hiy : loy, r.ny ? loy : hiy, r.nz ? hiz : loz, r.nz ? loz : hiz, lowest, tOut));
 }
 
 // FAST: every lane of the wave has a finite 1/d (the caller decides once per wave, not per box: a
@@ -481,14 +495,13 @@ __device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, 
 #endif
 	const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
 	float t0, t1, t2, t3;
-	const bool h0 = slab_any<FAST>(r, x01.x, x01.y, y01.x, y01.y, z01.x, z01.y, dist, t0);
-	const bool h1 = slab_any<FAST>(r, x01.z, x01.w, y01.z, y01.w, z01.z, z01.w, dist, t1);
-	const bool h2 = slab_any<FAST>(r, x23.x, x23.y, y23.x, y23.y, z23.x, z23.y, dist, t2);
-	const bool h3 = slab_any<FAST>(r, x23.z, x23.w, y23.z, y23.w, z23.z, z23.w, dist, t3);
+	const lanemask H0 = slab_any<FAST>(r, x01.x, x01.y, y01.x, y01.y, z01.x, z01.y, dist, t0);
+	const lanemask H1 = slab_any<FAST>(r, x01.z, x01.w, y01.z, y01.w, z01.z, z01.w, dist, t1);
+	const lanemask H2 = slab_any<FAST>(r, x23.x, x23.y, y23.x, y23.y, z23.x, z23.y, dist, t2);
+	const lanemask H3 = slab_any<FAST>(r, x23.z, x23.w, y23.z, y23.w, z23.z, z23.w, dist, t3);
 	// No special cases: an unused slot's box is at +infinity and never hit, and the slots of a synthetic node (the
 	// consecutive chunks of one over-long leaf, bvh.h:131) have boxes from -inf to +inf that every ray enters at
 	// -inf, with order bits that swap nothing (host/bvh_layout.cpp).
-	const lanemask H0 = lanes_where(h0), H1 = lanes_where(h1), H2 = lanes_where(h2), H3 = lanes_where(h3);
 	if (!ORDERED) {
 		QuadHits o;
 		o.ref[0] = r0, o.ref[1] = r1, o.ref[2] = r2, o.ref[3] = r3;
