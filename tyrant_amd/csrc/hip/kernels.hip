@@ -1381,6 +1381,10 @@ __global__ void __launch_bounds__(kBlock) k_connect_persistent(const FrameParams
 // ======================================================================================
 __device__ __forceinline__ bool ref_is_leaf(uint32_t ref) { return (ref & kRefLeaf) && ref < kRefPop; }
 __device__ __forceinline__ bool ref_is_traversing(uint32_t ref) { return ((int)ref >= 0) || ref == kRefPop; }
+// the same as wave-wide masks, one ballot per comparison (the ballot of a compound condition goes through a 0/1
+// VGPR and a second comparison, see slab_fast_mask)
+__device__ __forceinline__ unsigned long long lanes_traversing(uint32_t ref) { return __builtin_amdgcn_ballot_w64((int)ref >= 0) | __builtin_amdgcn_ballot_w64(ref == kRefPop); }
+__device__ __forceinline__ unsigned long long lanes_at_leaf(uint32_t ref) { return __builtin_amdgcn_ballot_w64((ref & kRefLeaf) != 0u) & __builtin_amdgcn_ballot_w64(ref < kRefPop); }
 
 #ifdef TYR_QUAD_STATS
 constexpr bool kLoopStats = true; // diagnostic build: the production (quad) kernel fills tyr_counters.debug too, tools/loop_occupancy.py
@@ -1610,14 +1614,14 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
 		// ---- descent: one pop attempt + one pair test per lane per trip ----
 		for (;;) {
-			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
+			const uint32_t nTrav = __popcll(lanes_traversing(ref));
 			if (nTrav == 0)
 				break;
 			// leave the descent when few lanes are still descending and there is anything else to do (leaves, or a
 			// refill).  (Also leaving once many lanes hold a leaf, so that triangle tests run wide, was measured at
 			// every threshold and never paid; the test cost eight instructions per trip.)
 			if (nTrav < P.minTraversing) {
-				const bool anyLeaf = __ballot(ref_is_leaf(ref)) != 0ull;
+				const bool anyLeaf = lanes_at_leaf(ref) != 0ull;
 				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
 				if (anyLeaf || canRefill)
 					break;
@@ -1846,14 +1850,14 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 		allRegular = (__ballot(live && !regular) == 0ull);
 		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
 		for (;;) {
-			const uint32_t nTrav = __popcll(__ballot(ref_is_traversing(ref)));
+			const uint32_t nTrav = __popcll(lanes_traversing(ref));
 			if (nTrav == 0)
 				break;
 			// leave the descent when few lanes are still descending and there is anything else to do (leaves, or a
 			// refill).  (Also leaving once many lanes hold a leaf, so that triangle tests run wide, was measured at
 			// every threshold and never paid; the test cost eight instructions per trip.)
 			if (nTrav < P.minTraversing) {
-				const bool anyLeaf = __ballot(ref_is_leaf(ref)) != 0ull;
+				const bool anyLeaf = lanes_at_leaf(ref) != 0ull;
 				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
 				if (anyLeaf || canRefill)
 					break;

@@ -234,13 +234,21 @@ struct LdsStack {
 	// and the entry distance need not be kept: half the LDS per lane and ds_*_b32 instead of ds_*_b64.
 	static constexpr int kBlockThreads = 256;
 	typedef typename std::conditional<WITH_T, uint2, uint32_t>::type entry_t;
-	entry_t* lds;        // this thread's column: entry d at lds[d * kBlockThreads]
+	// An explicit LDS pointer: held as a generic pointer, the 4-byte variant's pop merged its LDS read and its
+	// private-memory read into ONE flat_load through a selected base -- a flat access (with a wait on vmcnt AND
+	// lgkmcnt behind it) for every pop of the any-hit traversal, instead of a ds_read_b32.
+#if defined(__HIP_DEVICE_COMPILE__)
+	typedef __attribute__((address_space(3))) entry_t* lds_column_t;
+#else
+	typedef entry_t* lds_column_t; // host pass of the same source: never executed
+#endif
+	lds_column_t lds;    // this thread's column: entry d at lds[d * kBlockThreads]
 	uint32_t* spillRef;  // kStackSize - LDS_DEPTH entries
 	float* spillT;
 	int n;
 	bool overflow;
 	__device__ __forceinline__ void bind(entry_t* ldsColumn, uint32_t* refs, float* ts) {
-		lds = ldsColumn;
+		lds = (lds_column_t)ldsColumn;
 		spillRef = refs;
 		spillT = ts;
 	}
