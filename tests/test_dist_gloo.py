@@ -96,15 +96,17 @@ def _gather_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_four_rank_gather_equals_reduce(tmp_path):
-    """the two ways of combining the frame agree for R = 4 (rows y % 4 == rank), on synthetic row contents"""
+@pytest.mark.parametrize("world", [4, 8])
+def test_gather_equals_reduce(tmp_path, world):
+    """the two ways of combining the frame agree for R = 4 and R = 8 (rows y % R == rank, the scaling runs' layouts),
+    on synthetic row contents"""
     import torch.multiprocessing as mp
 
-    mp.spawn(_gather_worker, args=(4, _free_port(), str(tmp_path)), nprocs=4, join=True)
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     g = np.load(tmp_path / "g.npy").reshape(24, 5, 4)
     assert np.array_equal(g, np.load(tmp_path / "s.npy").reshape(24, 5, 4))
     for y in range(24):
-        assert np.all(g[y] == 100 * (y % 4) + y)
+        assert np.all(g[y] == 100 * (y % world) + y)
 
 
 def test_shard_spec_and_rows():
