@@ -132,6 +132,55 @@ def test_reference_traversal_fixture_through_the_abi(orc, hip):
         assert np.array_equal(q["identifier"][hit], z["identifier"][hit]), name
 
 
+@pytest.mark.parametrize("variant", [4, 3, 2, 0])
+def test_axis_aligned_rays_and_long_leaves(orc, hip, variant):
+    """rays with zero direction components (1/d infinite: the generic box test, not the packed one) through a scene
+    whose leaves are longer than the device layout's inline limit (the quad layout's chains of -inf..+inf boxes) and
+    through an ordinary mesh: extend answers bit for bit, for mixed waves (regular and axis-aligned rays side by side)"""
+    from tyrant_amd import scenes
+
+    rng = np.random.default_rng(5)
+    # 40 identical-centroid triangles in one leaf + a second over-long leaf elsewhere, + the Cornell box around them
+    def stack(x0, n):
+        t = scenes.make_triangles(np.tile([x0 - 30, 0, 10], (n, 1)), np.tile([x0 + 30, 0, 10], (n, 1)), np.tile([x0, 0, 70], (n, 1)))
+        return t
+    tris = np.concatenate([scenes.cornell_box().triangles, stack(-10.0, 40), stack(15.0, 70)])
+    nodes, prims = orc.bvh_build(tris, scenes.triangle_bboxes(tris))
+    assert nodes["primitiveCount"].max() >= 40
+    n = 8192
+    rays = np.zeros(n, dtype=scenes.RAY_DTYPE)
+    rays["origin"] = np.stack([rng.uniform(-45, 45, n), np.full(n, -100.0), rng.uniform(2, 98, n)], axis=1).astype(np.float32)
+    axes = np.array([[0, 1, 0], [0, 1, 0], [0.6, 0.8, 0], [0, 0.8, 0.6], [0, 0.8, -0.6], [-0.6, 0.8, 0]], dtype=np.float32)
+    d = axes[rng.integers(0, len(axes), n)]
+    generic = rng.random(n) < 0.5  # the other half: ordinary directions, so that waves are mixed
+    dd = rng.normal(size=(n, 3)).astype(np.float32)
+    dd[:, 1] = np.abs(dd[:, 1]) + 0.5
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    rays["direction"] = np.where(generic[:, None], d, dd.astype(np.float32))
+    rays["direct"] = 1.0
+    rays["distance"] = 1e20
+    s = scenes.cornell_spheres()
+    s["position"] = np.array([0.0, 1e6, -1e6], dtype=np.float32)  # only the BVH answers
+    s["radius"] = 1.0
+    o = orc.Oracle(64, 64, n)
+    g = hip.Renderer(64, 64, n)
+    g.set_tuning(traversal_variant=variant)
+    for r in (o, g):
+        r.upload(nodes, prims)
+        r.set_spheres(s)
+        r.stage("begin")
+        r.import_work_queue(rays, n)
+        r.set_budget(0)
+        r.stage("primary")
+        r.stage("extend")
+    assert g.counters()["device_error"] == 0
+    qo, qg = o.ray_queue(0, n), g.ray_queue(0, n)
+    assert np.array_equal(bits(qo["distance"]), bits(qg["distance"]))
+    hit = qo["distance"] < 1e20
+    assert hit.sum() > n // 2
+    assert np.array_equal(qo["identifier"][hit], qg["identifier"][hit]) and np.array_equal(qo["geometry_type"][hit], qg["geometry_type"][hit])
+
+
 def test_visit_counters_match_reference_counting_rule(orc, hip):
     """TYR_FLAG_COUNT_VISITS reproduces the oracle's nodes-visited / triangles-tested counts (bvh.h:164-209 rule)"""
     o, g = pair(orc, hip, "cornell_soup2k", 96, 64, 6144, flags=4)
