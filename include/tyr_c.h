@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TYR_ABI_VERSION 1
+#define TYR_ABI_VERSION 2 /* 2: tyr_counters grows (rays_in_tree_*, debug[16]), tyr_dist_*, per-triangle colours */
 
 /* ---- record layouts (identical to the reference structs) ------------------ */
 
@@ -178,10 +178,14 @@ typedef struct tyr_counters {
 	uint64_t nodes_extend, tris_extend;   /* TYR_FLAG_COUNT_VISITS only */
 	uint64_t nodes_connect, tris_connect; /* TYR_FLAG_COUNT_VISITS only */
 	uint64_t n_survive, n_shadow_visible;
-	/* TYR_FLAG_COUNT_VISITS only: SIMD occupancy of the extend kernel's loops, as (wave iterations,
-	 * lane iterations) pairs: [0,1] node tests, [2,3] stack pops, [4,5] triangle tests, [6,7] refills / lanes refilled.
-	 * lane / (64 * wave) is the fraction of the 64 lanes doing work in that loop. */
-	uint64_t debug[8];
+	/* TYR_FLAG_COUNT_VISITS only: rays whose test of the root box passed, i.e. rays that enter the tree (the others cost the
+	 * reference one node visit and end there): bench.py's in-tree ray rate */
+	uint64_t rays_in_tree_extend, rays_in_tree_connect;
+	/* TYR_FLAG_COUNT_VISITS (and the instrumented diagnostics builds) only: SIMD occupancy of the extend kernel's loops, as
+	 * (wave iterations, lane iterations) pairs: [0,1] node tests, [2,3] stack pops, [4,5] triangle tests, [6,7] refills /
+	 * lanes refilled; lane / (64 * wave) is the fraction of the 64 lanes doing work in that loop.  [8..15]: a census of lane
+	 * states per descent trip (tools/loop_occupancy.py). */
+	uint64_t debug[16];
 } tyr_counters;
 int tyr_get_counters(tyr_ctx* ctx, tyr_counters* out);
 
@@ -238,6 +242,38 @@ enum {
 	TYR_TUNE_RAYS_PER_BLOCK = 6     /* variants 2/3: queue slots owned by one 256-thread block and handed to its free lanes through LDS (256..65536, default 1024; halved automatically for thin queues) */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);
+
+/* ---- multi-GPU: the frame's rows are dealt y % nranks == rank (tyr_config.rank / nranks) --------------------
+ * The reference is single-GPU (main.cpp:94 computes `multi_gpu` and never uses it); BASELINE.json's north_star makes
+ * the 8 GPUs of one node the target: one ctx (and one host thread or process) per device, every rank renders its rows
+ * with the unmodified loop into a zero-initialised full-frame blit_buffer, and ONE exchange over RCCL (xGMI) ends the
+ * render -- no collective inside the wavefront loop.  librccl is opened at run time (dlopen) by tyr_dist_create. */
+#define TYR_DIST_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+typedef struct tyr_dist tyr_dist;
+enum {
+	TYR_DIST_GATHER = 0, /* every rank ships only the rows it owns (1/nranks of the frame, ncclSend -> ncclRecv on `root`, point to
+	                      * point = one xGMI link per peer); packed into a double-buffered staging area first, so the blit_buffer is
+	                      * free for the next tyr_reset_accum at once and the exchange leaves the critical path */
+	TYR_DIST_REDUCE = 1  /* ncclReduce(sum) of the full zero-padded accumulation buffers onto `root`: the form north_star names;
+	                      * the next tyr_reset_accum waits for it */
+};
+/* ncclGetUniqueId: one rank calls it and hands the 128 bytes to the others (MPI, a socket, a file, torch.distributed ...) */
+int tyr_dist_unique_id(void* id_out128);
+/* ncclCommInitRank(nranks, id, rank) on ctx's device; (rank, nranks) must be the ctx's tyr_config pair.  Collective: every
+ * rank calls it.  nranks == 1 is allowed (a one-rank communicator: the self-test of the RCCL path on a single GPU). */
+int tyr_dist_create(tyr_dist** out, tyr_ctx* ctx, const void* id128, int32_t rank, int32_t nranks);
+int tyr_dist_destroy(tyr_dist* d);
+/* After tyr_render: combine the ranks' parts of the frame on `root` (collective, asynchronous on the communicator's own
+ * stream).  frame_out: device float4[width*height], read on `root` only (may be NULL elsewhere); afterwards it holds
+ * the complete accumulation buffer -- rgb sums and path counts of every pixel, i.e. what a one-GPU blit_buffer holds.
+ * tyr_dist_wait blocks the host until the last combine has finished. */
+int tyr_dist_combine(tyr_dist* d, int32_t mode, int32_t root, void* frame_out_device);
+int tyr_dist_wait(tyr_dist* d);
+/* Row ownership, pure host arithmetic (no device, no communicator): rank r of nranks owns rows r, r + nranks, ...;
+ * *n_rows = height / nranks; returns TYR_ERR_INVALID when height % nranks != 0 or rank >= nranks.
+ * tyr_dist_row_owner: the rank that owns row y, and that row's index in the owner's packed slab. */
+int tyr_dist_owned_rows(uint32_t height, uint32_t rank, uint32_t nranks, uint32_t* first_row, uint32_t* n_rows);
+int tyr_dist_row_owner(uint32_t y, uint32_t nranks, uint32_t* rank_out, uint32_t* local_row_out);
 
 /* ---- host side of the hot path ---------------------------------------------- */
 

@@ -20,12 +20,12 @@ inline int launch_kernels(void* array_rgba32f, vec4* blit_buffer, Scene::GPUScen
 	tyr_ctx* ctx = gpuScene.CUDACachedBVH.ctx;
 	if (!ctx)
 		return TYR_ERR_NO_SCENE;
-	static vec4* bound = nullptr;
 	int rc;
-	if (blit_buffer != bound || !tyr_get_blit_buffer(ctx)) {
+	// bind the caller's buffer when it is not the one the ctx holds (no function static: several ctxs / threads)
+	void* const have = tyr_get_blit_buffer(ctx);
+	if (blit_buffer ? have != static_cast<void*>(blit_buffer) : !have) {
 		if ((rc = tyr_set_blit_buffer(ctx, blit_buffer)))
 			return rc;
-		bound = blit_buffer;
 	}
 	const tyr_camera cam = { { camera.position.x, camera.position.y, camera.position.z }, { camera.direction.x, camera.direction.y, camera.direction.z },
 		{ camera.up.x, camera.up.y, camera.up.z }, camera.focalDistance, camera.lensRadius };

@@ -145,7 +145,7 @@ void orc_triangle_bbox(const orc_triangle* t, orc_bbox* out); /* Scene.cpp:29-33
 float orc_triangle_intersect(const orc_triangle* t, const float origin[3], const float direction[3]);
 int orc_bbox_intersect(const orc_bbox* b, const float origin[3], const float invDir[3], const int dirIsNeg[3], float lowest);
 /* closest hit; updates ray->distance / ray->identifier; returns hit flag.
- * counters (may be NULL): [0] += nodes visited, [1] += triangle tests. */
+ * counters (may be NULL, else 3 entries): [0] += nodes visited, [1] += triangle tests, [2] += 1 when the root box passed. */
 int orc_bvh_intersect(const orc_node* nodes, const orc_triangle* prims, orc_ray* ray, uint64_t* counters);
 int orc_bvh_intersect_simple(const orc_node* nodes, const orc_triangle* prims, const orc_shadow* ray, float closestAllowed, uint64_t* counters);
 float orc_sphere_intersect(const orc_sphere* s, const float origin[3], const float direction[3]); /* kernel.cu:83-93 */
@@ -167,6 +167,7 @@ typedef struct {
 	uint64_t nodes_extend, tris_extend;   /* reference-order visit counts (bvh.h:164-209 counting rule) */
 	uint64_t nodes_connect, tris_connect;
 	uint64_t n_survive, n_shadow_visible;
+	uint64_t rays_in_tree_extend, rays_in_tree_connect; /* rays whose test of the root box passed (the first bvh.h:127 / 222 test) */
 } orc_counters;
 
 orc_ctx* orc_create(uint32_t width, uint32_t height, uint32_t queue_size, uint32_t rank, uint32_t nranks, uint32_t flags);

@@ -64,11 +64,13 @@ int orc_bvh_intersect(const orc_node* nodes, const orc_triangle* prims, orc_ray*
 	int dirIsNeg[3] = { invDir[0] < 0, invDir[1] < 0, invDir[2] < 0 };
 	int toVisitOffset = 0, currentNodeIndex = 0;
 	int nodesToVisit[64];
-	uint64_t nn = 0, nt = 0;
+	uint64_t nn = 0, nt = 0, entered = 0;
 	for (;;) {
 		const orc_node* node = &nodes[currentNodeIndex];
 		++nn;
 		if (orc_bbox_intersect(&node->bbox, ray->origin, invDir, dirIsNeg, ray->distance)) {
+			if (nn == 1)
+				entered = 1; /* the root's box: this ray enters the tree */
 			if (node->primitiveCount > 0) {
 				for (int i = 0; i < node->primitiveCount; ++i) {
 					++nt;
@@ -100,6 +102,7 @@ int orc_bvh_intersect(const orc_node* nodes, const orc_triangle* prims, orc_ray*
 	if (counters) {
 		counters[0] += nn;
 		counters[1] += nt;
+		counters[2] += entered;
 	}
 	return hit;
 }
@@ -111,12 +114,14 @@ int orc_bvh_intersect_simple(const orc_node* nodes, const orc_triangle* prims, c
 	int dirIsNeg[3] = { invDir[0] < 0, invDir[1] < 0, invDir[2] < 0 };
 	int toVisitOffset = 0, currentNodeIndex = 0;
 	int nodesToVisit[64];
-	uint64_t nn = 0, nt = 0;
+	uint64_t nn = 0, nt = 0, entered = 0;
 	int result = 0;
 	for (;;) {
 		const orc_node* node = &nodes[currentNodeIndex];
 		++nn;
 		if (orc_bbox_intersect(&node->bbox, ray->origin, invDir, dirIsNeg, closestIntersection)) {
+			if (nn == 1)
+				entered = 1;
 			if (node->primitiveCount > 0) {
 				for (int i = 0; i < node->primitiveCount; ++i) {
 					++nt;
@@ -148,6 +153,7 @@ done:
 	if (counters) {
 		counters[0] += nn;
 		counters[1] += nt;
+		counters[2] += entered;
 	}
 	return result;
 }

@@ -323,7 +323,7 @@ void orc_stage_primary(orc_ctx* c) {
 
 /* ---- extend (kernel.cu:331-343) via intersect_scene (125-142) ------------- */
 void orc_stage_extend(orc_ctx* c) {
-	uint64_t cnt[2] = { 0, 0 };
+	uint64_t cnt[3] = { 0, 0, 0 };
 	for (uint32_t index = 0; index < c->k.n_live; ++index) {
 		orc_ray* ray = &c->ray_buffer[index];
 		float d;
@@ -341,6 +341,7 @@ void orc_stage_extend(orc_ctx* c) {
 	}
 	c->k.nodes_extend += cnt[0];
 	c->k.tris_extend += cnt[1];
+	c->k.rays_in_tree_extend += cnt[2];
 }
 
 /* NEE toward spheres[6] (kernel.cu:419-448 and 559-591); returns 1 if a shadow ray was produced */
@@ -629,7 +630,7 @@ void orc_stage_shade(orc_ctx* c) {
 
 /* ---- connect (kernel.cu:630-646) via intersect_scene_simple (162-174) ----- */
 void orc_stage_connect(orc_ctx* c) {
-	uint64_t cnt[2] = { 0, 0 };
+	uint64_t cnt[3] = { 0, 0, 0 };
 	for (uint32_t index = 0; index < c->k.shadow_ray_cnt; ++index) {
 		const orc_shadow* ray = &c->shadow_queue[index];
 		int occluded = 0;
@@ -654,6 +655,7 @@ void orc_stage_connect(orc_ctx* c) {
 	}
 	c->k.nodes_connect += cnt[0];
 	c->k.tris_connect += cnt[1];
+	c->k.rays_in_tree_connect += cnt[2];
 }
 
 void orc_stage_end(orc_ctx* c) {

@@ -61,6 +61,8 @@ class Counters(C.Structure):
         ("tris_connect", c_u64),
         ("n_survive", c_u64),
         ("n_shadow_visible", c_u64),
+        ("rays_in_tree_extend", c_u64),
+        ("rays_in_tree_connect", c_u64),
     ]
 
     def asdict(self):

@@ -40,7 +40,7 @@ for case in range(n_cases):
     bb = scenes.triangle_bboxes(sc.triangles)
     nodes, prims = pyorc.bvh_build(sc.triangles, bb)
     o = pyorc.Oracle(W, H, N, flags=flags)
-    g = binding.Renderer(W, H, N, flags=flags)
+    g = binding.Renderer(W, H, N, flags=flags, diag=True)  # every variant and stack depth: libtyrant_hip_diag.so
     for r in (o, g):
         r.load_scene(sc, nodes, prims)
         r.set_camera(cam)

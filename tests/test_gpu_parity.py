@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 LIVE_FIELDS = ("origin", "direction", "direct")
 
 
-def pair(orc, hip, name, W, H, N, flags=0, rank=0, nranks=1):
+def pair(orc, hip, name, W, H, N, flags=0, rank=0, nranks=1, diag=False):
     sc, nodes, prims = built_scene(name)
     if sc.triangle_materials:
         flags |= 1
@@ -24,7 +24,7 @@ def pair(orc, hip, name, W, H, N, flags=0, rank=0, nranks=1):
         flags |= 8
     o = orc.Oracle(W, H, N, rank=rank, nranks=nranks, flags=flags & 9)
     o.load_scene(sc, nodes, prims)
-    g = hip.Renderer(W, H, N, rank=rank, nranks=nranks, flags=flags)
+    g = hip.Renderer(W, H, N, rank=rank, nranks=nranks, flags=flags, diag=diag)  # diag: libtyrant_hip_diag.so (variants 0-3)
     g.load_scene(sc, nodes, prims)
     return o, g
 
@@ -163,7 +163,7 @@ def test_axis_aligned_rays_and_long_leaves(orc, hip, variant):
     s["position"] = np.array([0.0, 1e6, -1e6], dtype=np.float32)  # only the BVH answers
     s["radius"] = 1.0
     o = orc.Oracle(64, 64, n)
-    g = hip.Renderer(64, 64, n)
+    g = hip.Renderer(64, 64, n, diag=variant != 4)
     g.set_tuning(traversal_variant=variant)
     for r in (o, g):
         r.upload(nodes, prims)
@@ -343,7 +343,7 @@ def test_every_traversal_variant_is_bit_exact(orc, hip, variant, lds):
     """launch shape / node layout / stack placement never change results: each traversal variant reproduces
     the oracle's queues bit for bit over several iterations (bounce rays included)"""
     for name, W, H, N in (("cornell_soup2k", 80, 48, 4096), ("tyrant_default", 96, 64, 5000)):
-        o, g = pair(orc, hip, name, W, H, N)
+        o, g = pair(orc, hip, name, W, H, N, diag=True)
         g.set_tuning(traversal_variant=variant, stack_lds_depth=lds, refill_min_idle=8, min_traversing=24, ticket_chunk=64)
         for it in range(4):
             o.launch_kernels(), g.launch_kernels()
@@ -369,7 +369,7 @@ def test_work_distribution_knobs_never_change_results(orc, hip, knobs):
     when the descent loop is left -- at its extremes: queues stay bit-identical to the oracle's, on a scene whose
     tree is deeper than the LDS stack and on a queue that is not a multiple of anything"""
     for name, W, H, N in (("mesh128", 72, 40, 2999), ("cornell_soup2k", 50, 30, 777)):
-        o, g = pair(orc, hip, name, W, H, N)
+        o, g = pair(orc, hip, name, W, H, N, diag="traversal_variant" in knobs or "stack_lds_depth" in knobs)
         g.set_tuning(**knobs)
         for it in range(3):
             o.launch_kernels(), g.launch_kernels()

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(hip):
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in tyr_c.h but not exported"
     assert declared == set(hip.SYMBOLS), (declared ^ set(hip.SYMBOLS))
-    assert L.tyr_abi_version() == 1
+    assert L.tyr_abi_version() == 2
 
 
 def test_abi_struct_sizes(hip):
@@ -28,7 +28,7 @@ def test_abi_struct_sizes(hip):
 
     assert C.sizeof(hip.Config) == 40
     assert C.sizeof(hip.CameraC) == 44
-    assert C.sizeof(hip.Counters) == 24 + 18 * 8
+    assert C.sizeof(hip.Counters) == 24 + 28 * 8
     assert scenes.TRIANGLE_DTYPE.itemsize == 40 and scenes.NODE_DTYPE.itemsize == 32
     assert scenes.RAY_DTYPE.itemsize == 60 and scenes.SHADOW_DTYPE.itemsize == 44 and scenes.SPHERE_DTYPE.itemsize == 44
 

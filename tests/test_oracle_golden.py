@@ -131,7 +131,7 @@ def test_traversal_matches_reference_fixture(orc, name):
     hit = np.zeros(n, dtype=np.int32)
     nn = np.zeros(n, dtype=np.int64)
     for i in range(n):
-        cnt = (C.c_uint64 * 2)()
+        cnt = (C.c_uint64 * 3)()
         hit[i] = L.orc_bvh_intersect(nodes.ctypes.data, prims.ctypes.data, rays[i : i + 1].ctypes.data, cnt)
         nn[i] = cnt[0]
     assert np.array_equal(hit, z["hit"])

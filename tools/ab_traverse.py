@@ -23,7 +23,7 @@ sc = {"c1": scenes.cornell_box, "c2": lambda: scenes.cornell_soup(10000), "c3": 
 nodes, prims = binding.bvh_build(sc.triangles)
 W, H, N = 1920, 1080, 2097152
 flags = binding.TYR_FLAG_PROFILE | (binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0)
-r = binding.Renderer(W, H, N, flags=flags)
+r = binding.Renderer(W, H, N, flags=flags, diag=True)  # variants 0-3 live in libtyrant_hip_diag.so
 r.load_scene(sc, nodes, prims)
 for _ in range(args.iters):
     r.launch_kernels()

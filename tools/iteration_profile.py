@@ -16,7 +16,7 @@ base = binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0
 W, H, SPP = 1920, 1080, 8
 rows = {}
 for counting in (True, False):
-    r = binding.Renderer(W, H, W * H * SPP, flags=base | (binding.TYR_FLAG_COUNT_VISITS if counting else binding.TYR_FLAG_PROFILE))
+    r = binding.Renderer(W, H, W * H * SPP, flags=base | (binding.TYR_FLAG_COUNT_VISITS if counting else binding.TYR_FLAG_PROFILE), diag=("traversal_variant" in tune or "stack_lds_depth" in tune))
     r.load_scene(sc, nodes, prims)
     if tune:
         r.set_tuning(**tune)

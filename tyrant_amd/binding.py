@@ -15,12 +15,18 @@ from . import scenes
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TYRANT_HIP_LIBRARY: load another build of the same ABI (diagnostic builds made by tools/*.sh); never a CPU path
 LIB_PATH = os.environ.get("TYRANT_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libtyrant_hip.so")
+# the same ABI built with -DTYR_DIAG (make -C tyrant_amd/csrc diag): traversal variants 0-3 and the other LDS stack
+# depths behind tyr_set_tuning.  Loaded by tools/ and the variant parity tests only (Renderer(..., diag=True)).
+DIAG_LIB_PATH = os.path.join(_HERE, "lib", "libtyrant_hip_diag.so")
 
 TYR_FLAG_TRIANGLE_MATERIALS = 1
 TYR_FLAG_PROFILE = 2
 TYR_FLAG_COUNT_VISITS = 4
 TYR_FLAG_LIGHT_LIST = 8
 TYR_ERR_NO_DEVICE = -2
+TYR_ERR_UNSUPPORTED = -7
+TYR_DIST_GATHER, TYR_DIST_REDUCE = 0, 1
+TYR_DIST_ID_BYTES = 128
 KERNEL_NAMES = ("primary", "extend", "shade", "connect", "resolve")
 
 c_f, c_u32, c_u64, c_i32, P = C.c_float, C.c_uint32, C.c_uint64, C.c_int32, C.c_void_p
@@ -67,7 +73,9 @@ class Counters(C.Structure):
         ("tris_connect", c_u64),
         ("n_survive", c_u64),
         ("n_shadow_visible", c_u64),
-        ("debug", c_u64 * 8),
+        ("rays_in_tree_extend", c_u64),
+        ("rays_in_tree_connect", c_u64),
+        ("debug", c_u64 * 16),
     ]
 
     def asdict(self):
@@ -122,23 +130,30 @@ SYMBOLS = {
     "tyr_write_pfm": (C.c_int, [C.c_char_p, P, c_u32, c_u32]),
     "tyr_write_png": (C.c_int, [C.c_char_p, P, c_u32, c_u32]),
     "tyr_default_spheres": (C.c_int, [P]),
+    "tyr_dist_unique_id": (C.c_int, [P]),
+    "tyr_dist_create": (C.c_int, [C.POINTER(P), P, P, c_i32, c_i32]),
+    "tyr_dist_destroy": (C.c_int, [P]),
+    "tyr_dist_combine": (C.c_int, [P, c_i32, c_i32, P]),
+    "tyr_dist_wait": (C.c_int, [P]),
+    "tyr_dist_owned_rows": (C.c_int, [c_u32, c_u32, c_u32, C.POINTER(c_u32), C.POINTER(c_u32)]),
+    "tyr_dist_row_owner": (C.c_int, [c_u32, c_u32, C.POINTER(c_u32), C.POINTER(c_u32)]),
 }
 
-_lib = None
+_libs: dict = {}
 
 
-def lib() -> C.CDLL:
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` (there is no fallback path)")
-        L = C.CDLL(LIB_PATH)
+def lib(diag: bool = False) -> C.CDLL:
+    path = DIAG_LIB_PATH if diag else LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: build it with `python __graft_entry__.py build` (there is no fallback path)")
+        L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the ABI and the header disagree
             fn.restype = res
             fn.argtypes = args
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
 
 
 def status_string(status: int) -> str:
@@ -223,8 +238,8 @@ def default_spheres() -> np.ndarray:
 class Renderer:
     """one tyr_ctx"""
 
-    def __init__(self, width, height, queue_size, device=0, rank=0, nranks=1, flags=0, stream=None, blit_buffer=None):
-        self.L = lib()
+    def __init__(self, width, height, queue_size, device=0, rank=0, nranks=1, flags=0, stream=None, blit_buffer=None, diag=False):
+        self.L = lib(diag)
         self.W, self.H, self.N = width, height, queue_size
         cfg = Config(width, height, queue_size, device, rank, nranks, flags, stream)
         h = P()
@@ -328,3 +343,54 @@ class Renderer:
     def import_work_queue(self, rays: np.ndarray, n_survivors: int):
         r = np.ascontiguousarray(rays)
         _check(self.L.tyr_queue_import(self.h, _ptr(r), n_survivors), "tyr_queue_import")
+
+
+# ---- multi-GPU combine (RCCL behind the C ABI) --------------------------------------------------
+
+
+def dist_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: 128 opaque bytes that rank 0 hands to the other ranks"""
+    buf = (C.c_char * TYR_DIST_ID_BYTES)()
+    _check(lib().tyr_dist_unique_id(buf), "tyr_dist_unique_id")
+    return bytes(buf)
+
+
+def dist_owned_rows(height: int, rank: int, nranks: int):
+    first, n = c_u32(0), c_u32(0)
+    _check(lib().tyr_dist_owned_rows(height, rank, nranks, C.byref(first), C.byref(n)), "tyr_dist_owned_rows")
+    return first.value, n.value
+
+
+def dist_row_owner(y: int, nranks: int):
+    r, yl = c_u32(0), c_u32(0)
+    _check(lib().tyr_dist_row_owner(y, nranks, C.byref(r), C.byref(yl)), "tyr_dist_row_owner")
+    return r.value, yl.value
+
+
+class Dist:
+    """one tyr_dist: the RCCL communicator of a Renderer (same rank / nranks as its pixel shard)"""
+
+    def __init__(self, renderer: "Renderer", unique_id: bytes, rank: int, nranks: int):
+        assert len(unique_id) == TYR_DIST_ID_BYTES
+        self.L = renderer.L
+        self.r = renderer  # keeps the ctx alive
+        h = P()
+        _check(self.L.tyr_dist_create(C.byref(h), renderer.h, unique_id, rank, nranks), "tyr_dist_create")
+        self.h = h
+
+    def combine(self, frame_out_device_ptr, mode=TYR_DIST_GATHER, root=0):
+        _check(self.L.tyr_dist_combine(self.h, mode, root, frame_out_device_ptr), "tyr_dist_combine")
+
+    def wait(self):
+        _check(self.L.tyr_dist_wait(self.h), "tyr_dist_wait")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.tyr_dist_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

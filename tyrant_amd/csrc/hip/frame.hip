@@ -1,0 +1,160 @@
+// frame.hip -- the per-frame kernels around the traversal: primary_rays (kernel.cu:247-297),
+// set_wavefront_globals (kernel.cu:227-244), the sphere halves of intersect_scene / intersect_scene_simple
+// (kernel.cu:125-136, 168-172) as coherent pre-passes, blit_onto_framebuffer (kernel.cu:648-662).
+#include "device_common.hpp"
+
+namespace tyr {
+
+// ======================================================================================
+// primary_rays, kernel.cu:247-297.  One thread per new queue slot.
+// ======================================================================================
+__global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
+	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t cnt = P.k->primary_ray_cnt; // survivors already in the buffer (kernel.cu:253)
+	const unsigned long long room = (unsigned long long)(P.N - cnt);
+	const unsigned long long budget = P.k->budget_remaining;
+	const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
+	if (index >= nNew)
+		return;
+	const uint32_t slot = index + cnt;
+	uint32_t seed = (P.frame * 147565741u) * 720898027u * index; // kernel.cu:258
+
+	const uint32_t start = P.k->start_position;
+	const int x = (int)((start + index) % P.W);
+	const int yl = (int)(((start + index) / P.W) % P.localRows);
+	const int y = yl * (int)P.nranks + (int)P.rank; // nranks == 1: kernel.cu:264
+
+	float sx, sy;
+	stratified_sample(seed, sx, sy);
+	const float rand_point_pixelX = (float)x - sx; // kernel.cu:268-269 (jitter is subtracted)
+	const float rand_point_pixelY = (float)y - sy;
+	const float normalized_i = (rand_point_pixelX / (float)P.W) - 0.5f;
+	const float normalized_j = (((float)P.H - rand_point_pixelY) / (float)P.H) - 0.5f;
+
+	const f3 O = ld3(P.camPos), camera_direction = ld3(P.camDir), camera_right = ld3(P.camRight), camera_up = ld3(P.camUp);
+	f3 directionToFocalPlane = camera_direction + normalized_i * camera_right + normalized_j * camera_up;
+	directionToFocalPlane = normalize(directionToFocalPlane);
+	const int ImGui_slider_hack = 3; // kernel.cu:286
+	const f3 convergencePoint = O + (P.focalDistance * (float)ImGui_slider_hack) * directionToFocalPlane;
+
+	const float l0 = rng_float(seed);
+	const float l1 = rng_float(seed);
+	float dx, dy;
+	concentric_sample_disk(l0, l1, dx, dy);
+	const float pLx = P.lensRadius * dx, pLy = P.lensRadius * dy;
+	const f3 newOrigin = O + camera_right * pLx + camera_up * pLy;
+	const f3 direction = normalize(convergencePoint - newOrigin);
+
+	// kernel.cu:295: {origin, direction, {1,1,1}, 0, 0, 0, pixel}; lastSpecular defaults to true (variables.h:33)
+	P.work.o_dx[slot] = make_float4(newOrigin.x, newOrigin.y, newOrigin.z, direction.x);
+	P.work.dyz[slot] = make_float2(direction.y, direction.z);
+	P.work.direct_ix[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(y * (int)P.W + x));
+	P.work.flags[slot] = 0u | (1u << 8);
+	// extend's sphere pre-pass for this ray, while it is in registers (k_extend_spheres then only has the
+	// survivors of the last iteration to do: nothing at all in a render's first, largest wavefront)
+	P.work.hit[slot] = sphere_hit_record(P, newOrigin, direction);
+}
+
+// ======================================================================================
+// set_wavefront_globals, kernel.cu:227-244 (+ reset of the compaction descriptors)
+// ======================================================================================
+__global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_t nDesc) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i < nDesc)
+		P.scanDesc[i] = 0ull;
+	if (i < kTicketWords) {
+		P.k->extend_chunks[i * 32] = 0;
+		P.kc->chunks[i * 32] = 0;
+		P.k->shade_tiles[i * 32] = 0;
+	}
+	if (i == 0) {
+		DevCounters* k = P.k;
+		const uint32_t cnt = k->primary_ray_cnt;
+		const unsigned long long room = (unsigned long long)(P.N - cnt);
+		const unsigned long long budget = k->budget_remaining;
+		const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
+		k->start_position = (uint32_t)(((unsigned long long)k->start_position + nNew) % P.localPixels);
+		k->n_live = cnt + nNew;
+		k->first_fresh = cnt;
+		k->shadow_ray_cnt = 0;
+		k->primary_ray_cnt = 0;
+		k->extend_ticket = 0;
+		P.kc->ticket = 0;
+		P.kc->shadow_cnt = 0;
+		if (budget != ~0ull)
+			k->budget_remaining = budget - nNew;
+		k->total_primary_rays += nNew;
+		k->total_extend_rays += cnt + nNew;
+	}
+}
+
+// extend pre-pass: kernel.cu:125-136 (spheres first; their distance bounds the BVH search)
+__global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) {
+	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+	if (slot == 0)
+		P.k->extend_ticket = 0; // the persistent kernel that follows on the stream starts from slot 0
+	if (slot >= P.k->first_fresh) // slots from there to n_live are this iteration's primary rays: k_primary has done them
+		return;
+	const float4 a = P.work.o_dx[slot];
+	const float2 b = P.work.dyz[slot];
+	P.work.hit[slot] = sphere_hit_record(P, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+}
+
+// connect pre-pass: the sphere half of intersect_scene_simple (kernel.cu:168-172).  Any-hit does not
+// depend on test order, so spheres go first and an occluded ray never enters the BVH.
+// color.w (unused by the reference's 44-byte record) carries the flag.
+__global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P) {
+	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
+	if (index == 0)
+		P.kc->ticket = 0;
+	if (index >= P.kc->shadow_cnt)
+		return;
+	const float4 a = P.shadow.o_dx[index];
+	const float4 b = P.shadow.dyz_cd_ix[index];
+	const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+	const float closest = b.z;
+	bool occluded = false;
+#pragma unroll
+	for (int i = TYR_NUM_SPHERES; i--;) {
+		const float t = sphere_intersect(P.spheres[i], o, d);
+		occluded = occluded || (t && (t + kEpsilon) < closest);
+	}
+	reinterpret_cast<float*>(&P.shadow.color[index])[3] = occluded ? 1.0f : 0.0f;
+}
+
+// ======================================================================================
+// blit_onto_framebuffer, kernel.cu:648-662 -> linear RGBA32F
+// ======================================================================================
+__global__ void __launch_bounds__(kBlock) k_resolve(const float4* __restrict__ blit, float4* __restrict__ out, uint32_t nPixels) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= nPixels)
+		return;
+	const float4 color = blit[i];
+	const float r = color.x / color.w, g = color.y / color.w, b = color.z / color.w;
+	constexpr float inv_gamma = 1.0f / 2.2f;
+	out[i] = make_float4(dm::powf_det(r / (r + 1.f), inv_gamma), dm::powf_det(g / (g + 1.f), inv_gamma), dm::powf_det(b / (b + 1.f), inv_gamma),
+		dm::powf_det(1.f / (1.f + 1.f), inv_gamma));
+}
+
+// ---- launch wrappers ---------------------------------------------------------------------
+
+void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
+	if (maxNew == 0)
+		return;
+	hipLaunchKernelGGL(k_primary, dim3(blocks_for(maxNew)), dim3(kBlock), 0, stream, P);
+}
+void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream) {
+	hipLaunchKernelGGL(k_globals, dim3(blocks_for(nDesc ? nDesc : 1)), dim3(kBlock), 0, stream, P, nDesc);
+}
+void launch_extend_spheres(const FrameParams& P, uint32_t nSurvivors, hipStream_t stream) {
+	if (nSurvivors != 0)
+		hipLaunchKernelGGL(k_extend_spheres, dim3(blocks_for(nSurvivors)), dim3(kBlock), 0, stream, P);
+}
+void launch_connect_spheres(const FrameParams& P, uint32_t maxShadow, hipStream_t stream) {
+	hipLaunchKernelGGL(k_connect_spheres, dim3(blocks_for(maxShadow)), dim3(kBlock), 0, stream, P);
+}
+void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream) {
+	hipLaunchKernelGGL(k_resolve, dim3(blocks_for(nPixels)), dim3(kBlock), 0, stream, blit, out, nPixels);
+}
+
+} // namespace tyr

@@ -52,10 +52,11 @@ struct DevCounters {
 	unsigned long long nodes_extend, tris_extend;
 	unsigned long long nodes_connect, tris_connect;
 	unsigned long long n_survive, n_shadow_visible;
+	unsigned long long rays_in_tree_extend, rays_in_tree_connect; // counting build: rays that passed the root box
 	// counting build only: where the extend kernel's lanes spend their wave-iterations.
 	// [0]/[1] node-test loop: wave iterations / lane iterations; [2]/[3] pop loop; [4]/[5] triangle loop;
-	// [6]/[7] refills / lanes refilled
-	unsigned long long debug[8];
+	// [6]/[7] refills / lanes refilled; [8..15] lane-state census of the descent trips (TYR_QUAD_STATS builds)
+	unsigned long long debug[16];
 	// variant 4: chunk tickets of the persistent traversal kernels, one word per 128 bytes so that the eight words
 	// are eight L2 lines (a single word serves only ~88 returning atomics per microsecond)
 	uint32_t extend_chunks[kTicketWords * 32];
@@ -122,14 +123,30 @@ struct Tuning {
 
 constexpr int kBlock = 256; // 4 wave64 per workgroup
 
+// Per-context cache of the occupancy queries that size the persistent grids (a slow host call: asked once per
+// kernel, not once per launch).  Lives in tyr_ctx -- one ctx per device, no process-wide statics.
+enum { kLcExtend = 0, kLcConnect, kLcShade, kLcDiagExtend, kLcDiagConnect, kLcDiagExtendCount, kLcDiagConnectCount, kLcKinds };
+struct LaunchCache {
+	int perCU[kLcKinds][6] = {};
+};
+constexpr int stack_slot(int stackLds) { return stackLds == 0 ? 0 : stackLds == 8 ? 1 : stackLds == 10 ? 2 : stackLds == 12 ? 3 : stackLds == 16 ? 4 : 5; }
+
 // launches (all on `stream`); grids are sized by the host from upper bounds, kernels bound-check
 // against the device counters
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream);
 void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream);
 // nSurvivors: upper bound of the slots the sphere pre-pass still has to do (primary rays get theirs in k_primary)
-void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream);
-void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, hipStream_t stream);
-void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, hipStream_t stream);
+void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
+void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCache& lc, hipStream_t stream);
+void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
+// the sphere pre-passes of extend / connect (frame.hip), launched by the traversal launchers
+void launch_extend_spheres(const FrameParams& P, uint32_t nSurvivors, hipStream_t stream);
+void launch_connect_spheres(const FrameParams& P, uint32_t maxShadow, hipStream_t stream);
+#ifdef TYR_DIAG
+// libtyrant_hip_diag.so only: traversal variants 0 and 1 (traverse_diag.hip)
+void launch_extend_diag(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
+void launch_connect_diag(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
+#endif
 void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream);
 
 } // namespace tyr

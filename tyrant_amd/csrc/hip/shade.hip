@@ -1,0 +1,685 @@
+// shade.hip -- shade (kernel.cu:347-627) with a STABLE device-wide compaction of survivors and shadow rays
+// (wave ballot + popcount, LDS across the four waves, decoupled look-back across tiles) in place of
+// atomicAdd(&primary_ray_cnt, 1) (kernel.cu:607): slot order equals the serial ticket order, which makes a
+// fixed-seed render reproducible (the RNG seed depends on the slot, kernel.cu:363).
+#include "device_common.hpp"
+
+namespace tyr {
+
+// ======================================================================================
+// shade, kernel.cu:347-627
+// ======================================================================================
+struct ShadeOut {
+	bool survive, shadow;
+	f3 origin, direction, direct; // survivor state
+	uint32_t flags;
+	f3 sOrigin, sDir, sColor;      // shadow ray
+	float sClosest;
+	f3 color;                      // kernel.cu:622-625: contribution to the pixel, added at the end of the kernel
+	int newFrame;
+};
+
+// NEE toward spheres[6], kernel.cu:419-447 / 559-590 (common part)
+struct LightSample {
+	f3 lightDir, lightVector;
+	float cosSurfaceToLight, cosLightToSurface;
+	bool valid;
+};
+__device__ __forceinline__ LightSample sample_sphere_light(const tyr_sphere& ls, uint32_t& seed, f3 origin, f3 normal) {
+	LightSample L;
+	const float cosPhi = 2.0f * rng_float(seed) - 1.0f;
+	const float sinPhi = sqrtf(1.0f - cosPhi * cosPhi);
+	const float theta = 2.0f * kPi * rng_float(seed);
+	float st, ct;
+	dm::sincosf_det(theta, st, ct);
+	const float x = ls.position[0] + ls.radius * sinPhi * st;
+	const float y = ls.position[1] + ls.radius * cosPhi;
+	const float z = ls.position[2] + ls.radius * sinPhi * ct;
+	const f3 p = mk3(x, y, z);
+	L.lightVector = p - origin;
+	const f3 nL = normalize(p - ld3(ls.position));
+	L.lightDir = normalize(L.lightVector);
+	L.cosSurfaceToLight = dot(normal, L.lightDir);
+	L.cosLightToSurface = dot(nL, -L.lightDir);
+	L.valid = L.cosSurfaceToLight > 0 && L.cosLightToSurface > 0;
+	return L;
+}
+
+// The emitter a next-event sample goes to.  LIGHTS = TYR_FLAG_LIGHT_LIST (extension, SURVEY.md 8f-3: the reference's
+// "TODO Use light array", kernel.cu:420 / 560): with emissive triangles in the scene one of nLights + 1 emitters is
+// picked uniformly -- k == nLights is spheres[6], otherwise triangle lights[k], sampled uniformly over its area and
+// emitting from its front side (e1 x e2, loader.h:28).  `emission` carries the 1/(pick probability), `area` is what
+// the solid-angle term of kernel.cu:438-440 multiplies.  Without LIGHTS (a separate instantiation of the shade
+// kernel), or with no emissive triangle, this is the sphere sample and draws nothing extra.
+struct EmitterSample {
+	LightSample L;
+	f3 emission;
+	float area;
+};
+template <bool LIGHTS>
+__device__ __forceinline__ EmitterSample sample_emitter(const FrameParams& P, uint32_t& seed, f3 origin, f3 normal) {
+	const tyr_sphere& ls = P.spheres[6]; // kernel.cu:421, 561
+	EmitterSample E;
+	float pick = 1.0f;
+	if (LIGHTS && P.nLights != 0) {
+		const int k = rng_int_0_max(seed, (int)P.nLights);
+		pick = (float)(P.nLights + 1u);
+		if (k < (int)P.nLights) {
+			const uint32_t id = P.lights[k];
+			const float4 t0 = P.scene.tris[3 * id + 0];
+			const float4 t1 = P.scene.tris[3 * id + 1];
+			const float4 t2 = P.scene.tris[3 * id + 2];
+			const float u1 = rng_float(seed);
+			const float u2 = rng_float(seed);
+			const float su = sqrtf(u1);
+			const float b1 = su * (1.0f - u2);
+			const float b2 = su * u2;
+			const f3 e1 = mk3(t0.w, t1.x, t1.y), e2 = mk3(t1.z, t1.w, t2.x);
+			const f3 p = (mk3(t0.x, t0.y, t0.z) + e1 * b1) + e2 * b2;
+			const f3 cr = cross(e1, e2);
+			E.L.lightVector = p - origin;
+			const f3 nL = normalize(cr);
+			E.L.lightDir = normalize(E.L.lightVector);
+			E.L.cosSurfaceToLight = dot(normal, E.L.lightDir);
+			E.L.cosLightToSurface = dot(nL, -E.L.lightDir);
+			E.L.valid = E.L.cosSurfaceToLight > 0 && E.L.cosLightToSurface > 0;
+			E.emission = mk3(P.triEmission[0], P.triEmission[1], P.triEmission[2]) * pick;
+			E.area = 0.5f * length(cr);
+			return E;
+		}
+	}
+	E.L = sample_sphere_light(ls, seed, origin, normal);
+	E.emission = (LIGHTS && P.nLights != 0) ? ld3(ls.emmission) * pick : ld3(ls.emmission);
+	E.area = 4 * kPi * ls.radius * ls.radius;
+	return E;
+}
+
+// `afterLoads` runs once, for every lane, at the point where this ray's last vector load has been consumed and
+// only arithmetic follows: the place to issue memory traffic nobody waits for (k_shade: the pixel atomics of the tile
+// before).
+// Lanes past the end of the queue come along with valid = false (they load nothing and produce nothing) so that
+// afterLoads is reached by the whole wave.
+template <bool LIGHTS, class AfterLoads>
+__device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, bool valid, ShadeOut& out, AfterLoads&& afterLoads) {
+	float4 a = make_float4(0.f, 0.f, 0.f, 0.f), dq = a;
+	float2 b = make_float2(0.f, 0.f), h = make_float2(kVeryFar, 0.f);
+	uint32_t fl = 0;
+	if (valid) {
+		a = P.work.o_dx[slot];
+		b = P.work.dyz[slot];
+		h = P.work.hit[slot];
+		dq = P.work.direct_ix[slot];
+		fl = P.work.flags[slot];
+	}
+
+	f3 origin = mk3(a.x, a.y, a.z), direction = mk3(a.w, b.x, b.y), direct = mk3(dq.x, dq.y, dq.z);
+	const int pixel = __float_as_int(dq.w);
+	const float distance = h.x;
+	const uint32_t ident = __float_as_uint(h.y);
+	int bounces = (int)(fl & 0xffu);
+	bool lastSpecular = ((fl >> 8) & 1u) != 0;
+
+	int new_frame = 0;
+	f3 color = mk3(0.f, 0.f, 0.f);
+	f3 object_color = mk3(0.f, 0.f, 0.f);
+	uint32_t seed = (P.frame * (uint32_t)pixel * 147565741u) * 720898027u * slot; // kernel.cu:363
+	int reflection_type = TYR_DIFF;
+	out.survive = false;
+	out.shadow = false;
+
+	enum { kAtmoNone = 0, kAtmoSun, kAtmoSky, kAtmoSunSky };
+	int atmo = kAtmoNone;   // what this ray wants from the atmosphere model, evaluated once for the whole wave below
+	float atmoScale = 0.0f;
+	const bool hit = valid && distance < kVeryFar;
+	f3 normal = mk3(0.f, 0.f, 0.f);
+	if (hit) {
+		origin = origin + direction * distance;
+		if (ident & kHitSphere) {
+			const tyr_sphere& object = P.spheres[ident & 7u];
+			normal = (origin - ld3(object.position)) / object.radius;
+			reflection_type = object.refl;
+			if (reflection_type != TYR_REFR && reflection_type != TYR_LIGHT)
+				direct = direct * ld3(object.color);
+			object_color = ld3(object.color);
+		} else {
+			// kernel.cu:380-383: normal from e1 x e2, white DIFF
+			const float4 t0 = P.scene.tris[3 * ident + 0];
+			const float4 t1 = P.scene.tris[3 * ident + 1];
+			const float4 t2 = P.scene.tris[3 * ident + 2];
+			normal = normalize(cross(mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x)));
+			reflection_type = TYR_DIFF;
+			object_color = mk3(1.f, 1.f, 1.f);
+			if (P.flags & TYR_FLAG_TRIANGLE_MATERIALS) {
+				const uint32_t m = __float_as_uint(t2.y);
+				reflection_type = m <= (uint32_t)(LIGHTS ? TYR_LIGHT : TYR_PHONG) ? (int)m : TYR_DIFF;
+			}
+		}
+	}
+	afterLoads();
+	if (hit) {
+		const bool outside = dot(normal, direction) < 0;
+		normal = outside ? normal : normal * -1.f;
+		origin = origin + normal * kEpsilon;
+
+		if (reflection_type == TYR_LIGHT) {
+			if (lastSpecular) {
+				if (LIGHTS && !(ident & kHitSphere))
+					color = direct * mk3(P.triEmission[0], P.triEmission[1], P.triEmission[2]);
+				else
+					color = direct * ld3(P.spheres[ident & 7u].emmission);
+			} else {
+				color = mk3(0.f, 0.f, 0.f);
+				direct = mk3(0.f, 0.f, 0.f);
+			}
+		}
+		lastSpecular = false;
+		constexpr float phongexponent = 40.0f;
+		switch (reflection_type) {
+		case TYR_LIGHT:
+			break;
+		case TYR_DIFF: {
+			const f3 sunSampleDir = cone_sample(P.sun, seed);
+			const float sunLight = dot(normal, sunSampleDir);
+			if (rng_float(seed) < 0.5f) {
+				if (sunLight > 0.f) {
+					out.shadow = true;
+					out.sOrigin = origin;
+					out.sDir = sunSampleDir;
+					out.sColor = 2.0f * direct; // x ((sun(sunSampleDir) * sunLight) * 1E-5f) below, kernel.cu:414
+					atmo = kAtmoSun;
+					atmoScale = sunLight;
+					out.sClosest = 1e20f; // variables.h:41
+				}
+			} else {
+				const EmitterSample E = sample_emitter<LIGHTS>(P, seed, origin, normal);
+				const LightSample& L = E.L;
+				if (L.valid) {
+					const float closestAllowed = length(L.lightVector);
+					const float solidAngle = (L.cosLightToSurface * E.area) / dot(L.lightVector, L.lightVector);
+					out.shadow = true;
+					out.sOrigin = origin;
+					out.sDir = L.lightDir;
+					out.sColor = ((((E.emission * 2.0f) * direct) * solidAngle) * kInvPi) * L.cosSurfaceToLight;
+					out.sClosest = closestAllowed;
+				}
+			}
+			if (bounces < kMaxBounces) {
+				const float r1 = 2.f * kPi * rng_float(seed);
+				const float r2 = rng_float(seed);
+				const float r2s = sqrtf(r2);
+				f3 u, v;
+				orthonormal_basis_naive(normal, u, v);
+				float s1, c1;
+				dm::sincosf_det(r1, s1, c1);
+				direction = normalize((u * c1) * r2s + (v * s1) * r2s + normal * sqrtf(1 - r2));
+			}
+			break;
+		}
+		case TYR_SPEC: {
+			lastSpecular = true;
+			direction = reflect(direction, normal);
+			break;
+		}
+		case TYR_REFR: {
+			// kernel.cu:476-515 (n1/n2 = 1.2/1.0 "defying convention")
+			const float n1 = outside ? 1.2f : 1.0f;
+			const float n2 = outside ? 1.0f : 1.2f;
+			float fresnel = 0;
+			float r0 = (n1 - n2) / (n1 + n2);
+			r0 *= r0;
+			const float cosI = -dot(normal, direction);
+			const float n = n2 / n1;
+			const float sinT2 = n * n * (1.0f - cosI * cosI);
+			if (sinT2 > 1.0f) {
+				fresnel = 1.0f;
+			} else {
+				const float x = 1.0f - cosI;
+				fresnel = r0 + (1.0f - r0) * x * x * x * x * x;
+			}
+			if (rng_float(seed) < fresnel) {
+				lastSpecular = true;
+				direction = reflect(direction, normal);
+			} else {
+				origin = origin - (normal * 2.f) * kEpsilon;
+				const float cosT = sqrtf(1.0f - sinT2);
+				direction = n * direction + (n * cosI - cosT) * normal;
+			}
+			if (!outside) {
+				const f3 e = (-object_color) * distance;
+				direct = direct * mk3(dm::expf_det(e.x), dm::expf_det(e.y), dm::expf_det(e.z));
+			}
+			break;
+		}
+		case TYR_PHONG: {
+			f3 w, u, v, d;
+			do {
+				const float phi = 2 * kPi * rng_float(seed);
+				const float r2 = rng_float(seed);
+				const float cosTheta = dm::powf_det(1.0f - r2, 1.0f / (phongexponent + 1.0f));
+				const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+				w = direction - (normal * 2.0f) * dot(normal, direction);
+				w = normalize(w);
+				orthonormal_basis_naive(w, u, v);
+				float sp, cp;
+				dm::sincosf_det(phi, sp, cp);
+				d = (u * cp) * sinTheta + (v * sp) * sinTheta + w * cosTheta;
+				d = normalize(d);
+			} while (dot(d, normal) <= kEpsilon);
+
+			const f3 sunSampleDir = cone_sample(P.sun, seed);
+			float sunLight = dot(normal, sunSampleDir);
+			if (rng_float(seed) < 0.5f) {
+				if (sunLight > 0.f) {
+					const float phongCos = dot(sunSampleDir, w);
+					if (phongCos > kEpsilon) {
+						sunLight *= dm::powf_det(phongCos, phongexponent);
+						out.shadow = true;
+						out.sOrigin = origin;
+						out.sDir = sunSampleDir;
+						out.sColor = (2.0f * direct) * ((phongexponent + 2) * 0.5f * kInvPi); // x ((sun(..) * sunLight) * 1E-5f) below
+						atmo = kAtmoSun;
+						atmoScale = sunLight;
+						out.sClosest = 1e20f;
+					}
+				}
+			} else {
+				const EmitterSample E = sample_emitter<LIGHTS>(P, seed, origin, normal);
+				const LightSample& L = E.L;
+				if (L.valid) {
+					float phongCos = dot(L.lightDir, w);
+					if (phongCos > kEpsilon) {
+						phongCos = dm::powf_det(phongCos, phongexponent);
+						const float closestAllowed = length(L.lightVector);
+						const float solidAngle = (L.cosLightToSurface * E.area) / dot(L.lightVector, L.lightVector);
+						f3 sc = (E.emission * 2.0f) * direct;
+						sc = sc * solidAngle;
+						sc = sc * (phongexponent + 2);
+						sc = sc * 0.5f;
+						sc = sc * kInvPi;
+						sc = sc * phongCos;
+						sc = sc * L.cosSurfaceToLight;
+						out.shadow = true;
+						out.sOrigin = origin;
+						out.sDir = L.lightDir;
+						out.sColor = sc;
+						out.sClosest = closestAllowed;
+					}
+				}
+			}
+			origin = origin + w * kEpsilon;
+			direction = d;
+			break;
+		}
+		}
+
+	} else if (valid) {
+		atmo = lastSpecular ? kAtmoSunSky : kAtmoSky; // kernel.cu:613-617: nothing hit
+	}
+
+	// The atmosphere (sunsky.cu) is the most expensive thing a ray can ask for here, and three kinds of lanes ask:
+	// a diffuse or Phong hit whose next-event sample went to the sun (sun(sunSampleDir), kernel.cu:414 / 553), and a
+	// miss (sky / sunsky(direction), kernel.cu:613-617).  A ray asks at most once, nothing random is drawn in
+	// between, so all of them evaluate it HERE, in one pass of the wave, instead of one pass per place of call; every
+	// lane still performs exactly the operations the reference's order of evaluation prescribes.
+	if (atmo != kAtmoNone) {
+		const bool miss = !hit;
+		const f3 viewDir = miss ? direction : out.sDir;
+		if (atmo == kAtmoSunSky && P.sun.sunAngularDiameterCos == 1.0f) {
+			color = color + direct * mk3(1.0f, 0.0f, 0.0f); // sunsky.cu:118-119
+		} else {
+			const Atmosphere a = atmosphere(P.sun, viewDir);
+			if (atmo == kAtmoSun)
+				out.sColor = out.sColor * ((sun_radiance(P.sun, a) * atmoScale) * 1E-5f);
+			else
+				color = color + (atmo == kAtmoSky ? direct * sky_radiance(a) : direct * sunsky_radiance(P.sun, a));
+		}
+	}
+
+	if (hit) {
+		// Russian roulette, kernel.cu:599-611
+		const float p = gmin(1.0f, gmax(direct.z, gmax(direct.x, direct.y)));
+		if (bounces < kMaxBounces && p > (0 + kEpsilon) && rng_float(seed) <= p) {
+			bounces++;
+			direct = direct * (1.0f / p);
+			out.survive = true;
+			out.origin = origin;
+			out.direction = direction;
+			out.direct = direct;
+			out.flags = (uint32_t)bounces | ((lastSpecular ? 1u : 0u) << 8);
+		} else {
+			new_frame++;
+		}
+	} else if (valid) {
+		new_frame++;
+	}
+
+	out.color = color;
+	out.newFrame = new_frame;
+}
+
+// look-back descriptor: [63:62] status, [61:31] survivors, [30:0] shadow rays
+constexpr unsigned long long kDescAggregate = 1ull << 62;
+constexpr unsigned long long kDescInclusive = 2ull << 62;
+__device__ __forceinline__ unsigned long long desc_pack(uint32_t s, uint32_t h) { return ((unsigned long long)s << 31) | (unsigned long long)h; }
+__device__ __forceinline__ uint32_t desc_s(unsigned long long d) { return (uint32_t)((d >> 31) & 0x7fffffffull); }
+__device__ __forceinline__ uint32_t desc_h(unsigned long long d) { return (uint32_t)(d & 0x7fffffffull); }
+
+// Tile order without a ticket.  The stable compaction needs every tile's predecessors to be running
+// (or done) while it looks back.  The first version drew a virtual tile id from an atomic counter at
+// block start -- 8192 returning atomics on one word per launch, ~0.2 ms of a 0.3 ms kernel (one word
+// serves ~88 of them per microsecond; measured by replacing the ticket: 0.30 -> 0.096 ms per launch).
+// Now the grid is small enough to be entirely co-resident (at most 4 blocks of 256 threads per CU) and
+// block b shades tiles b, b + G, b + 2G, ...: the predecessor of any tile belongs to a block that is
+// resident, whatever order the hardware dispatched them in, so the look-back cannot starve.
+//
+// Deferred look-back.  With "shade tile i, look back for tile i, write tile i" every block waited, tile after
+// tile, for the SLOWEST of its predecessors to publish an aggregate (all resident blocks shade the same
+// generation of tiles at the same time and shading time has a long tail): an s_memtime build showed two thirds
+// of a tile's time inside the look-back, and fetching more descriptors per round trip did not help.  Now the
+// tile's compacted records wait in LDS (survivors and shadow rays at their rank inside the tile) and the
+// look-back for tile i runs AFTER tile i+G has been shaded: by then every predecessor has long published, the
+// look-back is pure round trips (kWindows x 64 descriptors each), and the records leave LDS as coalesced stores
+// (thread t writes record t).
+struct ShadeStage { // one tile's compacted output, 23 KB
+	float4 sv_o_dx[kBlock];
+	float2 sv_dyz[kBlock];
+	float4 sv_direct_ix[kBlock];
+	uint32_t sv_flags[kBlock];
+	float4 sh_o_dx[kBlock];
+	float4 sh_dyz_cd_ix[kBlock];
+	float4 sh_color[kBlock];
+};
+
+// Exclusive prefix of tile vb over all lower tiles, computed by the whole block; publishes the tile's inclusive
+// prefix.  Wave w inspects descriptors vb-1-512w ... vb-512(w+1) (kWindows x 64, lane i of window k reads one), so
+// one memory round trip covers 2048 predecessors -- more than the distance to the nearest inclusive prefix, which
+// is one to two generations of resident tiles (<= 1024 each) because the look-back is deferred by one tile.
+// With wave 0 alone and 512 descriptors per step it took three steps, 36 % of a tile's time.
+__device__ __forceinline__ void shade_lookback(const FrameParams& P, uint32_t vb, uint32_t totS, uint32_t totH, uint32_t tid, uint32_t nTiles, uint32_t* sh, uint32_t& esOut, uint32_t& ehOut) {
+	constexpr int kWindows = 2;
+	constexpr int kPerWave = 64 * kWindows, kPerStep = kPerWave * (int)(kBlock / 64);
+	const uint32_t lane = tid & 63u, wave = tid >> 6;
+	uint32_t es = 0, eh = 0;
+	if (vb > 0) { // block-uniform
+		int base = (int)vb - 1; // nearest predecessor of this step
+		for (;;) {
+			const int first = base - kPerWave * (int)wave; // nearest descriptor of this wave's share
+			unsigned long long d[kWindows];
+#pragma unroll
+			for (int k = 0; k < kWindows; ++k) {
+				const int idx = first - 64 * k - (int)lane;
+				d[k] = kDescInclusive; // below tile 0: an inclusive prefix of zero
+				if (idx >= 0)
+					d[k] = __hip_atomic_load(&P.scanDesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			bool found = false, timeout = false;
+			uint32_t ps = 0, ph = 0;
+#pragma unroll
+			for (int k = 0; k < kWindows; ++k) {
+				if (found)
+					continue; // (wave-uniform) an inclusive prefix was found in a nearer window
+				const int idx = first - 64 * k - (int)lane;
+				uint32_t spins = 0;
+				const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();
+				while (!(d[k] >> 62)) { // not published yet: poll this one
+					if (++spins > (1u << 25)) { // every wait is bounded (~4 s): report, never hang
+						timeout = true;
+						d[k] = kDescInclusive;
+						// what timed out, for TYR_VERBOSE's report (host/driver.cpp check_device_error)
+						P.k->debug[0] = vb;
+						P.k->debug[1] = (unsigned long long)idx;
+						P.k->debug[2] = blockIdx.x;
+						P.k->debug[3] = gridDim.x;
+						P.k->debug[4] = __builtin_amdgcn_s_memrealtime() - t0_; // 100 MHz ticks
+						break;
+					}
+					__builtin_amdgcn_s_sleep(1);
+					d[k] = __hip_atomic_load(&P.scanDesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				const unsigned long long inclMask = __ballot((d[k] >> 62) == 2ull);
+				// lanes up to and including the nearest inclusive descriptor contribute
+				const uint32_t stop = inclMask ? (uint32_t)__ffsll((long long)inclMask) - 1u : 63u;
+				unsigned long long v = (lane <= stop) ? (d[k] & ~(3ull << 62)) : 0ull;
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1)
+					v += __shfl_xor(v, o, 64);
+				ps += desc_s(v);
+				ph += desc_h(v);
+				found = (inclMask != 0ull);
+			}
+			if (__ballot(timeout) != 0ull && lane == 0)
+				atomicOr(&P.k->device_error, kErrScanTimeout);
+			if (lane == 0) {
+				sh[16 + 3 * wave + 0] = ps;
+				sh[16 + 3 * wave + 1] = ph;
+				sh[16 + 3 * wave + 2] = found ? 1u : 0u;
+			}
+			__syncthreads();
+			bool any = false;
+#pragma unroll
+			for (uint32_t w = 0; w < kBlock / 64; ++w) {
+				if (!any) {
+					es += sh[16 + 3 * w + 0];
+					eh += sh[16 + 3 * w + 1];
+					any = sh[16 + 3 * w + 2] != 0u;
+				}
+			}
+			__syncthreads(); // sh[16..] may be rewritten by another step
+			if (any)
+				break;
+			base -= kPerStep;
+		}
+	}
+	if (tid == 0) {
+		__hip_atomic_store(&P.scanDesc[vb], kDescInclusive | desc_pack(es + totS, eh + totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (vb == nTiles - 1) {
+			// kernel.cu:607 / 416: the totals the next top-up and connect read
+			P.k->primary_ray_cnt = es + totS;
+			P.k->shadow_ray_cnt = eh + totH;
+			P.kc->shadow_cnt = eh + totH;
+			P.k->total_shadow_rays += eh + totH;
+			P.k->n_survive += es + totS;
+		}
+	}
+	esOut = es;
+	ehOut = eh;
+}
+
+template <bool LIGHTS>
+__global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t nTiles) {
+	__shared__ uint32_t sh[32];
+	__shared__ ShadeStage stage;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63u, wave = tid >> 6;
+	const uint32_t nLive = P.k->n_live;
+	const unsigned long long below = (1ull << lane) - 1ull;
+#ifdef TYR_SHADE_TIMING
+	// diagnostic build: where a tile's time goes, in s_memtime ticks summed over this block's tiles (thread 0;
+	// debug[0] shade, [1] ranks + barrier, [2] look-back, [3] barrier after it, [4] copy out + barrier, [5] stage +
+	// pixel atomics, [7] tiles)
+	unsigned long long tacc_[6] = { 0, 0, 0, 0, 0, 0 }, t_ = __builtin_amdgcn_s_memtime(), ntiles_ = 0;
+#define TYR_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc_[i] += now_ - t_; t_ = now_; }
+#else
+#define TYR_STAMP(i)
+#endif
+	bool havePrev = false;            // a shaded tile whose records wait in `stage`
+	uint32_t pendPixel = 0;           // this lane's pixel contribution of that tile, not yet added
+	int pendNew = 0;
+	f3 pendColor = mk3(0.f, 0.f, 0.f);
+	uint32_t prevVb = 0, prevS = 0, prevH = 0;
+
+	// finish the waiting tile: look back, then move its records from LDS to their slots (kernel.cu:607-608, 416-417)
+	auto flush_prev = [&]() {
+		uint32_t es, eh;
+		shade_lookback(P, prevVb, prevS, prevH, tid, nTiles, sh, es, eh);
+		TYR_STAMP(2)
+		// one array at a time (the compiler barrier keeps it from loading all seven records first): this copy is where
+		// the kernel's register count peaks
+		if (tid < prevS) {
+			P.next.o_dx[es + tid] = stage.sv_o_dx[tid];
+			__asm__ volatile("" ::: "memory");
+			P.next.direct_ix[es + tid] = stage.sv_direct_ix[tid];
+			__asm__ volatile("" ::: "memory");
+			P.next.dyz[es + tid] = stage.sv_dyz[tid];
+			P.next.flags[es + tid] = stage.sv_flags[tid];
+		}
+		__asm__ volatile("" ::: "memory");
+		if (tid < prevH) {
+			P.shadow.o_dx[eh + tid] = stage.sh_o_dx[tid];
+			__asm__ volatile("" ::: "memory");
+			P.shadow.dyz_cd_ix[eh + tid] = stage.sh_dyz_cd_ix[tid];
+			__asm__ volatile("" ::: "memory");
+			P.shadow.color[eh + tid] = stage.sh_color[tid];
+		}
+		__syncthreads(); // `stage` and sh[] are free again
+		TYR_STAMP(4)
+	};
+
+	// Tiles are drawn from eight tickets (word w hands out tiles w, w + 8, ...; a block starts at word
+	// blockIdx % 8 and moves on when a word is used up).  A tile is only ever started after every lower tile of
+	// its word, and the lowest tile not yet started always belongs to a word whose running tiles are lower still,
+	// so every tile a look-back waits for is being shaded by some block: no starvation, whatever the grid size.
+	// Unlike the fixed assignment b, b + G, ... a slow block simply shades fewer tiles instead of holding up every
+	// look-back of its generation; one word per tile id would be a single ticket again (88 draws/us: 0.74 ms for
+	// the 64.8 k tiles of a full queue).
+	uint32_t word = blockIdx.x % kTicketWords, tried = 0;
+	auto draw_tile = [&]() -> uint32_t { // block-uniform; nTiles when nothing is left
+		uint32_t vbNext = nTiles;
+		if (tid == 0) {
+			while (tried < kTicketWords) {
+				const uint32_t t = atomicAdd(&P.k->shade_tiles[word * 32], 1u);
+				const unsigned long long cand = (unsigned long long)t * kTicketWords + word;
+				if (cand < nTiles) {
+					vbNext = (uint32_t)cand;
+					break;
+				}
+				word = (word + 1) % kTicketWords;
+				++tried;
+			}
+			sh[3] = vbNext;
+		}
+		__syncthreads();
+		vbNext = sh[3];
+		__syncthreads();
+		return vbNext;
+	};
+	for (uint32_t vb = draw_tile(); vb < nTiles; vb = draw_tile()) { // vb = tile id = queue order
+		const uint32_t slot = vb * kBlock + tid;
+		ShadeOut out = {};
+		uint32_t pixelBits = 0;
+		// kernel.cu:622-625 for the tile BEFORE this one.  vmcnt retires loads and atomics in issue order, and an
+		// atomic that has to reach the memory side takes thousands of cycles under load: issued at the end of a
+		// tile they sat in front of the next tile's ray loads (0.34 ms of a render's 1.77 ms of shade, measured by
+		// leaving them out).  Issued here -- this tile's loads are back, ~1000 instructions of arithmetic follow --
+		// nobody waits for them.
+		auto flush_pixels = [&]() { // reached by every lane of every wave: lanes with nothing pending add nothing
+			accumulate_pixels_wave(P.blit, (int)pendPixel, pendColor, pendNew);
+			pendColor = mk3(0.f, 0.f, 0.f);
+			pendNew = 0;
+		};
+		const bool valid = slot < nLive;
+		if (valid)
+			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
+		shade_ray<LIGHTS>(P, slot, valid, out, flush_pixels);
+		TYR_STAMP(0)
+
+		// ---- stable compaction of survivors and shadow rays: ranks inside the tile ----
+		const unsigned long long bs = __ballot(out.survive);
+		const unsigned long long bh = __ballot(out.shadow);
+		const uint32_t rs = __popcll(bs & below), rh = __popcll(bh & below);
+		if (lane == 0) {
+			sh[4 + wave] = __popcll(bs);
+			sh[8 + wave] = __popcll(bh);
+		}
+		__syncthreads();
+		uint32_t ws = 0, wh = 0, totS = 0, totH = 0;
+#pragma unroll
+		for (uint32_t w = 0; w < kBlock / 64; ++w) {
+			const uint32_t cs = sh[4 + w], ch = sh[8 + w];
+			if (w < wave) {
+				ws += cs;
+				wh += ch;
+			}
+			totS += cs;
+			totH += ch;
+		}
+		totS = (uint32_t)__builtin_amdgcn_readfirstlane((int)totS); // block-uniform: keep them out of the vector registers
+		totH = (uint32_t)__builtin_amdgcn_readfirstlane((int)totH);
+		// the aggregate goes out at once: later tiles can add it up long before this tile knows its own prefix.
+		// Descriptor = 8 bytes {status, survivors, shadows} written by one relaxed agent-scope store: payload and
+		// flag travel together, no fence needed.  Tile 0 publishes one too: its inclusive prefix only appears when its
+		// deferred look-back runs, and every look-back of the first generation would sit waiting for it.
+		if (tid == 0)
+			__hip_atomic_store(&P.scanDesc[vb], kDescAggregate | desc_pack(totS, totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		TYR_STAMP(1)
+		if (havePrev)
+			flush_prev(); // ends with a barrier: sh[4..11] have been read by every thread
+		else
+			__syncthreads();
+		if (out.survive) {
+			const uint32_t k = ws + rs;
+			stage.sv_o_dx[k] = make_float4(out.origin.x, out.origin.y, out.origin.z, out.direction.x);
+			stage.sv_dyz[k] = make_float2(out.direction.y, out.direction.z);
+			stage.sv_direct_ix[k] = make_float4(out.direct.x, out.direct.y, out.direct.z, __uint_as_float(pixelBits));
+			stage.sv_flags[k] = out.flags;
+		}
+		if (out.shadow) {
+			const uint32_t k = wh + rh;
+			stage.sh_o_dx[k] = make_float4(out.sOrigin.x, out.sOrigin.y, out.sOrigin.z, out.sDir.x);
+			stage.sh_dyz_cd_ix[k] = make_float4(out.sDir.y, out.sDir.z, out.sClosest, __uint_as_float(pixelBits));
+			stage.sh_color[k] = make_float4(out.sColor.x, out.sColor.y, out.sColor.z, 0.0f);
+		}
+		havePrev = true;
+		prevVb = vb;
+		prevS = totS;
+		prevH = totH;
+		// goes to the pixel under the next tile's arithmetic (or after the loop); zeros for lanes past the end
+		pendPixel = pixelBits;
+		pendColor = out.color;
+		pendNew = out.newFrame;
+		// no barrier here: the next tile's first barrier orders these LDS writes before flush_prev reads them
+		TYR_STAMP(5)
+#ifdef TYR_SHADE_TIMING
+		++ntiles_;
+#endif
+	}
+	accumulate_pixels_wave(P.blit, (int)pendPixel, pendColor, pendNew);
+	if (havePrev) {
+		__syncthreads();
+		flush_prev();
+	}
+#ifdef TYR_SHADE_TIMING
+	if (tid == 0) {
+		for (int i = 0; i < 6; ++i)
+			atomicAdd(&P.k->debug[i], tacc_[i]);
+		atomicAdd(&P.k->debug[7], ntiles_);
+	}
+#endif
+#undef TYR_STAMP
+}
+
+
+void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCache& lc, hipStream_t stream) {
+	if (maxLive == 0)
+		return;
+	const uint32_t nTiles = blocks_for(maxLive);
+	// A persistent grid: as many blocks as stay resident (more would only wait for a slot and then find no tile
+	// left; the tile tickets make any grid size safe).  Asked once: the occupancy query is a slow host call.
+	const bool lights = (P.flags & TYR_FLAG_LIGHT_LIST) != 0; // its own instantiation: the default kernel keeps its registers
+	int* perCU = lc.perCU[kLcShade]; // [0] default kernel, [1] the light-list instantiation
+	if (perCU[lights] == 0) {
+		int q = 0;
+		const hipError_t e = lights ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<true>, kBlock, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<false>, kBlock, 0);
+		if (e != hipSuccess || q < 1)
+			q = 2;
+		perCU[lights] = q > 6 ? 6 : q;
+	}
+	const uint32_t resident = (uint32_t)perCU[lights] * (uint32_t)numCUs;
+	const dim3 grid(nTiles < resident ? nTiles : resident);
+	if (lights)
+		hipLaunchKernelGGL(k_shade<true>, grid, dim3(kBlock), 0, stream, P, nTiles);
+	else
+		hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), 0, stream, P, nTiles);
+}
+
+} // namespace tyr

@@ -1,0 +1,707 @@
+// traverse_flat.hip -- extend (kernel.cu:331-343 via intersect_scene, kernel.cu:125-142) and connect
+// (kernel.cu:630-646 via intersect_scene_simple, kernel.cu:162-174) as flat per-lane state machines on persistent
+// waves.  Production = quad nodes on a persistent grid (variant 4); the counting build (TYR_FLAG_COUNT_VISITS) = the
+// same state machine on pair nodes, which reproduces the reference's visit counts (bvh.h:164-209).  Variants 0-3 and
+// the other stack depths live in traverse_diag.hip / the -DTYR_DIAG build (libtyrant_hip_diag.so).
+#include "device_common.hpp"
+
+namespace tyr {
+
+// Register budget of the flat traversal kernels, as waves per SIMD.  Five (<= 96 VGPRs) measured 7-10 % faster in
+// extend than the four the allocator picks by itself (99 VGPRs); six (80 VGPRs) spills 32 registers in the descent
+// loop and is 40 % slower.  Deeper LDS stacks cap the occupancy below five anyway.
+#ifndef TYR_CONNECT_ORDERED
+#define TYR_CONNECT_ORDERED false
+#endif
+#ifndef TYR_FLAT_WAVES_PER_EU
+#define TYR_FLAT_WAVES_PER_EU (STACK_LDS <= 8 ? 6 : STACK_LDS <= 12 ? 5 : STACK_LDS <= 16 ? 3 : 2)
+#endif
+
+// ======================================================================================
+// Flat traversal (variant 2): persistent waves, lane refill, and NO nested divergent loops.
+//
+// Measured on variant 1 with the counting build (tools/loop_occupancy.py, C2 at 1080p): the
+// node-test loop ran at 19.7 % lane occupancy and the nested pop loop at 6 %, because (a) a lane
+// that reaches a leaf or finishes its ray waits until the LAST lane of the wave stops descending,
+// and (b) `while (pop) {...}` inside the divergent "both children missed" branch runs four lanes
+// wide while sixty wait.  Here every lane is a small state machine --
+//      interior ref | leaf ref | kRefPop (must pop) | kRefDone --
+// and one trip of the descent loop does at most ONE pop attempt and ONE pair test per lane, so
+// lanes in different states advance together.  The descent loop is left as soon as fewer than
+// `minTraversing` lanes are still descending and there is other work for the wave (leaves to
+// intersect, or enough free lanes for a refill).
+// ======================================================================================
+__device__ __forceinline__ bool ref_is_leaf(uint32_t ref) { return (ref & kRefLeaf) && ref < kRefPop; }
+__device__ __forceinline__ bool ref_is_traversing(uint32_t ref) { return ((int)ref >= 0) || ref == kRefPop; }
+// the same as wave-wide masks, one ballot per comparison (the ballot of a compound condition goes through a 0/1
+// VGPR and a second comparison, see slab_fast_mask)
+__device__ __forceinline__ unsigned long long lanes_traversing(uint32_t ref) { return __builtin_amdgcn_ballot_w64((int)ref >= 0) | __builtin_amdgcn_ballot_w64(ref == kRefPop); }
+__device__ __forceinline__ unsigned long long lanes_at_leaf(uint32_t ref) { return __builtin_amdgcn_ballot_w64((ref & kRefLeaf) != 0u) & __builtin_amdgcn_ballot_w64(ref < kRefPop); }
+
+#ifdef TYR_QUAD_STATS
+constexpr bool kLoopStats = true; // diagnostic build: the production (quad) kernel fills tyr_counters.debug too, tools/loop_occupancy.py
+#else
+constexpr bool kLoopStats = false;
+#endif
+#define TYR_DBG(i)                                                     \
+	if (COUNT || kLoopStats) {                                         \
+		const unsigned long long m_ = __ballot(1);                     \
+		if (lane == (uint32_t)__ffsll((long long)m_) - 1) {            \
+			dbg[i] += 1;                                               \
+			dbg[i + 1] += __popcll(m_);                                \
+		}                                                              \
+	}
+
+// Variant 4 work distribution: a PERSISTENT grid (as many blocks as stay resident) whose waves each own a private
+// range of queue slots and draw the next chunk from one of kTicketWords device-wide tickets when it runs out.
+// Chunk c of the queue belongs to ticket word c % kTicketWords; a wave starts at word blockIdx % kTicketWords
+// (its XCD under round-robin placement) and moves on to the next word when one is used up, so the last chunks
+// are shared by whoever is free.  Compared with block-owned ranges (variant 3) there is no per-block tail: the
+// four waves of a block never wait for the block's longest ray, only the end of the launch has partly filled waves.
+// -DTYR_GUARD_PASSES (make EXTRA_HIPFLAGS=...): an exit condition every wave of the flat traversal kernels reaches
+// whatever the feed logic does -- an outer pass (refill + descent + leaves) takes at least ~0.1 us and a launch a
+// few milliseconds, so 2^24 passes are never seen by a working build; a wave that gets there gives up and reports
+// kErrNoProgress instead of holding the GPU.  For work on the refill / exit logic (one mistake there is a hung GPU);
+// off in the shipped build, where the counter and its branch cost 2 % of extend (measured), and the logic is what
+// the soak and fuzz runs of profiles/ exercised.
+#ifdef TYR_GUARD_PASSES
+constexpr bool kGuardPasses = true;
+#else
+constexpr bool kGuardPasses = false;
+#endif
+constexpr uint32_t kMaxPasses = 1u << 24;
+
+struct ChunkFeed {
+	uint32_t next, end;   // this wave's private range of queue slots (wave-uniform)
+	uint32_t word, tried; // ticket word in use, words found empty so far
+	uint32_t chunk;       // slots per draw
+	__device__ __forceinline__ void init(uint32_t nItems, uint32_t chunkWanted) {
+		next = end = 0;
+		word = blockIdx.x % kTicketWords;
+		tried = 0;
+		// thin queues: smaller chunks, so that the rays spread over more CUs (never below one wave's worth).
+		// What the sweeps said (profiles/r01_chunk_feed_sweep.txt): a draw must be ONE round trip -- with a look
+		// at the word before every atomic, launches of short rays (the primary rays) were 30-60 % slower than
+		// block-owned ranges; with that gone, 64- and 128-slot chunks beat larger ones by 2-4 %.  Guided
+		// (shrinking) draws over 64-slot granules lost to fixed chunks.
+		const uint32_t waves = gridDim.x * (kBlock / 64);
+		chunk = chunkWanted;
+		while (chunk > 64 && (unsigned long long)waves * chunk > nItems)
+			chunk >>= 1;
+	}
+	// true when [next, end) is non-empty afterwards
+	__device__ __forceinline__ bool refill(uint32_t* tickets, uint32_t nItems, uint32_t lane) {
+		while (next == end && tried < kTicketWords) {
+			uint32_t t = 0;
+			if (lane == 0) {
+				uint32_t* w = tickets + word * 32;
+				// once a word has been found empty, look before drawing: at the end of a launch every wave walks all the
+				// words, and plain reads are served in parallel (an atomic on one word is not).  Before that, draw
+				// straight away -- a look first would double the round trip of every draw.
+				bool draw = true;
+				if (tried != 0) {
+					t = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					draw = (unsigned long long)(t * kTicketWords + word) * chunk < nItems;
+				}
+				if (draw)
+					t = atomicAdd(w, 1u);
+			}
+			t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+			const unsigned long long start = (unsigned long long)(t * kTicketWords + word) * chunk;
+			if (start < nItems) {
+				next = (uint32_t)start;
+				end = (start + chunk < nItems) ? (uint32_t)(start + chunk) : nItems;
+			} else {
+				word = (word + 1) % kTicketWords;
+				++tried;
+			}
+		}
+		return next != end;
+	}
+};
+
+// slots of the queue that each block of a persistent grid owns outright (a multiple of 64; 0 for thin queues)
+__device__ __forceinline__ uint32_t static_range(uint32_t nItems, uint32_t sixteenths) {
+	const unsigned long long share = (unsigned long long)nItems * sixteenths / 16ull;
+	return (uint32_t)(share / gridDim.x) & ~63u;
+}
+
+template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
+__global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(const FrameParams P) {
+	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
+	TYR_DECLARE_FLAT_STACK(st, true)
+	// variant 4: the top of the tree lives in LDS for the lifetime of the (persistent) block
+	__shared__ float4 stagedNodes[PERSIST ? 7 * kStagedNodes : 1];
+	const uint32_t nStaged = (PERSIST && QUAD) ? P.scene.nStaged : 0u;
+	if constexpr (PERSIST && QUAD) {
+		for (uint32_t i = threadIdx.x; i < 7 * nStaged; i += kBlock) {
+			const uint32_t v = i / nStaged, n = i - v * nStaged;
+			stagedNodes[v * kStagedNodes + n] = P.scene.quads[8 * n + v];
+		}
+		// visible to the block after the __syncthreads() that precedes the main loop
+	}
+	const uint32_t lane = lane_id();
+	const unsigned long long below = (1ull << lane) - 1ull;
+	const uint32_t nLive = P.k->n_live;
+	const DevScene& sc = P.scene;
+	// the ray of this lane as plain scalars: kept as one RayConst object across the refill branch, its first 16
+	// bytes (origin + direction.x) stayed in a private-memory slot that every descent and leaf phase re-read
+	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f;
+	bool regular = true;      // this lane's ray has a finite 1/d in all three components
+	bool allRegular = true;   // ... and so has every live ray of the wave (wave-uniform; refreshed at refills)
+	float dist = 0.0f;
+	uint32_t ref = kRefDone, slot = 0;
+	int prim = 0;
+	bool hitTri = false, live = false, overflow = false;
+	VisitCount vc{ 0, 0 };
+	uint32_t inTree = 0; // COUNT: rays of this lane that passed the root box
+	uint32_t dbg[16] = {};
+	// Work distribution: this block owns queue slots [blockIdx.x * raysPerBlock, +raysPerBlock) and hands
+	// them to the free lanes of its four waves through a counter in LDS.  Balancing ACROSS blocks is the
+	// hardware dispatcher's (grid = slots / raysPerBlock blocks, more than fit at once).  The first
+	// versions pulled from one device-wide ticket: a single word serves only ~88 returning atomics per
+	// microsecond (MI355X_MICROARCH.md "dequeue"), and with >= 2 pulls per wave that alone was a
+	// 0.26 ms floor per launch, whatever the traversal cost.
+	__shared__ uint32_t blockNext;
+	// variant 4 (PERSIST): the first staticShare/16 of the queue is dealt to the blocks as fixed ranges, handed out
+	// through LDS exactly like variant 3 (no device-wide atomic: a launch of short rays -- the primary rays --
+	// would spend a third of its time on ticket round trips); the rest goes out in ticketed chunks to whoever is
+	// free, which evens out the blocks and leaves no block waiting for its longest ray.
+	const uint32_t perBlock = PERSIST ? static_range(nLive, P.staticShare) : P.raysPerBlock;
+	const uint32_t dynBase = PERSIST ? perBlock * gridDim.x : 0u;
+	const uint32_t blockBegin = blockIdx.x * perBlock;
+	const uint32_t blockEnd = PERSIST ? blockBegin + perBlock : ((blockBegin + perBlock) < nLive ? (blockBegin + perBlock) : nLive);
+	ChunkFeed feed;
+	feed.init(nLive - dynBase, P.ticketChunk);
+	bool staticDone = (perBlock == 0); // wave-uniform
+	if (threadIdx.x == 0)
+		blockNext = blockBegin;
+	__syncthreads();
+	bool exhausted = (sc.rootRef == kRefDone) || (PERSIST ? nLive == 0 : blockBegin >= nLive);
+	uint32_t passes = 0; // see kMaxPasses
+
+	for (;;) {
+		if (kGuardPasses && ++passes > kMaxPasses)
+			break;
+		// ---- refill free lanes from the queue ----
+		const unsigned long long idleMask = __ballot(!live);
+		const uint32_t nIdle = __popcll(idleMask);
+		if (!exhausted && nIdle >= P.refillMinIdle) {
+			const uint32_t rank = __popcll(idleMask & below);
+			uint32_t s = 0;
+			bool fed = false;
+			if (PERSIST) {
+				uint32_t got = 0; // idle lanes served so far; one refill may take from the fixed range and from two chunks
+				if (!staticDone) {
+					uint32_t base = 0;
+					if (lane == 0)
+						base = atomicAdd(&blockNext, nIdle); // LDS
+					base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, 0, 64));
+					const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+					got = avail < nIdle ? avail : nIdle;
+					if (!live && rank < got) {
+						s = base + rank;
+						fed = true;
+					}
+					staticDone = (base + nIdle >= blockEnd);
+				}
+				while (staticDone && got < nIdle) {
+					if (!feed.refill(P.k->extend_chunks, nLive - dynBase, lane)) {
+						exhausted = true;
+						break;
+					}
+					const uint32_t avail = feed.end - feed.next, room = nIdle - got;
+					const uint32_t take = avail < room ? avail : room;
+					if (!live && rank >= got && rank < got + take) {
+						s = dynBase + feed.next + (rank - got);
+						fed = true;
+					}
+					feed.next += take;
+					got += take;
+				}
+			} else {
+				uint32_t base = 0;
+				if (lane == 0)
+					base = atomicAdd(&blockNext, nIdle); // LDS
+				base = __shfl(base, 0, 64);
+				const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+				const uint32_t take = avail < nIdle ? avail : nIdle;
+				exhausted = (base + nIdle >= blockEnd);
+				s = base + rank;
+				fed = !live && rank < take;
+			}
+			{
+				if (fed) {
+					TYR_DBG(6)
+					const float4 a = P.work.o_dx[s];
+					const float2 b = P.work.dyz[s];
+					const float2 h = P.work.hit[s];
+					const RayConst nr = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+					rox = nr.o.x, roy = nr.o.y, roz = nr.o.z, rdx = nr.d.x, rdy = nr.d.y, rdz = nr.d.z, rix = nr.inv.x, riy = nr.inv.y, riz = nr.inv.z;
+					regular = ray_is_regular(nr);
+					dist = h.x;
+					slot = s;
+					hitTri = false;
+					st.reset();
+					ref = root_ref(sc, nr, dist);
+					if (QUAD && ref != kRefDone)
+						ref = sc.quadRootRef;
+					// a ray that misses the root box (or is already stopped short of it by a sphere) is finished here:
+					// the pre-pass's answer stands, nothing to write, the lane stays free
+					live = (ref != kRefDone);
+					if (COUNT) {
+						vc.nodes += 1;
+						inTree += live ? 1u : 0u;
+					}
+				}
+			}
+			// Primary rays mostly end right there (three in four on C3): top the wave up again rather than run
+			// the descent loop a quarter full.  Every pass consumes queue slots, so this terminates.
+			if (!exhausted && (uint32_t)__popcll(__ballot(live)) < P.minTraversing)
+				continue;
+		}
+		if (__ballot(live) == 0ull) {
+			if (exhausted)
+				break;
+			continue;
+		}
+		allRegular = (__ballot(live && !regular) == 0ull);
+		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
+		// ---- descent: one pop attempt + one pair test per lane per trip ----
+		for (;;) {
+			const uint32_t nTrav = __popcll(lanes_traversing(ref));
+			if (nTrav == 0)
+				break;
+			// leave the descent when few lanes are still descending and there is anything else to do (leaves, or a
+			// refill).  (Also leaving once many lanes hold a leaf, so that triangle tests run wide, was measured at
+			// every threshold and never paid; the test cost eight instructions per trip.)
+			if (nTrav < P.minTraversing) {
+				const bool anyLeaf = lanes_at_leaf(ref) != 0ull;
+				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
+				if (anyLeaf || canRefill)
+					break;
+			}
+			if (kLoopStats) {
+				// lane-state census at the top of a descent trip (tools/loop_occupancy.py census=1): [8] trips, lanes [9] holding
+				// a leaf (waiting for the descent to end), [10] without a ray, [11] finished but not yet retired; [12] stale pops
+				const unsigned long long mLeaf = lanes_at_leaf(ref), mIdle = __ballot(!live), mDone = __ballot(live && ref == kRefDone);
+				if (lane == 0) {
+					dbg[8] += 1;
+					dbg[9] += __popcll(mLeaf);
+					dbg[10] += __popcll(mIdle);
+					dbg[11] += __popcll(mDone);
+				}
+			}
+			if (ref == kRefPop) {
+				TYR_DBG(2)
+				uint32_t pr;
+				float pt;
+				if (st.pop(pr, pt)) {
+					if (pt < dist) // the pop-time half of Bbox.h:61
+						ref = pr;
+					else if (kLoopStats)
+						dbg[12] += 1; // (per lane: summed over the wave at the end)
+				} else {
+					ref = kRefDone;
+				}
+			}
+			if ((int)ref >= 0) {
+				TYR_DBG(0)
+				if (QUAD) {
+					const QuadHits q = allRegular ? test_quad<true, true, PERSIST>(sc.quads, ref, r, dist, stagedNodes, nStaged) : test_quad<false, true, PERSIST>(sc.quads, ref, r, dist, stagedNodes, nStaged);
+					// the earliest hit in visit order is entered now, the later ones are pushed latest first:
+					// entry k is pushed iff it hit and an earlier entry hit too
+					const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
+					st.push3(q.hit[3] & any012, q.ref[3], q.t[3], q.hit[2] & any01, q.ref[2], q.t[2], q.hit[1] & q.hit[0], q.ref[1], q.t[1]);
+					ref = lane_in(q.hit[0]) ? q.ref[0] : lane_in(q.hit[1]) ? q.ref[1] : lane_in(q.hit[2]) ? q.ref[2] : lane_in(q.hit[3]) ? q.ref[3] : kRefPop;
+				} else {
+					const PairTest p = allRegular ? test_pair_fast(sc.nodes, ref, r, dist) : test_pair(sc.nodes, ref, r, dist);
+					if (COUNT && !p.synthetic)
+						vc.nodes += 2;
+					if (p.nearHit) {
+						if (p.farHit)
+							st.push(p.farRef, p.farT);
+						ref = p.nearRef;
+					} else if (p.farHit) {
+						ref = p.farRef;
+					} else {
+						ref = kRefPop;
+					}
+				}
+			}
+		}
+		// ---- leaves: bvh.h:129-140 ----
+		if (ref_is_leaf(ref)) {
+			const uint32_t off = ref & (kMaxPrimOffset - 1);
+			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+			TriData tri = triangle_load(sc.tris, off);
+			for (uint32_t i = 0; i < cnt; ++i) {
+				TYR_DBG(4)
+				// the next primitive of the leaf is on its way while this one is tested (a leaf is 1..4 consecutive records)
+				const TriData cur = tri;
+				if (i + 1 < cnt)
+					tri = triangle_load(sc.tris, off + i + 1);
+				const float t = triangle_test(cur, r);
+				if (COUNT)
+					vc.tris += 1;
+				if (t > kEpsilon && t < dist && ((dist - t) > kEpsilon)) {
+					prim = (int)(off + i);
+					dist = t;
+					hitTri = true;
+				}
+			}
+			ref = kRefPop;
+		}
+		// ---- finished rays: a triangle hit replaces the sphere answer of the pre-pass (kernel.cu:138-140).
+		// (Holding the record back until the wave's next refill, one store for all lanes that finished in between,
+		// was measured: +1 %.) ----
+		if (live && ref == kRefDone) {
+			if (hitTri)
+				P.work.hit[slot] = make_float2(dist, __uint_as_float((uint32_t)prim));
+			overflow = overflow || st.overflow;
+			live = false;
+		}
+	}
+	if (overflow)
+		atomicOr(&P.k->device_error, kErrStackOverflow);
+	if (kGuardPasses && passes > kMaxPasses)
+		atomicOr(&P.k->device_error, kErrNoProgress);
+	if (COUNT) {
+		wave_add_u64(&P.k->nodes_extend, vc.nodes);
+		wave_add_u64(&P.k->tris_extend, vc.tris);
+		wave_add_u64(&P.k->rays_in_tree_extend, inTree);
+	}
+	if (COUNT || kLoopStats) {
+		for (int i = 0; i < 16; ++i)
+			wave_add_u64(&P.k->debug[i], dbg[i]);
+	}
+}
+
+template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
+__global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(const FrameParams P) {
+	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
+	constexpr bool kKeepT = !(QUAD && !COUNT); // the pair / counting path marks failed boxes through the entry distance
+	TYR_DECLARE_FLAT_STACK(st, kKeepT)
+	// variant 4: the top of the tree lives in LDS for the lifetime of the (persistent) block
+	__shared__ float4 stagedNodes[PERSIST ? 7 * kStagedNodes : 1];
+	const uint32_t nStaged = (PERSIST && QUAD) ? P.scene.nStaged : 0u;
+	if constexpr (PERSIST && QUAD) {
+		for (uint32_t i = threadIdx.x; i < 7 * nStaged; i += kBlock) {
+			const uint32_t v = i / nStaged, n = i - v * nStaged;
+			stagedNodes[v * kStagedNodes + n] = P.scene.quads[8 * n + v];
+		}
+		// visible to the block after the __syncthreads() that precedes the main loop
+	}
+	const uint32_t lane = lane_id();
+	const unsigned long long below = (1ull << lane) - 1ull;
+	const uint32_t nRays = P.kc->shadow_cnt;
+	const DevScene& sc = P.scene;
+	const bool haveBvh = (sc.rootRef != kRefDone);
+	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f; // see k_extend_flat
+	bool regular = true;      // this lane's ray has a finite 1/d in all three components
+	bool allRegular = true;   // ... and so has every live ray of the wave (wave-uniform; refreshed at refills)
+	float closest = 0.0f;
+	uint32_t ref = kRefDone, index = 0;
+	bool live = false, occluded = false, overflow = false;
+	VisitCount vc{ 0, 0 };
+	uint32_t inTree = 0; // COUNT: rays of this lane that passed the root box
+	uint32_t visible = 0;
+	// kernel.cu:640-644, deferred: a lane whose ray came through unoccluded notes the slot and goes idle; the wave
+	// adds all such colours to their pixels at its next refill (and once after the loop), loads batched with the new
+	// rays' loads and the atomics transposed (accumulate_pixels_wave) -- instead of two dependent loads and three
+	// scattered atomics in the middle of the descent every time some lane finishes.
+	constexpr uint32_t kNoPending = 0xffffffffu;
+	uint32_t pendIdx = kNoPending;
+	auto flush_visible = [&]() {
+		float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+		int px = 0;
+		if (pendIdx != kNoPending) {
+			c = P.shadow.color[pendIdx];
+			px = __float_as_int(P.shadow.dyz_cd_ix[pendIdx].w);
+		}
+		accumulate_pixels_wave(P.blit, px, mk3(c.x, c.y, c.z), 0);
+		pendIdx = kNoPending;
+	};
+	__shared__ uint32_t blockNext;
+	const uint32_t perBlock = PERSIST ? static_range(nRays, P.staticShare) : P.raysPerBlock; // see k_extend_flat
+	const uint32_t dynBase = PERSIST ? perBlock * gridDim.x : 0u;
+	const uint32_t blockBegin = blockIdx.x * perBlock;
+	const uint32_t blockEnd = PERSIST ? blockBegin + perBlock : ((blockBegin + perBlock) < nRays ? (blockBegin + perBlock) : nRays);
+	ChunkFeed feed;
+	feed.init(nRays - dynBase, P.ticketChunk);
+	bool staticDone = (perBlock == 0); // wave-uniform
+	if (threadIdx.x == 0)
+		blockNext = blockBegin;
+	__syncthreads();
+	bool exhausted = PERSIST ? nRays == 0 : (blockBegin >= nRays);
+	const float kFailed = __builtin_inff();
+	uint32_t passes = 0; // see kMaxPasses
+
+	for (;;) {
+		if (kGuardPasses && ++passes > kMaxPasses)
+			break;
+		const unsigned long long idleMask = __ballot(!live);
+		const uint32_t nIdle = __popcll(idleMask);
+		if (!exhausted && nIdle >= P.refillMinIdle) {
+			const uint32_t rank = __popcll(idleMask & below);
+			uint32_t s = 0;
+			bool fed = false;
+			if (PERSIST) {
+				uint32_t got = 0;
+				if (!staticDone) {
+					uint32_t base = 0;
+					if (lane == 0)
+						base = atomicAdd(&blockNext, nIdle); // LDS
+					base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, 0, 64));
+					const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+					got = avail < nIdle ? avail : nIdle;
+					if (!live && rank < got) {
+						s = base + rank;
+						fed = true;
+					}
+					staticDone = (base + nIdle >= blockEnd);
+				}
+				while (staticDone && got < nIdle) {
+					if (!feed.refill(P.kc->chunks, nRays - dynBase, lane)) {
+						exhausted = true;
+						break;
+					}
+					const uint32_t avail = feed.end - feed.next, room = nIdle - got;
+					const uint32_t take = avail < room ? avail : room;
+					if (!live && rank >= got && rank < got + take) {
+						s = dynBase + feed.next + (rank - got);
+						fed = true;
+					}
+					feed.next += take;
+					got += take;
+				}
+			} else {
+				uint32_t base = 0;
+				if (lane == 0)
+					base = atomicAdd(&blockNext, nIdle); // LDS
+				base = __shfl(base, 0, 64);
+				const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+				const uint32_t take = avail < nIdle ? avail : nIdle;
+				exhausted = (base + nIdle >= blockEnd);
+				s = base + rank;
+				fed = !live && rank < take;
+			}
+			if (__ballot(pendIdx != kNoPending) != 0ull)
+				flush_visible();
+			{
+				if (fed) {
+					const float4 a = P.shadow.o_dx[s];
+					const float4 b = P.shadow.dyz_cd_ix[s];
+					const float sphereOccluded = reinterpret_cast<const float*>(&P.shadow.color[s])[3];
+					index = s;
+					closest = b.z;
+					occluded = (sphereOccluded != 0.0f);
+					live = true;
+					st.reset();
+					ref = kRefDone;
+					if (haveBvh && (COUNT || !occluded)) {
+						const RayConst nr = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+						rox = nr.o.x, roy = nr.o.y, roz = nr.o.z, rdx = nr.d.x, rdy = nr.d.y, rdz = nr.d.z, rix = nr.inv.x, riy = nr.inv.y, riz = nr.inv.z;
+						regular = ray_is_regular(nr);
+						ref = root_ref(sc, nr, closest);
+						if (QUAD && ref != kRefDone)
+							ref = sc.quadRootRef;
+						if (COUNT) {
+							vc.nodes += 1;
+							inTree += (ref != kRefDone) ? 1u : 0u;
+						}
+					}
+				}
+			}
+		}
+		if (__ballot(live) == 0ull) {
+			if (exhausted)
+				break;
+			continue;
+		}
+		allRegular = (__ballot(live && !regular) == 0ull);
+		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
+		for (;;) {
+			const uint32_t nTrav = __popcll(lanes_traversing(ref));
+			if (nTrav == 0)
+				break;
+			// leave the descent when few lanes are still descending and there is anything else to do (leaves, or a
+			// refill).  (Also leaving once many lanes hold a leaf, so that triangle tests run wide, was measured at
+			// every threshold and never paid; the test cost eight instructions per trip.)
+			if (nTrav < P.minTraversing) {
+				const bool anyLeaf = lanes_at_leaf(ref) != 0ull;
+				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
+				if (anyLeaf || canRefill)
+					break;
+			}
+			if (ref == kRefPop) {
+				uint32_t pr;
+				float pt;
+				if (st.pop(pr, pt)) {
+					if (COUNT)
+						vc.nodes += 1; // the reference fetches the popped node before testing its box (bvh.h:222-224)
+					if (pt < closest)
+						ref = pr;
+				} else {
+					ref = kRefDone;
+				}
+			}
+			if ((int)ref >= 0) {
+				if (QUAD) {
+					const QuadHits q = allRegular ? test_quad<true, TYR_CONNECT_ORDERED, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged) : test_quad<false, TYR_CONNECT_ORDERED, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged);
+					const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
+					st.push3(q.hit[3] & any012, q.ref[3], q.t[3], q.hit[2] & any01, q.ref[2], q.t[2], q.hit[1] & q.hit[0], q.ref[1], q.t[1]);
+					ref = lane_in(q.hit[0]) ? q.ref[0] : lane_in(q.hit[1]) ? q.ref[1] : lane_in(q.hit[2]) ? q.ref[2] : lane_in(q.hit[3]) ? q.ref[3] : kRefPop;
+					continue;
+				}
+				const PairTest p = allRegular ? test_pair_fast(sc.nodes, ref, r, closest) : test_pair(sc.nodes, ref, r, closest);
+				if (COUNT && !p.synthetic) {
+					vc.nodes += 1;
+					st.push(p.farRef, p.farHit ? p.farT : kFailed);
+					ref = p.nearHit ? p.nearRef : kRefPop;
+				} else if (p.nearHit) {
+					if (p.farHit)
+						st.push(p.farRef, p.farT);
+					ref = p.nearRef;
+				} else if (p.farHit) {
+					ref = p.farRef;
+				} else {
+					ref = kRefPop;
+				}
+			}
+		}
+		if (ref_is_leaf(ref)) {
+			const uint32_t off = ref & (kMaxPrimOffset - 1);
+			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+			bool found = false;
+			TriData tri = triangle_load(sc.tris, off);
+			for (uint32_t i = 0; i < cnt && !found; ++i) {
+				const TriData cur = tri; // next record in flight while this one is tested
+				if (i + 1 < cnt)
+					tri = triangle_load(sc.tris, off + i + 1);
+				const float t = triangle_test(cur, r);
+				if (COUNT)
+					vc.tris += 1;
+				found = (t > kEpsilon && ((closest - t) > kEpsilon)); // bvh.h:232-236
+			}
+			if (found) {
+				occluded = true;
+				ref = kRefDone;
+			} else {
+				ref = kRefPop;
+			}
+		}
+		if (live && ref == kRefDone) {
+			if (!occluded) {
+				pendIdx = index;
+				visible += 1;
+			}
+			overflow = overflow || st.overflow;
+			live = false;
+		}
+	}
+	flush_visible();
+	if (overflow)
+		atomicOr(&P.k->device_error, kErrStackOverflow);
+	if (kGuardPasses && passes > kMaxPasses)
+		atomicOr(&P.k->device_error, kErrNoProgress);
+	wave_add_u64(&P.k->n_shadow_visible, visible);
+	if (COUNT) {
+		wave_add_u64(&P.k->nodes_connect, vc.nodes);
+		wave_add_u64(&P.k->tris_connect, vc.tris);
+		wave_add_u64(&P.k->rays_in_tree_connect, inTree);
+	}
+}
+#undef TYR_DBG
+
+
+template <bool COUNT, int STACK_LDS>
+static void launch_extend_t(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
+	launch_extend_spheres(P, nSurvivors, stream);
+	const uint32_t flatBlocks = (maxLive + P.raysPerBlock - 1) / P.raysPerBlock;
+	if (COUNT) {
+		// pair nodes: the only layout that reproduces the reference's visit counts (bvh.h:164-209)
+		hipLaunchKernelGGL((k_extend_flat<true, STACK_LDS, false, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+		return;
+	}
+#ifdef TYR_DIAG
+	if (t.traversalVariant == 3) {
+		hipLaunchKernelGGL((k_extend_flat<false, STACK_LDS, true, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+		return;
+	}
+	if (t.traversalVariant == 2) {
+		hipLaunchKernelGGL((k_extend_flat<false, STACK_LDS, false, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+		return;
+	}
+#endif
+	hipLaunchKernelGGL((k_extend_flat<false, STACK_LDS, true, true>), dim3(persistent_blocks(k_extend_flat<false, STACK_LDS, true, true>, maxLive, t, numCUs, lc.perCU[kLcExtend][stack_slot(STACK_LDS)])), dim3(kBlock), 0, stream, P);
+}
+template <bool COUNT, int STACK_LDS>
+static void launch_connect_t(const FrameParams& P, uint32_t maxShadow, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
+	launch_connect_spheres(P, maxShadow, stream);
+	const uint32_t flatBlocks = (maxShadow + P.raysPerBlock - 1) / P.raysPerBlock;
+	if (COUNT) {
+		hipLaunchKernelGGL((k_connect_flat<true, STACK_LDS, false, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+		return;
+	}
+#ifdef TYR_DIAG
+	if (t.traversalVariant == 3) {
+		hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, true, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+		return;
+	}
+	if (t.traversalVariant == 2) {
+		hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, false, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
+		return;
+	}
+#endif
+	hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, true, true>), dim3(persistent_blocks(k_connect_flat<false, STACK_LDS, true, true>, maxShadow, t, numCUs, lc.perCU[kLcConnect][stack_slot(STACK_LDS)])), dim3(kBlock), 0, stream, P);
+}
+
+// The stack depths that are compiled in.  The shipped library has the production depth only (12 entries per lane in
+// LDS, the rest in scratch); the diagnostics build keeps the others selectable (TYR_TUNE_STACK_LDS_DEPTH).
+#ifdef TYR_DIAG
+#define TYR_DISPATCH_STACK(FN, COUNT, ...)          \
+	switch (t.stackLdsDepth) {                      \
+	case 0: FN<COUNT, 0>(__VA_ARGS__); break;       \
+	case 8: FN<COUNT, 8>(__VA_ARGS__); break;       \
+	case 10: FN<COUNT, 10>(__VA_ARGS__); break;     \
+	case 16: FN<COUNT, 16>(__VA_ARGS__); break;     \
+	case 24: FN<COUNT, 24>(__VA_ARGS__); break;     \
+	default: FN<COUNT, 12>(__VA_ARGS__); break;     \
+	}
+#else
+#define TYR_DISPATCH_STACK(FN, COUNT, ...) FN<COUNT, 12>(__VA_ARGS__);
+#endif
+
+void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
+	if (maxLive == 0)
+		return;
+#ifdef TYR_DIAG
+	if (t.traversalVariant <= 1) {
+		launch_extend_diag(P, maxLive, nSurvivors, countVisits, t, numCUs, lc, stream);
+		return;
+	}
+#endif
+	if (countVisits) {
+		TYR_DISPATCH_STACK(launch_extend_t, true, P, maxLive, nSurvivors, t, numCUs, lc, stream)
+	} else {
+		TYR_DISPATCH_STACK(launch_extend_t, false, P, maxLive, nSurvivors, t, numCUs, lc, stream)
+	}
+}
+void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
+	if (maxShadow == 0)
+		return;
+#ifdef TYR_DIAG
+	if (t.traversalVariant <= 1) {
+		launch_connect_diag(P, maxShadow, countVisits, t, numCUs, lc, stream);
+		return;
+	}
+#endif
+	if (countVisits) {
+		TYR_DISPATCH_STACK(launch_connect_t, true, P, maxShadow, t, numCUs, lc, stream)
+	} else {
+		TYR_DISPATCH_STACK(launch_connect_t, false, P, maxShadow, t, numCUs, lc, stream)
+	}
+}
+
+} // namespace tyr

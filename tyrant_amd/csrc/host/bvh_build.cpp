@@ -30,7 +30,16 @@
 #include <thread>
 #include <vector>
 
+#ifdef TYR_HOST_ONLY // the ThreadSanitizer build (make tsan): this file alone under g++ -fsanitize=thread, no HIP headers
+#include "../../../include/tyr_c.h"
+namespace tyr {
+int bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo);
+void triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out);
+void set_build_threads(int threads);
+} // namespace tyr
+#else
 #include "host.hpp"
+#endif
 
 namespace tyr {
 

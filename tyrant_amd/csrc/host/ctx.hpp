@@ -1,0 +1,74 @@
+// ctx.hpp -- tyr_ctx, the state behind the C ABI's opaque handle (private to the library: host/driver.cpp owns it,
+// host/dist.cpp reads the stream, the blit buffer and the sharding from it).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "host.hpp"
+
+using tyr::ConnectCounters;
+using tyr::DevCounters;
+using tyr::DevScene;
+using tyr::LaunchCache;
+using tyr::RayQ;
+using tyr::ShadowQ;
+using tyr::SunParams;
+using tyr::Tuning;
+
+struct tyr_ctx {
+	tyr_config cfg{};
+	hipStream_t stream = nullptr;
+	bool ownStream = false;
+	uint32_t localRows = 0, localPixels = 0;
+
+	RayQ q[2]{};
+	int cur = 0; // q[cur] = work queue, q[cur ^ 1] = next (the caller's std::swap, main.cpp:169)
+	ShadowQ shadow{};
+	DevCounters* dK = nullptr;
+	DevCounters* hK = nullptr; // pinned host mirror
+	ConnectCounters* dKc = nullptr; // two sets, iteration i uses set i & 1
+	uint32_t iter = 0;
+
+	// tyr_render only: connect(i) runs on `side` while the host already reads shade(i)'s counts and `stream` runs
+	// primary / extend of iteration i + 1; shade(i + 1) waits for it (it rewrites the shadow queue)
+	hipStream_t side = nullptr;
+	hipEvent_t evShadeDone = nullptr, evConnectDone = nullptr, evSnapshot = nullptr;
+	bool connectPending = false;
+	hipEvent_t evSide[2][2]{}; // TYR_FLAG_PROFILE: connect's start / stop on `side`, per set
+	bool evSideUsed[2]{};
+	unsigned long long* scanDesc = nullptr;
+	uint32_t nDescCap = 0;
+	float4* blit = nullptr;
+	bool ownBlit = false;
+
+	float4* dNodes = nullptr;
+	float4* dQuads = nullptr;
+	float4* dTris = nullptr;
+	uint32_t* dLights = nullptr; // TYR_FLAG_LIGHT_LIST: emissive triangles, array order
+	uint32_t nLights = 0;
+	float triEmission[3] = { 3.0f, 3.0f, 3.0f }; // kernel.cu:680
+	DevScene scene{};
+	bool haveScene = false;
+
+	tyr_sphere spheres[TYR_NUM_SPHERES]{};
+	tyr_camera cam{};
+	float sunPos[2] = { 0.05f, 0.3f }; // variables.cpp:3
+	bool sunChanged = true;             // variables.cpp:4
+	SunParams sun{};
+
+	// launch_kernels statics, kernel.cu:665-667, 688-691
+	bool firstTime = true;
+	uint32_t frame = 1;
+	float lastPos[3] = { 0, 0, 0 }, lastDir[3] = { 0, 0, 0 };
+	float lastFocal = 1.0f, lastLens = 0.02f;
+	float camRight[3]{}, camUp[3]{};
+
+	Tuning tuning{};
+	LaunchCache launchCache{}; // occupancy answers of the persistent kernels, per ctx (not process-wide)
+	int numCUs = 256;
+
+	hipEvent_t ev[2 * TYR_K_COUNT]{};
+	bool evUsed[TYR_K_COUNT]{};
+	tyr_timings timings{};
+};
+

@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "ctx.hpp"
 #include "host.hpp"
 
 using namespace tyr;
@@ -31,62 +32,6 @@ constexpr size_t kWhatIfQuadPad = size_t(8) << 20; // float4s: 1 Mi quad nodes
 #else
 constexpr size_t kWhatIfQuadPad = 0;
 #endif
-
-struct tyr_ctx {
-	tyr_config cfg{};
-	hipStream_t stream = nullptr;
-	bool ownStream = false;
-	uint32_t localRows = 0, localPixels = 0;
-
-	RayQ q[2]{};
-	int cur = 0; // q[cur] = work queue, q[cur ^ 1] = next (the caller's std::swap, main.cpp:169)
-	ShadowQ shadow{};
-	DevCounters* dK = nullptr;
-	DevCounters* hK = nullptr; // pinned host mirror
-	ConnectCounters* dKc = nullptr; // two sets, iteration i uses set i & 1
-	uint32_t iter = 0;
-
-	// tyr_render only: connect(i) runs on `side` while the host already reads shade(i)'s counts and `stream` runs
-	// primary / extend of iteration i + 1; shade(i + 1) waits for it (it rewrites the shadow queue)
-	hipStream_t side = nullptr;
-	hipEvent_t evShadeDone = nullptr, evConnectDone = nullptr, evSnapshot = nullptr;
-	bool connectPending = false;
-	hipEvent_t evSide[2][2]{}; // TYR_FLAG_PROFILE: connect's start / stop on `side`, per set
-	bool evSideUsed[2]{};
-	unsigned long long* scanDesc = nullptr;
-	uint32_t nDescCap = 0;
-	float4* blit = nullptr;
-	bool ownBlit = false;
-
-	float4* dNodes = nullptr;
-	float4* dQuads = nullptr;
-	float4* dTris = nullptr;
-	uint32_t* dLights = nullptr; // TYR_FLAG_LIGHT_LIST: emissive triangles, array order
-	uint32_t nLights = 0;
-	float triEmission[3] = { 3.0f, 3.0f, 3.0f }; // kernel.cu:680
-	DevScene scene{};
-	bool haveScene = false;
-
-	tyr_sphere spheres[TYR_NUM_SPHERES]{};
-	tyr_camera cam{};
-	float sunPos[2] = { 0.05f, 0.3f }; // variables.cpp:3
-	bool sunChanged = true;             // variables.cpp:4
-	SunParams sun{};
-
-	// launch_kernels statics, kernel.cu:665-667, 688-691
-	bool firstTime = true;
-	uint32_t frame = 1;
-	float lastPos[3] = { 0, 0, 0 }, lastDir[3] = { 0, 0, 0 };
-	float lastFocal = 1.0f, lastLens = 0.02f;
-	float camRight[3]{}, camUp[3]{};
-
-	Tuning tuning{};
-	int numCUs = 256;
-
-	hipEvent_t ev[2 * TYR_K_COUNT]{};
-	bool evUsed[TYR_K_COUNT]{};
-	tyr_timings timings{};
-};
 
 namespace {
 
@@ -328,17 +273,17 @@ void enqueue_extend(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t 
 	KernelTimer t(c, TYR_K_EXTEND);
 	FrameParams P = P0;
 	P.raysPerBlock = rays_per_block_for(c, nLive);
-	launch_extend(P, nLive, nSurvivors, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->stream);
+	launch_extend(P, nLive, nSurvivors, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, c->stream);
 }
 void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	KernelTimer t(c, TYR_K_SHADE);
-	launch_shade(P, nLive, c->numCUs, c->stream);
+	launch_shade(P, nLive, c->numCUs, c->launchCache, c->stream);
 }
 void enqueue_connect(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow) {
 	KernelTimer t(c, TYR_K_CONNECT);
 	FrameParams P = P0;
 	P.raysPerBlock = rays_per_block_for(c, maxShadow);
-	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->stream);
+	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, c->stream);
 }
 // Inside tyr_render the host does not wait for connect: shade's counts are all it needs to launch the next
 // iteration (connect only adds to pixels), so connect goes out either on the side stream (onSide: beside the next
@@ -360,7 +305,7 @@ int enqueue_connect_unwaited(tyr_ctx* c, const FrameParams& P0, uint32_t maxShad
 	}
 	FrameParams P = P0;
 	P.raysPerBlock = rays_per_block_for(c, maxShadow);
-	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, s);
+	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, s);
 	if (timed) {
 		HIPCHK(hipEventRecord(c->evSide[set][1], s));
 		c->evSideUsed[set] = true;
@@ -714,7 +659,9 @@ int tyr_get_counters(tyr_ctx* c, tyr_counters* out) {
 	out->tris_connect = k.tris_connect;
 	out->n_survive = k.n_survive;
 	out->n_shadow_visible = k.n_shadow_visible;
-	for (int i = 0; i < 8; ++i)
+	out->rays_in_tree_extend = k.rays_in_tree_extend;
+	out->rays_in_tree_connect = k.rays_in_tree_connect;
+	for (int i = 0; i < 16; ++i)
 		out->debug[i] = k.debug[i];
 	return TYR_OK;
 }
@@ -1058,6 +1005,10 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 	case TYR_TUNE_TRAVERSAL_VARIANT:
 		if (value < 0 || value > 4)
 			return TYR_ERR_INVALID;
+#ifndef TYR_DIAG
+		if (value != 4)
+			return TYR_ERR_UNSUPPORTED; // variants 0-3 live in libtyrant_hip_diag.so (make diag)
+#endif
 		c->tuning.traversalVariant = value;
 		return TYR_OK;
 	case TYR_TUNE_REFILL_MIN_IDLE:
@@ -1110,6 +1061,10 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 	case TYR_TUNE_STACK_LDS_DEPTH:
 		if (value != 0 && value != 8 && value != 10 && value != 12 && value != 16 && value != 24)
 			return TYR_ERR_INVALID;
+#ifndef TYR_DIAG
+		if (value != 12)
+			return TYR_ERR_UNSUPPORTED; // the other depths are compiled into libtyrant_hip_diag.so only
+#endif
 		c->tuning.stackLdsDepth = value;
 		return TYR_OK;
 	default:
