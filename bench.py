@@ -1,38 +1,60 @@
 #!/usr/bin/env python3
 """bench.py -- Mrays/s of the wavefront path-tracing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torchrun, one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One step = one complete render of the workload through the C ABI (tyr_reset_accum +
-tyr_render: top-up -> extend -> shade -> connect until every path has finished) plus, for
-N > 1, the RCCL sum-reduction of the accumulation buffer onto rank 0.  The scene lives in HBM
-before the timed region starts; nothing crosses PCIe inside it except 120-byte counter reads.
+With N > 1 and no launcher in the environment the parent starts the N ranks itself (torch.distributed.run as a
+child process, before anything here has touched a GPU) and relays rank 0's JSON line; under a launcher
+(RANK / WORLD_SIZE set) every rank runs main() directly, one rank per GPU.
+
+One step = one complete render of the workload through the C ABI (tyr_reset_accum + tyr_render: top-up -> extend ->
+shade -> connect until every path has finished) plus, for N > 1, the combine of the ranks' rows on rank 0 over RCCL.
+The scene lives in HBM before the timed region starts; nothing crosses PCIe inside it except 200-byte counter reads.
 
 Workloads (BASELINE.json configs):
-    c2  Cornell box + 10,000 seeded random diffuse triangles, 1920x1080, 8 spp     (default: configs[1])
-    c3  room + 706x706 height-field mesh (996,882 triangles), 30 % SPEC, 1920x1080, 8 spp
-Queue size: the reference's ray_queue_buffer_size (2,097,152, variables.h:44) was chosen for a small
-GPU and forces 20 thin wavefront iterations per 8-spp frame.  It is a runtime parameter here, and the
-headline run sizes it for the GPU -- spp x pixels slots (16.6 M, 2.5 GB of 288 GB), i.e. every primary of
-the render in flight at once and 6 fat iterations.  The same workload at the reference's queue size is
-measured too and reported under config.reference_queue_size.
+    c3  room + 706x706 height-field mesh (996,882 triangles), 30 % SPEC, 1920x1080, 8 spp   (default: the scene
+        north_star's target names; N = 1)
+    c2  Cornell box + 10,000 seeded random diffuse triangles, 1920x1080, 8 spp
+    c5  room + 2236x2236 mesh (9,999,402 triangles), 5 % REFR, thin lens, sun; quoted at --width 3840 --height 2160 --spp 16
+    N > 1 (default --scaling strong) is config C4: the c3 scene at 64 spp IN TOTAL, the frame's rows dealt
+    y % N == rank, so the job is fixed and every GPU renders 64 spp over 1/N of the pixels (N = 8: exactly the one-GPU
+    c3 job per GPU).  rank 0 afterwards renders the same 64-spp job alone: config.strong_scaling holds the one-GPU
+    time of the SAME job, the speed-up and the efficiency.  --scaling weak renders 8*N spp (fixed work per GPU).
+Queue size: the reference's ray_queue_buffer_size (2,097,152, variables.h:44) was chosen for a small GPU and forces 20
+thin wavefront iterations per 8-spp frame.  It is a runtime parameter here and the headline run sizes it for the GPU --
+spp x local pixels slots (16.6 M, 2.5 GB of 288 GB; capped at 32 Mi), i.e. every primary ray of the render in flight at
+once.  The same workload at the reference's queue size is measured too (config.reference_queue_size).
 
-At N GPUs the frame is pixel-sharded (rows y % N == rank) and rendered at 8*N spp, so each
-GPU traces what one GPU traces at N = 1: weak scaling (N = 8 is BASELINE config C4's 64 spp).
+Mrays/s = (extend rays + shadow rays traced by all ranks) / wall time.  config.in_tree_Mrays/s
+is the same with only the rays that pass the root box (three primary rays in four miss the tree on c3 and cost one box
+test each).
 
-Mrays/s = (extend rays + shadow rays traced by all ranks) / wall time.
-roofline: the extend kernel; achieved = algorithmic bytes / hipEvent time of its launches
-inside the timed region, algorithmic bytes per ray = 24 + 8 + 32 * nodes + 36 * triangles
-with nodes / triangles per ray counted by the library's counting build of the same kernel
-in an untimed pass.  cpu_baseline: the oracle's serial loop on this host, 1 core, on the
-first wavefront iterations of the same workload (N = 1 only).
+roofline: the dominant kernel (the production extend kernel).  Three fractions are reported and `bound` names the
+tightest: the HBM fraction from the memory-side counters (FETCH_SIZE x 2 + WRITE_SIZE per launch / launch time / 8 TB/s),
+and the vector / scalar instruction-issue fractions (SQ_ACTIVE_INST_VALU / _SCA against the SIMD / scalar-unit cycles).
+The counters are measured live: before this process touches the GPU it runs three `rocprofv3 --pmc` passes over a
+one-render child of itself (--pmc off skips them and falls back to the committed profiles/pmc_<workload>.json).  The
+ALGORITHMIC figure of SURVEY.md 8d (24 + 8 + 32 B per node and 36 B per triangle the REFERENCE's binary tree visits,
+counted by the library's counting build on pair nodes, not by the timed quad-node kernel) over the hipEvent time of
+the timed launches is reported beside it as roofline.algorithmic -- the tree is largely cache resident, so that
+figure prices bytes the fabric never carried and may exceed the HBM peak; it is not `frac`.
+
+cpu_baseline (N = 1): the oracle's serial wavefront loop on this host, 1 core, on the first iterations of the same
+workload; plus, on ONE common ray set (the next iteration's queue), the oracle's traversal and the reference's own
+CachedBVH::intersect (oracle/_ref, bvh.h:118-161) side by side.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,6 +62,55 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+NUM_XCD, NUM_SIMD, NUM_CU = 8, 1024, 256  # MI355X: 8 XCDs x 32 CUs x 4 SIMDs
+REF_N = 2097152  # variables.h:44
+EXTEND_KERNEL = "k_extend_flat<false, 12, true, true>"
+PMC_PASSES = (
+    ("FETCH_SIZE",),
+    ("WRITE_SIZE",),
+    ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"),
+)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel: 0 = the configuration's (8 at one GPU; N > 1: 64 in total when --scaling strong, 8 per GPU when weak)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = BASELINE config C4, 64 spp in total whatever N; weak = 8*N spp")
+    ap.add_argument("--queue", type=int, default=0, help="ray_queue_buffer_size (variables.h:44); 0 = sized for the GPU: spp x local pixels, at most 32 Mi slots")
+    ap.add_argument("--no-reference-queue", action="store_true", help="skip the second measurement at the reference's queue size (2,097,152)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-gpu-job", action="store_true", help="N > 1, strong: skip rank 0's solo render of the same job (strong_scaling block)")
+    ap.add_argument("--cpu-iterations", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearse the multi-rank path with every rank on ONE GPU (the combine then goes through host memory and torch)")
+    ap.add_argument("--combine", default="gather", choices=["gather", "reduce"], help="N > 1: rank 0 gets the rows each rank owns (1/N of the frame per rank) or the sum of the full buffers")
+    ap.add_argument("--combine-impl", default="native", choices=["native", "torch"], help="native = tyr_dist_* (RCCL behind the C ABI, double-buffered); torch = torch.distributed collectives (always used with --backend gloo)")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto: N = 1 and rocprofv3 present -> three --pmc child passes feed the roofline block")
+    ap.add_argument("--save-pmc", default="", help="write the live PMC counters to this JSON file (copied to profiles/pmc_<workload>.json, the fallback when rocprofv3 cannot run beside the bench)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--tune", action="append", default=[], help="launch-shape knob of tyr_set_tuning, e.g. --tune refill_min_idle=8 (never changes results)")
+    return ap.parse_args(argv)
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """--gpus N > 1 without a launcher: start N ranks as a CHILD (this process has not touched a GPU and never will:
+    no exec of a process that holds the device), relay their output and exit code"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def build_workload(name: str, binding, scenes):
@@ -62,98 +133,307 @@ def build_workload(name: str, binding, scenes):
     return sc, nodes, prims, label, time.perf_counter() - t0
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"])
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=8, help="samples per pixel per GPU (total spp = spp * gpus)")
-    ap.add_argument("--queue", type=int, default=0, help="ray_queue_buffer_size (variables.h:44); 0 = sized for the GPU: spp x local pixels, i.e. every primary ray of the render in flight at once (16.6 M slots = 2.5 GB of the 288 GB)")
-    ap.add_argument("--no-reference-queue", action="store_true", help="skip the second measurement at the reference's queue size (2,097,152)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iterations", type=int, default=3)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearse the multi-rank path with every rank on one GPU (the reduce then goes through host memory)")
-    ap.add_argument("--combine", default="gather", choices=["gather", "reduce"], help="N > 1: how rank 0 gets the frame -- gather of the rows each rank owns (1/N of the frame per rank; falls back to the reduce if a probe of dist.gather fails on any rank) or sum-reduce of the full buffers")
-    ap.add_argument("--tune", action="append", default=[], help="launch-shape knob of tyr_set_tuning, e.g. --tune shade_tiles=2 (never changes results)")
-    args = ap.parse_args()
+def job_shape(args, world: int):
+    """(spp_total, queue slots per rank)"""
+    if args.spp > 0:
+        spp_total = args.spp * (world if args.scaling == "weak" else 1)
+    elif world == 1:
+        spp_total = 8
+    else:
+        spp_total = 64 if args.scaling == "strong" else 8 * world
+    local_pixels = args.width * (args.height // world)
+    N = args.queue if args.queue > 0 else min(spp_total * local_pixels, 1 << 25)
+    return spp_total, N
 
-    import numpy as np
+
+# ---------------------------------------------------------------------------------------------------------------
+# PMC child passes (N = 1): `rocprofv3 --pmc <counters> -- python3 bench.py --pmc-child ...`, the program itself after
+# `--`, no tracing domain combined with --pmc, one pass per counter group (FETCH_SIZE and WRITE_SIZE do not fit one).
+# ---------------------------------------------------------------------------------------------------------------
+def pmc_child(args) -> int:
+    """one cold + one counted render of the workload, no torch, no timing: what the profiler looks at"""
+    from tyrant_amd import binding, scenes
+
+    spp_total, N = job_shape(args, 1)
+    sc, nodes, prims, _, _ = build_workload(args.workload, binding, scenes)
+    flags = binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0
+    r = binding.Renderer(args.width, args.height, N, flags=flags)
+    r.load_scene(sc, nodes, prims)
+    tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune)}
+    if tune:
+        r.set_tuning(**tune)
+    iters = 0
+    for _ in range(2):
+        r.reset_accum()
+        iters = r.render(spp_total)
+    assert r.counters()["device_error"] == 0
+    r.close()
+    print(json.dumps({"pmc_child_iterations": iters}), flush=True)
+    return 0
+
+
+def find_rocprof():
+    p = shutil.which("rocprofv3")
+    if p is None and os.path.exists("/opt/rocm/bin/rocprofv3"):
+        p = "/opt/rocm/bin/rocprofv3"
+    return p
+
+
+def run_pmc_passes(args, timeout_s: float = 150.0):
+    """-> {"counters": {name: average per launch of the production extend kernel in the LAST render}, "launches": n} or None"""
+    rocprof = find_rocprof()
+    if rocprof is None:
+        return None
+    out_root = tempfile.mkdtemp(prefix="tyr_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp),
+             "--queue", str(args.queue)] + [x for kv in args.tune for x in ("--tune", kv)]
+    counters, launches = {}, None
+    try:
+        for i, group in enumerate(PMC_PASSES):
+            d = os.path.join(out_root, f"g{i}")
+            cmd = [rocprof, "--pmc", *group, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=out_root, env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
+            if p.returncode != 0:
+                print(f"[bench] rocprofv3 --pmc {' '.join(group)} failed (rc {p.returncode}): {(p.stderr or p.stdout)[-300:]}", file=sys.stderr)
+                return None
+            iters = None
+            for line in p.stdout.splitlines():
+                if line.startswith('{"pmc_child_iterations"'):
+                    iters = json.loads(line)["pmc_child_iterations"]
+            rows = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    rows += [r for r in csv.DictReader(f) if EXTEND_KERNEL in r["Kernel_Name"]]
+            if not rows or not iters:
+                print(f"[bench] rocprofv3 pass {group}: no rows for {EXTEND_KERNEL}", file=sys.stderr)
+                return None
+            for name in group:
+                mine = sorted((r for r in rows if r["Counter_Name"] == name), key=lambda r: int(r["Dispatch_Id"]))
+                if len(mine) < iters:
+                    return None
+                last = mine[-iters:]  # the second (warm) render's launches
+                counters[name] = sum(float(r["Counter_Value"]) for r in last) / len(last)
+                launches = len(last)
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        print(f"[bench] PMC passes abandoned: {e!r}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(out_root, ignore_errors=True)
+    return {"counters": counters, "launches_averaged": launches, "source": "live: rocprofv3 --pmc child passes of this command (" + " | ".join(" ".join(g) for g in PMC_PASSES) + ")"}
+
+
+def committed_pmc(workload: str, N: int):
+    try:
+        with open(os.path.join(ROOT, "profiles", f"pmc_{workload}.json")) as f:
+            j = json.load(f)
+        if j.get("queue_size") == N:
+            return {"counters": j["counters"], "launches_averaged": j.get("launches_averaged"), "source": f"committed: profiles/pmc_{workload}.json ({j.get('source', '')})"}
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_render):
+    """`bound` = the tightest of the measured resource fractions; the algorithmic-bytes figure is a separate entry"""
+    avg_launch_s = ext_ms / max(ext_launches, 1) * 1e-3
+    bytes_per_ext = 24 + 8 + 32 * visits["nodes_per_ext"] + 36 * visits["tris_per_ext"]
+    alg_bytes_per_launch = bytes_per_ext * ext_rays / max(ext_launches, 1)
+    alg_gbs = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    out = {
+        "kernel": f"{EXTEND_KERNEL} (the production extend kernel: quad nodes, persistent grid)",
+        "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+        "launches": ext_launches,
+        "launch_time_source": "hipEvent pairs on the ctx stream around the extend stage (sphere pre-pass of the survivors + the traversal kernel) inside the timed region",
+    }
+    fr = {}
+    if pmc:
+        c = pmc["counters"]
+        hbm_bytes = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0  # KB; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM)
+        traffic = hbm_bytes / avg_launch_s / 1e9
+        cyc = c["GRBM_GUI_ACTIVE"] / NUM_XCD  # the counter sums the XCDs' clocks
+        fr["hbm"] = traffic / HBM_PEAK_GBS
+        fr["valu-issue"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (NUM_SIMD * cyc)  # quad-cycles a SIMD spends issuing vector ALU work
+        fr["salu-issue"] = 4.0 * c["SQ_ACTIVE_INST_SCA"] / (NUM_SIMD * cyc)   # = busy cycles of the CU's one scalar unit (shared by 4 SIMDs)
+        lanes = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        bound = max(fr, key=fr.get)
+        out.update({
+            "bound": bound,
+            "achieved": round(traffic, 2) if bound == "hbm" else round(100.0 * fr[bound], 2),
+            "peak": HBM_PEAK_GBS if bound == "hbm" else 100.0,
+            "unit": "GB/s" if bound == "hbm" else "% of issue cycles (SQ_ACTIVE_INST_* x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))",
+            "frac": round(fr[bound], 4),
+            "traffic": round(traffic, 2),
+            "hbm_counter_frac": round(fr["hbm"], 4),
+            "valu_issue_frac": round(fr["valu-issue"], 4),
+            "salu_issue_frac": round(fr["salu-issue"], 4),
+            "lanes_active_per_valu_inst": round(lanes, 4),
+            "useful_lane_issue_frac": round(fr["valu-issue"] * lanes, 4),
+            "wave_wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAVE_CYCLES") else None,
+            "traffic_detail": {"hbm_bytes_per_launch": round(hbm_bytes), "FETCH_SIZE_KB": round(c["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(c["WRITE_SIZE"], 1), "correction": "FETCH_SIZE x 2 (gfx950), WRITE_SIZE as is"},
+            "pmc_source": pmc["source"],
+            "pmc_launches_averaged": pmc["launches_averaged"],
+        })
+    else:
+        # no counters at all: only the nominal figure exists; it is an HBM fraction only while it stays below 1
+        out.update({"bound": "hbm", "achieved": round(min(alg_gbs, HBM_PEAK_GBS), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(min(alg_gbs / HBM_PEAK_GBS, 1.0), 4), "traffic": None,
+                    "note": "no PMC data (rocprofv3 absent and no committed profile): algorithmic bytes, clamped at the peak"})
+    out["algorithmic"] = {
+        "GBps": round(alg_gbs, 2),
+        "frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
+        "bytes_per_ray": round(bytes_per_ext, 1),
+        "bytes_per_launch": round(alg_bytes_per_launch),
+        "nodes_per_ray": round(visits["nodes_per_ext"], 2),
+        "tris_per_ray": round(visits["tris_per_ext"], 3),
+        "connect_nodes_per_ray": round(visits["nodes_per_con"], 2),
+        "connect_tris_per_ray": round(visits["tris_per_con"], 3),
+        "note": "SURVEY.md 8d: 24 + 8 + 32 B x nodes + 36 B x triangles the REFERENCE's binary tree visits per ray, counted by the counting build (k_extend_flat<true, 12, false, false>, pair nodes) in an untimed render -- not by the timed quad-node kernel; nominal, exceeds the HBM peak when the tree is cache resident",
+    }
+    out["kernel_ms_per_render"] = kernel_ms_per_render
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.pmc_child:
+        sys.exit(pmc_child(args))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    spp_total, N = job_shape(args, world)
+
+    # the counter passes run in child processes BEFORE this process initialises the GPU
+    pmc = None
+    if world == 1 and args.pmc == "auto":
+        pmc = run_pmc_passes(args)
+    if pmc is not None and args.save_pmc:
+        with open(args.save_pmc, "w") as f:
+            json.dump({"workload": args.workload, "resolution": f"{args.width}x{args.height}", "spp": spp_total, "queue_size": N, "kernel": EXTEND_KERNEL, "counters": pmc["counters"],
+                       "launches_averaged": pmc["launches_averaged"], "source": pmc["source"], "units": "per launch of the kernel, averaged over the launches of one warm render; FETCH_SIZE / WRITE_SIZE in KB"}, f, indent=1)
+    if pmc is None and world == 1:
+        pmc = committed_pmc(args.workload, N)
+
+    import numpy as np  # noqa: F401
     import torch
 
     from tyrant_amd import binding, scenes
     from tyrant_amd import dist as tdist
 
-    rank, local_rank, world = tdist.env_rank_world()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 needs `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`")
-        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     if args.backend == "gloo":
         local_rank = 0  # rehearsal: all ranks share device 0
     torch.cuda.set_device(local_rank)
     dist = tdist.init_process_group(args.backend) if world > 1 else None
+    dev = f"cuda:{local_rank}"
+    cdev = "cpu" if args.backend == "gloo" else dev  # where torch's collectives live
 
     W, H = args.width, args.height
-    spp_total = args.spp * world
-    N = args.queue if args.queue > 0 else min(args.spp * W * H, 1 << 25)
     sc, nodes, prims, label, t_build = build_workload(args.workload, binding, scenes)
     flags = binding.TYR_FLAG_PROFILE | (binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0)
     shard = tdist.shard_spec(rank, world, H)
-    # how rank 0 gets the frame: the ranks' own rows by point-to-point gather when that works everywhere, else the sum
-    use_gather = False
-    if world > 1 and args.combine == "gather":
-        use_gather = tdist.agree_gather_works("cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
+    tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune)}
+    native = world > 1 and args.combine_impl == "native" and args.backend == "nccl"
+    mode = binding.TYR_DIST_GATHER if args.combine == "gather" else binding.TYR_DIST_REDUCE
+    use_torch_gather = False
+    if world > 1 and not native and args.combine == "gather":
+        use_torch_gather = tdist.agree_gather_works(cdev)
 
-    def measure(N, steps, warmup):
-        """one renderer at queue size N: untimed counting render, warm-up, `steps` timed renders"""
-        # the caller owns blit_buffer (main.cpp:129-130); here it is a torch tensor so RCCL can reduce it in place
-        accum = torch.zeros(H * W * 4, dtype=torch.float32, device=f"cuda:{local_rank}")
+    def measure(N, steps, warmup, spp, shard, ranks):
+        """one renderer at queue size N: untimed counting render, warm-up, `steps` timed renders (ranks > 1: + the combine)"""
+        # the caller owns blit_buffer (main.cpp:129-130): a torch tensor here (device memory is torch's job in this script)
+        accum = torch.zeros(H * W * 4, dtype=torch.float32, device=dev)
+        frame = torch.zeros(H * W * 4, dtype=torch.float32, device=dev) if (ranks > 1 and rank == 0) else None
         torch.cuda.synchronize()  # the library launches on its own stream
         r = binding.Renderer(W, H, N, device=local_rank, flags=flags, blit_buffer=accum.data_ptr(), **shard)
         r.load_scene(sc, nodes, prims)
         if tune:
             r.set_tuning(**tune)
+        comm = None
+        native_ok = [True]
+        if ranks > 1 and native:
+            # ncclCommInitRank is collective: first agree that every rank can open librccl at all
+            ok, uid = 1, bytes(binding.TYR_DIST_ID_BYTES)
+            try:
+                uid = binding.dist_unique_id()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: tyr_dist_unique_id failed ({e!r})", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native_ok[0] = bool(int(flag.item()))
+            if native_ok[0]:
+                # the 128-byte ncclUniqueId travels over the process group that exists anyway; the communicator itself is the library's
+                idt = torch.tensor(list(uid), dtype=torch.uint8, device=cdev)
+                dist.broadcast(idt, src=0)
+                comm = binding.Dist(r, bytes(idt.cpu().tolist()), rank, world)
 
         def step():
             r.reset_accum()
-            it = r.render(spp_total)
-            if world > 1:
-                combine = (lambda t: tdist.gather_rows(t, H, W, rank, world, dst=0)) if use_gather else (lambda t: tdist.reduce_accum(t, dst=0))
-                if args.backend == "gloo":
-                    host = accum.cpu()
-                    combine(host)
-                    if rank == 0:
-                        accum.copy_(host)
+            it = r.render(spp)
+            if ranks > 1:
+                if comm is not None and native_ok[0]:
+                    # pack on the render stream, ship on the communicator's: the next reset_accum / render overlaps it
+                    comm.combine(frame.data_ptr() if frame is not None else None, mode=mode, root=0)
                 else:
-                    combine(accum)
-                    # the collective is enqueued on torch's stream, the library renders on its own: the next step's
-                    # tyr_reset_accum must not zero the buffer while RCCL still reads it
-                    torch.cuda.current_stream().synchronize()
+                    # (after a failed native check: the sum-reduce, which needs no probing)
+                    combine = (lambda t: tdist.gather_rows(t, H, W, rank, world, dst=0)) if use_torch_gather else (lambda t: tdist.reduce_accum(t, dst=0))
+                    if args.backend == "gloo":
+                        host = accum.cpu()
+                        combine(host)
+                        if rank == 0:
+                            frame.copy_(host)
+                    else:
+                        combine(accum)
+                        torch.cuda.current_stream().synchronize()  # torch's stream: the next tyr_reset_accum must not zero what RCCL still reads
+                        if rank == 0:
+                            frame.copy_(accum)
             return it
 
         def fence():
-            if world > 1:
+            if comm is not None and native_ok[0]:
+                comm.wait()
+            if ranks > 1:
                 dist.barrier()
             torch.cuda.synchronize()
 
-        # untimed: nodes / triangles per ray from the counting build of the same kernels (one render, this rank's shard)
+        # untimed: nodes / triangles per ray and rays entering the tree, from the counting build (one render, this rank's shard)
         rc = binding.Renderer(W, H, N, device=local_rank, flags=flags | binding.TYR_FLAG_COUNT_VISITS, **shard)
         rc.load_scene(sc, nodes, prims)
-        rc.render(spp_total)
+        rc.render(spp)
         kc = rc.counters()
+        ne, ns = max(kc["total_extend_rays"], 1), max(kc["total_shadow_rays"], 1)
         visits = {
-            "nodes_per_ext": kc["nodes_extend"] / max(kc["total_extend_rays"], 1),
-            "tris_per_ext": kc["tris_extend"] / max(kc["total_extend_rays"], 1),
-            "nodes_per_con": kc["nodes_connect"] / max(kc["total_shadow_rays"], 1),
-            "tris_per_con": kc["tris_connect"] / max(kc["total_shadow_rays"], 1),
+            "nodes_per_ext": kc["nodes_extend"] / ne,
+            "tris_per_ext": kc["tris_extend"] / ne,
+            "nodes_per_con": kc["nodes_connect"] / ns,
+            "tris_per_con": kc["tris_connect"] / ns,
+            "in_tree_frac": (kc["rays_in_tree_extend"] + kc["rays_in_tree_connect"]) / (ne + ns),
+            "in_tree_ext_frac": kc["rays_in_tree_extend"] / ne,
         }
         rc.close()
 
+        if comm is not None:
+            # The native exchange has only ever met one GPU per box before the driver's multi-GPU run: check one combined
+            # frame (every pixel must hold exactly spp finished paths) and let ALL ranks fall back to torch.distributed
+            # together if it does not -- a wrong or failing exchange must cost the path, not the measurement.
+            ok = 1
+            try:
+                step()
+                fence()
+                if rank == 0:
+                    a = frame.view(H * W, 4)[:, 3]
+                    ok = int(float(a.min()) == float(a.max()) == float(spp))
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: native combine failed ({e!r})", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native_ok[0] = bool(int(flag.item()))
+            if not native_ok[0] and rank == 0:
+                print("[bench] native combine did not verify: using torch.distributed for the exchange", file=sys.stderr)
         if warmup > 0:
             step()  # cold: the first launches load the code objects and size the persistent grids (~75 ms), not a timing of anything
         r.timings(reset=True)
@@ -168,6 +448,7 @@ def main():
             r.set_tuning(profile_mask=1 << 1)  # TYR_K_EXTEND
         k0 = r.counters()
         r.timings(reset=True)
+        fence()
         t0 = time.perf_counter()
         iters = 0
         for _ in range(steps):
@@ -179,74 +460,67 @@ def main():
         assert k1["device_error"] == 0, k1
         ext = k1["total_extend_rays"] - k0["total_extend_rays"]
         shd = k1["total_shadow_rays"] - k0["total_shadow_rays"]
-        stats = torch.tensor([float(ext), float(shd), dt], dtype=torch.float64, device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
-        if world > 1:
+        stats = torch.tensor([float(ext), float(shd), dt], dtype=torch.float64, device=cdev)
+        if ranks > 1:
             tmax = stats[2:3].clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(stats[0:2], op=dist.ReduceOp.SUM)
             stats[2] = tmax[0]
         ext_all, shd_all, dt_all = (float(x) for x in stats.tolist())
         if rank == 0:
-            # sanity of the reduced frame: every pixel has exactly spp_total completed paths
-            a = accum.view(H * W, 4)[:, 3]
-            assert float(a.min()) == float(a.max()) == float(spp_total), (float(a.min()), float(a.max()), spp_total)
+            # sanity of the combined frame: every pixel has exactly spp completed paths
+            a = (frame if frame is not None else accum).view(H * W, 4)[:, 3]
+            assert float(a.min()) == float(a.max()) == float(spp), (float(a.min()), float(a.max()), spp)
+        native_used = comm is not None and native_ok[0]
+        if comm is not None:
+            comm.close()
+            comm = True if native_used else None  # (only its truth value is reported below)
         r.close()
         per_render = {k: round(v["ms"] / warmup, 3) for k, v in tm_all.items()} if tm_all is not None else {k: round(v["ms"] / steps, 3) for k, v in tm.items()}
-        return {"ext": ext, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, **visits}
+        return {"native_combine": bool(comm is not None and native_ok[0]), "ext": ext, "shd": shd, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, **visits}
 
-    tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune)}
-    m = measure(N, args.steps, args.warmup)
-    ext, ext_all, shd_all, dt_all, iters, tm = m["ext"], m["ext_all"], m["shd_all"], m["dt_all"], m["iters"], m["tm"]
-    nodes_per_ext, tris_per_ext, nodes_per_con, tris_per_con = m["nodes_per_ext"], m["tris_per_ext"], m["nodes_per_con"], m["tris_per_con"]
-    REF_N = 2097152  # variables.h:44
+    m = measure(N, args.steps, args.warmup, spp_total, shard, world)
     mref = None
     if not args.no_reference_queue and N != REF_N:
-        mref = measure(REF_N, max(1, min(args.steps, 2)), 1)
+        mref = measure(REF_N, max(1, min(args.steps, 2)), 1, spp_total, shard, world)
+    # strong scaling: the SAME job (spp_total over the whole frame) on ONE GPU, rank 0 alone; the others wait at the barrier
+    solo = None
+    if world > 1 and args.scaling == "strong" and not args.no_one_gpu_job:
+        if rank == 0:
+            solo = measure(min(spp_total * W * H, 1 << 25), max(1, min(args.steps, 2)), 1, spp_total, tdist.shard_spec(0, 1, H), 1)
+        dist.barrier()
 
     if rank == 0:
-        mrays = (ext_all + shd_all) / dt_all / 1e6
-        # roofline of the dominant kernel (extend), this rank's launches inside the timed region
-        bytes_per_ext = 24 + 8 + 32 * nodes_per_ext + 36 * tris_per_ext
-        ext_ms, ext_launches = tm["extend"]["ms"], max(tm["extend"]["launches"], 1)
-        bytes_per_launch = bytes_per_ext * ext / ext_launches
-        achieved = (bytes_per_launch / (ext_ms / ext_launches * 1e-3)) / 1e9 if ext_ms > 0 else 0.0
-        # HBM bytes per extend launch from rocprofv3 PMC passes of this same command (tools/pmc_traffic.sh); bench.py
-        # cannot run under a profiler itself, so the committed measurement is attached when it matches the run
-        traffic, traffic_detail = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")) as f:
-                tj = json.load(f)
-            if tj["queue_size"] == N and world == 1:
-                # same unit as `achieved`: bytes per launch / average launch duration
-                traffic = round(tj["hbm_bytes_per_launch_corrected"] / (ext_ms / ext_launches * 1e-3) / 1e9, 2)
-                traffic_detail = {"hbm_bytes_per_launch": round(tj["hbm_bytes_per_launch_corrected"]), "algorithmic_bytes_per_launch": round(bytes_per_launch), "source": tj["source"]}
-        except (OSError, KeyError, ValueError):
-            pass
+        mrays = (m["ext_all"] + m["shd_all"]) / m["dt_all"] / 1e6
+        tm = m["tm"]
         out = {
-            "metric": "Mrays/s at 1080p 8spp",
+            "metric": "Mrays/s at 1080p 8spp" if (world == 1 and (W, H, spp_total) == (1920, 1080, 8)) else f"Mrays/s at {W}x{H} {spp_total}spp",
             "value": round(mrays, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt_all / args.steps * 1e3, 3),
+            "ms_per_step": round(m["dt_all"] / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": label,
+                "workload": label + (f"; as BASELINE config C4: {spp_total} spp in total shared by {world} GPUs" if world > 1 and args.scaling == "strong" else ""),
                 "resolution": f"{W}x{H}",
                 "spp_total": spp_total,
-                "spp_per_gpu": args.spp,
                 "queue_size": N,
                 "triangles": int(prims.shape[0]),
                 "bvh_nodes": int(nodes.shape[0]),
-                "sharding": (f"rows y % {world} == rank, " + ("RCCL gather of each rank's rows onto rank 0" if use_gather else "RCCL reduce of the accumulation buffer")) if world > 1 else "none",
-                "wavefront_iterations_per_step": iters / args.steps,
-                "extend_Mrays/s": round(ext_all / dt_all / 1e6, 3),
-                "shadow_Mrays/s": round(shd_all / dt_all / 1e6, 3),
+                "sharding": (f"rows y % {world} == rank; " + (("tyr_dist_combine (RCCL behind the C ABI): " + ("ncclSend/ncclRecv of each rank's packed rows, double-buffered" if args.combine == "gather" else "ncclReduce(sum) of the full buffers"))
+                                                            if m["native_combine"] else ("torch.distributed gather of each rank's rows" if use_torch_gather else "torch.distributed reduce(sum) of the accumulation buffer"))) if world > 1 else "none",
+                "backend": args.backend if world > 1 else None,
+                "wavefront_iterations_per_step": m["iters"] / args.steps,
+                "extend_Mrays/s": round(m["ext_all"] / m["dt_all"] / 1e6, 3),
+                "shadow_Mrays/s": round(m["shd_all"] / m["dt_all"] / 1e6, 3),
+                "in_tree_Mrays/s": round(mrays * m["in_tree_frac"], 3),
+                "in_tree_fraction": {"all_rays": round(m["in_tree_frac"], 4), "extend_rays": round(m["in_tree_ext_frac"], 4), "note": "rays whose test of the root box passes (counting build, rank 0's shard); the others cost one box test"},
                 "host_bvh_build_s": round(t_build, 3),
                 **({"tuning": tune} if tune else {}),
                 **(
@@ -262,27 +536,22 @@ def main():
                     else {}
                 ),
             },
-            "roofline": {
-                "kernel": "extend stage = k_extend_spheres (sphere pre-pass) + k_extend_flat, one hipEvent pair around both",
-                "bound": "hbm",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "traffic_detail": traffic_detail,
-                "algorithmic_bytes_per_ray": round(bytes_per_ext, 1),
-                "nodes_per_ray": round(nodes_per_ext, 2),
-                "tris_per_ray": round(tris_per_ext, 3),
-                "avg_launch_ms": round(ext_ms / ext_launches, 4),
-                "launches": ext_launches,
-                "connect_nodes_per_ray": round(nodes_per_con, 2),
-                "connect_tris_per_ray": round(tris_per_con, 3),
-                "kernel_ms_per_render": m["kernel_ms_per_render"],  # all stages: from the warm-up render(s); inside the timed region only extend is bracketed
-            },
+            "roofline": roofline_block(pmc, tm["extend"]["ms"], tm["extend"]["launches"], m["ext"], m, m["kernel_ms_per_render"]),
         }
+        if solo is not None:
+            nsteps_solo = max(1, min(args.steps, 2))
+            t1, tn = solo["dt_all"] / nsteps_solo, m["dt_all"] / args.steps
+            out["config"]["strong_scaling"] = {
+                "job": f"{spp_total} spp over the whole {W}x{H} frame",
+                "one_gpu_ms": round(t1 * 1e3, 3),
+                "one_gpu_Mrays/s": round((solo["ext_all"] + solo["shd_all"]) / solo["dt_all"] / 1e6, 3),
+                f"{world}_gpu_ms": round(tn * 1e3, 3),
+                "speedup_vs_1gpu": round(t1 / tn, 3),
+                "efficiency_vs_1gpu": round(t1 / tn / world, 4),
+                "note": "rank 0 renders the same job alone after the timed region (same process, same build)",
+            }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, W, H, N, args.cpu_iterations if N <= 4 * REF_N else 2, sc.triangle_materials, spp_total)
+            out["cpu_baseline"] = cpu_baseline(sc, W, H, N, args.cpu_iterations, sc.triangle_materials, spp_total)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -290,8 +559,13 @@ def main():
 
 
 def cpu_baseline(sc, W, H, N, iterations, tri_materials, spp):
-    """the oracle (a serial CPU port of the reference's loop) on the first `iterations` wavefront
-    iterations of the same workload: same scene, resolution, queue size, seeds; 1 core"""
+    """the oracle (a serial CPU port of the reference's loop) on the first `iterations` wavefront iterations of the same
+    workload: same scene, resolution, queue size, seeds; 1 core.  Then ONE ray set -- the queue of the next iteration,
+    bounce rays included -- through the port's traversal and through the reference's own, side by side."""
+    import ctypes
+
+    import numpy as np
+
     from oracle import pyorc
     from tyrant_amd import scenes
 
@@ -312,35 +586,38 @@ def cpu_baseline(sc, W, H, N, iterations, tri_materials, spp):
         "unit": "Mrays/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"first {iterations} wavefront iterations of the same workload ({k['total_extend_rays']} extend + {k['total_shadow_rays']} shadow rays) in {dt:.1f} s",
+        "sample": f"first {iterations} wavefront iterations of the same workload ({k['total_extend_rays']} extend + {k['total_shadow_rays']} shadow rays, all stages) in {dt:.1f} s",
         "bvh_build_s": round(t_build, 3),
         "host_cpus": os.cpu_count(),
     }
-    # The reference's own traversal, where it can be had: oracle/_ref/libref_traverse.so is CachedBVH::intersect
-    # (bvh.h:118-161) compiled from the reference's header in the authoring container (the builder and the kernels
-    # cannot be built there).  Timed on the rays the next iteration would trace, through the same BVH, 1 core.
+    # one common ray set: the first 2 Mi rays of the next iteration's queue, traversal only (no spheres, no shading)
+    o.stage("begin"), o.stage("primary")
+    n = min(o.counters()["n_live"], 1 << 21)
+    q = np.ascontiguousarray(o.ray_queue(0, n))
+    q["distance"] = 1e20  # VERY_FAR, variables.h:13: extend starts every ray there
+    L = pyorc.lib()
+    nd, pr = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
+    qa = q.copy()
+    hit_p = np.zeros(n, dtype=np.int32)
+    t0 = time.perf_counter()
+    L.orc_bvh_intersect_batch(nd.ctypes.data, pr.ctypes.data, qa.ctypes.data, n, hit_p.ctypes.data)
+    dtp = time.perf_counter() - t0
+    hits_port = int(hit_p.sum())
+    trace = {
+        "ray_set": f"the first {n} rays of iteration {iterations + 1}'s queue (survivors of {iterations} bounces in front, fresh primary rays behind), BVH only",
+        "port": {"value": round(n / dtp / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port", "seconds": round(dtp, 2), "hits": int(hits_port), "note": "orc_bvh_intersect_batch (the oracle's restatement of bvh.h:118-161), one call for the batch"},
+    }
     R = pyorc.ref()
     if R is not None:
-        import ctypes
-
-        import numpy as np
-
-        o.stage("begin"), o.stage("primary")
-        n = min(o.counters()["n_live"], 1 << 21)
-        q = np.ascontiguousarray(o.ray_queue(0, n))
-        q["distance"] = 1e20  # VERY_FAR, variables.h:13: extend starts every ray there
+        qb = q.copy()
         hit = np.zeros(n, dtype=np.int32)
-        nd, pr = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
         t0 = time.perf_counter()
-        R.ref_bvh_intersect(nd.ctypes.data_as(ctypes.c_void_p), pr.ctypes.data_as(ctypes.c_void_p), q.ctypes.data_as(ctypes.c_void_p), n, hit.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), None)
+        R.ref_bvh_intersect(nd.ctypes.data_as(ctypes.c_void_p), pr.ctypes.data_as(ctypes.c_void_p), qb.ctypes.data_as(ctypes.c_void_p), n, hit.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), None)
         dtr = time.perf_counter() - t0
-        out["reference_trace"] = {
-            "value": round(n / dtr / 1e6, 4),
-            "unit": "Mrays/s",
-            "cores": 1,
-            "kind": "reference",
-            "sample": f"CachedBVH::intersect of the reference's bvh.h over the first {n} rays of iteration {iterations + 1}'s queue (BVH only, no spheres, no shading) in {dtr:.1f} s; {int(hit.sum())} hits",
-        }
+        same = bool(np.array_equal(qa["distance"].view(np.uint32), qb["distance"].view(np.uint32)))
+        trace["reference"] = {"value": round(n / dtr / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference", "seconds": round(dtr, 2), "hits": int(hit.sum()),
+                              "note": "CachedBVH::intersect of the reference's bvh.h (oracle/_ref/libref_traverse.so), one call for the batch", "distances_bit_identical_to_port": same}
+    out["trace_same_ray_set"] = trace
     return out
 
 

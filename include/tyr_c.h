@@ -216,6 +216,20 @@ int tyr_sync(tyr_ctx* ctx);
 int tyr_queue_export(tyr_ctx* ctx, int which, tyr_ray_queue* host, uint32_t count);
 int tyr_queue_import(tyr_ctx* ctx, const tyr_ray_queue* host, uint32_t n_survivors);
 int tyr_shadow_export(tyr_ctx* ctx, tyr_shadow_queue* host, uint32_t count);
+/* overwrite the shadow queue with `n` records (the input of the next tyr_stage_connect; kernel-level parity tests) */
+int tyr_shadow_import(tyr_ctx* ctx, const tyr_shadow_queue* host, uint32_t n);
+
+/* What tyr_scene_upload made of the tree: sizes of the private device layout against its encoding limits (a quad-node
+ * reference has 25 index bits, a leaf reference 26 offset bits; bvh.h:124's 64-entry stack is checked at run time and
+ * reported through tyr_counters.device_error). */
+typedef struct tyr_scene_info {
+	uint32_t n_prims, n_pair_nodes, n_quad_nodes, n_staged_nodes, n_lights;
+	uint32_t max_quad_nodes;   /* 1 << 25 */
+	uint32_t max_prim_offset;  /* 1 << 26 */
+	uint32_t reserved;
+	uint64_t device_bytes;     /* quad nodes + pair nodes + 48-byte triangles resident in HBM */
+} tyr_scene_info;
+int tyr_get_scene_info(tyr_ctx* ctx, tyr_scene_info* out);
 
 /* ---- measurement ------------------------------------------------------------ */
 enum { TYR_K_PRIMARY = 0, TYR_K_EXTEND = 1, TYR_K_SHADE = 2, TYR_K_CONNECT = 3, TYR_K_RESOLVE = 4, TYR_K_COUNT = 5 };
@@ -274,6 +288,12 @@ int tyr_dist_wait(tyr_dist* d);
  * tyr_dist_row_owner: the rank that owns row y, and that row's index in the owner's packed slab. */
 int tyr_dist_owned_rows(uint32_t height, uint32_t rank, uint32_t nranks, uint32_t* first_row, uint32_t* n_rows);
 int tyr_dist_row_owner(uint32_t y, uint32_t nranks, uint32_t* rank_out, uint32_t* local_row_out);
+/* The two copies tyr_dist_combine puts around the exchange, for a host that moves the slabs itself (all GPUs in one
+ * process with hipMemcpyPeer, its own communicator, ...): pack the rows `rank` owns out of a full-frame buffer into a
+ * contiguous slab (float4[width * height / nranks]); scatter nranks slabs, stored one after the other, into the rows of
+ * a full frame.  Device pointers; asynchronous on `stream` (a hipStream_t; NULL = the default stream). */
+int tyr_dist_pack_rows(const void* frame_device, void* slab_device, uint32_t width, uint32_t height, uint32_t rank, uint32_t nranks, void* stream);
+int tyr_dist_scatter_rows(const void* slabs_device, void* frame_device, uint32_t width, uint32_t height, uint32_t nranks, void* stream);
 
 /* ---- host side of the hot path ---------------------------------------------- */
 

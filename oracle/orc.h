@@ -147,6 +147,7 @@ int orc_bbox_intersect(const orc_bbox* b, const float origin[3], const float inv
 /* closest hit; updates ray->distance / ray->identifier; returns hit flag.
  * counters (may be NULL, else 3 entries): [0] += nodes visited, [1] += triangle tests, [2] += 1 when the root box passed. */
 int orc_bvh_intersect(const orc_node* nodes, const orc_triangle* prims, orc_ray* ray, uint64_t* counters);
+void orc_bvh_intersect_batch(const orc_node* nodes, const orc_triangle* prims, orc_ray* rays, int n, int* hit_out);
 int orc_bvh_intersect_simple(const orc_node* nodes, const orc_triangle* prims, const orc_shadow* ray, float closestAllowed, uint64_t* counters);
 float orc_sphere_intersect(const orc_sphere* s, const float origin[3], const float direction[3]); /* kernel.cu:83-93 */
 

@@ -107,6 +107,12 @@ int orc_bvh_intersect(const orc_node* nodes, const orc_triangle* prims, orc_ray*
 	return hit;
 }
 
+/* the same over a batch of 60-byte RayQueue records, updated in place (bench.py times this beside the reference's own loop) */
+void orc_bvh_intersect_batch(const orc_node* nodes, const orc_triangle* prims, orc_ray* rays, int n, int* hit_out) {
+	for (int i = 0; i < n; ++i)
+		hit_out[i] = orc_bvh_intersect(nodes, prims, &rays[i], NULL);
+}
+
 /* bvh.h:213-256 */
 int orc_bvh_intersect_simple(const orc_node* nodes, const orc_triangle* prims, const orc_shadow* ray, float closestAllowed, uint64_t* counters) {
 	float closestIntersection = closestAllowed;

@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
         L.orc_bbox_intersect.argtypes = [P, fp, fp, C.POINTER(c_i), c_f]
         L.orc_bvh_intersect.restype = c_i
         L.orc_bvh_intersect.argtypes = [P, P, P, C.POINTER(c_u64)]
+        L.orc_bvh_intersect_batch.argtypes = [P, P, P, c_i, P]
         L.orc_bvh_intersect_simple.restype = c_i
         L.orc_bvh_intersect_simple.argtypes = [P, P, P, c_f, C.POINTER(c_u64)]
         L.orc_sphere_intersect.restype = c_f

@@ -1,0 +1,190 @@
+"""BASELINE.json's configurations C4 and C5 and the remaining kernel-level parity holes, on an MI355X (`pytest -m gpu`),
+through the C ABI:
+
+  C4  the 1 M-triangle scene sharded over R = 2 / 4 / 8 ranks at 1080p: every rank's first wavefront (primary, extend,
+      shade) bit-exact against the oracle run with the same (rank, nranks); a full render per rank checked through ray
+      conservation and exact sample counts on the rows the rank owns (and zeros elsewhere).
+  C5  the 10 M-triangle glass + depth-of-field + sun scene at 3840x2160, BVH built by the PRODUCT's builder
+      (tyr_bvh_build, 16 threads): first 2 Mi-slot wavefront against the oracle, the device layout inside its encoding
+      limits (25-bit quad index, 26-bit primitive offset, 64-entry stack), conservation on a 1-spp render.
+  a15 blit_onto_framebuffer (kernel.cu:648-662): tyr_resolve bit-exact against orc_resolve, the 0/0 pixel included.
+  a11 the reference's any-hit answers (tests/golden/ref_traverse_*.npz, CachedBVH::intersectSimple) through the HIP
+      connect kernel.
+  f1  tyr_bvh_build on the GPU box's host: C3's tree, bytes against the oracle's builder.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits, built_scene
+from test_gpu_parity import assert_state_equal
+
+pytestmark = pytest.mark.gpu
+
+W1080, H1080, N2M = 1920, 1080, 2097152
+
+
+def first_wavefront_bit_exact(o, g, tag, min_hit=0.0):
+    for r in (o, g):
+        r.stage("begin"), r.stage("primary")
+    ko, kg = o.counters(), g.counters()
+    assert kg["device_error"] == 0 and ko["n_live"] == kg["n_live"] and ko["start_position"] == kg["start_position"], tag
+    n = ko["n_live"]
+    assert_state_equal(o.ray_queue(0, n), g.ray_queue(0, n), tag + " primary rays")
+    o.stage("extend"), g.stage("extend")
+    qo, qg = o.ray_queue(0, n), g.ray_queue(0, n)
+    assert np.array_equal(bits(qo["distance"]), bits(qg["distance"])), tag + " extend distance"
+    hit = qo["distance"] < 1e20
+    assert hit.mean() >= min_hit, (tag, hit.mean())
+    assert np.array_equal(qo["identifier"][hit], qg["identifier"][hit]) and np.array_equal(qo["geometry_type"][hit], qg["geometry_type"][hit]), tag + " extend identifier"
+    o.stage("shade"), g.stage("shade")
+    ko, kg = o.counters(), g.counters()
+    assert kg["device_error"] == 0 and ko["primary_ray_cnt"] == kg["primary_ray_cnt"] and ko["shadow_ray_cnt"] == kg["shadow_ray_cnt"], tag
+    assert_state_equal(o.ray_queue(1, ko["primary_ray_cnt"]), g.ray_queue(1, kg["primary_ray_cnt"]), tag + " survivors")
+    assert o.shadow_queue(ko["shadow_ray_cnt"]).tobytes() == g.shadow_queue(kg["shadow_ray_cnt"]).tobytes(), tag + " shadow rays"
+    o.stage("connect"), g.stage("connect")
+    assert o.counters()["n_shadow_visible"] == g.counters()["n_shadow_visible"], tag
+    return ko
+
+
+@pytest.mark.parametrize("R,ranks", [(8, (0, 1, 2, 3, 4, 5, 6, 7)), (2, (1,)), (4, (2,))])
+def test_c4_sharded_million_triangle_scene(orc, hip, R, ranks):
+    """BASELINE config C4's workload per rank: mesh706 at 1920x1080, the reference's queue size, rows y % R == rank"""
+    sc, nodes, prims = built_scene("mesh706")
+    spp = 8
+    for rank in ranks:
+        tag = f"C4 rank {rank} of {R}"
+        o = orc.Oracle(W1080, H1080, N2M, rank=rank, nranks=R, flags=1)
+        g = hip.Renderer(W1080, H1080, N2M, rank=rank, nranks=R, flags=1)
+        o.load_scene(sc, nodes, prims), g.load_scene(sc, nodes, prims)
+        first_wavefront_bit_exact(o, g, tag, min_hit=0.2)
+        o.close(), g.close()
+        # a whole render of this rank's shard: conservation, and `a == spp` on owned rows only
+        g = hip.Renderer(W1080, H1080, N2M, rank=rank, nranks=R, flags=1)
+        g.load_scene(sc, nodes, prims)
+        g.render(spp)
+        k = g.counters()
+        local = W1080 * (H1080 // R)
+        assert k["device_error"] == 0 and k["total_primary_rays"] == spp * local, tag
+        assert k["total_extend_rays"] == k["total_primary_rays"] + k["n_survive"], tag
+        b = g.blit_buffer().reshape(H1080, W1080, 4)
+        assert np.all(b[rank::R, :, 3] == spp), tag + ": sample counts on owned rows"
+        mask = np.ones(H1080, dtype=bool)
+        mask[rank::R] = False
+        assert not b[mask].any(), tag + ": something was written outside the rank's rows"
+        assert np.all(np.isfinite(b)) and np.all(b[..., :3] >= 0), tag
+        g.close()
+
+
+def test_c5_ten_million_triangles_4k(orc, hip):
+    """BASELINE config C5's scene and resolution on one GPU; the tree comes from the product's own builder"""
+    from tyrant_amd import scenes
+
+    W, H = 3840, 2160
+    sc = scenes.glass_dof_scene(2236)
+    assert sc.triangles.shape[0] == 9999402 and sc.triangle_materials and sc.camera.lensRadius > 0
+    hip.set_build_threads(16)
+    nodes, prims = hip.bvh_build(sc.triangles)  # tyr_bvh_build: 12.6 M nodes
+    hip.set_build_threads(0)
+    assert nodes.shape[0] > 12_000_000 and int(nodes["primitiveCount"].max()) <= 4
+    g = hip.Renderer(W, H, N2M, flags=1)
+    g.load_scene(sc, nodes, prims)
+    info = g.scene_info()
+    assert info["n_prims"] == 9999402
+    assert 0 < info["n_quad_nodes"] < info["max_quad_nodes"] == 1 << 25, info   # the 25-bit quad index of an interior reference
+    leaves = nodes["primitiveCount"] > 0
+    assert int((nodes["offset"][leaves].astype(np.int64) + nodes["primitiveCount"][leaves]).max()) <= info["max_prim_offset"] == 1 << 26, info  # 26-bit primitive offset
+    assert info["n_pair_nodes"] == int((~leaves).sum())
+    o = orc.Oracle(W, H, N2M, flags=1)
+    o.load_scene(sc, nodes, prims)
+    k = first_wavefront_bit_exact(o, g, "C5 first wavefront", min_hit=0.2)
+    assert k["shadow_ray_cnt"] > 0
+    o.close(), g.close()
+    # a 1-spp render at 4K with a GPU-sized queue: every primary in flight, the drain follows; no stack overflow
+    g = hip.Renderer(W, H, W * H, flags=1)
+    g.load_scene(sc, nodes, prims)
+    g.render(1)
+    k = g.counters()
+    assert k["device_error"] == 0, k  # bit 1 = the 64-entry traversal stack (bvh.h:124) overflowed
+    assert k["total_primary_rays"] == W * H and k["total_extend_rays"] == k["total_primary_rays"] + k["n_survive"]
+    b = g.blit_buffer()
+    assert np.all(b[:, 3] == 1) and np.all(np.isfinite(b)) and np.all(b[:, :3] >= 0)
+
+
+def test_resolve_is_bit_exact(orc, hip):
+    """blit_onto_framebuffer (kernel.cu:648-662): rgb / a -> c / (c + 1) -> pow(1 / 2.2), on the SAME accumulation buffer on
+    both sides (the oracle's, copied into the caller-owned device buffer), pixels without a finished path (0 / 0) included"""
+    import torch
+
+    W, H, N = 96, 64, 2048  # N < W * H: after two iterations most pixels have no finished path yet
+    sc, nodes, prims = built_scene("tyrant_default")
+    o = orc.Oracle(W, H, N)
+    o.load_scene(sc, nodes, prims)
+    for _ in range(3):
+        o.launch_kernels()
+    acc = o.blit_buffer()
+    assert (acc[:, 3] == 0).any() and (acc[:, 3] > 0).any()
+    acc[5] = (0.0, 0.0, 0.0, 2.0)       # finished paths that found nothing: 0 / 2
+    acc[6] = (1e30, 4.0, 1e-30, 1.0)    # c / (c + 1) at both ends of the range
+    expect = np.zeros_like(acc)
+    L = orc.lib()
+    src = np.ascontiguousarray(acc)
+    # the oracle resolves its own buffer: write the edited one back through the pointer it hands out
+    C.memmove(L.orc_blit_buffer(o.h), src.ctypes.data, src.nbytes)
+    L.orc_resolve(o.h, expect.ctypes.data)
+    dev_acc = torch.from_numpy(src.reshape(-1)).cuda()
+    dev_out = torch.zeros(W * H * 4, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    g = hip.Renderer(W, H, N, blit_buffer=dev_acc.data_ptr())
+    g.resolve_into(dev_out.data_ptr())
+    got = dev_out.cpu().numpy().reshape(-1, 4)
+    assert np.array_equal(bits(got), bits(expect)), f"{np.count_nonzero(bits(got) != bits(expect))} components differ"
+    assert np.isnan(got[acc[:, 3] == 0][:, :3]).all()  # 0 / 0, as in the reference
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["cornell36", "soup2k", "mesh32"])
+def test_reference_anyhit_fixture_through_the_connect_kernel(hip, name):
+    """the committed answers of the reference's CachedBVH::intersectSimple (bvh.h:213-256), reproduced by the HIP connect
+    kernel: the fixture's rays go in as ShadowQueue records with colour (1, 1, 1) and one pixel each; a pixel receives
+    its colour exactly when the reference found no occluder"""
+    from tyrant_amd import scenes
+
+    z = np.load(os.path.join(GOLDEN, f"ref_traverse_{name}.npz"))
+    nodes = np.ascontiguousarray(z["nodes"]).view(scenes.NODE_DTYPE).reshape(-1)
+    prims = np.ascontiguousarray(z["prims"]).view(scenes.TRIANGLE_DTYPE).reshape(-1)
+    n = z["origin"].shape[0]
+    W, H = 64, n // 64
+    g = hip.Renderer(W, H, n)
+    g.upload(nodes, prims)
+    s = scenes.cornell_spheres()
+    s["position"] = np.array([0.0, 1e6, -1e6], dtype=np.float32)  # only the BVH answers
+    s["radius"] = 1.0
+    g.set_spheres(s)
+    sh = np.zeros(n, dtype=scenes.SHADOW_DTYPE)
+    sh["origin"], sh["direction"], sh["closestDistance"] = z["origin"], z["direction"], z["closest"]
+    sh["color"] = 1.0
+    sh["buffer_index"] = np.arange(n, dtype=np.int32)
+    g.stage("begin")
+    g.import_shadow_queue(sh)
+    g.stage("connect")
+    k = g.counters()
+    occluded = z["anyhit"].astype(bool)
+    assert k["device_error"] == 0 and k["n_shadow_visible"] == int((~occluded).sum()), name
+    b = g.blit_buffer()
+    assert np.array_equal(b[:, 0] == 1.0, ~occluded) and np.array_equal(b[:, :3].sum(axis=1) == 0.0, occluded), name
+
+
+def test_product_builder_builds_c3_on_this_host(orc, hip):
+    """tyr_bvh_build (task-parallel, 16 threads) on the GPU box's host cores: C3's 996,882 triangles,
+    node and primitive bytes identical to the oracle's restatement of bvh.cpp:3-225 (and to the serial build)"""
+    sc, nodes_o, prims_o = built_scene("mesh706")
+    hip.set_build_threads(16)
+    nodes, prims = hip.bvh_build(sc.triangles)
+    hip.set_build_threads(1)
+    nodes1, prims1 = hip.bvh_build(sc.triangles)
+    hip.set_build_threads(0)
+    assert nodes.tobytes() == nodes_o.tobytes() and prims.tobytes() == prims_o.tobytes()
+    assert nodes1.tobytes() == nodes_o.tobytes() and prims1.tobytes() == prims_o.tobytes()

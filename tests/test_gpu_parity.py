@@ -415,9 +415,10 @@ def test_render_with_and_without_the_deferred_connect(orc, hip, name, W, H, N, s
 
 
 def test_bench_two_ranks_on_one_gpu(hip):
-    """bench.py's N > 1 path end to end on hardware: two ranks (gloo, both on device 0), rows dealt y % 2 == rank,
-    16 spp in total, reduce onto rank 0 -- bench.py itself asserts that every pixel of the reduced frame holds
-    exactly spp_total completed paths"""
+    """bench.py's N > 1 path under an external launcher (the driver's form: torch.distributed.run sets RANK / WORLD_SIZE),
+    weak scaling: two ranks (gloo, both on device 0), rows dealt y % 2 == rank, 2 spp per GPU = 4 in total, sum-reduce onto
+    rank 0 -- bench.py itself asserts that every pixel of the combined frame holds exactly spp_total completed paths.
+    (The self-launching form and strong scaling: tests/test_bench_contract.py.)"""
     import json
     import os
     import subprocess
@@ -432,7 +433,7 @@ def test_bench_two_ranks_on_one_gpu(hip):
         port = sock.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo", "--workload", "c1", "--width", "320", "--height", "180", "--queue", "32768", "--spp", "2"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo", "--workload", "c1", "--width", "320", "--height", "180", "--queue", "32768", "--spp", "2", "--scaling", "weak", "--combine", "reduce", "--no-reference-queue"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]

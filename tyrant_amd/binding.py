@@ -84,6 +84,11 @@ class Counters(C.Structure):
         return d
 
 
+class SceneInfo(C.Structure):
+    _fields_ = [("n_prims", c_u32), ("n_pair_nodes", c_u32), ("n_quad_nodes", c_u32), ("n_staged_nodes", c_u32), ("n_lights", c_u32), ("max_quad_nodes", c_u32), ("max_prim_offset", c_u32),
+                ("reserved", c_u32), ("device_bytes", c_u64)]
+
+
 class Timings(C.Structure):
     _fields_ = [("ms", C.c_double * 5), ("launches", c_u64 * 5)]
 
@@ -118,6 +123,8 @@ SYMBOLS = {
     "tyr_queue_export": (C.c_int, [P, C.c_int, P, c_u32]),
     "tyr_queue_import": (C.c_int, [P, P, c_u32]),
     "tyr_shadow_export": (C.c_int, [P, P, c_u32]),
+    "tyr_shadow_import": (C.c_int, [P, P, c_u32]),
+    "tyr_get_scene_info": (C.c_int, [P, C.POINTER(SceneInfo)]),
     "tyr_get_timings": (C.c_int, [P, C.POINTER(Timings), C.c_int]),
     "tyr_set_tuning": (C.c_int, [P, C.c_int, C.c_int]),
     "tyr_bvh_build": (C.c_int, [P, c_i32, P, P, c_i32]),
@@ -137,6 +144,8 @@ SYMBOLS = {
     "tyr_dist_wait": (C.c_int, [P]),
     "tyr_dist_owned_rows": (C.c_int, [c_u32, c_u32, c_u32, C.POINTER(c_u32), C.POINTER(c_u32)]),
     "tyr_dist_row_owner": (C.c_int, [c_u32, c_u32, C.POINTER(c_u32), C.POINTER(c_u32)]),
+    "tyr_dist_pack_rows": (C.c_int, [P, P, c_u32, c_u32, c_u32, c_u32, P]),
+    "tyr_dist_scatter_rows": (C.c_int, [P, P, c_u32, c_u32, c_u32, P]),
 }
 
 _libs: dict = {}
@@ -339,6 +348,15 @@ class Renderer:
         out = np.zeros(n, dtype=scenes.SHADOW_DTYPE)
         _check(self.L.tyr_shadow_export(self.h, _ptr(out), n), "tyr_shadow_export")
         return out
+
+    def import_shadow_queue(self, rays: np.ndarray):
+        r = np.ascontiguousarray(rays)
+        _check(self.L.tyr_shadow_import(self.h, _ptr(r), r.shape[0]), "tyr_shadow_import")
+
+    def scene_info(self) -> dict:
+        s = SceneInfo()
+        _check(self.L.tyr_get_scene_info(self.h, C.byref(s)), "tyr_get_scene_info")
+        return {k: int(getattr(s, k)) for k, _ in s._fields_}
 
     def import_work_queue(self, rays: np.ndarray, n_survivors: int):
         r = np.ascontiguousarray(rays)

@@ -142,6 +142,23 @@ int tyr_dist_row_owner(uint32_t y, uint32_t nranks, uint32_t* rank_out, uint32_t
 	return TYR_OK;
 }
 
+int tyr_dist_pack_rows(const void* frame_device, void* slab_device, uint32_t width, uint32_t height, uint32_t rank, uint32_t nranks, void* stream) {
+	if (!frame_device || !slab_device || width == 0 || nranks == 0 || rank >= nranks || height == 0 || height % nranks != 0)
+		return TYR_ERR_INVALID;
+	launch_pack_rows(static_cast<const float4*>(frame_device), static_cast<float4*>(slab_device), width, height / nranks, rank, nranks, static_cast<hipStream_t>(stream));
+	HIPCHK(hipGetLastError());
+	return TYR_OK;
+}
+
+int tyr_dist_scatter_rows(const void* slabs_device, void* frame_device, uint32_t width, uint32_t height, uint32_t nranks, void* stream) {
+	if (!slabs_device || !frame_device || width == 0 || nranks == 0 || height == 0 || height % nranks != 0)
+		return TYR_ERR_INVALID;
+	const float4* slabs = static_cast<const float4*>(slabs_device);
+	launch_scatter_rows(slabs, slabs, nranks /* no rank's slab is replaced */, static_cast<float4*>(frame_device), width, height / nranks, nranks, static_cast<hipStream_t>(stream));
+	HIPCHK(hipGetLastError());
+	return TYR_OK;
+}
+
 int tyr_dist_unique_id(void* id_out128) {
 	if (!id_out128)
 		return TYR_ERR_INVALID;

@@ -998,6 +998,51 @@ int tyr_shadow_export(tyr_ctx* c, tyr_shadow_queue* host, uint32_t count) {
 	return TYR_OK;
 }
 
+int tyr_shadow_import(tyr_ctx* c, const tyr_shadow_queue* host, uint32_t n) {
+	if (!c || (!host && n) || n > c->cfg.queue_size)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if ((rc = join_connect(c)) || (rc = sync_counters(c)))
+		return rc;
+	std::vector<float4> a(n), b(n), col(n);
+	for (uint32_t i = 0; i < n; ++i) {
+		const tyr_shadow_queue& s = host[i];
+		float ix;
+		std::memcpy(&ix, &s.buffer_index, 4);
+		a[i] = make_float4(s.origin[0], s.origin[1], s.origin[2], s.direction[0]);
+		b[i] = make_float4(s.direction[1], s.direction[2], s.closestDistance, ix);
+		col[i] = make_float4(s.color[0], s.color[1], s.color[2], 0.0f);
+	}
+	if (n) {
+		HIPCHK(hipMemcpy(c->shadow.o_dx, a.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(c->shadow.dyz_cd_ix, b.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(c->shadow.color, col.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+	}
+	// what shade's last tile writes (kernel.cu:416-417): the count connect reads, in this iteration's set
+	c->hK->shadow_ray_cnt = n;
+	HIPCHK(hipMemcpy(&(c->dKc + (c->iter & 1u))->shadow_cnt, &n, sizeof(uint32_t), hipMemcpyHostToDevice));
+	return push_counters(c);
+}
+
+int tyr_get_scene_info(tyr_ctx* c, tyr_scene_info* out) {
+	if (!c || !out)
+		return TYR_ERR_INVALID;
+	if (!c->haveScene)
+		return TYR_ERR_NO_SCENE;
+	std::memset(out, 0, sizeof *out);
+	out->n_prims = c->scene.nPrims;
+	out->n_pair_nodes = c->scene.nPairs;
+	out->n_quad_nodes = c->scene.nQuads;
+	out->n_staged_nodes = c->scene.nStaged;
+	out->n_lights = c->nLights;
+	out->max_quad_nodes = 1u << kQuadOrderShift;
+	out->max_prim_offset = kMaxPrimOffset;
+	out->device_bytes = static_cast<uint64_t>(c->scene.nQuads) * 128 + static_cast<uint64_t>(c->scene.nPairs) * 64 + static_cast<uint64_t>(c->scene.nPrims) * 48;
+	return TYR_OK;
+}
+
 int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 	if (!c)
 		return TYR_ERR_INVALID;
