@@ -231,6 +231,13 @@ typedef struct tyr_scene_info {
 } tyr_scene_info;
 int tyr_get_scene_info(tyr_ctx* ctx, tyr_scene_info* out);
 
+/* The vector functions every kernel is built from (hip/vecmath.hpp: glm's dot, cross, normalize, length, reflect, min,
+ * max, clamp, mix, smoothstep and the vec3 operators in glm's evaluation order -- Dependencies/glm-0.9.9.3/glm/detail/
+ * func_geometric.inl:14-116, func_common.inl:16-29, 103-111, 257-265, 566 -- plus the deterministic pow / exp), run ON
+ * THE DEVICE over n float3 triples of host arrays a, b, c into host array out (float3 each): the hook that pins the
+ * device arithmetic to the vendored glm's own answers (tests/golden/ref_glm.npz).  op codes: oracle/ref_harness.cpp. */
+int tyr_vecmath_probe(int32_t device, int32_t op, const float* a, const float* b, const float* c, uint32_t n, float* out);
+
 /* ---- measurement ------------------------------------------------------------ */
 enum { TYR_K_PRIMARY = 0, TYR_K_EXTEND = 1, TYR_K_SHADE = 2, TYR_K_CONNECT = 3, TYR_K_RESOLVE = 4, TYR_K_COUNT = 5 };
 typedef struct tyr_timings {

@@ -151,6 +151,10 @@ void orc_bvh_intersect_batch(const orc_node* nodes, const orc_triangle* prims, o
 int orc_bvh_intersect_simple(const orc_node* nodes, const orc_triangle* prims, const orc_shadow* ray, float closestAllowed, uint64_t* counters);
 float orc_sphere_intersect(const orc_sphere* s, const float origin[3], const float direction[3]); /* kernel.cu:83-93 */
 
+void orc_bbox_host_ops(const float* vertices, int n, orc_bbox* bbox_out, float* out2); /* Bbox.h:8-36 */
+/* the v3 helpers of orc_internal.h (glm's evaluation order) over arrays of float3: op codes of oracle/ref_harness.cpp ref_glm */
+int orc_glm(int op, const float* a, const float* b, const float* c, int n, float* out);
+
 /* ---- a5-a7, a12, a15, a16: the wavefront loop ----------------------------- */
 typedef struct orc_ctx orc_ctx;
 

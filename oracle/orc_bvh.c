@@ -64,6 +64,17 @@ static int bbox_largest_extent(const orc_bbox* b) {
 
 /* Scene.cpp:22-33: bbox of the three vertices of a {vert,e1,e2} triangle.
  * Scene::Load has the vertices; from the stored form they are vert, vert+e1, vert+e2. */
+/* the host BBox operations over n vertices (Bbox.h:8-36): bbox_out = the box, out2 = {surfaceArea, largestExtent};
+ * same shape as oracle/ref_harness.cpp ref_bbox_host_ops, which runs the reference's own Bbox.h */
+void orc_bbox_host_ops(const float* vertices, int n, orc_bbox* bbox_out, float* out2) {
+	orc_bbox b = bbox_empty();
+	for (int i = 0; i < n; ++i)
+		bbox_add_vertex(&b, vertices + 3 * i);
+	*bbox_out = b;
+	out2[0] = bbox_surface_area(&b);
+	out2[1] = (float)bbox_largest_extent(&b);
+}
+
 void orc_triangle_bbox(const orc_triangle* t, orc_bbox* out) {
 	float v1[3], v2[3];
 	for (int k = 0; k < 3; ++k) {

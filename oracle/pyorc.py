@@ -151,6 +151,9 @@ def lib() -> C.CDLL:
         for name in ("orc_stage_begin", "orc_stage_primary", "orc_stage_extend", "orc_stage_shade", "orc_stage_connect", "orc_stage_end"):
             getattr(L, name).argtypes = [P]
         L.orc_import_work_queue.argtypes = [P, P, c_u32]
+        L.orc_bbox_host_ops.argtypes = [P, c_i, P, P]
+        L.orc_glm.restype = c_i
+        L.orc_glm.argtypes = [c_i, P, P, P, c_i, P]
         _lib = L
     return _lib
 
@@ -174,6 +177,9 @@ def ref() -> C.CDLL | None:
         R.ref_bbox_host_ops.argtypes = [fp, c_i, P, fp]
         R.ref_bvh_intersect.argtypes = [P, P, P, c_i, C.POINTER(c_i), C.POINTER(c_i)]
         R.ref_bvh_intersect_simple.argtypes = [P, P, P, c_i, C.POINTER(c_i)]
+        if hasattr(R, "ref_glm"):
+            R.ref_glm.restype = c_i
+            R.ref_glm.argtypes = [c_i, P, P, P, c_i, P]
         _ref = R
     return _ref
 

@@ -125,4 +125,47 @@ void ref_bvh_intersect_simple(const void* nodes, const void* prims, void* rays, 
 	}
 }
 
+
+/* ---- the vendored glm itself (Dependencies/glm-0.9.9.3): the vector functions the path calls ------------------
+ * kernel.cu / sunsky.cu / bvh.cpp go through glm::dot, cross, normalize, length, reflect, min, max, clamp, mix,
+ * smoothstep, pow, exp and the vec3 operators; the restatement (oracle/orc_internal.h v3*) and the device code
+ * (hip/vecmath.hpp) re-implement them in glm's evaluation order.  This export runs the REAL glm on arrays so that both
+ * can be pinned to it bit for bit (tests/golden/ref_glm.npz).  n elements; a, b, c are float3 arrays, out is float3.
+ * op: 0 dot  1 cross  2 normalize  3 length  4 reflect  5 min  6 max  7 clamp(a, b.x, b.y)  8 mix(a, b, c.x)
+ *     9 smoothstep(c.x, c.y, a.x)  10 pow(a, b)  11 a / c.x  12 a * c.x  13 c.x * a  14 exp(a)  15 a * b  16 a / b  17 -a
+ *     18 a + b  19 a - b  */
+int ref_glm(int op, const float* a, const float* b, const float* c, int n, float* out) {
+	for (int i = 0; i < n; ++i) {
+		const glm::vec3 A(a[3 * i], a[3 * i + 1], a[3 * i + 2]), B(b[3 * i], b[3 * i + 1], b[3 * i + 2]), Cc(c[3 * i], c[3 * i + 1], c[3 * i + 2]);
+		glm::vec3 r(0.0f);
+		switch (op) {
+		case 0: r.x = glm::dot(A, B); break;
+		case 1: r = glm::cross(A, B); break;
+		case 2: r = glm::normalize(A); break;
+		case 3: r.x = glm::length(A); break;
+		case 4: r = glm::reflect(A, B); break;
+		case 5: r = glm::min(A, B); break;
+		case 6: r = glm::max(A, B); break;
+		case 7: r = glm::clamp(A, B.x, B.y); break;
+		case 8: r = glm::mix(A, B, Cc.x); break;
+		case 9: r.x = glm::smoothstep(Cc.x, Cc.y, A.x); break;
+		case 10: r = glm::pow(A, B); break;
+		case 11: r = A / Cc.x; break;
+		case 12: r = A * Cc.x; break;
+		case 13: r = Cc.x * A; break;
+		case 14: r = glm::exp(A); break;
+		case 15: r = A * B; break;
+		case 16: r = A / B; break;
+		case 17: r = -A; break;
+		case 18: r = A + B; break;
+		case 19: r = A - B; break;
+		default: return -1;
+		}
+		out[3 * i] = r.x;
+		out[3 * i + 1] = r.y;
+		out[3 * i + 2] = r.z;
+	}
+	return 0;
+}
+
 } /* extern "C" */

@@ -25,14 +25,18 @@ if tune:
 r.set_budget(W * H * SPP)
 prev = r.counters()
 print(f"{wl} {'production quad kernel' if production else 'counting build (pair nodes)'} {tune}")
-print(" it      rays | node trips/64 rays  lanes | pop trips  lanes | triangle trips  lanes | refills  lanes")
+print(" it      rays | node trips/64 rays  lanes | pop trips  lanes | triangle trips  lanes | refills  lanes" + (" || descent trips: lanes at a leaf / without a ray / finished, stale pops per trip" if production else ""))
 for it in range(6):
     r.launch_kernels()
     k = r.counters()
-    d = [k["debug"][i] - prev["debug"][i] for i in range(8)]
+    d = [k["debug"][i] - prev["debug"][i] for i in range(16)]
     rays = k["total_extend_rays"] - prev["total_extend_rays"]
     prev = k
     if rays == 0:
         break
     f = lambda i: f"{d[i] / rays * 64:9.2f} {d[i + 1] / max(d[i], 1) / 64 * 100:5.1f}%"  # noqa: E731
-    print(f"{it:3d} {rays:9d} | {f(0)}        | {f(2)} | {f(4)}      | {f(6)}")
+    census = ""
+    if production and d[8]:
+        # TYR_QUAD_STATS: lane states at the top of every descent trip (64 lanes = 100 %)
+        census = f" || {d[9] / d[8] / 64 * 100:5.1f}% {d[10] / d[8] / 64 * 100:5.1f}% {d[11] / d[8] / 64 * 100:5.1f}%  {d[12] / d[8]:5.2f}"
+    print(f"{it:3d} {rays:9d} | {f(0)}        | {f(2)} | {f(4)}      | {f(6)}{census}")

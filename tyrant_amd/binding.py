@@ -125,6 +125,7 @@ SYMBOLS = {
     "tyr_shadow_export": (C.c_int, [P, P, c_u32]),
     "tyr_shadow_import": (C.c_int, [P, P, c_u32]),
     "tyr_get_scene_info": (C.c_int, [P, C.POINTER(SceneInfo)]),
+    "tyr_vecmath_probe": (C.c_int, [c_i32, c_i32, P, P, P, c_u32, P]),
     "tyr_get_timings": (C.c_int, [P, C.POINTER(Timings), C.c_int]),
     "tyr_set_tuning": (C.c_int, [P, C.c_int, C.c_int]),
     "tyr_bvh_build": (C.c_int, [P, c_i32, P, P, c_i32]),
@@ -361,6 +362,14 @@ class Renderer:
     def import_work_queue(self, rays: np.ndarray, n_survivors: int):
         r = np.ascontiguousarray(rays)
         _check(self.L.tyr_queue_import(self.h, _ptr(r), n_survivors), "tyr_queue_import")
+
+
+def vecmath_probe(op: int, a: np.ndarray, b: np.ndarray, c: np.ndarray, device: int = 0) -> np.ndarray:
+    """hip/vecmath.hpp function `op` on the device over float3 arrays (op codes: oracle/ref_harness.cpp ref_glm)"""
+    a, b, c = (np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 3) for x in (a, b, c))
+    out = np.zeros_like(a)
+    _check(lib().tyr_vecmath_probe(device, op, _ptr(a), _ptr(b), _ptr(c), a.shape[0], _ptr(out)), "tyr_vecmath_probe")
+    return out
 
 
 # ---- multi-GPU combine (RCCL behind the C ABI) --------------------------------------------------

@@ -136,6 +136,47 @@ __global__ void __launch_bounds__(kBlock) k_resolve(const float4* __restrict__ b
 		dm::powf_det(1.f / (1.f + 1.f), inv_gamma));
 }
 
+// ======================================================================================
+// tyr_vecmath_probe: hip/vecmath.hpp (and the deterministic pow / exp) evaluated ON THE DEVICE over arrays, so that the
+// functions every kernel is built from can be pinned to the vendored glm's answers (tests/golden/ref_glm.npz).
+// Same op codes as oracle/ref_harness.cpp ref_glm.
+// ======================================================================================
+__global__ void __launch_bounds__(kBlock) k_vecmath_probe(int op, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, uint32_t n, float* __restrict__ out) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n)
+		return;
+	const f3 A = ld3(a + 3 * i), B = ld3(b + 3 * i), Cc = ld3(c + 3 * i);
+	f3 r = mk3(0.f, 0.f, 0.f);
+	switch (op) {
+	case 0: r.x = dot(A, B); break;
+	case 1: r = cross(A, B); break;
+	case 2: r = normalize(A); break;
+	case 3: r.x = length(A); break;
+	case 4: r = reflect(A, B); break;
+	case 5: r = mk3(gmin(A.x, B.x), gmin(A.y, B.y), gmin(A.z, B.z)); break;
+	case 6: r = mk3(gmax(A.x, B.x), gmax(A.y, B.y), gmax(A.z, B.z)); break;
+	case 7: r = mk3(gclamp(A.x, B.x, B.y), gclamp(A.y, B.x, B.y), gclamp(A.z, B.x, B.y)); break;
+	case 8: r = gmix(A, B, Cc.x); break;
+	case 9: r.x = gsmoothstep(Cc.x, Cc.y, A.x); break;
+	case 10: // exponent 0.5 is the path's closed form sqrt (sunsky.hpp: pow(somethingElse * Fex, vec3(0.5)), sunsky.cu:66)
+		r = mk3(B.x == 0.5f ? sqrtf(A.x) : dm::powf_det(A.x, B.x), B.y == 0.5f ? sqrtf(A.y) : dm::powf_det(A.y, B.y), B.z == 0.5f ? sqrtf(A.z) : dm::powf_det(A.z, B.z));
+		break;
+	case 11: r = A / Cc.x; break;
+	case 12: r = A * Cc.x; break;
+	case 13: r = Cc.x * A; break;
+	case 14: r = mk3(dm::expf_det(A.x), dm::expf_det(A.y), dm::expf_det(A.z)); break;
+	case 15: r = A * B; break;
+	case 16: r = A / B; break;
+	case 17: r = -A; break;
+	case 18: r = A + B; break;
+	case 19: r = A - B; break;
+	default: break;
+	}
+	out[3 * i + 0] = r.x;
+	out[3 * i + 1] = r.y;
+	out[3 * i + 2] = r.z;
+}
+
 // ---- launch wrappers ---------------------------------------------------------------------
 
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
@@ -145,6 +186,9 @@ void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
 }
 void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream) {
 	hipLaunchKernelGGL(k_globals, dim3(blocks_for(nDesc ? nDesc : 1)), dim3(kBlock), 0, stream, P, nDesc);
+}
+void launch_vecmath_probe(int op, const float* a, const float* b, const float* c, uint32_t n, float* out, hipStream_t stream) {
+	hipLaunchKernelGGL(k_vecmath_probe, dim3(blocks_for(n ? n : 1)), dim3(kBlock), 0, stream, op, a, b, c, n, out);
 }
 void launch_extend_spheres(const FrameParams& P, uint32_t nSurvivors, hipStream_t stream) {
 	if (nSurvivors != 0)

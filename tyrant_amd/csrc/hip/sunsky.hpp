@@ -73,9 +73,7 @@ __device__ __forceinline__ Atmosphere atmosphere(const SunParams& S, f3 viewDir)
 	f3 sky = somethingElse * mk3(1.0f - Fex.x, 1.0f - Fex.y, 1.0f - Fex.z);
 	// mix(vec3(1), pow(somethingElse * Fex, vec3(0.5)), a) = 1 + a * (y - 1)  (func_common.inl:103-111)
 	const f3 sf = somethingElse * Fex;
-	const float a = S.mixFactor;
-	const f3 m = mk3(1.0f + a * (sqrtf(sf.x) - 1.0f), 1.0f + a * (sqrtf(sf.y) - 1.0f), 1.0f + a * (sqrtf(sf.z) - 1.0f));
-	sky = sky * m;
+	sky = sky * gmix(mk3(1.0f, 1.0f, 1.0f), mk3(sqrtf(sf.x), sqrtf(sf.y), sqrtf(sf.z)), S.mixFactor);
 	return Atmosphere{ cosViewSunAngle, Fex, sky };
 }
 
@@ -95,8 +93,7 @@ __device__ __forceinline__ f3 sky_radiance(const Atmosphere& a) { return (1.f * 
 __device__ __forceinline__ f3 sunsky_radiance(const SunParams& S, const Atmosphere& a) {
 	const float e0 = S.sunAngularDiameterCos;
 	const float e1 = S.sunAngularDiameterCos + 0.00002f;
-	const float t = gclamp((a.cosViewSunAngle - e0) / (e1 - e0), 0.0f, 1.0f); // smoothstep, func_common.inl:257-265
-	const float sundisk = t * t * (3.0f - 2.0f * t);
+	const float sundisk = gsmoothstep(e0, e1, a.cosViewSunAngle);
 	const f3 sun = (((S.sunE * 19000.0f) * a.Fex) * sundisk) * 1E-5f;
 	return 0.01f * (sun + a.sky);
 }

@@ -5,6 +5,10 @@
 //   normalize  func_geometric.inl:88-96    v * (1 / sqrt(dot(v, v)))
 //   reflect    func_geometric.inl:110-116  I - N * dot(N, I) * 2
 //   min / max  func_common.inl:16-29
+//   clamp      func_common.inl:566         min(max(x, lo), hi)
+//   mix        func_common.inl:103-111     x + a * (y - x)
+//   smoothstep func_common.inl:257-265     t = clamp((x - e0) / (e1 - e0), 0, 1); t * t * (3 - 2 * t)
+// Pinned to the vendored glm itself: tests/golden/ref_glm.npz (oracle/ref_harness.cpp ref_glm) through tyr_vecmath_probe.
 // Every operation is one IEEE binary32 op; the library is built with -ffp-contract=off
 // so nothing is fused (DESIGN.md "Numeric contract").
 #pragma once
@@ -45,6 +49,11 @@ TYR_HD f3 reflect(f3 I, f3 N) { return I - N * dot(N, I) * 2.0f; }
 TYR_HD float gmin(float x, float y) { return (y < x) ? y : x; }
 TYR_HD float gmax(float x, float y) { return (x < y) ? y : x; }
 TYR_HD float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+TYR_HD f3 gmix(f3 x, f3 y, float a) { return x + a * (y - x); }
+TYR_HD float gsmoothstep(float edge0, float edge1, float x) {
+	const float t = gclamp((x - edge0) / (edge1 - edge0), 0.0f, 1.0f);
+	return t * t * (3.0f - 2.0f * t);
+}
 
 constexpr float kPi = 3.1415926535897932f; // variables.h:3
 constexpr float kInvPi = 1.0f / kPi;        // variables.h:4

@@ -145,6 +145,7 @@ int tyr_dist_row_owner(uint32_t y, uint32_t nranks, uint32_t* rank_out, uint32_t
 int tyr_dist_pack_rows(const void* frame_device, void* slab_device, uint32_t width, uint32_t height, uint32_t rank, uint32_t nranks, void* stream) {
 	if (!frame_device || !slab_device || width == 0 || nranks == 0 || rank >= nranks || height == 0 || height % nranks != 0)
 		return TYR_ERR_INVALID;
+	(void)hipGetLastError(); // the thread's last-error slot may hold another library's stale code (hipGetLastError reads AND clears)
 	launch_pack_rows(static_cast<const float4*>(frame_device), static_cast<float4*>(slab_device), width, height / nranks, rank, nranks, static_cast<hipStream_t>(stream));
 	HIPCHK(hipGetLastError());
 	return TYR_OK;
@@ -154,6 +155,7 @@ int tyr_dist_scatter_rows(const void* slabs_device, void* frame_device, uint32_t
 	if (!slabs_device || !frame_device || width == 0 || nranks == 0 || height == 0 || height % nranks != 0)
 		return TYR_ERR_INVALID;
 	const float4* slabs = static_cast<const float4*>(slabs_device);
+	(void)hipGetLastError();
 	launch_scatter_rows(slabs, slabs, nranks /* no rank's slab is replaced */, static_cast<float4*>(frame_device), width, height / nranks, nranks, static_cast<hipStream_t>(stream));
 	HIPCHK(hipGetLastError());
 	return TYR_OK;
@@ -247,6 +249,7 @@ int tyr_dist_combine(tyr_dist* d, int32_t mode, int32_t root, void* frame_out_de
 		return TYR_ERR_INVALID;
 	Rccl& R = rccl();
 	HIPCHK(hipSetDevice(c->cfg.device));
+	(void)hipGetLastError(); // start from a clean last-error slot (shared with every other HIP user of this thread)
 	const uint32_t W = c->cfg.width, H = c->cfg.height, rows = c->localRows;
 	float4* frameOut = static_cast<float4*>(frame_out_device);
 

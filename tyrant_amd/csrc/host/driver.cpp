@@ -94,7 +94,13 @@ bool finite_n(const float* p, int n) {
 	return true;
 }
 
-int use_device(tyr_ctx* c) { return static_cast<int>(hipSetDevice(c->cfg.device)); }
+// Every entry point starts here.  Also empties the thread's last-error slot: it is shared with every other HIP user of
+// the thread (a stale code left by another library would otherwise surface at this library's next hipGetLastError check).
+int use_device(tyr_ctx* c) {
+	const hipError_t e = hipSetDevice(c->cfg.device);
+	(void)hipGetLastError();
+	return static_cast<int>(e);
+}
 
 // refresh the pinned host mirror of the device counters; the stream is idle afterwards
 int sync_counters(tyr_ctx* c) {
@@ -1024,6 +1030,35 @@ int tyr_shadow_import(tyr_ctx* c, const tyr_shadow_queue* host, uint32_t n) {
 	c->hK->shadow_ray_cnt = n;
 	HIPCHK(hipMemcpy(&(c->dKc + (c->iter & 1u))->shadow_cnt, &n, sizeof(uint32_t), hipMemcpyHostToDevice));
 	return push_counters(c);
+}
+
+int tyr_vecmath_probe(int32_t device, int32_t op, const float* a, const float* b, const float* c, uint32_t n, float* out) {
+	if (!a || !b || !c || !out || n == 0 || op < 0 || op > 19)
+		return TYR_ERR_INVALID;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+		return TYR_ERR_NO_DEVICE;
+	HIPCHK(hipSetDevice(device));
+	float* d[4] = { nullptr, nullptr, nullptr, nullptr };
+	const size_t bytes = static_cast<size_t>(n) * 3 * sizeof(float);
+	int rc = TYR_OK;
+	for (auto& p : d)
+		if (!rc && hipMalloc(reinterpret_cast<void**>(&p), bytes) != hipSuccess)
+			rc = TYR_ERR_OOM;
+	const float* src[3] = { a, b, c };
+	for (int i = 0; i < 3 && !rc; ++i)
+		if (hipMemcpy(d[i], src[i], bytes, hipMemcpyHostToDevice) != hipSuccess)
+			rc = TYR_ERR_DEVICE;
+	if (!rc) {
+		(void)hipGetLastError();
+		launch_vecmath_probe(op, d[0], d[1], d[2], n, d[3], nullptr);
+		if (hipGetLastError() != hipSuccess || hipMemcpy(out, d[3], bytes, hipMemcpyDeviceToHost) != hipSuccess)
+			rc = TYR_ERR_DEVICE;
+	}
+	for (auto& p : d)
+		if (p)
+			(void)hipFree(p);
+	return rc;
 }
 
 int tyr_get_scene_info(tyr_ctx* c, tyr_scene_info* out) {
