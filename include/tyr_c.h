@@ -102,7 +102,8 @@ enum {
 	TYR_ERR_NO_BUFFER = -4,  /* no blit_buffer bound */
 	TYR_ERR_OOM = -5,
 	TYR_ERR_DEVICE = -6,     /* a kernel reported an internal error (stack overflow, scan timeout) */
-	TYR_ERR_UNSUPPORTED = -7
+	TYR_ERR_UNSUPPORTED = -7,
+	TYR_ERR_IO = -8          /* a file could not be opened, or a write came up short */
 };
 const char* tyr_status_string(int status);
 int tyr_abi_version(void);
@@ -275,8 +276,8 @@ enum {
 	TYR_DIST_GATHER = 0, /* every rank ships only the rows it owns (1/nranks of the frame, ncclSend -> ncclRecv on `root`, point to
 	                      * point = one xGMI link per peer); packed into a double-buffered staging area first, so the blit_buffer is
 	                      * free for the next tyr_reset_accum at once and the exchange leaves the critical path */
-	TYR_DIST_REDUCE = 1  /* ncclReduce(sum) of the full zero-padded accumulation buffers onto `root`: the form north_star names;
-	                      * the next tyr_reset_accum waits for it */
+	TYR_DIST_REDUCE = 1  /* ncclReduce(sum) of the full zero-padded accumulation buffers onto `root`: the form north_star names
+	                      * (every rank ships the whole frame; staged through one copy, so the blit_buffer is free at once too) */
 };
 /* ncclGetUniqueId: one rank calls it and hands the 128 bytes to the others (MPI, a socket, a file, torch.distributed ...) */
 int tyr_dist_unique_id(void* id_out128);

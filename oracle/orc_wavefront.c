@@ -267,7 +267,10 @@ void orc_stage_primary(orc_ctx* c) {
 
 	for (uint32_t index = 0; index < n_new; ++index) {
 		const uint32_t ray_index_buffer = index + cnt;
-		uint32_t seed = (frame * 147565741u) * 720898027u * index;
+		/* kernel.cu:258 seeds by the ticket `index`.  Sharded (nranks > 1, an extension) every rank would draw the SAME
+		 * jitter and lens samples for its index-th ray, i.e. for the pixels (x, yl * R + r), r = 0..R-1: correlated noise in
+		 * groups of R rows.  The ranks' tickets are interleaved instead; nranks == 1 is the reference's expression. */
+		uint32_t seed = (frame * 147565741u) * 720898027u * (index * c->nranks + c->rank);
 
 		const int x = (int)((c->k.start_position + index) % W);
 		const int yl = (int)(((c->k.start_position + index) / W) % Hl);

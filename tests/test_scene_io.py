@@ -139,3 +139,39 @@ def test_image_export(hip, tmp_path):
     big = np.random.default_rng(1).random((40 * 700, 4)).astype(np.float32)
     hip.write_image(str(tmp_path / "b.png"), big, 700, 40)
     assert np.array_equal(decode_png((tmp_path / "b.png").read_bytes()), (np.clip(big[:, :3], 0, 1) * 255.0 + 0.5).astype(np.uint8))
+
+
+def test_hostile_ply_headers_and_write_errors(hip, tmp_path):
+    """tyr_load_ply trusts nothing in the header: counts are bounded by the file size before anything is sized from
+    them, non-finite coordinates / indices / list counts are refused before any integer cast, and no exception leaves
+    the extern "C" boundary; the image writers report a failed open or a short write as TYR_ERR_IO"""
+    head = "ply\nformat ascii 1.0\nelement vertex {nv}\nproperty float x\nproperty float y\nproperty float z\nelement face {nf}\nproperty list uchar int vertex_indices\nend_header\n"
+    body = "0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n"
+    cases = {
+        "huge_vertex_count": head.format(nv=2**62, nf=1) + body,       # would be a 55-exabyte resize
+        "huge_face_count": head.format(nv=3, nf=2**40) + body,
+        "nan_index": head.format(nv=3, nf=1) + "0 0 0\n1 0 0\n0 1 0\n3 0 nan 2\n",
+        "nan_list_count": head.format(nv=3, nf=1) + "0 0 0\n1 0 0\n0 1 0\nnan 0 1 2\n",
+        "inf_coordinate": head.format(nv=3, nf=1) + "0 0 0\ninf 0 0\n0 1 0\n3 0 1 2\n",
+        "index_out_of_range": head.format(nv=3, nf=1) + "0 0 0\n1 0 0\n0 1 0\n3 0 1 3\n",
+        "negative_index": head.format(nv=3, nf=1) + "0 0 0\n1 0 0\n0 1 0\n3 0 -1 2\n",
+        "truncated": head.format(nv=3, nf=1) + "0 0 0\n1 0 0\n",
+    }
+    for name, text in cases.items():
+        p = tmp_path / f"{name}.ply"
+        p.write_text(text)
+        with pytest.raises(hip.TyrError) as e:
+            hip.load_ply(str(p))
+        assert e.value.status in (-1, -5), (name, e.value.status)  # TYR_ERR_INVALID (or OOM), never a crash
+    good = tmp_path / "good.ply"
+    good.write_text(head.format(nv=3, nf=1) + body)
+    assert hip.load_ply(str(good)).shape[0] == 1
+    rgba = np.zeros((4, 4, 4), dtype=np.float32)
+    for ext in ("ppm", "png", "pfm"):
+        with pytest.raises(hip.TyrError) as e:
+            hip.write_image(str(tmp_path / "no_such_dir" / f"x.{ext}"), rgba, 4, 4)
+        assert e.value.status == -8  # TYR_ERR_IO
+    if os.path.exists("/dev/full"):
+        with pytest.raises(hip.TyrError) as e:
+            hip.write_image("/dev/full", np.zeros((256, 256, 4), dtype=np.float32), 256, 256)  # ENOSPC on write / close
+        assert e.value.status == -8

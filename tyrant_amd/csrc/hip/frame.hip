@@ -17,7 +17,9 @@ __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 	if (index >= nNew)
 		return;
 	const uint32_t slot = index + cnt;
-	uint32_t seed = (P.frame * 147565741u) * 720898027u * index; // kernel.cu:258
+	// kernel.cu:258 seeds by the ticket `index`; with pixel sharding (nranks > 1) the ranks' tickets are interleaved so that
+	// rows y = yl * R + r, r = 0..R-1, do not share their jitter and lens samples (nranks == 1: the reference's expression)
+	uint32_t seed = (P.frame * 147565741u) * 720898027u * (index * P.nranks + P.rank);
 
 	const uint32_t start = P.k->start_position;
 	const int x = (int)((start + index) % P.W);

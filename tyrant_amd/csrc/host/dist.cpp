@@ -12,12 +12,17 @@
 //                    stream into one of two staging buffers and shipped on the communicator's own stream, so the
 //                    next render may reset and refill the blit buffer while the exchange is still in flight.
 //
-// librccl is opened with dlopen when the first communicator is made: the render library itself loads and runs on a
-// box without RCCL, and a process that already carries an RCCL (PyTorch's) shares that copy.
+// librccl is opened with dlopen when the first communicator is made, so the render library itself loads and runs on a
+// box without RCCL.  WHICH librccl matters: a process may hold a second HIP runtime (PyTorch's wheels bundle their own
+// libamdhip64 and librccl), and streams, events and allocations of one runtime mean nothing to the other.  The copy
+// opened here is the one that sits next to the libamdhip64 THIS library is linked against (found with dladdr), and RCCL
+// is only ever handed buffers and streams this library made itself: what the caller owns (blit_buffer, frame_out --
+// possibly another runtime's allocations) is touched by this library's own copy kernels alone.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -60,15 +65,19 @@ struct Rccl {
 Rccl& rccl() {
 	static Rccl R; // the dynamic loader's handle: process-wide by nature (function-local static: thread-safe init)
 	static const bool once = [] {
-		// a copy that is already in the process first (PyTorch brings its own), then the system's
-		const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
-		for (const char* n : names)
-			if ((R.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL)))
+		// the librccl beside the HIP runtime this library uses (same ROCm installation, same libamdhip64); by absolute
+		// path, so that a differently built copy already in the process is not picked up by its SONAME
+		std::string dir;
+		Dl_info info;
+		if (dladdr(reinterpret_cast<const void*>(&hipMalloc), &info) && info.dli_fname) {
+			dir = info.dli_fname;
+			const size_t slash = dir.rfind('/');
+			dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+		}
+		const std::string candidates[] = { dir + "librccl.so.1", dir + "librccl.so", "/opt/rocm/lib/librccl.so.1", "librccl.so.1" };
+		for (const std::string& n : candidates)
+			if (!n.empty() && (R.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL)))
 				break;
-		if (!R.handle)
-			for (const char* n : names)
-				if ((R.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
-					break;
 		if (!R.handle)
 			return false;
 		auto sym = [&](const char* s) { return dlsym(R.handle, s); };
@@ -96,6 +105,16 @@ int nccl_status(int rc, const char* what) {
 	return TYR_ERR_DEVICE;
 }
 
+// The first HIP call of a thread into THIS library's runtime must not be a kernel launch (it fails with
+// hipErrorNoDevice when another runtime initialised the GPU): make the runtime current on its device first.
+int ensure_runtime() {
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || hipSetDevice(dev) != hipSuccess)
+		return TYR_ERR_NO_DEVICE;
+	(void)hipGetLastError(); // and start from a clean last-error slot
+	return TYR_OK;
+}
+
 #define HIPCHK(expr)                       \
 	do {                                   \
 		hipError_t e_ = (expr);            \
@@ -112,6 +131,7 @@ struct tyr_dist {
 	hipStream_t commStream = nullptr;
 	float4* staging[2] = { nullptr, nullptr }; // this rank's packed rows, alternating
 	float4* recvSlabs = nullptr;               // root only, allocated on first use: nranks slabs
+	float4* fullStage = nullptr, *fullRecv = nullptr; // reduce mode, allocated on first use: whole frames RCCL may touch
 	hipEvent_t evPacked = nullptr;             // ctx stream: the slab is packed (or, reduce: the render is complete)
 	hipEvent_t evShipped[2] = { nullptr, nullptr }; // comm stream: staging[i] has left (it may be packed again)
 	bool shippedValid[2] = { false, false };
@@ -145,7 +165,8 @@ int tyr_dist_row_owner(uint32_t y, uint32_t nranks, uint32_t* rank_out, uint32_t
 int tyr_dist_pack_rows(const void* frame_device, void* slab_device, uint32_t width, uint32_t height, uint32_t rank, uint32_t nranks, void* stream) {
 	if (!frame_device || !slab_device || width == 0 || nranks == 0 || rank >= nranks || height == 0 || height % nranks != 0)
 		return TYR_ERR_INVALID;
-	(void)hipGetLastError(); // the thread's last-error slot may hold another library's stale code (hipGetLastError reads AND clears)
+	if (int rc = ensure_runtime())
+		return rc;
 	launch_pack_rows(static_cast<const float4*>(frame_device), static_cast<float4*>(slab_device), width, height / nranks, rank, nranks, static_cast<hipStream_t>(stream));
 	HIPCHK(hipGetLastError());
 	return TYR_OK;
@@ -155,7 +176,8 @@ int tyr_dist_scatter_rows(const void* slabs_device, void* frame_device, uint32_t
 	if (!slabs_device || !frame_device || width == 0 || nranks == 0 || height == 0 || height % nranks != 0)
 		return TYR_ERR_INVALID;
 	const float4* slabs = static_cast<const float4*>(slabs_device);
-	(void)hipGetLastError();
+	if (int rc = ensure_runtime())
+		return rc;
 	launch_scatter_rows(slabs, slabs, nranks /* no rank's slab is replaced */, static_cast<float4*>(frame_device), width, height / nranks, nranks, static_cast<hipStream_t>(stream));
 	HIPCHK(hipGetLastError());
 	return TYR_OK;
@@ -227,8 +249,9 @@ int tyr_dist_destroy(tyr_dist* d) {
 	for (auto& s : d->staging)
 		if (s)
 			(void)hipFree(s);
-	if (d->recvSlabs)
-		(void)hipFree(d->recvSlabs);
+	for (float4* p : { d->recvSlabs, d->fullStage, d->fullRecv })
+		if (p)
+			(void)hipFree(p);
 	for (hipEvent_t e : { d->evPacked, d->evDone, d->evShipped[0], d->evShipped[1] })
 		if (e)
 			(void)hipEventDestroy(e);
@@ -254,15 +277,34 @@ int tyr_dist_combine(tyr_dist* d, int32_t mode, int32_t root, void* frame_out_de
 	float4* frameOut = static_cast<float4*>(frame_out_device);
 
 	if (mode == TYR_DIST_REDUCE) {
-		// the sum over ranks IS the frame: ranks own disjoint pixels and every other element of their buffers is zero
-		HIPCHK(hipEventRecord(d->evPacked, c->stream));
+		// the sum over ranks IS the frame: ranks own disjoint pixels and every other element of their buffers is zero.
+		// RCCL works on this library's own copies (see the note on runtimes at the top): blit -> fullStage on the render
+		// stream, ncclReduce fullStage -> fullRecv and fullRecv -> frame_out on the communicator's stream.
+		const size_t pixels = static_cast<size_t>(W) * H;
+		for (float4** p : { &d->fullStage, isRoot ? &d->fullRecv : nullptr }) {
+			if (p && !*p) {
+				void* v = nullptr;
+				if (hipMalloc(&v, pixels * sizeof(float4)) != hipSuccess)
+					return TYR_ERR_OOM;
+				*p = static_cast<float4*>(v);
+			}
+		}
+		if (d->shippedValid[0]) // one staging frame: the previous reduce must have read it
+			HIPCHK(hipStreamWaitEvent(c->stream, d->evShipped[0], 0));
+		launch_pack_rows(c->blit, d->fullStage, W, H, 0u, 1u, c->stream); // nranks = 1: a plain copy of the frame
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(d->evPacked, c->stream)); // from here on the blit buffer is the renderer's again
 		HIPCHK(hipStreamWaitEvent(d->commStream, d->evPacked, 0));
-		const int rc = nccl_status(R.Reduce(c->blit, isRoot ? static_cast<void*>(frameOut) : nullptr, static_cast<size_t>(W) * H * 4, kNcclFloat, kNcclSum, root, d->comm, d->commStream), "ncclReduce");
+		const int rc = nccl_status(R.Reduce(d->fullStage, isRoot ? static_cast<void*>(d->fullRecv) : nullptr, pixels * 4, kNcclFloat, kNcclSum, root, d->comm, d->commStream), "ncclReduce");
 		if (rc)
 			return rc;
+		if (isRoot) {
+			launch_pack_rows(d->fullRecv, frameOut, W, H, 0u, 1u, d->commStream);
+			HIPCHK(hipGetLastError());
+		}
+		HIPCHK(hipEventRecord(d->evShipped[0], d->commStream));
+		d->shippedValid[0] = true;
 		HIPCHK(hipEventRecord(d->evDone, d->commStream));
-		// RCCL reads the blit buffer: whatever the render stream does next (tyr_reset_accum) waits for it
-		HIPCHK(hipStreamWaitEvent(c->stream, d->evDone, 0));
 		return TYR_OK;
 	}
 

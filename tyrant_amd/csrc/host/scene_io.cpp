@@ -104,13 +104,18 @@ extern "C" {
 
 void tyr_free(void* p) { std::free(p); }
 
-int tyr_load_ply(const char* path, tyr_triangle** prims_out) {
-	if (!path || !prims_out)
-		return TYR_ERR_INVALID;
-	*prims_out = nullptr;
+} // extern "C"
+
+namespace {
+
+int load_ply(const char* path, tyr_triangle** prims_out) {
 	std::ifstream in(path, std::ios::binary);
 	if (!in)
 		return TYR_ERR_INVALID;
+	// every count in the header is checked against this before anything is sized from it
+	in.seekg(0, std::ios::end);
+	const uint64_t fileSize = static_cast<uint64_t>(std::max<std::streamoff>(in.tellg(), 0));
+	in.seekg(0, std::ios::beg);
 	std::string line;
 	if (!std::getline(in, line) || strip_annotation(line).rfind("ply", 0) != 0)
 		return TYR_ERR_INVALID;
@@ -136,6 +141,9 @@ int tyr_load_ply(const char* path, tyr_triangle** prims_out) {
 		} else if (kw == "element") {
 			PlyElement e;
 			ls >> e.name >> e.count;
+			// an element instance occupies at least one byte in either format: a larger count is a corrupt (or hostile) header
+			if (!ls || e.count > fileSize)
+				return TYR_ERR_INVALID;
 			elements.push_back(e);
 		} else if (kw == "property" && !elements.empty()) {
 			PlyProperty p;
@@ -211,6 +219,9 @@ int tyr_load_ply(const char* path, tyr_triangle** prims_out) {
 					double v;
 					if (!next_value(e.props[k].type, v))
 						return TYR_ERR_INVALID;
+					const bool coord = static_cast<int>(k) == ix || static_cast<int>(k) == iy || static_cast<int>(k) == iz;
+					if (coord && !std::isfinite(v))
+						return TYR_ERR_INVALID; // non-finite geometry is rejected at upload anyway: say so here
 					if (static_cast<int>(k) == ix)
 						verts[3 * i + 0] = static_cast<float>(v);
 					else if (static_cast<int>(k) == iy)
@@ -231,7 +242,7 @@ int tyr_load_ply(const char* path, tyr_triangle** prims_out) {
 							return TYR_ERR_INVALID;
 						continue;
 					}
-					if (!next_value(p.countType, v) || v < 0 || v > 255)
+					if (!next_value(p.countType, v) || !(v >= 0 && v <= 255)) // (also false for NaN)
 						return TYR_ERR_INVALID;
 					const size_t n = static_cast<size_t>(v);
 					const bool isIndexList = (p.name == "vertex_indices" || p.name == "vertex_index");
@@ -240,7 +251,7 @@ int tyr_load_ply(const char* path, tyr_triangle** prims_out) {
 						if (!next_value(p.type, v))
 							return TYR_ERR_INVALID;
 						if (isIndexList) {
-							if (v < 0 || static_cast<size_t>(v) >= nVerts)
+							if (!(v >= 0 && v < static_cast<double>(nVerts))) // NaN, negative and out-of-range indices end here, before the cast
 								return TYR_ERR_INVALID;
 							idx.push_back(static_cast<uint32_t>(v));
 						}
@@ -269,7 +280,7 @@ int tyr_load_ply(const char* path, tyr_triangle** prims_out) {
 						if (!next_value(p.type, v))
 							return TYR_ERR_INVALID;
 					} else {
-						if (!next_value(p.countType, v) || v < 0)
+						if (!next_value(p.countType, v) || !(v >= 0 && v <= static_cast<double>(fileSize)))
 							return TYR_ERR_INVALID;
 						for (size_t k = 0, n = static_cast<size_t>(v); k < n; ++k)
 							if (!next_value(p.type, v))
@@ -290,13 +301,63 @@ int tyr_load_ply(const char* path, tyr_triangle** prims_out) {
 	return static_cast<int>(tris.size());
 }
 
+// fwrite / fclose results folded into one status: a short write (full disk, closed pipe) is an error, not TYR_OK
+struct OutFile {
+	FILE* fp;
+	bool ok = true;
+	explicit OutFile(const char* path) : fp(std::fopen(path, "wb")) {}
+	void write(const void* p, size_t size, size_t n) { ok = ok && fp && std::fwrite(p, size, n, fp) == n; }
+	int close() {
+		if (!fp)
+			return TYR_ERR_IO;
+		ok = (std::fclose(fp) == 0) && ok;
+		fp = nullptr;
+		return ok ? TYR_OK : TYR_ERR_IO;
+	}
+	~OutFile() {
+		if (fp)
+			std::fclose(fp);
+	}
+};
+
+// nothing may leave an extern "C" function by exception (the caller may be C, or Python through ctypes)
+template <class F>
+int guarded(F&& f) {
+	try {
+		return f();
+	} catch (const std::bad_alloc&) {
+		return TYR_ERR_OOM;
+	} catch (const std::exception&) {
+		return TYR_ERR_INVALID;
+	}
+}
+
+} // namespace
+
+extern "C" {
+
+int tyr_load_ply(const char* path, tyr_triangle** prims_out) {
+	if (!path || !prims_out)
+		return TYR_ERR_INVALID;
+	*prims_out = nullptr;
+	const int n = guarded([&] { return load_ply(path, prims_out); });
+	if (n < 0 && *prims_out) {
+		std::free(*prims_out);
+		*prims_out = nullptr;
+	}
+	return n;
+}
+
 int tyr_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t height) {
 	if (!path || !rgba || width == 0 || height == 0)
 		return TYR_ERR_INVALID;
-	FILE* fp = std::fopen(path, "wb");
-	if (!fp)
-		return TYR_ERR_INVALID;
-	std::fprintf(fp, "P6 %u %u 255\n", width, height);
+	return guarded([&]() -> int {
+	OutFile out(path);
+	if (!out.fp)
+		return TYR_ERR_IO;
+	char head[64];
+	const int hn = std::snprintf(head, sizeof head, "P6 %u %u 255\n", width, height);
+	out.write(head, 1, static_cast<size_t>(hn));
 	std::vector<unsigned char> row(static_cast<size_t>(width) * 3);
 	for (uint32_t y = 0; y < height; ++y) {
 		for (uint32_t x = 0; x < width; ++x) {
@@ -307,10 +368,10 @@ int tyr_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t 
 				row[3 * x + c] = static_cast<unsigned char>(v * 255.0f + 0.5f);
 			}
 		}
-		std::fwrite(row.data(), 1, row.size(), fp);
+		out.write(row.data(), 1, row.size());
 	}
-	std::fclose(fp);
-	return TYR_OK;
+	return out.close();
+	});
 }
 
 // PNG, 8-bit RGB, "stored" deflate blocks (no compression: the file is W*H*3 bytes plus a few per row block), so that the
@@ -338,36 +399,37 @@ void put_be32(std::vector<unsigned char>& v, uint32_t x) {
 	v.push_back(static_cast<unsigned char>(x >> 8));
 	v.push_back(static_cast<unsigned char>(x));
 }
-void write_chunk(FILE* fp, const Crc32& crc, const char type[4], const std::vector<unsigned char>& data) {
+void write_chunk(OutFile& out, const Crc32& crc, const char type[4], const std::vector<unsigned char>& data) {
 	std::vector<unsigned char> head;
 	put_be32(head, static_cast<uint32_t>(data.size()));
-	std::fwrite(head.data(), 1, 4, fp);
-	std::fwrite(type, 1, 4, fp);
+	out.write(head.data(), 1, 4);
+	out.write(type, 1, 4);
 	if (!data.empty())
-		std::fwrite(data.data(), 1, data.size(), fp);
+		out.write(data.data(), 1, data.size());
 	uint32_t c = crc.run(0xFFFFFFFFu, reinterpret_cast<const unsigned char*>(type), 4);
 	c = crc.run(c, data.data(), data.size()) ^ 0xFFFFFFFFu;
 	std::vector<unsigned char> tail;
 	put_be32(tail, c);
-	std::fwrite(tail.data(), 1, 4, fp);
+	out.write(tail.data(), 1, 4);
 }
 } // namespace
 
 int tyr_write_png(const char* path, const float* rgba, uint32_t width, uint32_t height) {
 	if (!path || !rgba || width == 0 || height == 0 || static_cast<uint64_t>(width) * height > (1ull << 28))
 		return TYR_ERR_INVALID;
-	FILE* fp = std::fopen(path, "wb");
-	if (!fp)
-		return TYR_ERR_INVALID;
+	return guarded([&]() -> int {
+	OutFile out(path);
+	if (!out.fp)
+		return TYR_ERR_IO;
 	static const Crc32 crc;
 	static const unsigned char magic[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n' };
-	std::fwrite(magic, 1, 8, fp);
+	out.write(magic, 1, 8);
 	std::vector<unsigned char> ihdr;
 	put_be32(ihdr, width);
 	put_be32(ihdr, height);
 	const unsigned char rest[5] = { 8, 2, 0, 0, 0 }; // 8 bits, colour type 2 (RGB), deflate, adaptive filtering, no interlace
 	ihdr.insert(ihdr.end(), rest, rest + 5);
-	write_chunk(fp, crc, "IHDR", ihdr);
+	write_chunk(out, crc, "IHDR", ihdr);
 	// raw image: per scan line one filter byte (0 = none) + RGB
 	const size_t stride = static_cast<size_t>(width) * 3 + 1;
 	std::vector<unsigned char> raw(stride * height);
@@ -404,28 +466,31 @@ int tyr_write_png(const char* path, const float* rgba, uint32_t width, uint32_t 
 		off += n;
 	}
 	put_be32(z, (b << 16) | a);
-	write_chunk(fp, crc, "IDAT", z);
-	write_chunk(fp, crc, "IEND", {});
-	std::fclose(fp);
-	return TYR_OK;
+	write_chunk(out, crc, "IDAT", z);
+	write_chunk(out, crc, "IEND", {});
+	return out.close();
+	});
 }
 
 int tyr_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height) {
 	if (!path || !rgba || width == 0 || height == 0)
 		return TYR_ERR_INVALID;
-	FILE* fp = std::fopen(path, "wb");
-	if (!fp)
-		return TYR_ERR_INVALID;
-	std::fprintf(fp, "PF\n%u %u\n-1.0\n", width, height); // negative scale = little endian
+	return guarded([&]() -> int {
+	OutFile out(path);
+	if (!out.fp)
+		return TYR_ERR_IO;
+	char head[64];
+	const int hn = std::snprintf(head, sizeof head, "PF\n%u %u\n-1.0\n", width, height); // negative scale = little endian
+	out.write(head, 1, static_cast<size_t>(hn));
 	std::vector<float> row(static_cast<size_t>(width) * 3);
 	for (uint32_t y = height; y-- > 0;) { // PFM rows run bottom to top
 		for (uint32_t x = 0; x < width; ++x)
 			for (int c = 0; c < 3; ++c)
 				row[3 * x + c] = rgba[4 * (static_cast<size_t>(y) * width + x) + c];
-		std::fwrite(row.data(), sizeof(float), row.size(), fp);
+		out.write(row.data(), sizeof(float), row.size());
 	}
-	std::fclose(fp);
-	return TYR_OK;
+	return out.close();
+	});
 }
 
 } // extern "C"
