@@ -69,7 +69,7 @@ Rccl& rccl() {
 		// path, so that a differently built copy already in the process is not picked up by its SONAME
 		std::string dir;
 		Dl_info info;
-		if (dladdr(reinterpret_cast<const void*>(&hipMalloc), &info) && info.dli_fname) {
+		if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
 			dir = info.dli_fname;
 			const size_t slash = dir.rfind('/');
 			dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
