@@ -64,7 +64,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 NUM_XCD, NUM_SIMD, NUM_CU = 8, 1024, 256  # MI355X: 8 XCDs x 32 CUs x 4 SIMDs
 REF_N = 2097152  # variables.h:44
-EXTEND_KERNEL = "k_extend_flat<false, 12, true, true>"
+TRACE_KERNEL = "k_trace_flat<12>"  # extend(i + 1) + connect(i) in one launch (the default, TYR_TUNE_MERGE_TRACE)
+EXTEND_KERNEL = "k_extend_flat<false, 12, true, true>"  # --tune merge_trace=0
+
+
+def dominant_kernel(tune_args) -> str:
+    return EXTEND_KERNEL if "merge_trace=0" in tune_args else TRACE_KERNEL
 PMC_PASSES = (
     ("FETCH_SIZE",),
     ("WRITE_SIZE",),
@@ -188,6 +193,7 @@ def run_pmc_passes(args, timeout_s: float = 150.0):
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp),
              "--queue", str(args.queue)] + [x for kv in args.tune for x in ("--tune", kv)]
     counters, launches = {}, None
+    kernel = dominant_kernel(args.tune)
     try:
         for i, group in enumerate(PMC_PASSES):
             d = os.path.join(out_root, f"g{i}")
@@ -203,9 +209,9 @@ def run_pmc_passes(args, timeout_s: float = 150.0):
             rows = []
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
-                    rows += [r for r in csv.DictReader(f) if EXTEND_KERNEL in r["Kernel_Name"]]
+                    rows += [r for r in csv.DictReader(f) if kernel in r["Kernel_Name"]]
             if not rows or not iters:
-                print(f"[bench] rocprofv3 pass {group}: no rows for {EXTEND_KERNEL}", file=sys.stderr)
+                print(f"[bench] rocprofv3 pass {group}: no rows for {kernel}", file=sys.stderr)
                 return None
             for name in group:
                 mine = sorted((r for r in rows if r["Counter_Name"] == name), key=lambda r: int(r["Dispatch_Id"]))
@@ -219,7 +225,7 @@ def run_pmc_passes(args, timeout_s: float = 150.0):
         return None
     finally:
         shutil.rmtree(out_root, ignore_errors=True)
-    return {"counters": counters, "launches_averaged": launches, "source": "live: rocprofv3 --pmc child passes of this command (" + " | ".join(" ".join(g) for g in PMC_PASSES) + ")"}
+    return {"counters": counters, "launches_averaged": launches, "kernel": kernel, "source": "live: rocprofv3 --pmc child passes of this command (" + " | ".join(" ".join(g) for g in PMC_PASSES) + ")"}
 
 
 def committed_pmc(workload: str, N: int):
@@ -227,23 +233,34 @@ def committed_pmc(workload: str, N: int):
         with open(os.path.join(ROOT, "profiles", f"pmc_{workload}.json")) as f:
             j = json.load(f)
         if j.get("queue_size") == N:
-            return {"counters": j["counters"], "launches_averaged": j.get("launches_averaged"), "source": f"committed: profiles/pmc_{workload}.json ({j.get('source', '')})"}
+            return {"counters": j["counters"], "launches_averaged": j.get("launches_averaged"), "kernel": j.get("kernel"), "source": f"committed: profiles/pmc_{workload}.json ({j.get('source', '')})"}
     except (OSError, KeyError, ValueError):
         pass
     return None
 
 
-def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_render):
-    """`bound` = the tightest of the measured resource fractions; the algorithmic-bytes figure is a separate entry"""
+def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_render, kernel=EXTEND_KERNEL, con_ms=0.0, shadow_rays=0.0):
+    """`bound` = the tightest of the measured resource fractions of the dominant kernel; the algorithmic-bytes figure of
+    SURVEY.md 8d is a separate entry.  Merged launches (kernel = TRACE_KERNEL): the kernel traces this iteration's extend
+    rays and the previous iteration's shadow rays; ext_ms is the time of those launches, con_ms that of the connect launch
+    the last iteration's shadow rays get; the algorithmic figure then covers the whole traversal stage (all extend + all
+    shadow rays over ext_ms + con_ms)."""
     avg_launch_s = ext_ms / max(ext_launches, 1) * 1e-3
     bytes_per_ext = 24 + 8 + 32 * visits["nodes_per_ext"] + 36 * visits["tris_per_ext"]
-    alg_bytes_per_launch = bytes_per_ext * ext_rays / max(ext_launches, 1)
-    alg_gbs = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    merged = kernel == TRACE_KERNEL
+    if merged:
+        bytes_per_con = 44 + 32 * visits["nodes_per_con"] + 36 * visits["tris_per_con"] + 12 * visits.get("visible_frac", 0.0)
+        alg_total = bytes_per_ext * ext_rays + bytes_per_con * shadow_rays
+        alg_gbs = alg_total / ((ext_ms + con_ms) * 1e-3) / 1e9 if ext_ms + con_ms > 0 else 0.0
+        alg_bytes_per_launch = alg_total / max(ext_launches, 1)
+    else:
+        alg_bytes_per_launch = bytes_per_ext * ext_rays / max(ext_launches, 1)
+        alg_gbs = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     out = {
-        "kernel": f"{EXTEND_KERNEL} (the production extend kernel: quad nodes, persistent grid)",
+        "kernel": f"{kernel} " + ("(extend of an iteration + connect of the one before in one persistent launch: quad nodes, closest- and any-hit rays side by side)" if merged else "(the production extend kernel: quad nodes, persistent grid)"),
         "avg_launch_ms": round(avg_launch_s * 1e3, 4),
         "launches": ext_launches,
-        "launch_time_source": "hipEvent pairs on the ctx stream around the extend stage (sphere pre-pass of the survivors + the traversal kernel) inside the timed region",
+        "launch_time_source": "hipEvent pairs on the ctx stream around the stage (sphere pre-passes + the traversal kernel) inside the timed region",
     }
     fr = {}
     if pmc:
@@ -280,13 +297,14 @@ def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_re
     out["algorithmic"] = {
         "GBps": round(alg_gbs, 2),
         "frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
-        "bytes_per_ray": round(bytes_per_ext, 1),
+        "bytes_per_extend_ray": round(bytes_per_ext, 1),
         "bytes_per_launch": round(alg_bytes_per_launch),
+        "covers": "every extend and every shadow ray of the timed renders over the time of the trace launches + the last iteration's connect launch" if merged else "the extend launches",
         "nodes_per_ray": round(visits["nodes_per_ext"], 2),
         "tris_per_ray": round(visits["tris_per_ext"], 3),
         "connect_nodes_per_ray": round(visits["nodes_per_con"], 2),
         "connect_tris_per_ray": round(visits["tris_per_con"], 3),
-        "note": "SURVEY.md 8d: 24 + 8 + 32 B x nodes + 36 B x triangles the REFERENCE's binary tree visits per ray, counted by the counting build (k_extend_flat<true, 12, false, false>, pair nodes) in an untimed render -- not by the timed quad-node kernel; nominal, exceeds the HBM peak when the tree is cache resident",
+        "note": "SURVEY.md 8d: 24 + 8 + 32 B x nodes + 36 B x triangles the REFERENCE's binary tree visits per extend ray (44 + 32 x nodes + 36 x triangles + 12 x p_visible per shadow ray), counted by the counting build (k_extend_flat / k_connect_flat<true, 12, false, false>, pair nodes) in an untimed render -- not by the timed quad-node kernel; nominal, exceeds the HBM peak when the tree is cache resident",
     }
     out["kernel_ms_per_render"] = kernel_ms_per_render
     return out
@@ -310,7 +328,7 @@ def main():
         pmc = run_pmc_passes(args)
     if pmc is not None and args.save_pmc:
         with open(args.save_pmc, "w") as f:
-            json.dump({"workload": args.workload, "resolution": f"{args.width}x{args.height}", "spp": spp_total, "queue_size": N, "kernel": EXTEND_KERNEL, "counters": pmc["counters"],
+            json.dump({"workload": args.workload, "resolution": f"{args.width}x{args.height}", "spp": spp_total, "queue_size": N, "kernel": pmc["kernel"], "counters": pmc["counters"],
                        "launches_averaged": pmc["launches_averaged"], "source": pmc["source"], "units": "per launch of the kernel, averaged over the launches of one warm render; FETCH_SIZE / WRITE_SIZE in KB"}, f, indent=1)
     if pmc is None and world == 1:
         pmc = committed_pmc(args.workload, N)
@@ -410,6 +428,7 @@ def main():
             "tris_per_ext": kc["tris_extend"] / ne,
             "nodes_per_con": kc["nodes_connect"] / ns,
             "tris_per_con": kc["tris_connect"] / ns,
+            "visible_frac": kc["n_shadow_visible"] / ns,
             "in_tree_frac": (kc["rays_in_tree_extend"] + kc["rays_in_tree_connect"]) / (ne + ns),
             "in_tree_ext_frac": kc["rays_in_tree_extend"] / ne,
         }
@@ -445,7 +464,7 @@ def main():
         # the pair the roofline needs, around the extend stage.
         tm_all = r.timings() if warmup > 0 else None
         if tm_all is not None:
-            r.set_tuning(profile_mask=1 << 1)  # TYR_K_EXTEND
+            r.set_tuning(profile_mask=(1 << 1) | (1 << 3))  # TYR_K_EXTEND (the trace launches) + TYR_K_CONNECT (merged renders: one launch per render)
         k0 = r.counters()
         r.timings(reset=True)
         fence()
@@ -536,7 +555,7 @@ def main():
                     else {}
                 ),
             },
-            "roofline": roofline_block(pmc, tm["extend"]["ms"], tm["extend"]["launches"], m["ext"], m, m["kernel_ms_per_render"]),
+            "roofline": roofline_block(pmc, tm["extend"]["ms"], tm["extend"]["launches"], m["ext"], m, m["kernel_ms_per_render"], kernel=dominant_kernel(args.tune), con_ms=tm["connect"]["ms"], shadow_rays=m["shd"]),
         }
         if solo is not None:
             nsteps_solo = max(1, min(args.steps, 2))

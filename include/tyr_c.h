@@ -250,7 +250,7 @@ int tyr_get_timings(tyr_ctx* ctx, tyr_timings* out, int reset);
 /* Launch-shape knobs of the two traversal kernels (the reference's equivalents are the literals
  * `sm_cores * 8, 128` at kernel.cu:719-726).  They never change results. */
 enum {
-	TYR_TUNE_TRAVERSAL_VARIANT = 0, /* 0 = one thread per queue slot; 1 = persistent waves, finished lanes take new rays; 2 = 1 as a flat per-lane state machine; 3 = 2 on 128-byte quad nodes, each block owning a range of queue slots; 4 = 3 as a persistent grid whose waves draw chunks of slots from eight tickets (the counting build always uses 2) */
+	TYR_TUNE_TRAVERSAL_VARIANT = 0, /* 0 = one thread per queue slot; 1 = persistent waves, finished lanes take new rays; 2 = 1 as a flat per-lane state machine; 3 = 2 on 128-byte quad nodes, each block owning a range of queue slots; 4 = 3 as a persistent grid whose waves draw chunks of slots from eight tickets; 5 = 4 with the refill off the critical path: every wave keeps a ring of prepared rays in LDS, topped up at full occupancy behind the leaf phases, and a lane that finishes takes the next one inside the descent loop -- measured and rejected, DESIGN.md 4.4 (the counting build always uses 2; libtyrant_hip.so has 4 only, the diagnostics build all) */
 	TYR_TUNE_REFILL_MIN_IDLE = 1,   /* variants 1-4: refill a wave when at least this many of its 64 lanes are free (1..64, default 16) */
 	TYR_TUNE_WAVES_PER_SIMD = 2,    /* variants 1 and 4 (persistent grids): resident 256-thread blocks per CU = waves per SIMD; 0 (default) = the occupancy query's answer */
 	TYR_TUNE_STACK_LDS_DEPTH = 3,   /* traversal-stack entries per lane held in LDS: 0, 8, 10, 12 (default), 16 or 24; deeper entries spill to scratch */
@@ -261,6 +261,7 @@ enum {
 	TYR_TUNE_STAGED_NODES = 9,      /* variant 4: top-of-tree quad nodes each block keeps in LDS (0..64, default 64) */
 	TYR_TUNE_OVERLAP_CONNECT = 10,  /* tyr_render: connect(i) on a second stream while the first already does primary / extend of iteration i + 1 (shade(i + 1) waits for it): 0 = never (one stream, kernel after kernel), 1 = always, 2 (default) = when queue_size is at most 6 Mi slots, where ramp and tail dominate a launch and the neighbour fills them; fixed per-block ranges are switched off beside a running connect.  tyr_launch_kernels is always one stream. */
 	TYR_TUNE_PROFILE_MASK = 11,     /* with TYR_FLAG_PROFILE: bit TYR_K_* set = that stage is bracketed by a hipEvent pair (default 31 = all five).  An event between two kernels costs ~10 us of idle GPU, ~2 % of a 1080p render with all of them on. */
+	TYR_TUNE_MERGE_TRACE = 12,      /* tyr_render: 1 (default) = connect(i) shares the launch of extend(i + 1) -- both only depend on shade(i), and every traversal launch ends in a latency-bound drain as long as its longest ray (40-60 % of a launch at 1080p): one drain per iteration instead of two; the last iteration's shadow rays get a launch of their own.  0 = separate launches (with TYR_TUNE_OVERLAP_CONNECT deciding the stream).  Ignored by the counting build and by variants other than 4.  tyr_launch_kernels is always extend, shade, connect, done when it returns. */
 	TYR_TUNE_RAYS_PER_BLOCK = 6     /* variants 2/3: queue slots owned by one 256-thread block and handed to its free lanes through LDS (256..65536, default 1024; halved automatically for thin queues) */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);

@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
         L.orc_render.restype = c_i
         L.orc_render.argtypes = [P, c_u32, c_i]
         L.orc_reset_accum.argtypes = [P]
+        L.orc_reset_accum.argtypes = [P]
         L.orc_get_counters.argtypes = [P, C.POINTER(Counters)]
         L.orc_blit_buffer.restype = P
         L.orc_blit_buffer.argtypes = [P]
@@ -293,6 +294,9 @@ class Oracle:
 
     def render(self, spp, max_iterations=1 << 30):
         return self.L.orc_render(self.h, spp, max_iterations)
+
+    def reset_accum(self):
+        self.L.orc_reset_accum(self.h)
 
     def stage(self, name):
         getattr(self.L, "orc_stage_" + name)(self.h)

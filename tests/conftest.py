@@ -14,6 +14,16 @@ import sys
 import numpy as np
 import pytest
 
+# PyTorch's wheels bundle their own HIP runtime (libamdhip64.so + ROCr, loaded into the global symbol scope); the product
+# library links the ROCm installation's.  A process must end up with ONE of them: when PyTorch is imported first, the
+# library's HIP calls bind to PyTorch's copy (what bench.py has always done); loaded the other way round, the process
+# holds two runtimes and the second one to initialise finds no device.  The GPU tests that use torch for device memory
+# therefore import it here, before any fixture loads the library (tyrant_amd/binding.py lib()).
+try:
+    import torch  # noqa: F401
+except ImportError:  # the library alone: one runtime anyway
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -132,7 +132,7 @@ def test_reference_traversal_fixture_through_the_abi(orc, hip):
         assert np.array_equal(q["identifier"][hit], z["identifier"][hit]), name
 
 
-@pytest.mark.parametrize("variant", [4, 3, 2, 0])
+@pytest.mark.parametrize("variant", [5, 4, 3, 2, 0])
 def test_axis_aligned_rays_and_long_leaves(orc, hip, variant):
     """rays with zero direction components (1/d infinite: the generic box test, not the packed one) through a scene
     whose leaves are longer than the device layout's inline limit (the quad layout's chains of -inf..+inf boxes) and
@@ -338,7 +338,7 @@ def test_cpp_host_api_example(hip):
     assert os.path.getsize(out) > 640 * 360 * 3
 
 
-@pytest.mark.parametrize("variant,lds", [(0, 0), (0, 8), (1, 0), (1, 16), (2, 12), (2, 0), (3, 12), (3, 0), (3, 24), (4, 12), (4, 0), (4, 8)])
+@pytest.mark.parametrize("variant,lds", [(0, 0), (0, 8), (1, 0), (1, 16), (2, 12), (2, 0), (3, 12), (3, 0), (3, 24), (4, 12), (4, 0), (4, 8), (5, 12)])
 def test_every_traversal_variant_is_bit_exact(orc, hip, variant, lds):
     """launch shape / node layout / stack placement never change results: each traversal variant reproduces
     the oracle's queues bit for bit over several iterations (bounce rays included)"""
@@ -363,13 +363,15 @@ def test_every_traversal_variant_is_bit_exact(orc, hip, variant, lds):
     dict(static_share=0, ticket_chunk=64), dict(static_share=15, ticket_chunk=4096), dict(static_share=8, ticket_chunk=256, staged_nodes=0),
     dict(staged_nodes=1), dict(staged_nodes=21, stack_lds_depth=10), dict(refill_min_idle=1, min_traversing=1), dict(refill_min_idle=64, min_traversing=64, min_leaves=1),
     dict(traversal_variant=3, rays_per_block=256), dict(traversal_variant=3, rays_per_block=65536),
+    dict(traversal_variant=5), dict(traversal_variant=5, static_share=0, ticket_chunk=64, min_traversing=1), dict(traversal_variant=5, static_share=15, ticket_chunk=4096, min_traversing=64),
+    dict(traversal_variant=5, staged_nodes=0, min_traversing=16),
 ])
 def test_work_distribution_knobs_never_change_results(orc, hip, knobs):
     """every launch-shape knob of tyr_set_tuning -- how queue slots reach the waves, how much of the tree sits in LDS,
     when the descent loop is left -- at its extremes: queues stay bit-identical to the oracle's, on a scene whose
     tree is deeper than the LDS stack and on a queue that is not a multiple of anything"""
     for name, W, H, N in (("mesh128", 72, 40, 2999), ("cornell_soup2k", 50, 30, 777)):
-        o, g = pair(orc, hip, name, W, H, N, diag="traversal_variant" in knobs or "stack_lds_depth" in knobs)
+        o, g = pair(orc, hip, name, W, H, N, diag=knobs.get("traversal_variant", 4) != 4 or "stack_lds_depth" in knobs)
         g.set_tuning(**knobs)
         for it in range(3):
             o.launch_kernels(), g.launch_kernels()
@@ -391,27 +393,36 @@ def test_render_with_and_without_the_deferred_connect(orc, hip, name, W, H, N, s
     nothing may be in flight) and a second render back to back"""
     o, g1 = pair(orc, hip, name, W, H, N)
     _, g0 = pair(orc, hip, name, W, H, N)
-    g0.set_tuning(overlap_connect=0)
-    g1.set_tuning(overlap_connect=1)
+    _, g2 = pair(orc, hip, name, W, H, N)
+    g0.set_tuning(overlap_connect=0, merge_trace=0)
+    g1.set_tuning(overlap_connect=1, merge_trace=0)
+    g2.set_tuning(merge_trace=1)  # (the default) connect(i) inside the launch of extend(i + 1): k_trace_flat
     from tyrant_amd import scenes
 
     sc, _, _ = built_scene(name)
     moved = scenes.Camera(position=tuple(np.array(sc.camera.position) + np.array([3.0, 2.0, -1.0])), direction=sc.camera.direction, up=sc.camera.up)
     for cam in (sc.camera, moved):
-        for r in (o, g0, g1):
+        for r in (o, g0, g1, g2):
             r.set_camera(cam)
-        io, i0, i1 = o.render(spp), g0.render(spp), g1.render(spp)
-        assert io == i0 == i1
-        ko, k0, k1 = o.counters(), g0.counters(), g1.counters()
-        assert k0["device_error"] == 0 and k1["device_error"] == 0
+        io, i0, i1, i2 = o.render(spp), g0.render(spp), g1.render(spp), g2.render(spp)
+        assert io == i0 == i1 == i2
+        ko, k0, k1, k2 = o.counters(), g0.counters(), g1.counters(), g2.counters()
+        assert k0["device_error"] == 0 and k1["device_error"] == 0 and k2["device_error"] == 0
         for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible", "start_position", "frame"):
-            assert ko[f] == k0[f] == k1[f], (name, f)
+            assert ko[f] == k0[f] == k1[f] == k2[f], (name, f)
         assert_accum_close(o.blit_buffer(), g0.blit_buffer(), name + " one stream")
         assert_accum_close(o.blit_buffer(), g1.blit_buffer(), name + " deferred connect")
-    # stage by stage right after a render with deferred connects: nothing is left in flight
+        assert_accum_close(o.blit_buffer(), g2.blit_buffer(), name + " merged trace launches")
+    # stage by stage right after a render with deferred / merged connects: nothing is left in flight or owed
     for st in ("begin", "primary", "extend", "shade", "connect", "end"):
-        o.stage(st), g1.stage(st)
+        o.stage(st), g1.stage(st), g2.stage(st)
     assert_accum_close(o.blit_buffer(), g1.blit_buffer(), name + " staged iteration after the render")
+    assert_accum_close(o.blit_buffer(), g2.blit_buffer(), name + " staged iteration after the merged render")
+    # a render cut short by max_iterations still settles its last shadow rays before it returns
+    o.reset_accum(), g2.reset_accum()
+    assert o.render(spp, 2) == g2.render(spp, 2) == 2
+    assert o.counters()["n_shadow_visible"] == g2.counters()["n_shadow_visible"]
+    assert_accum_close(o.blit_buffer(), g2.blit_buffer(), name + " two iterations of a merged render")
 
 
 def test_bench_two_ranks_on_one_gpu(hip):
@@ -439,3 +450,41 @@ def test_bench_two_ranks_on_one_gpu(hip):
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["spp_total"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+
+
+def test_feed_variant_at_full_size(orc, hip):
+    """traversal variant 5 (rings of prepared rays, refill inside the descent loop) on BASELINE config C3 at 1080p: the first
+    wavefront's queues bit-exact against the oracle, and a whole GPU-sized render with exactly the ray totals of variant 4
+    (which ray a lane traces never changes an answer: every result goes to its own slot)"""
+    W, H, N = 1920, 1080, 2097152
+    sc, nodes, prims = built_scene("mesh706")
+    o = orc.Oracle(W, H, N, flags=1)
+    g = hip.Renderer(W, H, N, flags=1, diag=True)
+    g.set_tuning(traversal_variant=5)
+    o.load_scene(sc, nodes, prims), g.load_scene(sc, nodes, prims)
+    for r in (o, g):
+        r.stage("begin"), r.stage("primary"), r.stage("extend")
+    qo, qg = o.ray_queue(0), g.ray_queue(0)
+    assert g.counters()["device_error"] == 0
+    assert np.array_equal(bits(qo["distance"]), bits(qg["distance"]))
+    hit = qo["distance"] < 1e20
+    assert np.array_equal(qo["identifier"][hit], qg["identifier"][hit]) and np.array_equal(qo["geometry_type"][hit], qg["geometry_type"][hit])
+    o.stage("shade"), g.stage("shade")
+    ko, kg = o.counters(), g.counters()
+    assert ko["primary_ray_cnt"] == kg["primary_ray_cnt"] and ko["shadow_ray_cnt"] == kg["shadow_ray_cnt"]
+    assert o.shadow_queue(ko["shadow_ray_cnt"]).tobytes() == g.shadow_queue(kg["shadow_ray_cnt"]).tobytes()
+    o.stage("connect"), g.stage("connect")
+    assert o.counters()["n_shadow_visible"] == g.counters()["n_shadow_visible"]
+    o.close(), g.close()
+    totals = []
+    for variant in (4, 5):
+        g = hip.Renderer(W, H, W * H * 4, flags=1, diag=True)
+        g.set_tuning(traversal_variant=variant)
+        g.load_scene(sc, nodes, prims)
+        g.render(4)
+        k = g.counters()
+        assert k["device_error"] == 0 and k["total_primary_rays"] == 4 * W * H
+        totals.append(({f: k[f] for f in ("total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible")}, g.blit_buffer()))
+        g.close()
+    assert totals[0][0] == totals[1][0], totals
+    assert np.array_equal(totals[0][1][:, 3], totals[1][1][:, 3]) and np.allclose(totals[0][1], totals[1][1], rtol=1e-5, atol=1e-6)

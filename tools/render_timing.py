@@ -8,13 +8,17 @@ sys.path.insert(0, os.getcwd())
 from tyrant_amd import binding, scenes
 import numpy as np
 W,H,spp=1920,1080,8
-N = int(sys.argv[1]) if len(sys.argv) > 1 else W*H*spp  # queue size; 2097152 = the reference's
+args = [a for a in sys.argv[1:] if "=" not in a]
+tune = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a)}  # e.g. traversal_variant=5 min_traversing=24
+N = int(args[0]) if args else W*H*spp  # queue size; 2097152 = the reference's
 for name, sc in (("c2", scenes.cornell_soup(10000)), ("c3", scenes.mesh_scene(706))):
     bb=scenes.triangle_bboxes(sc.triangles)
     nodes, prims = binding.bvh_build(sc.triangles, bb)
     flags = (0 if os.environ.get('NOPROFILE') else binding.TYR_FLAG_PROFILE) | (1 if sc.triangle_materials else 0)
     r = binding.Renderer(W,H,N, flags=flags)
     r.load_scene(sc,nodes,prims)
+    if tune:
+        r.set_tuning(**tune)
     r.render(spp)
     r.reset_accum(); r.timings(reset=True)
     import time
@@ -23,4 +27,5 @@ for name, sc in (("c2", scenes.cornell_soup(10000)), ("c3", scenes.mesh_scene(70
         r.reset_accum(); r.render(spp)
     dt=(time.perf_counter()-t0)/3
     tm=r.timings()
-    print(os.environ.get("TYRANT_HIP_LIBRARY","default"), name, "N", N, "ms/render %.3f"%(dt*1e3), {k:round(v["ms"]/3,3) for k,v in tm.items() if v["launches"]}, "launches/render", tm["extend"]["launches"]//3, "(no per-kernel events)" if os.environ.get("NOPROFILE") else "")
+    assert r.counters()["device_error"] == 0
+    print(os.path.basename(os.environ.get("TYRANT_HIP_LIBRARY","default")), tune, name, "N", N, "ms/render %.3f"%(dt*1e3), {k:round(v["ms"]/3,3) for k,v in tm.items() if v["launches"]}, "launches/render", tm["extend"]["launches"]//3, "(no per-kernel events)" if os.environ.get("NOPROFILE") else "")

@@ -87,6 +87,9 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 			k->budget_remaining = budget - nNew;
 		k->total_primary_rays += nNew;
 		k->total_extend_rays += cnt + nNew;
+#if defined(TYR_QUAD_STATS) || defined(TYR_LAUNCH_ANATOMY)
+		k->debug[13] = k->debug[14] = k->debug[15] = 0ull; // launch anatomy of this iteration's extend (tools/launch_tail.py)
+#endif
 	}
 }
 

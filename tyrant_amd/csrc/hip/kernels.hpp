@@ -93,6 +93,7 @@ struct FrameParams {
 	float4* blit;            // main.cpp:129-130
 	DevCounters* k;
 	ConnectCounters* kc;     // this iteration's set
+	ConnectCounters* kcPrev; // the previous iteration's set (k_trace_flat: its shadow rays are traced beside this iteration's extend)
 	unsigned long long* scanDesc; // one look-back descriptor per shade block
 	uint32_t refillMinIdle;       // persistent traversal: refill a wave once this many lanes are free
 	uint32_t minTraversing;       // flat traversal: leave the descent loop below this many descending lanes
@@ -116,6 +117,7 @@ struct Tuning {
 	int stagedNodes = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
+	int mergeTrace = 1;       // tyr_render: connect(i) rides in the launch of extend(i + 1) (k_trace_flat): one drain per iteration instead of two
 	int overlapConnect = 2;   // tyr_render: connect(i) on a second stream next to primary / extend of iteration i + 1: 0 never, 1 always, 2 for thin wavefronts
 	int profileMask = 31;     // TYR_FLAG_PROFILE: which stages (bit TYR_K_*) get a hipEvent pair; every pair is ~10 us of idle GPU
 	int stackLdsDepth = 12;   // traversal-stack entries per lane kept in LDS (0, 8, 10, 12, 16, 24); the rest spill to scratch
@@ -125,7 +127,7 @@ constexpr int kBlock = 256; // 4 wave64 per workgroup
 
 // Per-context cache of the occupancy queries that size the persistent grids (a slow host call: asked once per
 // kernel, not once per launch).  Lives in tyr_ctx -- one ctx per device, no process-wide statics.
-enum { kLcExtend = 0, kLcConnect, kLcShade, kLcDiagExtend, kLcDiagConnect, kLcDiagExtendCount, kLcDiagConnectCount, kLcKinds };
+enum { kLcExtend = 0, kLcConnect, kLcShade, kLcTrace, kLcExtendFeed, kLcConnectFeed, kLcDiagExtend, kLcDiagConnect, kLcDiagExtendCount, kLcDiagConnectCount, kLcKinds };
 struct LaunchCache {
 	int perCU[kLcKinds][6] = {};
 };
@@ -139,6 +141,7 @@ void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream);
 void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
 void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCache& lc, hipStream_t stream);
 void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
+void launch_trace(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, uint32_t maxShadowPrev, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
 // the sphere pre-passes of extend / connect (frame.hip), launched by the traversal launchers
 void launch_extend_spheres(const FrameParams& P, uint32_t nSurvivors, hipStream_t stream);
 void launch_connect_spheres(const FrameParams& P, uint32_t maxShadow, hipStream_t stream);

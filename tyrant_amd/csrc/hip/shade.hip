@@ -357,6 +357,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 	out.newFrame = new_frame;
 }
 
+constexpr unsigned long long kScanTimeoutTicks = 200000000ull; // 2 s of s_memrealtime (100 MHz)
 // look-back descriptor: [63:62] status, [61:31] survivors, [30:0] shadow rays
 constexpr unsigned long long kDescAggregate = 1ull << 62;
 constexpr unsigned long long kDescInclusive = 2ull << 62;
@@ -419,10 +420,12 @@ __device__ __forceinline__ void shade_lookback(const FrameParams& P, uint32_t vb
 				if (found)
 					continue; // (wave-uniform) an inclusive prefix was found in a nearer window
 				const int idx = first - 64 * k - (int)lane;
-				uint32_t spins = 0;
-				const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();
+				const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime(); // 100 MHz, independent of the shader clock
 				while (!(d[k] >> 62)) { // not published yet: poll this one
-					if (++spins > (1u << 25)) { // every wait is bounded (~4 s): report, never hang
+					// every wait is bounded by wall time (2 s; a launch is milliseconds): report, never hang.  The zero
+					// prefix written on that path only lets the block finish -- the launch is reported as failed
+					// (kErrScanTimeout -> TYR_ERR_DEVICE) and its queues are not to be used.
+					if (__builtin_amdgcn_s_memrealtime() - t0_ > kScanTimeoutTicks) {
 						timeout = true;
 						d[k] = kDescInclusive;
 						// what timed out, for TYR_VERBOSE's report (host/driver.cpp check_device_error)
@@ -537,8 +540,13 @@ __global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t 
 
 	// Tiles are drawn from eight tickets (word w hands out tiles w, w + 8, ...; a block starts at word
 	// blockIdx % 8 and moves on when a word is used up).  A tile is only ever started after every lower tile of
-	// its word, and the lowest tile not yet started always belongs to a word whose running tiles are lower still,
-	// so every tile a look-back waits for is being shaded by some block: no starvation, whatever the grid size.
+	// its word.  Liveness: let T be the lowest tile not yet drawn, w = T % 8.  The block that drew the latest tile of
+	// word w holds only tiles below T, every tile below T has been drawn (and a drawn tile publishes its aggregate
+	// without waiting for anybody), so that block's look-back completes and its next draw is T.  This needs every word
+	// to have a RESIDENT block serving it: blocks are dispatched in index order, so any eight resident blocks cover the
+	// eight words, and launch_shade never launches fewer than eight blocks when there are eight tiles (a device that
+	// keeps fewer than eight 256-thread blocks resident -- under four CUs -- cannot run this kernel: the bounded wait
+	// below then reports kErrScanTimeout instead of hanging).
 	// Unlike the fixed assignment b, b + G, ... a slow block simply shades fewer tiles instead of holding up every
 	// look-back of its generation; one word per tile id would be a single ticket again (88 draws/us: 0.74 ms for
 	// the 64.8 k tiles of a full queue).

@@ -470,7 +470,7 @@ __device__ __forceinline__ lanemask slab_any(const RayConst& r, float lox, float
 // FAST: every lane of the wave has a finite 1/d (the caller decides once per wave, not per box: a
 // per-lane choice made the compiler emit both paths with exec juggling around each of the four tests).
 // ORDERED: closest-hit needs the reference's visit order; any-hit (bvh.h:213-256) does not depend on it.
-template <bool FAST, bool ORDERED, bool STAGED = false>
+template <bool FAST, bool ORDERED, bool STAGED = false, int STAGE_STRIDE = (int)kStagedNodes>
 __device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, uint32_t ref, const RayConst& r, float dist, const float4* staged = nullptr, uint32_t nStaged = 0) {
 	const uint32_t idx = ref & kQuadIndexMask;
 	const float4* q = quads + 8 * idx;
@@ -492,8 +492,8 @@ __device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, 
 #else
 		const float4* c = staged + idx; // host pass of the same source: never executed
 #endif
-		x01 = c[0 * kStagedNodes], x23 = c[1 * kStagedNodes], y01 = c[2 * kStagedNodes], y23 = c[3 * kStagedNodes];
-		z01 = c[4 * kStagedNodes], z23 = c[5 * kStagedNodes], rf = c[6 * kStagedNodes];
+		x01 = c[0 * STAGE_STRIDE], x23 = c[1 * STAGE_STRIDE], y01 = c[2 * STAGE_STRIDE], y23 = c[3 * STAGE_STRIDE];
+		z01 = c[4 * STAGE_STRIDE], z23 = c[5 * STAGE_STRIDE], rf = c[6 * STAGE_STRIDE];
 		// keeps this tail different from the global branch's: otherwise the two sets of loads are merged into
 		// loads through one generic pointer (flat_load_dword x 28)
 		__asm__ volatile("" : "+v"(rf.x));

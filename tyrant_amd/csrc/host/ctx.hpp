@@ -34,6 +34,10 @@ struct tyr_ctx {
 	hipStream_t side = nullptr;
 	hipEvent_t evShadeDone = nullptr, evConnectDone = nullptr, evSnapshot = nullptr;
 	bool connectPending = false;
+	// tyr_render with TYR_TUNE_MERGE_TRACE: the shadow rays of the last shaded iteration have not been traced yet (they
+	// ride in the next iteration's trace launch, or in a connect of their own when the render ends)
+	bool shadowPending = false;
+	uint32_t shadowPendingMax = 0;
 	hipEvent_t evSide[2][2]{}; // TYR_FLAG_PROFILE: connect's start / stop on `side`, per set
 	bool evSideUsed[2]{};
 	unsigned long long* scanDesc = nullptr;

@@ -153,6 +153,7 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.blit = c->blit;
 	P.k = c->dK;
 	P.kc = c->dKc + (c->iter & 1u);
+	P.kcPrev = c->dKc + ((c->iter ^ 1u) & 1u);
 	P.scanDesc = c->scanDesc;
 	P.refillMinIdle = static_cast<uint32_t>(std::min(std::max(c->tuning.refillMinIdle, 1), 64));
 	P.minTraversing = static_cast<uint32_t>(std::min(std::max(c->tuning.minTraversing, 1), 64));
@@ -281,6 +282,11 @@ void enqueue_extend(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t 
 	P.raysPerBlock = rays_per_block_for(c, nLive);
 	launch_extend(P, nLive, nSurvivors, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, c->stream);
 }
+// extend of this iteration and connect of the previous one in one launch (tyr_render, TYR_TUNE_MERGE_TRACE)
+void enqueue_trace(tyr_ctx* c, const FrameParams& P, uint32_t nLive, uint32_t nSurvivors, uint32_t maxShadowPrev) {
+	KernelTimer t(c, TYR_K_EXTEND);
+	launch_trace(P, nLive, nSurvivors, maxShadowPrev, c->tuning, c->numCUs, c->launchCache, c->stream);
+}
 void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	KernelTimer t(c, TYR_K_SHADE);
 	launch_shade(P, nLive, c->numCUs, c->launchCache, c->stream);
@@ -320,6 +326,19 @@ int enqueue_connect_unwaited(tyr_ctx* c, const FrameParams& P0, uint32_t maxShad
 		HIPCHK(hipEventRecord(c->evConnectDone, c->side));
 		c->connectPending = true;
 	}
+	return TYR_OK;
+}
+
+void enqueue_connect(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow);
+// the shadow rays a merged render still owes (those of the last shaded iteration): a connect launch of their own
+int flush_pending_shadow(tyr_ctx* c) {
+	if (!c->shadowPending)
+		return TYR_OK;
+	c->shadowPending = false;
+	FrameParams P = make_params(c);
+	P.kc = P.kcPrev; // stage_end has advanced `iter`: the rays belong to the previous iteration's counter set
+	enqueue_connect(c, P, c->shadowPendingMax);
+	HIPCHK(hipGetLastError());
 	return TYR_OK;
 }
 
@@ -774,10 +793,17 @@ static int launch_iteration(tyr_ctx* c, int overlap, bool pipelined) {
 	// overlap 2 = by queue size: a thin wavefront is mostly ramp and tail on a 256-CU part, and that is what the
 	// neighbouring kernel fills (N = 2 Mi: +8 % C2, +13 % C3; from ~8 M rays up the two grids only stretch each other;
 	// deciding per iteration by nLive instead was neutral on a 16.6 M queue: profiles/r01_deferred_connect_ab.txt)
-	const bool deferConnect = overlap == 1 || (overlap == 2 && c->cfg.queue_size <= kOverlapMaxLive);
+	// merged traversal launches (k_trace_flat): connect(i) waits for the launch of extend(i + 1)
+	const bool merge = pipelined && c->tuning.mergeTrace != 0 && c->tuning.traversalVariant == 4 && !(c->cfg.flags & TYR_FLAG_COUNT_VISITS) && c->scene.rootRef != kRefDone;
+	const bool deferConnect = !merge && (overlap == 1 || (overlap == 2 && c->cfg.queue_size <= kOverlapMaxLive));
 	FrameParams P = make_params(c);
 	enqueue_primary(c, P, nNew, nLive);
-	{
+	if (merge && c->shadowPending) {
+		c->shadowPending = false;
+		enqueue_trace(c, P, nLive, nLive - nNew, c->shadowPendingMax);
+	} else {
+		if ((rc = flush_pending_shadow(c))) // (a render whose merge setting changed between iterations: never, but cheap)
+			return rc;
 		// next to a connect that is still running, blocks become resident late: no fixed per-block ranges then
 		FrameParams Pe = P;
 		if (overlap == 2 && c->connectPending)
@@ -787,7 +813,15 @@ static int launch_iteration(tyr_ctx* c, int overlap, bool pipelined) {
 	if ((rc = join_connect(c))) // shade rewrites the shadow queue connect(i - 1) reads
 		return rc;
 	enqueue_shade(c, P, nLive);
-	if (deferConnect || pipelined) {
+	if (merge) {
+		// everything the host needs to launch iteration i + 1 (survivors, budget, the shadow-ray count) is final here
+		HIPCHK(hipMemcpyAsync(c->hK, c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipEventRecord(c->evSnapshot, c->stream));
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventSynchronize(c->evSnapshot));
+		c->shadowPending = c->hK->shadow_ray_cnt != 0;
+		c->shadowPendingMax = c->hK->shadow_ray_cnt;
+	} else if (deferConnect || pipelined) {
 		if (deferConnect && overlap == 2)
 			P.staticShare = 0;
 		// the counters as shade left them, on their way to the host before connect starts
@@ -838,7 +872,10 @@ int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iter
 	{
 		// the last connect: back onto `stream` if it ran beside it, counters refreshed (connect's included),
 		// nothing in flight when this returns
-		int rcj = join_connect(c);
+		int rcj = rc ? TYR_OK : flush_pending_shadow(c);
+		c->shadowPending = false;
+		if (!rcj)
+			rcj = join_connect(c);
 		if (!rcj)
 			rcj = sync_counters(c);
 		collect_side_timings(c, true);
@@ -1084,11 +1121,11 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		return TYR_ERR_INVALID;
 	switch (key) {
 	case TYR_TUNE_TRAVERSAL_VARIANT:
-		if (value < 0 || value > 4)
+		if (value < 0 || value > 5)
 			return TYR_ERR_INVALID;
 #ifndef TYR_DIAG
 		if (value != 4)
-			return TYR_ERR_UNSUPPORTED; // variants 0-3 live in libtyrant_hip_diag.so (make diag)
+			return TYR_ERR_UNSUPPORTED; // variants 0-3 and 5 live in libtyrant_hip_diag.so (make diag)
 #endif
 		c->tuning.traversalVariant = value;
 		return TYR_OK;
@@ -1133,6 +1170,11 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		if (value < 0 || value >= (1 << TYR_K_COUNT))
 			return TYR_ERR_INVALID;
 		c->tuning.profileMask = value;
+		return TYR_OK;
+	case TYR_TUNE_MERGE_TRACE:
+		if (value < 0 || value > 1)
+			return TYR_ERR_INVALID;
+		c->tuning.mergeTrace = value;
 		return TYR_OK;
 	case TYR_TUNE_OVERLAP_CONNECT:
 		if (value < 0 || value > 2)
