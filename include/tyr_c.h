@@ -257,11 +257,12 @@ enum {
 	TYR_TUNE_MIN_TRAVERSING = 4,    /* variants 2-4: leave the descent loop when fewer lanes than this are descending and leaves / refills are pending (1..64, default 32) */
 	TYR_TUNE_TICKET_CHUNK = 5,      /* variants 1/4: queue slots a wave reserves per global atomic (64..65536, default 64) */
 	TYR_TUNE_MIN_LEAVES = 7,        /* retired (leaving the descent loop once this many lanes hold a leaf never paid): accepted, no effect */
-	TYR_TUNE_STATIC_SHARE = 8,      /* variant 4: sixteenths of the queue dealt to the blocks as fixed ranges before the ticketed chunks start (0..15, default 4) */
+	TYR_TUNE_STATIC_SHARE = 8,      /* variant 4: sixteenths of the queue dealt to the blocks as fixed ranges before the ticketed chunks start (0..15, default 12) */
 	TYR_TUNE_STAGED_NODES = 9,      /* variant 4: top-of-tree quad nodes each block keeps in LDS (0..64, default 64) */
 	TYR_TUNE_OVERLAP_CONNECT = 10,  /* tyr_render: connect(i) on a second stream while the first already does primary / extend of iteration i + 1 (shade(i + 1) waits for it): 0 = never (one stream, kernel after kernel), 1 = always, 2 (default) = when queue_size is at most 6 Mi slots, where ramp and tail dominate a launch and the neighbour fills them; fixed per-block ranges are switched off beside a running connect.  tyr_launch_kernels is always one stream. */
 	TYR_TUNE_PROFILE_MASK = 11,     /* with TYR_FLAG_PROFILE: bit TYR_K_* set = that stage is bracketed by a hipEvent pair (default 31 = all five).  An event between two kernels costs ~10 us of idle GPU, ~2 % of a 1080p render with all of them on. */
 	TYR_TUNE_MERGE_TRACE = 12,      /* tyr_render: 1 (default) = connect(i) shares the launch of extend(i + 1) -- both only depend on shade(i), and every traversal launch ends in a latency-bound drain as long as its longest ray (40-60 % of a launch at 1080p): one drain per iteration instead of two; the last iteration's shadow rays get a launch of their own.  0 = separate launches (with TYR_TUNE_OVERLAP_CONNECT deciding the stream).  Ignored by the counting build and by variants other than 4.  tyr_launch_kernels is always extend, shade, connect, done when it returns. */
+	TYR_TUNE_STATIC_INTERLEAVE = 13, /* variant 4: the fixed per-block part of the queue (TYR_TUNE_STATIC_SHARE) as interleaved 64-slot chunks -- block b owns chunks b, b + G, b + 2 G, ... -- (1, default) or as one contiguous range per block (0): contiguous ranges give single blocks whole regions of the frame (the queue is in scan-line order) and the launch ends on the block that drew the dense one */
 	TYR_TUNE_RAYS_PER_BLOCK = 6     /* variants 2/3: queue slots owned by one 256-thread block and handed to its free lanes through LDS (256..65536, default 1024; halved automatically for thin queues) */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);

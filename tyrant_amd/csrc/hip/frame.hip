@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 		k->total_extend_rays += cnt + nNew;
 #if defined(TYR_QUAD_STATS) || defined(TYR_LAUNCH_ANATOMY)
 		k->debug[13] = k->debug[14] = k->debug[15] = 0ull; // launch anatomy of this iteration's extend (tools/launch_tail.py)
+		k->debug[9] = k->debug[10] = k->debug[11] = k->debug[12] = 0ull; // ... and its longest rays (k_trace_flat, TYR_QUAD_STATS)
 #endif
 	}
 }

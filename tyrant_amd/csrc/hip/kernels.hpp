@@ -100,6 +100,7 @@ struct FrameParams {
 	uint32_t ticketChunk;         // variants 1 / 4: queue slots a wave takes per draw from a device-wide ticket
 	uint32_t raysPerBlock;        // variants 2 / 3: queue slots owned by one 256-thread block
 	uint32_t staticShare;         // variant 4: sixteenths of the queue handed out as fixed per-block ranges
+	uint32_t staticInterleave;    // ... as 64-slot chunks b, b + G, ... (1) or as one contiguous range per block (0)
 	// TYR_FLAG_LIGHT_LIST (extension): emissive triangles, as indices into scene.tris in array order
 	const uint32_t* lights;
 	uint32_t nLights;
@@ -113,7 +114,8 @@ struct Tuning {
 	int minTraversing = 32;
 	int ticketChunk = 64;
 	int raysPerBlock = 1024;
-	int staticShare = 4;
+	int staticShare = 12;     // sixteenths of the queue dealt out as fixed (interleaved) per-block chunks before the ticketed rest (4 with contiguous ranges in round 1; 12 measured best with interleaved ones: profiles/r02_knob_sweep_merged.txt)
+	int staticInterleave = 1; // the fixed per-block part of the queue in interleaved 64-slot chunks (every block the same mix of the frame)
 	int stagedNodes = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits

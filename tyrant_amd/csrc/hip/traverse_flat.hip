@@ -131,6 +131,20 @@ __device__ __forceinline__ uint32_t static_range(uint32_t nItems, uint32_t sixte
 	return (uint32_t)(share / gridDim.x) & ~63u;
 }
 
+// Which queue slot the `local`-th slot of a block's fixed range is.  Contiguous ranges (block b = slots
+// [b * perBlock, +perBlock)) hand whole image regions to single blocks -- the queue is in scan-line order, and so are the
+// survivors inside every generation -- and a block that drew the dense part of the frame is still inside its fixed range
+// when the ticketed rest of the queue has long been used up by the others: the launch anatomy (tools/launch_tail.py)
+// showed ~330 us between the first wave finding the tickets gone and the last wave's exit, also for the short primary
+// rays.  Interleaved, block b owns the 64-slot chunks b, b + G, b + 2 G, ... of the fixed part: every block gets the
+// same mix.  (perBlock is a multiple of 64.)
+__device__ __forceinline__ uint32_t static_slot(uint32_t s, uint32_t blockBegin, bool interleave) {
+	if (!interleave)
+		return s;
+	const uint32_t local = s - blockBegin;
+	return (((local >> 6) * gridDim.x + blockIdx.x) << 6) + (local & 63u);
+}
+
 template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
 __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(const FrameParams P) {
 	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
@@ -209,7 +223,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 					const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
 					got = avail < nIdle ? avail : nIdle;
 					if (!live && rank < got) {
-						s = base + rank;
+						s = static_slot(base + rank, blockBegin, P.staticInterleave != 0u);
 						fed = true;
 					}
 					staticDone = (base + nIdle >= blockEnd);
@@ -475,7 +489,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 					const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
 					got = avail < nIdle ? avail : nIdle;
 					if (!live && rank < got) {
-						s = base + rank;
+						s = static_slot(base + rank, blockBegin, P.staticInterleave != 0u);
 						fed = true;
 					}
 					staticDone = (base + nIdle >= blockEnd);
@@ -673,6 +687,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	bool isShadow = false, occluded = false;
 	uint32_t visible = 0;
 	uint32_t dbg[16] = {};
+	uint32_t steps = 0; // TYR_QUAD_STATS: quad steps of this lane's current ray
 	unsigned long long tExhausted = 0ull;
 	const unsigned long long tStart = kAnatomy ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	// kernel.cu:640-644, deferred to the wave's next refill (see k_connect_flat)
@@ -719,7 +734,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 				const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
 				got = avail < nIdle ? avail : nIdle;
 				if (!live && rank < got) {
-					s = base + rank;
+					s = static_slot(base + rank, blockBegin, P.staticInterleave != 0u);
 					fed = true;
 				}
 				staticDone = (base + nIdle >= blockEnd);
@@ -812,6 +827,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 			}
 			if ((int)ref >= 0) {
 				TYR_DBG(0)
+				if (kLoopStats)
+					steps += 1;
 				const QuadHits q = allRegular ? test_quad<true, true, true>(sc.quads, ref, r, dist, stagedNodes, nStaged) : test_quad<false, true, true>(sc.quads, ref, r, dist, stagedNodes, nStaged);
 				const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
 				st.push3(q.hit[3] & any012, q.ref[3], q.t[3], q.hit[2] & any01, q.ref[2], q.t[2], q.hit[1] & q.hit[0], q.ref[1], q.t[1]);
@@ -854,6 +871,17 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 			}
 			overflow = overflow || st.overflow;
 			live = false;
+			if (kLoopStats) {
+				// the launch's longest rays: debug[12] = most quad steps of one ray, [9] / [10] / [11] = rays with > 64 / 128 / 256
+				atomicMax(&P.k->debug[12], (unsigned long long)steps);
+				if (steps > 64)
+					atomicAdd(&P.k->debug[9], 1ull);
+				if (steps > 128)
+					atomicAdd(&P.k->debug[10], 1ull);
+				if (steps > 256)
+					atomicAdd(&P.k->debug[11], 1ull);
+				steps = 0;
+			}
 		}
 	}
 	flush_visible();
@@ -863,7 +891,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		atomicOr(&P.k->device_error, kErrNoProgress);
 	wave_add_u64(&P.k->n_shadow_visible, visible);
 	if (kLoopStats) {
-		for (int i = 0; i < 13; ++i)
+		for (int i = 0; i < 9; ++i)
 			wave_add_u64(&P.k->debug[i], dbg[i]);
 	}
 	if (kAnatomy && lane == 0) {

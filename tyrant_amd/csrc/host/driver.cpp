@@ -160,6 +160,7 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.ticketChunk = static_cast<uint32_t>(std::min(std::max(c->tuning.ticketChunk, 64), 65536));
 	P.raysPerBlock = static_cast<uint32_t>(std::min(std::max(c->tuning.raysPerBlock, 256), 65536));
 	P.staticShare = static_cast<uint32_t>(std::min(std::max(c->tuning.staticShare, 0), 15));
+	P.staticInterleave = c->tuning.staticInterleave ? 1u : 0u;
 	P.lights = c->dLights;
 	P.nLights = c->nLights;
 	std::memcpy(P.triEmission, c->triEmission, 12);
@@ -821,6 +822,18 @@ static int launch_iteration(tyr_ctx* c, int overlap, bool pipelined) {
 		HIPCHK(hipEventSynchronize(c->evSnapshot));
 		c->shadowPending = c->hK->shadow_ray_cnt != 0;
 		c->shadowPendingMax = c->hK->shadow_ray_cnt;
+#if defined(TYR_QUAD_STATS) || defined(TYR_LAUNCH_ANATOMY)
+		if (std::getenv("TYR_ANATOMY")) {
+			// launch anatomy of this iteration's traversal launch (s_memrealtime, 100 MHz): first wave's start, first wave to
+			// find the queue used up, last wave's exit
+			const unsigned long long t0 = ~c->hK->debug[13], tx = ~c->hK->debug[14], t1 = c->hK->debug[15];
+			std::fprintf(stderr, "[anatomy] iteration %u: %u rays: feed %.1f us, drain %.1f us", c->iter, nLive, (tx - t0) / 100.0, (t1 - tx) / 100.0);
+#ifdef TYR_QUAD_STATS
+			std::fprintf(stderr, "; longest ray %llu quad steps, rays with > 64 / 128 / 256 steps: %llu / %llu / %llu (running totals)", c->hK->debug[12], c->hK->debug[9], c->hK->debug[10], c->hK->debug[11]);
+#endif
+			std::fprintf(stderr, "\n");
+		}
+#endif
 	} else if (deferConnect || pipelined) {
 		if (deferConnect && overlap == 2)
 			P.staticShare = 0;
@@ -1170,6 +1183,11 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		if (value < 0 || value >= (1 << TYR_K_COUNT))
 			return TYR_ERR_INVALID;
 		c->tuning.profileMask = value;
+		return TYR_OK;
+	case TYR_TUNE_STATIC_INTERLEAVE:
+		if (value < 0 || value > 1)
+			return TYR_ERR_INVALID;
+		c->tuning.staticInterleave = value;
 		return TYR_OK;
 	case TYR_TUNE_MERGE_TRACE:
 		if (value < 0 || value > 1)
