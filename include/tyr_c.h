@@ -130,6 +130,12 @@ typedef struct tyr_config {
                                         * estimation next to spheres[6] -- the light array kernel.cu:420 / 560 leave as a TODO.  Off = the
                                         * reference's behaviour and random sequence. */
 
+#define TYR_FLAG_TRIANGLE_COLORS 16u   /* with TRIANGLE_MATERIALS: colour and emission per triangle -- the reference's commented-out `tempTriangle.color =
+                                        * mesh.color` (Scene.cpp:44).  The 40-byte Triangle record keeps its layout: the first of its three padding bytes
+                                        * (offset 37) indexes a 256-entry palette (tyr_set_triangle_palette).  The colour acts like a sphere's
+                                        * (kernel.cu:375-377: throughput x colour unless REFR / LIGHT; REFR absorbs with it, kernel.cu:511-513); with
+                                        * LIGHT_LIST an emissive triangle emits its own palette emission.  Off = white triangles, one emission. */
+
 typedef struct tyr_ctx tyr_ctx;
 
 int tyr_create(tyr_ctx** out, const tyr_config* cfg);
@@ -144,6 +150,9 @@ int tyr_scene_upload(tyr_ctx* ctx, const tyr_bvh_node* nodes, int32_t nNodes, co
 int tyr_set_spheres(tyr_ctx* ctx, const tyr_sphere* spheres);
 /* TYR_FLAG_LIGHT_LIST: the emission of every LIGHT triangle, float[3]; default (3,3,3), the reference light's (kernel.cu:680) */
 int tyr_set_triangle_emission(tyr_ctx* ctx, const float* rgb);
+/* TYR_FLAG_TRIANGLE_COLORS: 256 colours (float[256][3]) and, optionally, 256 emissions (NULL keeps (3,3,3)); entry i serves the
+ * triangles whose byte 37 is i.  Defaults: white, (3,3,3). */
+int tyr_set_triangle_palette(tyr_ctx* ctx, const float* color_rgb256, const float* emission_rgb256);
 /* the global `camera` (camera.h:24) read at kernel.cu:699-702, 719 */
 int tyr_set_camera(tyr_ctx* ctx, const tyr_camera* cam);
 /* sun_position / sun_position_changed (variables.h:16-17, kernel.cu:704-710) */

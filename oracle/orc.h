@@ -111,6 +111,7 @@ typedef struct {
 
 /* flags */
 #define ORC_FLAG_TRIANGLE_MATERIALS 1u /* extension: shade switch driven by Triangle::materialType */
+#define ORC_FLAG_TRIANGLE_COLORS 16u     /* extension (with TRIANGLE_MATERIALS): colour / emission per triangle from a 256-entry palette indexed by Triangle::pad_[0]; same value as TYR_FLAG_TRIANGLE_COLORS */
 #define ORC_FLAG_LIGHT_LIST 8u          /* extension (with the former): LIGHT triangles emit and are sampled by NEE; same value as TYR_FLAG_LIGHT_LIST */
 
 /* ---- a1-a3: RNG and sampling helpers (kernel.cu:23-65, 181-208) ---------- */
@@ -180,6 +181,7 @@ void orc_destroy(orc_ctx* c);
 /* nodes/prims are copied (Scene.cpp:55-67) */
 int orc_scene_upload(orc_ctx* c, const orc_node* nodes, int nNodes, const orc_triangle* prims, int nPrims);
 void orc_set_spheres(orc_ctx* c, const orc_sphere spheres[ORC_NUM_SPHERES]);
+void orc_set_triangle_palette(orc_ctx* c, const float* color_rgb256, const float* emission_rgb256); /* ORC_FLAG_TRIANGLE_COLORS; emission may be NULL */
 void orc_set_triangle_emission(orc_ctx* c, const float rgb[3]); /* ORC_FLAG_LIGHT_LIST; default (3,3,3) like kernel.cu:680 */
 void orc_default_spheres(orc_sphere out[ORC_NUM_SPHERES]); /* kernel.cu:674-680 */
 void orc_set_camera(orc_ctx* c, const orc_camera* cam);

@@ -33,6 +33,8 @@ struct orc_ctx {
 	uint32_t* lights;
 	int nLights;
 	float tri_emission[3];
+	/* ORC_FLAG_TRIANGLE_COLORS (extension): colour and emission of a triangle = palette entry Triangle::pad_[0] */
+	float palette_color[256][3], palette_emission[256][3];
 	orc_sphere spheres[ORC_NUM_SPHERES];
 	orc_camera camera;
 	float sun_position[2];
@@ -70,6 +72,8 @@ void orc_default_spheres(orc_sphere s[ORC_NUM_SPHERES]) {
 orc_ctx* orc_create(uint32_t W, uint32_t H, uint32_t N, uint32_t rank, uint32_t nranks, uint32_t flags) {
 	if (W == 0 || H == 0 || N == 0 || nranks == 0 || rank >= nranks || (H % nranks) != 0)
 		return NULL;
+	if ((flags & ORC_FLAG_TRIANGLE_COLORS) && !(flags & ORC_FLAG_TRIANGLE_MATERIALS))
+		return NULL;
 	if ((flags & ORC_FLAG_LIGHT_LIST) && !(flags & ORC_FLAG_TRIANGLE_MATERIALS))
 		return NULL;
 	orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
@@ -91,6 +95,11 @@ orc_ctx* orc_create(uint32_t W, uint32_t H, uint32_t N, uint32_t rank, uint32_t 
 	c->sun_position_changed = 1; /* variables.cpp:4 */
 	c->first_time = 1;
 	c->tri_emission[0] = c->tri_emission[1] = c->tri_emission[2] = 3.0f; /* kernel.cu:680 */
+	for (int i = 0; i < 256; ++i)
+		for (int k = 0; k < 3; ++k) {
+			c->palette_color[i][k] = 1.0f;    /* kernel.cu:383: triangles are white */
+			c->palette_emission[i][k] = 3.0f; /* kernel.cu:680 */
+		}
 	c->frame = 1;
 	c->last_focaldistance = 1.0f;
 	c->last_lensradius = 0.02f;
@@ -155,6 +164,15 @@ int orc_scene_upload(orc_ctx* c, const orc_node* nodes, int nNodes, const orc_tr
 }
 
 void orc_set_triangle_emission(orc_ctx* c, const float rgb[3]) { memcpy(c->tri_emission, rgb, 12); }
+void orc_set_triangle_palette(orc_ctx* c, const float* color_rgb256, const float* emission_rgb256) {
+	memcpy(c->palette_color, color_rgb256, sizeof c->palette_color);
+	if (emission_rgb256)
+		memcpy(c->palette_emission, emission_rgb256, sizeof c->palette_emission);
+}
+/* the emission of emissive triangle t: its palette entry with ORC_FLAG_TRIANGLE_COLORS, else the one colour of all */
+static v3 triangle_emission(const orc_ctx* c, const orc_triangle* t) {
+	return (c->flags & ORC_FLAG_TRIANGLE_COLORS) ? v3load(c->palette_emission[t->pad_[0]]) : v3load(c->tri_emission);
+}
 
 void orc_set_spheres(orc_ctx* c, const orc_sphere s[ORC_NUM_SPHERES]) { memcpy(c->spheres, s, sizeof(c->spheres)); }
 void orc_set_camera(orc_ctx* c, const orc_camera* cam) { c->camera = *cam; }
@@ -402,7 +420,7 @@ static int sample_light(const orc_ctx* c, uint32_t* seed, v3 origin, v3 normal, 
 	*lightDir = v3normalize(*lightVector);
 	*cosSurfaceToLight = v3dot(normal, *lightDir);
 	*cosLightToSurface = v3dot(nL, v3neg(*lightDir));
-	*emission = v3scale(v3load(c->tri_emission), pick);
+	*emission = v3scale(triangle_emission(c, t), pick);
 	*area = 0.5f * v3length(cr);
 	return *cosSurfaceToLight > 0 && *cosLightToSurface > 0;
 }
@@ -452,6 +470,13 @@ void orc_stage_shade(orc_ctx* c) {
 					const int highest = (c->flags & ORC_FLAG_LIGHT_LIST) ? ORC_LIGHT : ORC_PHONG;
 					reflection_type = triangle->materialType <= highest ? triangle->materialType : ORC_DIFF;
 				}
+				if (c->flags & ORC_FLAG_TRIANGLE_COLORS) {
+					/* the reference's commented-out `tempTriangle.color = mesh.color` (Scene.cpp:44), treated like a sphere's
+					 * colour (kernel.cu:375-377) */
+					object_color = v3load(c->palette_color[triangle->pad_[0]]);
+					if (reflection_type != ORC_REFR && reflection_type != ORC_LIGHT)
+						direct = v3mul(direct, object_color);
+				}
 			}
 
 			int outside = v3dot(normal, direction) < 0;
@@ -460,7 +485,7 @@ void orc_stage_shade(orc_ctx* c) {
 
 			if (reflection_type == ORC_LIGHT) {
 				if (ray.lastSpecular) {
-					color = v3mul(direct, ray.geometry_type == 0 ? v3load(c->spheres[ray.identifier].emmission) : v3load(c->tri_emission));
+					color = v3mul(direct, ray.geometry_type == 0 ? v3load(c->spheres[ray.identifier].emmission) : triangle_emission(c, &c->prims[ray.identifier]));
 				} else {
 					color = v3make(0.f, 0.f, 0.f);
 					direct = v3make(0.f, 0.f, 0.f);

@@ -129,6 +129,7 @@ def lib() -> C.CDLL:
         L.orc_scene_upload.argtypes = [P, P, c_i, P, c_i]
         L.orc_set_spheres.argtypes = [P, P]
         L.orc_set_triangle_emission.argtypes = [P, fp]
+        L.orc_set_triangle_palette.argtypes = [P, P, P]
         L.orc_default_spheres.argtypes = [P]
         L.orc_set_camera.argtypes = [P, C.POINTER(CameraC)]
         L.orc_set_sun_position.argtypes = [P, c_f, c_f]
@@ -288,6 +289,13 @@ class Oracle:
         self.set_camera(scene.camera)
         self.set_sun_position(*scene.sun_position)
         self.set_triangle_emission(getattr(scene, "triangle_emission", (3.0, 3.0, 3.0)))
+        if getattr(scene, "palette_color", None) is not None:
+            self.set_triangle_palette(scene.palette_color, scene.palette_emission)
+
+    def set_triangle_palette(self, color, emission=None):
+        col = np.ascontiguousarray(color, dtype=np.float32).reshape(256, 3)
+        em = None if emission is None else np.ascontiguousarray(emission, dtype=np.float32).reshape(256, 3)
+        self.L.orc_set_triangle_palette(self.h, _ptr(col), None if em is None else _ptr(em))
 
     def launch_kernels(self):
         return self.L.orc_launch_kernels(self.h)

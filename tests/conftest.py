@@ -73,6 +73,7 @@ def built_scene(name: str):
         "tyrant_default": scenes.tyrant_default,
         "glass_dof48": lambda: scenes.glass_dof_scene(48),
         "cornell_area_light": scenes.cornell_area_light,
+        "cornell_colored": scenes.cornell_colored,
     }
     sc = makers[name]()
     nodes, prims = pyorc.bvh_build(sc.triangles, scenes.triangle_bboxes(sc.triangles))

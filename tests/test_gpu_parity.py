@@ -22,7 +22,9 @@ def pair(orc, hip, name, W, H, N, flags=0, rank=0, nranks=1, diag=False):
         flags |= 1
     if sc.light_list:
         flags |= 8
-    o = orc.Oracle(W, H, N, rank=rank, nranks=nranks, flags=flags & 9)
+    if sc.triangle_colors:
+        flags |= 16
+    o = orc.Oracle(W, H, N, rank=rank, nranks=nranks, flags=flags & 25)
     o.load_scene(sc, nodes, prims)
     g = hip.Renderer(W, H, N, rank=rank, nranks=nranks, flags=flags, diag=diag)  # diag: libtyrant_hip_diag.so (variants 0-3)
     g.load_scene(sc, nodes, prims)
@@ -41,7 +43,7 @@ def assert_accum_close(bo, bg, what):
     assert np.allclose(bg[:, :3], bo[:, :3], rtol=1e-5, atol=1e-6), f"{what}: max rel err {np.max(np.abs(bg[:, :3] - bo[:, :3]) / np.maximum(np.abs(bo[:, :3]), 1e-3))}"
 
 
-@pytest.mark.parametrize("name,W,H,N", [("cornell36", 64, 64, 6000), ("tyrant_default", 96, 64, 5000), ("cornell_soup2k", 80, 48, 4096), ("mesh32", 64, 64, 4096), ("glass_dof48", 96, 54, 4096), ("cornell_area_light", 96, 64, 5000)])
+@pytest.mark.parametrize("name,W,H,N", [("cornell36", 64, 64, 6000), ("tyrant_default", 96, 64, 5000), ("cornell_soup2k", 80, 48, 4096), ("mesh32", 64, 64, 4096), ("glass_dof48", 96, 54, 4096), ("cornell_area_light", 96, 64, 5000), ("cornell_colored", 96, 64, 5000)])
 def test_stage_by_stage_bit_parity(orc, hip, name, W, H, N):
     """every kernel of every iteration, fed by its predecessors on each side, matches the oracle bit for bit"""
     o, g = pair(orc, hip, name, W, H, N)
@@ -80,7 +82,7 @@ def test_stage_by_stage_bit_parity(orc, hip, name, W, H, N):
         o.stage("end"), g.stage("end")
 
 
-@pytest.mark.parametrize("name,W,H,N,spp", [("cornell36", 128, 128, 16384, 4), ("tyrant_default", 160, 96, 10000, 4), ("cornell_soup10k", 128, 72, 8192, 3), ("mesh128", 96, 96, 8192, 2), ("glass_dof48", 128, 72, 8192, 3), ("cornell_area_light", 128, 96, 8192, 4)])
+@pytest.mark.parametrize("name,W,H,N,spp", [("cornell36", 128, 128, 16384, 4), ("tyrant_default", 160, 96, 10000, 4), ("cornell_soup10k", 128, 72, 8192, 3), ("mesh128", 96, 96, 8192, 2), ("glass_dof48", 128, 72, 8192, 3), ("cornell_area_light", 128, 96, 8192, 4), ("cornell_colored", 128, 96, 8192, 4)])
 def test_render_matches_oracle(orc, hip, name, W, H, N, spp):
     """launch_kernels loop with a primary budget: same iteration count, same ray totals, radiance within 1e-5 rel"""
     o, g = pair(orc, hip, name, W, H, N)
@@ -488,3 +490,29 @@ def test_feed_variant_at_full_size(orc, hip):
         g.close()
     assert totals[0][0] == totals[1][0], totals
     assert np.array_equal(totals[0][1][:, 3], totals[1][1][:, 3]) and np.allclose(totals[0][1], totals[1][1], rtol=1e-5, atol=1e-6)
+
+
+def test_triangle_colors_defaults_and_errors(orc, hip):
+    """TYR_FLAG_TRIANGLE_COLORS (per-triangle colour / emission, the reference's commented-out Scene.cpp:44): needs
+    TRIANGLE_MATERIALS; with the default palette (white, (3,3,3)) it is the run without the flag, bit for bit in the
+    queues; a palette set on a ctx without the flag is refused"""
+    with pytest.raises(Exception):
+        hip.Renderer(32, 32, 1024, flags=16)
+    sc, nodes, prims = built_scene("cornell_area_light")  # emission (4, 3.5, 3): set the palette's entry 0 to the same
+    em = np.full((256, 3), 3.0, dtype=np.float32)
+    em[0] = sc.triangle_emission
+    runs = []
+    for flags in (9, 25):
+        g = hip.Renderer(96, 64, 4000, flags=flags)
+        g.load_scene(sc, nodes, prims)
+        if flags & 16:
+            g.set_triangle_palette(np.ones((256, 3), dtype=np.float32), em)
+        for _ in range(3):
+            g.launch_kernels()
+        k = g.counters()
+        runs.append((k, g.ray_queue(0, k["primary_ray_cnt"]).tobytes(), g.shadow_queue(k["shadow_ray_cnt"]).tobytes(), g.blit_buffer()))
+        if not flags & 16:
+            with pytest.raises(hip.TyrError):
+                g.set_triangle_palette(np.ones((256, 3), dtype=np.float32))
+    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+    assert np.allclose(runs[0][3], runs[1][3], rtol=1e-5, atol=1e-6)

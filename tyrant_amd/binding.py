@@ -23,6 +23,7 @@ TYR_FLAG_TRIANGLE_MATERIALS = 1
 TYR_FLAG_PROFILE = 2
 TYR_FLAG_COUNT_VISITS = 4
 TYR_FLAG_LIGHT_LIST = 8
+TYR_FLAG_TRIANGLE_COLORS = 16
 TYR_ERR_NO_DEVICE = -2
 TYR_ERR_UNSUPPORTED = -7
 TYR_DIST_GATHER, TYR_DIST_REDUCE = 0, 1
@@ -102,6 +103,7 @@ SYMBOLS = {
     "tyr_scene_upload": (C.c_int, [P, P, c_i32, P, c_i32]),
     "tyr_set_spheres": (C.c_int, [P, P]),
     "tyr_set_triangle_emission": (C.c_int, [P, P]),
+    "tyr_set_triangle_palette": (C.c_int, [P, P, P]),
     "tyr_set_camera": (C.c_int, [P, C.POINTER(CameraC)]),
     "tyr_set_sun_position": (C.c_int, [P, c_f, c_f]),
     "tyr_set_blit_buffer": (C.c_int, [P, P]),
@@ -297,6 +299,13 @@ class Renderer:
         self.set_camera(scene.camera)
         self.set_sun_position(*scene.sun_position)
         self.set_triangle_emission(getattr(scene, "triangle_emission", (3.0, 3.0, 3.0)))
+        if getattr(scene, "palette_color", None) is not None:
+            self.set_triangle_palette(scene.palette_color, scene.palette_emission)
+
+    def set_triangle_palette(self, color, emission=None):
+        col = np.ascontiguousarray(color, dtype=np.float32).reshape(256, 3)
+        em = None if emission is None else np.ascontiguousarray(emission, dtype=np.float32).reshape(256, 3)
+        _check(self.L.tyr_set_triangle_palette(self.h, _ptr(col), None if em is None else _ptr(em)), "tyr_set_triangle_palette")
 
     def set_triangle_emission(self, rgb):
         _check(self.L.tyr_set_triangle_emission(self.h, (C.c_float * 3)(*[float(v) for v in rgb])), "tyr_set_triangle_emission")

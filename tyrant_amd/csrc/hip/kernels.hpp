@@ -105,6 +105,8 @@ struct FrameParams {
 	const uint32_t* lights;
 	uint32_t nLights;
 	float triEmission[3];
+	// TYR_FLAG_TRIANGLE_COLORS (extension): 256 x { colour rgb, emission rgb } as two float4 per entry
+	const float4* palette;
 };
 
 // traversal kernel structure (tyr_set_tuning)

@@ -56,6 +56,16 @@ struct EmitterSample {
 	f3 emission;
 	float area;
 };
+// the emission of an emissive triangle (its third record vector in hand): its palette entry with
+// TYR_FLAG_TRIANGLE_COLORS, else the one colour of all (tyr_set_triangle_emission)
+__device__ __forceinline__ f3 triangle_emission(const FrameParams& P, float4 t2) {
+	if (P.flags & TYR_FLAG_TRIANGLE_COLORS) {
+		const float4 e = P.palette[2u * (__float_as_uint(t2.z) & 255u) + 1u];
+		return mk3(e.x, e.y, e.z);
+	}
+	return mk3(P.triEmission[0], P.triEmission[1], P.triEmission[2]);
+}
+
 template <bool LIGHTS>
 __device__ __forceinline__ EmitterSample sample_emitter(const FrameParams& P, uint32_t& seed, f3 origin, f3 normal) {
 	const tyr_sphere& ls = P.spheres[6]; // kernel.cu:421, 561
@@ -83,7 +93,7 @@ __device__ __forceinline__ EmitterSample sample_emitter(const FrameParams& P, ui
 			E.L.cosSurfaceToLight = dot(normal, E.L.lightDir);
 			E.L.cosLightToSurface = dot(nL, -E.L.lightDir);
 			E.L.valid = E.L.cosSurfaceToLight > 0 && E.L.cosLightToSurface > 0;
-			E.emission = mk3(P.triEmission[0], P.triEmission[1], P.triEmission[2]) * pick;
+			E.emission = triangle_emission(P, t2) * pick;
 			E.area = 0.5f * length(cr);
 			return E;
 		}
@@ -132,6 +142,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 	float atmoScale = 0.0f;
 	const bool hit = valid && distance < kVeryFar;
 	f3 normal = mk3(0.f, 0.f, 0.f);
+	f3 triEmit = mk3(P.triEmission[0], P.triEmission[1], P.triEmission[2]); // what a LIGHT triangle hit head-on emits
 	if (hit) {
 		origin = origin + direction * distance;
 		if (ident & kHitSphere) {
@@ -153,6 +164,14 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 				const uint32_t m = __float_as_uint(t2.y);
 				reflection_type = m <= (uint32_t)(LIGHTS ? TYR_LIGHT : TYR_PHONG) ? (int)m : TYR_DIFF;
 			}
+			if (P.flags & TYR_FLAG_TRIANGLE_COLORS) {
+				// Scene.cpp:44's `tempTriangle.color`, treated like a sphere's colour (kernel.cu:375-377)
+				const float4 c = P.palette[2u * (__float_as_uint(t2.z) & 255u)];
+				object_color = mk3(c.x, c.y, c.z);
+				if (reflection_type != TYR_REFR && reflection_type != TYR_LIGHT)
+					direct = direct * object_color;
+				triEmit = triangle_emission(P, t2);
+			}
 		}
 	}
 	afterLoads();
@@ -164,7 +183,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 		if (reflection_type == TYR_LIGHT) {
 			if (lastSpecular) {
 				if (LIGHTS && !(ident & kHitSphere))
-					color = direct * mk3(P.triEmission[0], P.triEmission[1], P.triEmission[2]);
+					color = direct * triEmit;
 				else
 					color = direct * ld3(P.spheres[ident & 7u].emmission);
 			} else {

@@ -80,7 +80,7 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 		q[7] = t.e2[1];
 		q[8] = t.e2[2];
 		q[9] = bits(static_cast<uint32_t>(t.materialType));
-		q[10] = 0.0f;
+		q[10] = bits(static_cast<uint32_t>(t.pad_[0])); // TYR_FLAG_TRIANGLE_COLORS: palette index (the reference leaves the byte unused)
 		q[11] = 0.0f;
 	}
 

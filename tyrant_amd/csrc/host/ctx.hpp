@@ -51,6 +51,7 @@ struct tyr_ctx {
 	uint32_t* dLights = nullptr; // TYR_FLAG_LIGHT_LIST: emissive triangles, array order
 	uint32_t nLights = 0;
 	float triEmission[3] = { 3.0f, 3.0f, 3.0f }; // kernel.cu:680
+	float4* dPalette = nullptr;                   // TYR_FLAG_TRIANGLE_COLORS: 256 x { colour, emission }
 	DevScene scene{};
 	bool haveScene = false;
 

@@ -164,6 +164,7 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.lights = c->dLights;
 	P.nLights = c->nLights;
 	std::memcpy(P.triEmission, c->triEmission, 12);
+	P.palette = c->dPalette;
 	return P;
 }
 
@@ -414,8 +415,8 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		return TYR_ERR_INVALID;
 	if (static_cast<uint64_t>(cfg->width) * cfg->height >= (1ull << 31) || cfg->queue_size >= (1u << 31))
 		return TYR_ERR_INVALID;
-	if ((cfg->flags & TYR_FLAG_LIGHT_LIST) && !(cfg->flags & TYR_FLAG_TRIANGLE_MATERIALS))
-		return TYR_ERR_INVALID; // an emissive triangle is a triangle material
+	if ((cfg->flags & (TYR_FLAG_LIGHT_LIST | TYR_FLAG_TRIANGLE_COLORS)) && !(cfg->flags & TYR_FLAG_TRIANGLE_MATERIALS))
+		return TYR_ERR_INVALID; // an emissive or coloured triangle is a triangle material
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
 		return TYR_ERR_NO_DEVICE;
@@ -461,6 +462,18 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		return fail(TYR_ERR_NO_DEVICE);
 	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
+	if (cfg->flags & TYR_FLAG_TRIANGLE_COLORS) {
+		// the palette's defaults are the reference's constants: white triangles (kernel.cu:383), emission (3,3,3) (kernel.cu:680)
+		if ((rc = dev_alloc(c->dPalette, 512)))
+			return fail(rc);
+		std::vector<float4> pal(512);
+		for (int i = 0; i < 256; ++i) {
+			pal[2 * i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+			pal[2 * i + 1] = make_float4(3.0f, 3.0f, 3.0f, 0.0f);
+		}
+		if (hipMemcpy(c->dPalette, pal.data(), pal.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
+			return fail(TYR_ERR_NO_DEVICE);
+	}
 	if (hipEventCreateWithFlags(&c->evShadeDone, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evConnectDone, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->evSnapshot, hipEventDisableTiming) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
@@ -502,6 +515,7 @@ int tyr_destroy(tyr_ctx* c) {
 	dev_free(c->dQuads);
 	dev_free(c->dTris);
 	dev_free(c->dLights);
+	dev_free(c->dPalette);
 	if (c->ownBlit)
 		dev_free(c->blit);
 	if (c->hK)
@@ -591,6 +605,28 @@ int tyr_set_triangle_emission(tyr_ctx* c, const float* rgb) {
 	if (!c || !rgb || !finite_n(rgb, 3))
 		return TYR_ERR_INVALID;
 	std::memcpy(c->triEmission, rgb, 12);
+	return TYR_OK;
+}
+
+int tyr_set_triangle_palette(tyr_ctx* c, const float* color_rgb256, const float* emission_rgb256) {
+	if (!c || !color_rgb256 || !finite_n(color_rgb256, 768) || (emission_rgb256 && !finite_n(emission_rgb256, 768)))
+		return TYR_ERR_INVALID;
+	if (!c->dPalette)
+		return TYR_ERR_UNSUPPORTED; // the ctx was created without TYR_FLAG_TRIANGLE_COLORS
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if ((rc = join_connect(c)))
+		return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	std::vector<float4> pal(512);
+	HIPCHK(hipMemcpy(pal.data(), c->dPalette, pal.size() * sizeof(float4), hipMemcpyDeviceToHost));
+	for (int i = 0; i < 256; ++i) {
+		pal[2 * i] = make_float4(color_rgb256[3 * i], color_rgb256[3 * i + 1], color_rgb256[3 * i + 2], 0.0f);
+		if (emission_rgb256)
+			pal[2 * i + 1] = make_float4(emission_rgb256[3 * i], emission_rgb256[3 * i + 1], emission_rgb256[3 * i + 2], 0.0f);
+	}
+	HIPCHK(hipMemcpy(c->dPalette, pal.data(), pal.size() * sizeof(float4), hipMemcpyHostToDevice));
 	return TYR_OK;
 }
 

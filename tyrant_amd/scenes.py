@@ -81,6 +81,9 @@ class SceneData:
     triangle_materials: bool = False  # extension flag
     light_list: bool = False  # extension flag: LIGHT triangles emit and are sampled by NEE
     triangle_emission: tuple = (3.0, 3.0, 3.0)  # with light_list; the reference light's value (kernel.cu:680)
+    triangle_colors: bool = False  # extension flag: colour / emission per triangle, palette index = Triangle byte 37
+    palette_color: np.ndarray | None = None  # float32[256][3]
+    palette_emission: np.ndarray | None = None  # float32[256][3]
 
 
 def hash_u32(index: np.ndarray, seed: int) -> np.ndarray:
@@ -211,6 +214,44 @@ def cornell_area_light() -> SceneData:
     assert np.cross(panel["e1"][0], panel["e2"][0])[0] > 0  # faces +x, into the room
     tris = np.concatenate([room_walls(), short, tall, patch, panel])
     return SceneData("cornell_area_light", tris, cornell_spheres(light_z=70.0), CORNELL_CAMERA, triangle_materials=True, light_list=True, triangle_emission=(4.0, 3.5, 3.0))
+
+
+def cornell_colored() -> SceneData:
+    """The classic coloured Cornell box (extension, SURVEY.md 8f-3: the reference's commented-out `tempTriangle.color`,
+    Scene.cpp:44): red left wall, green right wall, a blue glass short box, a gold Phong tall box, a grey mirror strip
+    on the back wall, and two emissive triangle panels of DIFFERENT emission (warm ceiling patch, cold wall panel) next
+    to spheres[6].  Colour / emission index = the first padding byte of the 40-byte Triangle record."""
+    walls = room_walls()
+    walls["pad_"][:, 0] = 0
+    walls["pad_"][6:8, 0] = 1  # left wall
+    walls["pad_"][8:10, 0] = 2  # right wall
+    short = _box(18.0, -12.0, 15.0, 15.0, 0.0, 30.0, -0.3)
+    short["materialType"] = REFR
+    short["pad_"][:, 0] = 3
+    tall = _box(-16.0, 14.0, 15.0, 15.0, 0.0, 60.0, 0.3)
+    tall["materialType"] = PHONG
+    tall["pad_"][:, 0] = 4
+    strip = _quad((-30, 49.5, 55), (30, 49.5, 55), (30, 49.5, 85), (-30, 49.5, 85), (0, -1, 0))
+    strip["materialType"] = SPEC
+    strip["pad_"][:, 0] = 5
+    patch = _quad((-12, -12, 99.5), (-12, 12, 99.5), (12, 12, 99.5), (12, -12, 99.5), (0, 0, -1))
+    patch["materialType"] = LIGHT
+    patch["pad_"][:, 0] = 6
+    panel = make_triangles([(-49.5, -10.0, 40.0)], [(-49.5, 10.0, 40.0)], [(-49.5, 0.0, 60.0)], LIGHT)
+    panel["pad_"][:, 0] = 7
+    tris = np.concatenate([walls, short, tall, strip, patch, panel])
+    col = np.ones((256, 3), dtype=np.float32)
+    em = np.full((256, 3), 3.0, dtype=np.float32)
+    col[0] = (0.73, 0.73, 0.73)
+    col[1] = (0.65, 0.05, 0.05)
+    col[2] = (0.12, 0.45, 0.15)
+    col[3] = (0.02, 0.015, 0.004)  # REFR: Beer-Lambert absorption per unit length (kernel.cu:511-513)
+    col[4] = (0.9, 0.7, 0.3)
+    col[5] = (0.8, 0.8, 0.8)
+    em[6] = (6.0, 5.0, 3.5)
+    em[7] = (1.5, 2.5, 5.0)
+    return SceneData("cornell_colored", tris, cornell_spheres(light_z=70.0), CORNELL_CAMERA, triangle_materials=True, light_list=True, triangle_colors=True,
+                     palette_color=col, palette_emission=em)
 
 
 def random_soup(n: int, seed: int = 12345, lo=(-48.0, -48.0, 2.0), hi=(48.0, 48.0, 98.0), edge: float = 1.5) -> np.ndarray:
