@@ -689,6 +689,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	uint32_t dbg[16] = {};
 	uint32_t steps = 0; // TYR_QUAD_STATS: quad steps of this lane's current ray
 	unsigned long long tExhausted = 0ull;
+	uint32_t liveAtExhaustion = 0;
 	const unsigned long long tStart = kAnatomy ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	// kernel.cu:640-644, deferred to the wave's next refill (see k_connect_flat)
 	constexpr uint32_t kNoPending = 0xffffffffu;
@@ -742,8 +743,10 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 			while (staticDone && got < nIdle) {
 				if (!feed.refill(P.k->extend_chunks, nItems - dynBase, lane)) {
 					exhausted = true;
-					if (kAnatomy && tExhausted == 0ull)
+					if (kAnatomy && tExhausted == 0ull) {
 						tExhausted = __builtin_amdgcn_s_memrealtime();
+						liveAtExhaustion = (uint32_t)__popcll(__ballot(live)) + got;
+					}
 					break;
 				}
 				const uint32_t avail = feed.end - feed.next, room = nIdle - got;
@@ -899,6 +902,14 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		atomicMax(&P.k->debug[13], ~tStart);
 		atomicMax(&P.k->debug[14], ~(tExhausted ? tExhausted : tEnd));
 		atomicMax(&P.k->debug[15], tEnd);
+		// per-wave record for tools/drain_profile.py, parked in an array nobody uses during this launch (the NEXT queue's
+		// hit column): microseconds from this wave's start to "queue used up" and to its exit, and how many of its lanes
+		// still held a ray when the queue ran out
+		const uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+		if (w < P.N)
+			P.next.hit[w] = make_float2((float)((tExhausted ? tExhausted : tEnd) - tStart) * 0.01f, (float)(tEnd - tStart) * 0.01f + (float)liveAtExhaustion * 0.0f);
+		if (w < P.N)
+			P.next.flags[w] = liveAtExhaustion;
 	}
 }
 
