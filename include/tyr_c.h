@@ -136,6 +136,10 @@ typedef struct tyr_config {
                                         * (kernel.cu:375-377: throughput x colour unless REFR / LIGHT; REFR absorbs with it, kernel.cu:511-513); with
                                         * LIGHT_LIST an emissive triangle emits its own palette emission.  Off = white triangles, one emission. */
 
+#define TYR_FLAG_DEBUG_BVH 32u         /* the reference's compile-time BVH_DEBUG (kernel.cu:721-722): the extend stage is extend_debug_BVH (kernel.cu:300-328,
+                                        * intersect_debug bvh.h:164-209) -- spheres ignored, and the blit_buffer receives, per ray, green = steps x 0.0002 x 255.99
+                                        * (red instead from 70 steps on), a = 1 -- and tyr_launch_kernels / tyr_render run primary + that stage only */
+
 typedef struct tyr_ctx tyr_ctx;
 
 int tyr_create(tyr_ctx** out, const tyr_config* cfg);

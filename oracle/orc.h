@@ -112,6 +112,7 @@ typedef struct {
 /* flags */
 #define ORC_FLAG_TRIANGLE_MATERIALS 1u /* extension: shade switch driven by Triangle::materialType */
 #define ORC_FLAG_TRIANGLE_COLORS 16u     /* extension (with TRIANGLE_MATERIALS): colour / emission per triangle from a 256-entry palette indexed by Triangle::pad_[0]; same value as TYR_FLAG_TRIANGLE_COLORS */
+#define ORC_FLAG_DEBUG_BVH 32u           /* the reference's BVH_DEBUG build (kernel.cu:721-722): launch_kernels = primary + extend_debug_BVH, the traversal-cost picture; same value as TYR_FLAG_DEBUG_BVH */
 #define ORC_FLAG_LIGHT_LIST 8u          /* extension (with the former): LIGHT triangles emit and are sampled by NEE; same value as TYR_FLAG_LIGHT_LIST */
 
 /* ---- a1-a3: RNG and sampling helpers (kernel.cu:23-65, 181-208) ---------- */
@@ -203,6 +204,7 @@ const orc_sunparams* orc_sun_params(const orc_ctx* c);
 void orc_stage_begin(orc_ctx* c);   /* host prologue of launch_kernels: constants, camera basis, reset (kernel.cu:671-718) */
 void orc_stage_primary(orc_ctx* c); /* kernel.cu:247-297 + set_wavefront_globals 227-244 */
 void orc_stage_extend(orc_ctx* c);  /* kernel.cu:331-343 */
+void orc_stage_extend_debug(orc_ctx* c); /* kernel.cu:300-328 (ORC_FLAG_DEBUG_BVH) */
 void orc_stage_shade(orc_ctx* c);   /* kernel.cu:347-627 */
 void orc_stage_connect(orc_ctx* c); /* kernel.cu:630-646 */
 void orc_stage_end(orc_ctx* c);     /* frame++ and the caller's std::swap (kernel.cu:736-739, main.cpp:169) */

@@ -365,6 +365,32 @@ void orc_stage_extend(orc_ctx* c) {
 	c->k.rays_in_tree_extend += cnt[2];
 }
 
+/* ---- extend_debug_BVH (kernel.cu:300-328) via intersect_scene_DEBUG (143-160): the reference's compile-time BVH_DEBUG
+ * build -- spheres ignored, every ray starts at VERY_FAR, the pixel is coloured by the number of traversal steps
+ * (intersect_debug, bvh.h:164-209: loop iterations - 1); plain stores, the last ray of a pixel wins ------------------ */
+void orc_stage_extend_debug(orc_ctx* c) {
+	for (uint32_t index = 0; index < c->k.n_live; ++index) {
+		orc_ray* ray = &c->ray_buffer[index];
+		ray->distance = ORC_VERY_FAR;
+		int traversals = 0;
+		if (c->nPrims > 0) {
+			uint64_t cnt[3] = { 0, 0, 0 };
+			if (orc_bvh_intersect(c->nodes, c->prims, ray, cnt))
+				ray->geometry_type = 1;
+			traversals = (int)cnt[0] - 1;
+		}
+		float* px = &c->blit_buffer[4 * (size_t)ray->index];
+		int green = (int)((0.0002f * (float)traversals) * 255.99f);
+		green = green > 255 ? 255 : green;
+		px[1] = (float)green;
+		px[3] = 1.0f;
+		if (traversals >= 70) { /* "Color very costly regions distinctly" */
+			px[0] = (float)green;
+			px[1] = 0.0f;
+		}
+	}
+}
+
 /* NEE toward spheres[6] (kernel.cu:419-448 and 559-591); returns 1 if a shadow ray was produced */
 static int sample_sphere_light(const orc_ctx* c, uint32_t* seed, v3 origin, v3 normal, v3* lightDir, float* cosSurfaceToLight, float* cosLightToSurface, v3* lightVector) {
 	const orc_sphere* lightsource = &c->spheres[6];
@@ -705,6 +731,11 @@ void orc_stage_end(orc_ctx* c) {
 int orc_launch_kernels(orc_ctx* c) {
 	orc_stage_begin(c);
 	orc_stage_primary(c);
+	if (c->flags & ORC_FLAG_DEBUG_BVH) { /* kernel.cu:721-722: #if BVH_DEBUG */
+		orc_stage_extend_debug(c);
+		orc_stage_end(c);
+		return 0;
+	}
 	orc_stage_extend(c);
 	orc_stage_shade(c);
 	orc_stage_connect(c);

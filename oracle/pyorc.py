@@ -150,7 +150,7 @@ def lib() -> C.CDLL:
         L.orc_shadow_queue.argtypes = [P]
         L.orc_sun_params.restype = C.POINTER(SunParams)
         L.orc_sun_params.argtypes = [P]
-        for name in ("orc_stage_begin", "orc_stage_primary", "orc_stage_extend", "orc_stage_shade", "orc_stage_connect", "orc_stage_end"):
+        for name in ("orc_stage_begin", "orc_stage_primary", "orc_stage_extend", "orc_stage_extend_debug", "orc_stage_shade", "orc_stage_connect", "orc_stage_end"):
             getattr(L, name).argtypes = [P]
         L.orc_import_work_queue.argtypes = [P, P, c_u32]
         L.orc_bbox_host_ops.argtypes = [P, c_i, P, P]

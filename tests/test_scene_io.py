@@ -1,4 +1,5 @@
-"""PLY import with Scene::Load's conventions and image export.  CPU only."""
+"""PLY import with Scene::Load's conventions and image export.  CPU, plus one end-to-end test on
+the GPU (PLY -> BVH -> render -> resolve -> PNG / PFM)."""
 import os
 import struct
 
@@ -175,3 +176,62 @@ def test_hostile_ply_headers_and_write_errors(hip, tmp_path):
         with pytest.raises(hip.TyrError) as e:
             hip.write_image("/dev/full", np.zeros((256, 256, 4), dtype=np.float32), 256, 256)  # ENOSPC on write / close
         assert e.value.status == -8
+
+
+@pytest.mark.gpu
+def test_ply_to_png_on_the_gpu(hip, orc, tmp_path):
+    """SURVEY.md 8f-2 end to end on the GPU box: a mesh written as binary PLY -> tyr_load_ply (Scene::Load's conventions)
+    -> tyr_bvh_build -> tyr_scene_upload -> tyr_render -> tyr_resolve -> tyr_write_png / tyr_write_pfm; the triangles that
+    come out of the file are the generator's, the render equals the oracle's on the same arrays, the PFM holds the
+    resolved frame's floats, the PNG parses"""
+    import struct as st
+    import zlib
+
+    import torch
+
+    from conftest import bits
+    from tyrant_amd import scenes
+
+    sc = scenes.mesh_scene(24)
+    t = sc.triangles
+    v = np.stack([t["vert"], t["vert"] + t["e1"], t["vert"] + t["e2"]], axis=1).reshape(-1, 3).astype(np.float32)
+    keep = np.all((v.reshape(-1, 3, 3)[:, 1] - v.reshape(-1, 3, 3)[:, 0] == t["e1"]) & (v.reshape(-1, 3, 3)[:, 2] - v.reshape(-1, 3, 3)[:, 0] == t["e2"]), axis=1)
+    assert keep.mean() > 0.9  # (vert + e) - vert == e for nearly every edge: those triangles must come back bit for bit
+    nf = t.shape[0]
+    p = tmp_path / "mesh.ply"
+    with open(p, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nelement face %d\nproperty list uchar uint vertex_indices\nend_header\n" % (3 * nf, nf)).encode())
+        f.write(v.tobytes())
+        for i in range(nf):
+            f.write(st.pack("<BIII", 3, 3 * i, 3 * i + 1, 3 * i + 2))
+    loaded = hip.load_ply(str(p))
+    assert loaded.shape[0] == nf
+    for fld in ("vert", "e1", "e2"):
+        assert np.array_equal(bits(loaded[fld][keep]), bits(t[fld][keep])), fld
+    nodes, prims = hip.bvh_build(loaded)
+    W, H, N, spp = 160, 96, 8192, 2
+    g = hip.Renderer(W, H, N)
+    g.upload(nodes, prims), g.set_spheres(sc.spheres), g.set_camera(sc.camera), g.set_sun_position(*sc.sun_position)
+    o = orc.Oracle(W, H, N)
+    o.upload(nodes, prims), o.set_spheres(sc.spheres), o.set_camera(sc.camera), o.set_sun_position(*sc.sun_position)
+    assert g.render(spp) == o.render(spp)
+    bg, bo = g.blit_buffer(), o.blit_buffer()
+    assert np.array_equal(bg[:, 3], bo[:, 3]) and np.allclose(bg[:, :3], bo[:, :3], rtol=1e-5, atol=1e-6)
+    out = torch.zeros(W * H * 4, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    g.resolve_into(out.data_ptr())
+    frame = out.cpu().numpy().reshape(H * W, 4)
+    pfm, png = tmp_path / "frame.pfm", tmp_path / "frame.png"
+    hip.write_image(str(pfm), frame, W, H)
+    hip.write_image(str(png), frame, W, H)
+    raw = open(pfm, "rb").read()
+    head, body = raw.split(b"-1.0\n", 1)
+    assert head == b"PF\n%d %d\n" % (W, H)
+    got = np.frombuffer(body, dtype="<f4").reshape(H, W, 3)[::-1]  # PFM rows run bottom to top
+    assert np.array_equal(bits(got), bits(frame.reshape(H, W, 4)[:, :, :3]))
+    data = open(png, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n" and st.unpack(">II", data[16:24]) == (W, H)
+    idat = data[data.index(b"IDAT") + 4 : data.index(b"IEND") - 8]
+    rows = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(H, 1 + 3 * W)
+    c = np.nan_to_num(frame.reshape(H, W, 4)[:, :, :3], nan=0.0).clip(0.0, 1.0)
+    assert np.all(rows[:, 0] == 0) and np.array_equal(rows[:, 1:].reshape(H, W, 3), (c * np.float32(255.0) + np.float32(0.5)).astype(np.uint8))

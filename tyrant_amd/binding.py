@@ -24,6 +24,7 @@ TYR_FLAG_PROFILE = 2
 TYR_FLAG_COUNT_VISITS = 4
 TYR_FLAG_LIGHT_LIST = 8
 TYR_FLAG_TRIANGLE_COLORS = 16
+TYR_FLAG_DEBUG_BVH = 32
 TYR_ERR_NO_DEVICE = -2
 TYR_ERR_UNSUPPORTED = -7
 TYR_DIST_GATHER, TYR_DIST_REDUCE = 0, 1

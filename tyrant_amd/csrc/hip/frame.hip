@@ -183,6 +183,46 @@ __global__ void __launch_bounds__(kBlock) k_vecmath_probe(int op, const float* _
 	out[3 * i + 2] = r.z;
 }
 
+// ======================================================================================
+// extend_debug_BVH, kernel.cu:300-328 via intersect_scene_DEBUG (143-160) and CachedBVH::intersect_debug (bvh.h:164-209):
+// the reference's compile-time BVH_DEBUG picture of the traversal cost.  One thread per slot on the pair nodes with the
+// reference's counting rule (traversals = nodes visited - 1); a diagnostic, not a hot path.
+// ======================================================================================
+__global__ void __launch_bounds__(kBlock) k_extend_debug(const FrameParams P) {
+	uint32_t refs[kStackSize];
+	float ts[kStackSize];
+	TravStack<0> st;
+	st.bind(nullptr, refs, ts);
+	st.reset();
+	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+	if (slot >= P.k->n_live)
+		return;
+	const float4 a = P.work.o_dx[slot];
+	const float2 b = P.work.dyz[slot];
+	float dist = kVeryFar; // kernel.cu:145; the spheres are commented out there (147-155)
+	int prim = 0, traversals = 0;
+	if (P.scene.rootRef != kRefDone) {
+		VisitCount vc{ 0, 0 };
+		const RayConst r = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+		const bool hit = bvh_closest<true>(P.scene, r, dist, prim, st, vc);
+		traversals = (int)vc.nodes - 1; // bvh.h:172-175: the counter starts at -1 and counts loop iterations
+		P.work.hit[slot] = make_float2(dist, __uint_as_float(hit ? (uint32_t)prim : 0u));
+		if (st.overflow)
+			atomicOr(&P.k->device_error, kErrStackOverflow);
+	} else {
+		P.work.hit[slot] = make_float2(dist, 0.0f);
+	}
+	float* px = reinterpret_cast<float*>(&P.blit[__float_as_int(P.work.direct_ix[slot].w)]);
+	int green = (int)((0.0002f * (float)traversals) * 255.99f);
+	green = green > 255 ? 255 : green;
+	px[1] = (float)green;
+	px[3] = 1.0f;
+	if (traversals >= 70) { // "Color very costly regions distinctly"
+		px[0] = (float)green;
+		px[1] = 0.0f;
+	}
+}
+
 // ---- launch wrappers ---------------------------------------------------------------------
 
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
@@ -195,6 +235,10 @@ void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream) {
 }
 void launch_vecmath_probe(int op, const float* a, const float* b, const float* c, uint32_t n, float* out, hipStream_t stream) {
 	hipLaunchKernelGGL(k_vecmath_probe, dim3(blocks_for(n ? n : 1)), dim3(kBlock), 0, stream, op, a, b, c, n, out);
+}
+void launch_extend_debug(const FrameParams& P, uint32_t maxLive, hipStream_t stream) {
+	if (maxLive != 0)
+		hipLaunchKernelGGL(k_extend_debug, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
 }
 void launch_extend_spheres(const FrameParams& P, uint32_t nSurvivors, hipStream_t stream) {
 	if (nSurvivors != 0)

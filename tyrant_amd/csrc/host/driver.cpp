@@ -280,6 +280,10 @@ void enqueue_primary(tyr_ctx* c, const FrameParams& P, uint32_t nNew, uint32_t n
 // their sphere pre-pass; an upper bound is fine, the kernel checks against the device's count)
 void enqueue_extend(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t nSurvivors) {
 	KernelTimer t(c, TYR_K_EXTEND);
+	if (c->cfg.flags & TYR_FLAG_DEBUG_BVH) { // the reference's BVH_DEBUG build: kernel.cu:721-722
+		launch_extend_debug(P0, nLive, c->stream);
+		return;
+	}
 	FrameParams P = P0;
 	P.raysPerBlock = rays_per_block_for(c, nLive);
 	launch_extend(P, nLive, nSurvivors, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, c->stream);
@@ -831,6 +835,18 @@ static int launch_iteration(tyr_ctx* c, int overlap, bool pipelined) {
 	// neighbouring kernel fills (N = 2 Mi: +8 % C2, +13 % C3; from ~8 M rays up the two grids only stretch each other;
 	// deciding per iteration by nLive instead was neutral on a 16.6 M queue: profiles/r01_deferred_connect_ab.txt)
 	// merged traversal launches (k_trace_flat): connect(i) waits for the launch of extend(i + 1)
+	if (c->cfg.flags & TYR_FLAG_DEBUG_BVH) {
+		// kernel.cu:720-722 under BVH_DEBUG: primary_rays, set_wavefront_globals, extend_debug_BVH -- no shade, no connect
+		// (nothing survives: the next call regenerates the whole queue from the cursor)
+		FrameParams Pd = make_params(c);
+		enqueue_primary(c, Pd, nNew, nLive);
+		enqueue_extend(c, Pd, nLive, nLive - nNew);
+		HIPCHK(hipGetLastError());
+		rc = sync_counters(c);
+		collect_timings(c);
+		stage_end(c);
+		return rc ? rc : check_device_error(c);
+	}
 	const bool merge = pipelined && c->tuning.mergeTrace != 0 && c->tuning.traversalVariant == 4 && !(c->cfg.flags & TYR_FLAG_COUNT_VISITS) && c->scene.rootRef != kRefDone;
 	const bool deferConnect = !merge && (overlap == 1 || (overlap == 2 && c->cfg.queue_size <= kOverlapMaxLive));
 	FrameParams P = make_params(c);
