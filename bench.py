@@ -215,9 +215,9 @@ def run_pmc_passes(args, timeout_s: float = 150.0):
                 return None
             for name in group:
                 mine = sorted((r for r in rows if r["Counter_Name"] == name), key=lambda r: int(r["Dispatch_Id"]))
-                if len(mine) < iters:
+                if len(mine) < 2 or len(mine) % 2:
                     return None
-                last = mine[-iters:]  # the second (warm) render's launches
+                last = mine[len(mine) // 2:]  # the child renders twice: the second (warm) render's launches of this kernel
                 counters[name] = sum(float(r["Counter_Value"]) for r in last) / len(last)
                 launches = len(last)
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:

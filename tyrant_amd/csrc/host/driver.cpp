@@ -289,7 +289,9 @@ void enqueue_extend(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t 
 	launch_extend(P, nLive, nSurvivors, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, c->stream);
 }
 // extend of this iteration and connect of the previous one in one launch (tyr_render, TYR_TUNE_MERGE_TRACE)
-void enqueue_trace(tyr_ctx* c, const FrameParams& P, uint32_t nLive, uint32_t nSurvivors, uint32_t maxShadowPrev) {
+void enqueue_trace(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t nSurvivors, uint32_t maxShadowPrev) {
+	FrameParams P = P0;
+	P.traceShadow = maxShadowPrev != 0 ? 1u : 0u;
 	KernelTimer t(c, TYR_K_EXTEND);
 	launch_trace(P, nLive, nSurvivors, maxShadowPrev, c->tuning, c->numCUs, c->launchCache, c->stream);
 }
@@ -851,9 +853,10 @@ static int launch_iteration(tyr_ctx* c, int overlap, bool pipelined) {
 	const bool deferConnect = !merge && (overlap == 1 || (overlap == 2 && c->cfg.queue_size <= kOverlapMaxLive));
 	FrameParams P = make_params(c);
 	enqueue_primary(c, P, nNew, nLive);
-	if (merge && c->shadowPending) {
+	if (merge) { // every traversal launch of a merged render is k_trace_flat; the first one has no shadow rays to carry yet
+		const uint32_t carried = c->shadowPending ? c->shadowPendingMax : 0u;
 		c->shadowPending = false;
-		enqueue_trace(c, P, nLive, nLive - nNew, c->shadowPendingMax);
+		enqueue_trace(c, P, nLive, nLive - nNew, carried);
 	} else {
 		if ((rc = flush_pending_shadow(c))) // (a render whose merge setting changed between iterations: never, but cheap)
 			return rc;
