@@ -1482,6 +1482,9 @@ static void launch_connect_t(const FrameParams& P, uint32_t maxShadow, const Tun
 
 // extend of this iteration + connect of the previous one in one launch (tyr_render; production traversal only).
 // P.kc must be this iteration's set, P.kcPrev the previous iteration's (its shadow rays are still in the shadow queue).
+#ifndef TYR_TRACE_STACK
+#define TYR_TRACE_STACK 12 // LDS stack entries per lane of k_trace_flat (a what-if build may pair 8 with TYR_FLAT_WAVES_PER_EU=6)
+#endif
 void launch_trace(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, uint32_t maxShadowPrev, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
 	launch_extend_spheres(P, nSurvivors, stream);
 	if (maxShadowPrev != 0) {
@@ -1490,7 +1493,7 @@ void launch_trace(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, u
 		launch_connect_spheres(Pc, maxShadowPrev, stream);
 	}
 	const uint32_t items = maxLive + maxShadowPrev;
-	hipLaunchKernelGGL((k_trace_flat<12>), dim3(persistent_blocks(k_trace_flat<12>, items, t, numCUs, lc.perCU[kLcTrace][0])), dim3(kBlock), 0, stream, P);
+	hipLaunchKernelGGL((k_trace_flat<TYR_TRACE_STACK>), dim3(persistent_blocks(k_trace_flat<TYR_TRACE_STACK>, items, t, numCUs, lc.perCU[kLcTrace][0])), dim3(kBlock), 0, stream, P);
 }
 
 void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
