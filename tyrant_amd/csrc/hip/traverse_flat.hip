@@ -95,7 +95,9 @@ struct ChunkFeed {
 			chunk >>= 1;
 	}
 	// true when [next, end) is non-empty afterwards
-	__device__ __forceinline__ bool refill(uint32_t* tickets, uint32_t nItems, uint32_t lane) {
+	// softLimit (k_trace_flat's staggered exit): the chunk that starts at or behind it is this wave's last draw -- a drawn
+	// chunk is always traced, whoever drew it
+	__device__ __forceinline__ bool refill(uint32_t* tickets, uint32_t nItems, uint32_t lane, uint32_t softLimit = 0xffffffffu) {
 		while (next == end && tried < kTicketWords) {
 			uint32_t t = 0;
 			if (lane == 0) {
@@ -116,6 +118,8 @@ struct ChunkFeed {
 			if (start < nItems) {
 				next = (uint32_t)start;
 				end = (start + chunk < nItems) ? (uint32_t)(start + chunk) : nItems;
+				if (start >= softLimit)
+					tried = kTicketWords;
 			} else {
 				word = (word + 1) % kTicketWords;
 				++tried;
@@ -709,6 +713,17 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	const uint32_t blockBegin = blockIdx.x * perBlock, blockEnd = blockBegin + perBlock;
 	ChunkFeed feed;
 	feed.init(nItems - dynBase, P.ticketChunk);
+	// Staggered exit (TYR_TUNE_STAGGER_SHARE, off by default).  Every launch ends in a drain in which all of the grid's waves
+	// finish their last rays a few lanes wide, five to a SIMD, each step of each costing a full wave's instructions.  With
+	// the last n/64 of the rays reserved for one block in five (blocks b, b + G/5... land on the same CU when workgroups
+	// are dealt round-robin: one stayer wave per SIMD), the other four stop drawing early and drain while the stayers still
+	// have rays to feed on; the stayers' own drain then has the SIMD to itself.
+	uint32_t softLimit = 0xffffffffu;
+	if (P.staggerShare != 0u && (blockIdx.x % 5u) >= P.staggerStay) {
+		const uint32_t nDyn = nItems - dynBase;
+		const uint32_t keep = (uint32_t)(((unsigned long long)nItems * P.staggerShare) >> 6);
+		softLimit = nDyn > keep ? nDyn - keep : 0u;
+	}
 	bool staticDone = (perBlock == 0);
 	if (threadIdx.x == 0)
 		blockNext = blockBegin;
@@ -741,7 +756,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 				staticDone = (base + nIdle >= blockEnd);
 			}
 			while (staticDone && got < nIdle) {
-				if (!feed.refill(P.k->extend_chunks, nItems - dynBase, lane)) {
+				if (!feed.refill(P.k->extend_chunks, nItems - dynBase, lane, softLimit)) {
 					exhausted = true;
 					if (kAnatomy && tExhausted == 0ull) {
 						tExhausted = __builtin_amdgcn_s_memrealtime();
@@ -794,6 +809,10 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 				// an extend ray that misses the root box is finished here (the pre-pass's answer stands, nothing to write); a
 				// shadow ray a sphere blocks likewise; a shadow ray that misses the tree is visible: it retires below
 				live = (ref != kRefDone) || (isShadow && !blocked);
+#ifdef TYR_RAY_STEPS
+				if (!live && s < P.N)
+					P.next.hit[s] = make_float2(0.0f, isShadow ? 1.0f : 0.0f); // never entered the tree
+#endif
 			}
 			if (!exhausted && (uint32_t)__popcll(__ballot(live && ref != kRefDone)) < P.minTraversing)
 				if (__ballot(live && ref == kRefDone) == 0ull)
@@ -883,6 +902,15 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 					atomicAdd(&P.k->debug[10], 1ull);
 				if (steps > 256)
 					atomicAdd(&P.k->debug[11], 1ull);
+#ifdef TYR_RAY_STEPS
+				// per-ray record for tools/ray_length_probe.py (with -DTYR_QUAD_STATS), parked in the NEXT queue's hit column
+				// like the per-wave records of the anatomy build: quad steps of item s (shadow rays behind the extend rays)
+				{
+					const uint32_t item = isShadow ? nExt + slot : slot;
+					if (item < P.N)
+						P.next.hit[item] = make_float2((float)steps, isShadow ? 1.0f : 0.0f);
+				}
+#endif
 				steps = 0;
 			}
 		}
@@ -905,11 +933,13 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		// per-wave record for tools/drain_profile.py, parked in an array nobody uses during this launch (the NEXT queue's
 		// hit column): microseconds from this wave's start to "queue used up" and to its exit, and how many of its lanes
 		// still held a ray when the queue ran out
+#ifndef TYR_RAY_STEPS // (that build keeps per-RAY records in the same column)
 		const uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 		if (w < P.N)
 			P.next.hit[w] = make_float2((float)((tExhausted ? tExhausted : tEnd) - tStart) * 0.01f, (float)(tEnd - tStart) * 0.01f + (float)liveAtExhaustion * 0.0f);
 		if (w < P.N)
 			P.next.flags[w] = liveAtExhaustion;
+#endif
 	}
 }
 
