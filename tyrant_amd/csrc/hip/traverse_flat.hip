@@ -95,9 +95,7 @@ struct ChunkFeed {
 			chunk >>= 1;
 	}
 	// true when [next, end) is non-empty afterwards
-	// softLimit (k_trace_flat's staggered exit): the chunk that starts at or behind it is this wave's last draw -- a drawn
-	// chunk is always traced, whoever drew it
-	__device__ __forceinline__ bool refill(uint32_t* tickets, uint32_t nItems, uint32_t lane, uint32_t softLimit = 0xffffffffu) {
+	__device__ __forceinline__ bool refill(uint32_t* tickets, uint32_t nItems, uint32_t lane) {
 		while (next == end && tried < kTicketWords) {
 			uint32_t t = 0;
 			if (lane == 0) {
@@ -118,8 +116,6 @@ struct ChunkFeed {
 			if (start < nItems) {
 				next = (uint32_t)start;
 				end = (start + chunk < nItems) ? (uint32_t)(start + chunk) : nItems;
-				if (start >= softLimit)
-					tried = kTicketWords;
 			} else {
 				word = (word + 1) % kTicketWords;
 				++tried;
@@ -713,17 +709,6 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	const uint32_t blockBegin = blockIdx.x * perBlock, blockEnd = blockBegin + perBlock;
 	ChunkFeed feed;
 	feed.init(nItems - dynBase, P.ticketChunk);
-	// Staggered exit (TYR_TUNE_STAGGER_SHARE, off by default).  Every launch ends in a drain in which all of the grid's waves
-	// finish their last rays a few lanes wide, five to a SIMD, each step of each costing a full wave's instructions.  With
-	// the last n/64 of the rays reserved for one block in five (blocks b, b + G/5... land on the same CU when workgroups
-	// are dealt round-robin: one stayer wave per SIMD), the other four stop drawing early and drain while the stayers still
-	// have rays to feed on; the stayers' own drain then has the SIMD to itself.
-	uint32_t softLimit = 0xffffffffu;
-	if (P.staggerShare != 0u && (blockIdx.x % 5u) >= P.staggerStay) {
-		const uint32_t nDyn = nItems - dynBase;
-		const uint32_t keep = (uint32_t)(((unsigned long long)nItems * P.staggerShare) >> 6);
-		softLimit = nDyn > keep ? nDyn - keep : 0u;
-	}
 	bool staticDone = (perBlock == 0);
 	if (threadIdx.x == 0)
 		blockNext = blockBegin;
@@ -756,7 +741,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 				staticDone = (base + nIdle >= blockEnd);
 			}
 			while (staticDone && got < nIdle) {
-				if (!feed.refill(P.k->extend_chunks, nItems - dynBase, lane, softLimit)) {
+				if (!feed.refill(P.k->extend_chunks, nItems - dynBase, lane)) {
 					exhausted = true;
 					if (kAnatomy && tExhausted == 0ull) {
 						tExhausted = __builtin_amdgcn_s_memrealtime();

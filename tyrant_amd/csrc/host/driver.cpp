@@ -161,8 +161,6 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.raysPerBlock = static_cast<uint32_t>(std::min(std::max(c->tuning.raysPerBlock, 256), 65536));
 	P.staticShare = static_cast<uint32_t>(std::min(std::max(c->tuning.staticShare, 0), 15));
 	P.staticInterleave = c->tuning.staticInterleave ? 1u : 0u;
-	P.staggerShare = static_cast<uint32_t>(std::min(std::max(c->tuning.staggerShare, 0), 32));
-	P.staggerStay = static_cast<uint32_t>(std::min(std::max(c->tuning.staggerStay, 1), 4));
 	P.lights = c->dLights;
 	P.nLights = c->nLights;
 	std::memcpy(P.triEmission, c->triEmission, 12);
@@ -1240,16 +1238,6 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		if (value < 0 || value >= (1 << TYR_K_COUNT))
 			return TYR_ERR_INVALID;
 		c->tuning.profileMask = value;
-		return TYR_OK;
-	case TYR_TUNE_STAGGER_SHARE:
-		if (value < 0 || value > 32)
-			return TYR_ERR_INVALID;
-		c->tuning.staggerShare = value;
-		return TYR_OK;
-	case TYR_TUNE_STAGGER_STAY:
-		if (value < 1 || value > 4)
-			return TYR_ERR_INVALID;
-		c->tuning.staggerStay = value;
 		return TYR_OK;
 	case TYR_TUNE_STATIC_INTERLEAVE:
 		if (value < 0 || value > 1)
