@@ -249,6 +249,33 @@ def test_edge_cases(orc, hip):
     assert np.array_equal(acc[0][1][:, 3], acc[1][1][:, 3]) and np.allclose(acc[0][1], acc[1][1], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("N", [1, 63, 65, 257, 1000])
+def test_tiny_and_ragged_queue_sizes(orc, hip, N):
+    """queues far smaller than a wave / a tile / the frame: the top-up cursor walks the frame N rays at a time
+    (kernel.cu:227-244), every persistent grid is one partial block, and the render still equals the oracle's"""
+    W, H, spp = 16, 12, 2
+    o, g = pair(orc, hip, "cornell36", W, H, N)
+    for it in range(3):  # three iterations stage by stage (survivors + top-up in a queue of N slots)
+        o.stage("begin"), g.stage("begin")
+        o.stage("primary"), g.stage("primary")
+        n = o.counters()["n_live"]
+        assert n == g.counters()["n_live"] and n <= N
+        assert_state_equal(o.ray_queue(0, n), g.ray_queue(0, n), f"N={N} iteration {it} after primary")
+        for st in ("extend", "shade", "connect", "end"):
+            o.stage(st), g.stage(st)
+        ko, kg = o.counters(), g.counters()
+        assert kg["device_error"] == 0
+        assert ko["primary_ray_cnt"] == kg["primary_ray_cnt"] and ko["shadow_ray_cnt"] == kg["shadow_ray_cnt"]
+    o, g = pair(orc, hip, "cornell36", W, H, N)
+    assert o.render(spp) == g.render(spp)
+    ko, kg = o.counters(), g.counters()
+    assert kg["device_error"] == 0
+    for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible", "start_position", "frame"):
+        assert ko[f] == kg[f], (N, f)
+    assert np.all(g.blit_buffer()[:, 3] == spp)
+    assert_accum_close(o.blit_buffer(), g.blit_buffer(), f"N={N}")
+
+
 def test_sharded_ranks_match_oracle(orc, hip):
     """pixel sharding: each rank's render equals the oracle run with the same (rank, nranks); the sum covers the frame"""
     W, H, R, spp = 64, 48, 4, 2
