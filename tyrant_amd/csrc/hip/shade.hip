@@ -507,8 +507,11 @@ __device__ __forceinline__ void shade_lookback(const FrameParams& P, uint32_t vb
 	ehOut = eh;
 }
 
+#ifndef TYR_SHADE_BLOCKS_PER_CU
+#define TYR_SHADE_BLOCKS_PER_CU 4 // tiles in flight per CU: 128 vector registers each (a what-if build may ask for 5 or 6 and take the spills)
+#endif
 template <bool LIGHTS>
-__global__ void __launch_bounds__(kBlock) k_shade(const FrameParams P, uint32_t nTiles) {
+__global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const FrameParams P, uint32_t nTiles) {
 	__shared__ uint32_t sh[32];
 	__shared__ ShadeStage stage;
 	const uint32_t tid = threadIdx.x;
