@@ -54,6 +54,30 @@ def test_roofline_block_names_the_tightest_measured_resource_and_never_exceeds_o
     assert r["bound"] == "hbm" and r["frac"] <= 1.0 and r["traffic"] is None and "note" in r
 
 
+def test_roofline_block_of_the_merged_trace_kernel():
+    """merged launches: the algorithmic figure covers every extend AND every shadow ray of the timed renders over the
+    trace launches plus the last iteration's connect launch; the bound still comes from the counters alone"""
+    visits = {"nodes_per_ext": 12.3, "tris_per_ext": 0.9, "nodes_per_con": 14.9, "tris_per_con": 0.7, "visible_frac": 0.6}
+    pmc = {"counters": {"FETCH_SIZE": 1.2e6, "WRITE_SIZE": 1.0e5, "GRBM_GUI_ACTIVE": 8 * 1.8e6, "SQ_ACTIVE_INST_VALU": 2.9e8, "SQ_ACTIVE_INST_SCA": 5.0e7,
+                        "SQ_THREAD_CYCLES_VALU": 64 * 2.9e8 * 0.39, "SQ_INSTS_VALU": 2.8e8, "SQ_INSTS_SALU": 2.0e8, "SQ_WAVE_CYCLES": 9e9, "SQ_WAIT_ANY": 6e9},
+           "launches_averaged": 6, "kernel": bench.TRACE_KERNEL, "source": "unit test"}
+    ext_rays, shadow_rays = 31.0e6, 11.5e6
+    r = bench.roofline_block(pmc, ext_ms=4.4, ext_launches=6, ext_rays=ext_rays, visits=visits, kernel_ms_per_render={}, kernel=bench.TRACE_KERNEL, con_ms=0.26, shadow_rays=shadow_rays)
+    assert bench.TRACE_KERNEL in r["kernel"] and "connect" in r["kernel"]
+    assert r["bound"] == "valu-issue" and 0 < r["frac"] <= 1 and r["frac"] == r["valu_issue_frac"]
+    assert abs(r["lanes_active_per_valu_inst"] - 0.39) < 1e-3
+    per_ext = 24 + 8 + 32 * 12.3 + 36 * 0.9
+    per_con = 44 + 32 * 14.9 + 36 * 0.7 + 12 * 0.6
+    want = (per_ext * ext_rays + per_con * shadow_rays) / ((4.4 + 0.26) * 1e-3) / 1e9
+    assert abs(r["algorithmic"]["GBps"] - want) < 0.02 * want
+    assert r["algorithmic"]["bytes_per_launch"] == round((per_ext * ext_rays + per_con * shadow_rays) / 6)
+    assert "shadow" in r["algorithmic"]["covers"]
+    # the separate-launch form of the same numbers prices the extend launches only
+    r2 = bench.roofline_block(pmc, ext_ms=4.4, ext_launches=6, ext_rays=ext_rays, visits=visits, kernel_ms_per_render={})
+    assert bench.EXTEND_KERNEL in r2["kernel"] and r2["algorithmic"]["GBps"] < r["algorithmic"]["GBps"] * 1.2
+    assert abs(r2["algorithmic"]["GBps"] - per_ext * ext_rays / 4.4e-3 / 1e9) < 0.02 * r2["algorithmic"]["GBps"]
+
+
 def test_committed_pmc_profiles_parse():
     """profiles/pmc_<workload>.json is what bench.py falls back to when rocprofv3 cannot run beside it"""
     for wl, n in (("c3", 1920 * 1080 * 8),):
