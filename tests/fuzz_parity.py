@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tests/fuzz_parity.py [n] [seed] -- randomised end-to-end parity: random scenes (triangle soups and height-field meshes of
-random size, with and without per-triangle materials and emissive triangles), random resolutions, queue sizes, cameras and launch-shape knobs;
+random size, with and without per-triangle materials, emissive triangles and colour palettes), random resolutions, pixel shards (rank / nranks), queue sizes, cameras and
+launch-shape knobs (merged / separate / side-stream traversal launches, every traversal variant);
 each render is compared with the oracle's: identical iteration and ray counts, queues of the last iteration bit-exact,
 radiance within 1e-5 relative.  A checker like the tests (it is the only other place that drives the oracle), not collected by pytest (run time grows with n); prints one line per case."""
 import os
@@ -24,23 +25,35 @@ for case in range(n_cases):
     else:
         sc = scenes.tyrant_default(int(rng.integers(4, 40)), seed=int(rng.integers(1, 1 << 30)))
     W, H = int(rng.integers(17, 140)), int(rng.integers(11, 90))
+    nranks = int(rng.choice([1, 1, 1, 2, 3, 4, 8]))  # pixel sharding (rows y % nranks == rank), checked against the oracle's shard
+    H = max(nranks, H - H % nranks)
+    rank = int(rng.integers(0, nranks))
     N = int(rng.integers(65, 9000))
     spp = int(rng.integers(1, 4))
     cam = scenes.Camera(position=tuple(np.array(sc.camera.position) + rng.normal(0, 3, 3)), direction=sc.camera.direction, up=sc.camera.up,
                         focalDistance=float(rng.uniform(1, 80)), lensRadius=float(rng.choice([0.0, 0.0, rng.uniform(0.1, 3.0)])))
     knobs = dict(traversal_variant=int(rng.choice([4, 4, 4, 3, 2, 1, 0])), stack_lds_depth=int(rng.choice([0, 8, 10, 12, 16, 24])), refill_min_idle=int(rng.integers(1, 65)),
                  min_traversing=int(rng.integers(1, 65)), ticket_chunk=int(rng.choice([64, 128, 1024])), static_share=int(rng.integers(0, 16)), staged_nodes=int(rng.integers(0, 65)),
-                 rays_per_block=int(rng.choice([256, 1024, 4096])))
+                 rays_per_block=int(rng.choice([256, 1024, 4096])), merge_trace=int(rng.integers(0, 2)), static_interleave=int(rng.integers(0, 2)), overlap_connect=int(rng.integers(0, 3)))
+    if knobs["traversal_variant"] == 4 and rng.random() < 0.15:
+        knobs["traversal_variant"] = 5  # the ring-of-prepared-rays variant (diagnostics library)
+        knobs["stack_lds_depth"] = 12
     if sc.triangle_materials and rng.random() < 0.5:  # emissive triangles + light list (TYR_FLAG_LIGHT_LIST)
         lit = rng.choice(len(sc.triangles), size=int(rng.integers(1, min(40, len(sc.triangles)))), replace=False)
         sc.triangles["materialType"][lit] = scenes.LIGHT
         sc.light_list, sc.triangle_emission = True, tuple(float(v) for v in rng.uniform(0.5, 6.0, 3))
         sc.name += "+lights"
-    flags = (1 if sc.triangle_materials else 0) | (8 if sc.light_list else 0)
+    if sc.triangle_materials and rng.random() < 0.4:  # per-triangle colour / emission palette (TYR_FLAG_TRIANGLE_COLORS)
+        sc.triangles["pad_"][:, 0] = rng.integers(0, 256, len(sc.triangles)).astype(sc.triangles["pad_"].dtype)
+        sc.triangle_colors = True
+        sc.palette_color = rng.uniform(0.05, 1.0, (256, 3)).astype(np.float32)
+        sc.palette_emission = rng.uniform(0.0, 6.0, (256, 3)).astype(np.float32)
+        sc.name += "+colors"
+    flags = (1 if sc.triangle_materials else 0) | (8 if sc.light_list else 0) | (16 if sc.triangle_colors else 0)
     bb = scenes.triangle_bboxes(sc.triangles)
     nodes, prims = pyorc.bvh_build(sc.triangles, bb)
-    o = pyorc.Oracle(W, H, N, flags=flags)
-    g = binding.Renderer(W, H, N, flags=flags, diag=True)  # every variant and stack depth: libtyrant_hip_diag.so
+    o = pyorc.Oracle(W, H, N, rank=rank, nranks=nranks, flags=flags)
+    g = binding.Renderer(W, H, N, rank=rank, nranks=nranks, flags=flags, diag=True)  # every variant and stack depth: libtyrant_hip_diag.so
     for r in (o, g):
         r.load_scene(sc, nodes, prims)
         r.set_camera(cam)
@@ -71,7 +84,7 @@ for case in range(n_cases):
     except Exception as e:  # noqa: BLE001
         ok, why = False, repr(e)
     bad += not ok
-    print(f"case {case:3d} {sc.name:26s} {len(sc.triangles):7d} tris {W:3d}x{H:<3d} N={N:5d} spp={spp} lens={cam.lensRadius:.2f} {knobs} -> {'ok' if ok else 'FAIL ' + why}", flush=True)
+    print(f"case {case:3d} {sc.name:26s} {len(sc.triangles):7d} tris {W:3d}x{H:<3d} rank {rank}/{nranks} N={N:5d} spp={spp} lens={cam.lensRadius:.2f} {knobs} -> {'ok' if ok else 'FAIL ' + why}", flush=True)
     g.close()
 print("failures:", bad)
 sys.exit(1 if bad else 0)
