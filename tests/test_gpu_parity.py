@@ -423,22 +423,26 @@ def test_render_with_and_without_the_deferred_connect(orc, hip, name, W, H, N, s
     o, g1 = pair(orc, hip, name, W, H, N)
     _, g0 = pair(orc, hip, name, W, H, N)
     _, g2 = pair(orc, hip, name, W, H, N)
+    _, g3 = pair(orc, hip, name, W, H, N)
     g0.set_tuning(overlap_connect=0, merge_trace=0)
     g1.set_tuning(overlap_connect=1, merge_trace=0)
-    g2.set_tuning(merge_trace=1)  # (the default) connect(i) inside the launch of extend(i + 1): k_trace_flat
+    g2.set_tuning(merge_trace=1)  # (the default) connect(i) inside the launch of extend(i + 1): k_trace_flat, iteration i + 1 queued ahead of iteration i's counts
+    g3.set_tuning(merge_trace=1, run_ahead=0)  # ... with the host waiting for every iteration's counts
     from tyrant_amd import scenes
 
     sc, _, _ = built_scene(name)
     moved = scenes.Camera(position=tuple(np.array(sc.camera.position) + np.array([3.0, 2.0, -1.0])), direction=sc.camera.direction, up=sc.camera.up)
     for cam in (sc.camera, moved):
-        for r in (o, g0, g1, g2):
+        for r in (o, g0, g1, g2, g3):
             r.set_camera(cam)
-        io, i0, i1, i2 = o.render(spp), g0.render(spp), g1.render(spp), g2.render(spp)
-        assert io == i0 == i1 == i2
-        ko, k0, k1, k2 = o.counters(), g0.counters(), g1.counters(), g2.counters()
-        assert k0["device_error"] == 0 and k1["device_error"] == 0 and k2["device_error"] == 0
-        for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible", "start_position", "frame"):
-            assert ko[f] == k0[f] == k1[f] == k2[f], (name, f)
+        io, i0, i1, i2, i3 = o.render(spp), g0.render(spp), g1.render(spp), g2.render(spp), g3.render(spp)
+        assert io == i0 == i1 == i2 == i3
+        ko, k0, k1, k2, k3 = o.counters(), g0.counters(), g1.counters(), g2.counters(), g3.counters()
+        assert k0["device_error"] == 0 and k1["device_error"] == 0 and k2["device_error"] == 0 and k3["device_error"] == 0
+        # (n_live, shadow_ray_cnt: the iteration a run-ahead render queues for nothing must not show in the counters)
+        for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible", "start_position", "frame", "n_live", "shadow_ray_cnt", "primary_ray_cnt"):
+            assert ko[f] == k0[f] == k1[f] == k2[f] == k3[f], (name, f)
+        assert_accum_close(o.blit_buffer(), g3.blit_buffer(), name + " merged trace launches, no run-ahead")
         assert_accum_close(o.blit_buffer(), g0.blit_buffer(), name + " one stream")
         assert_accum_close(o.blit_buffer(), g1.blit_buffer(), name + " deferred connect")
         assert_accum_close(o.blit_buffer(), g2.blit_buffer(), name + " merged trace launches")
@@ -452,6 +456,15 @@ def test_render_with_and_without_the_deferred_connect(orc, hip, name, W, H, N, s
     assert o.render(spp, 2) == g2.render(spp, 2) == 2
     assert o.counters()["n_shadow_visible"] == g2.counters()["n_shadow_visible"]
     assert_accum_close(o.blit_buffer(), g2.blit_buffer(), name + " two iterations of a merged render")
+    # ... and the queues are where the reference's loop would have left them: the rest of the render, stage by stage
+    for it in range(2):
+        for st in ("begin", "primary"):
+            o.stage(st), g2.stage(st)
+        n = o.counters()["n_live"]
+        assert n == g2.counters()["n_live"]
+        assert_state_equal(o.ray_queue(0, n), g2.ray_queue(0, n), f"{name}: iteration {2 + it} after a render cut at two")
+        for st in ("extend", "shade", "connect", "end"):
+            o.stage(st), g2.stage(st)
 
 
 def test_bench_two_ranks_on_one_gpu(hip):

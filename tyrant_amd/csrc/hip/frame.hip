@@ -95,37 +95,41 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 }
 
 // extend pre-pass: kernel.cu:125-136 (spheres first; their distance bounds the BVH search)
+// (grid-stride over the device's count: the host may have sized the grid from an upper bound, and a capped grid makes a
+// loose bound free)
 __global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) {
-	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-	if (slot == 0)
+	const uint32_t first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+	if (first == 0)
 		P.k->extend_ticket = 0; // the persistent kernel that follows on the stream starts from slot 0
-	if (slot >= P.k->first_fresh) // slots from there to n_live are this iteration's primary rays: k_primary has done them
-		return;
-	const float4 a = P.work.o_dx[slot];
-	const float2 b = P.work.dyz[slot];
-	P.work.hit[slot] = sphere_hit_record(P, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+	const uint32_t n = P.k->first_fresh; // slots from there to n_live are this iteration's primary rays: k_primary has done them
+	for (uint32_t slot = first; slot < n; slot += stride) {
+		const float4 a = P.work.o_dx[slot];
+		const float2 b = P.work.dyz[slot];
+		P.work.hit[slot] = sphere_hit_record(P, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+	}
 }
 
 // connect pre-pass: the sphere half of intersect_scene_simple (kernel.cu:168-172).  Any-hit does not
 // depend on test order, so spheres go first and an occluded ray never enters the BVH.
 // color.w (unused by the reference's 44-byte record) carries the flag.
 __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P) {
-	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
-	if (index == 0)
+	const uint32_t first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+	if (first == 0)
 		P.kc->ticket = 0;
-	if (index >= P.kc->shadow_cnt)
-		return;
-	const float4 a = P.shadow.o_dx[index];
-	const float4 b = P.shadow.dyz_cd_ix[index];
-	const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
-	const float closest = b.z;
-	bool occluded = false;
+	const uint32_t n = P.kc->shadow_cnt;
+	for (uint32_t index = first; index < n; index += stride) {
+		const float4 a = P.shadow.o_dx[index];
+		const float4 b = P.shadow.dyz_cd_ix[index];
+		const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+		const float closest = b.z;
+		bool occluded = false;
 #pragma unroll
-	for (int i = TYR_NUM_SPHERES; i--;) {
-		const float t = sphere_intersect(P.spheres[i], o, d);
-		occluded = occluded || (t && (t + kEpsilon) < closest);
+		for (int i = TYR_NUM_SPHERES; i--;) {
+			const float t = sphere_intersect(P.spheres[i], o, d);
+			occluded = occluded || (t && (t + kEpsilon) < closest);
+		}
+		reinterpret_cast<float*>(&P.shadow.color[index])[3] = occluded ? 1.0f : 0.0f;
 	}
-	reinterpret_cast<float*>(&P.shadow.color[index])[3] = occluded ? 1.0f : 0.0f;
 }
 
 // ======================================================================================
@@ -225,6 +229,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_debug(const FrameParams P) {
 
 // ---- launch wrappers ---------------------------------------------------------------------
 
+constexpr uint32_t kPrepassMaxBlocks = 8192; // 8 waves of 256 threads per SIMD of a 256-CU part: enough to stream at full rate
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
 	if (maxNew == 0)
 		return;
@@ -242,10 +247,10 @@ void launch_extend_debug(const FrameParams& P, uint32_t maxLive, hipStream_t str
 }
 void launch_extend_spheres(const FrameParams& P, uint32_t nSurvivors, hipStream_t stream) {
 	if (nSurvivors != 0)
-		hipLaunchKernelGGL(k_extend_spheres, dim3(blocks_for(nSurvivors)), dim3(kBlock), 0, stream, P);
+		hipLaunchKernelGGL(k_extend_spheres, dim3(std::min(blocks_for(nSurvivors), kPrepassMaxBlocks)), dim3(kBlock), 0, stream, P);
 }
 void launch_connect_spheres(const FrameParams& P, uint32_t maxShadow, hipStream_t stream) {
-	hipLaunchKernelGGL(k_connect_spheres, dim3(blocks_for(maxShadow)), dim3(kBlock), 0, stream, P);
+	hipLaunchKernelGGL(k_connect_spheres, dim3(std::min(blocks_for(maxShadow), kPrepassMaxBlocks)), dim3(kBlock), 0, stream, P);
 }
 void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream) {
 	hipLaunchKernelGGL(k_resolve, dim3(blocks_for(nPixels)), dim3(kBlock), 0, stream, blit, out, nPixels);

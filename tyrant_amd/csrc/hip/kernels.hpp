@@ -122,6 +122,7 @@ struct Tuning {
 	int stagedNodes = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
+	int runAhead = 2;         // tyr_render (merged launches): queue iteration i + 1 before iteration i's counts are on the host: 0 never, 1 always, 2 for queues of at most 6 Mi slots
 	int mergeTrace = 1;       // tyr_render: connect(i) rides in the launch of extend(i + 1) (k_trace_flat): one drain per iteration instead of two
 	int overlapConnect = 2;   // tyr_render: connect(i) on a second stream next to primary / extend of iteration i + 1: 0 never, 1 always, 2 for thin wavefronts
 	int profileMask = 31;     // TYR_FLAG_PROFILE: which stages (bit TYR_K_*) get a hipEvent pair; every pair is ~10 us of idle GPU

@@ -511,12 +511,13 @@ __device__ __forceinline__ void shade_lookback(const FrameParams& P, uint32_t vb
 #define TYR_SHADE_BLOCKS_PER_CU 4 // tiles in flight per CU: 128 vector registers each (a what-if build may ask for 5 or 6 and take the spills)
 #endif
 template <bool LIGHTS>
-__global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const FrameParams P, uint32_t nTiles) {
+__global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const FrameParams P) {
 	__shared__ uint32_t sh[32];
 	__shared__ ShadeStage stage;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u, wave = tid >> 6;
 	const uint32_t nLive = P.k->n_live;
+	const uint32_t nTiles = (nLive + kBlock - 1) / kBlock; // from the device's count: the host may have sized the grid from an upper bound (tyr_render runs one iteration ahead of the counts)
 	const unsigned long long below = (1ull << lane) - 1ull;
 #ifdef TYR_SHADE_TIMING
 	// diagnostic build: where a tile's time goes, in s_memtime ticks summed over this block's tiles (thread 0;
@@ -692,7 +693,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCache& lc, hipStream_t stream) {
 	if (maxLive == 0)
 		return;
-	const uint32_t nTiles = blocks_for(maxLive);
+	const uint32_t nTiles = blocks_for(maxLive); // an upper bound is fine: the kernel takes the tile count from the device
 	// A persistent grid: as many blocks as stay resident (more would only wait for a slot and then find no tile
 	// left; the tile tickets make any grid size safe).  Asked once: the occupancy query is a slow host call.
 	const bool lights = (P.flags & TYR_FLAG_LIGHT_LIST) != 0; // its own instantiation: the default kernel keeps its registers
@@ -707,9 +708,9 @@ void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCach
 	const uint32_t resident = (uint32_t)perCU[lights] * (uint32_t)numCUs;
 	const dim3 grid(nTiles < resident ? nTiles : resident);
 	if (lights)
-		hipLaunchKernelGGL(k_shade<true>, grid, dim3(kBlock), 0, stream, P, nTiles);
+		hipLaunchKernelGGL(k_shade<true>, grid, dim3(kBlock), 0, stream, P);
 	else
-		hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), 0, stream, P, nTiles);
+		hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), 0, stream, P);
 }
 
 } // namespace tyr

@@ -26,6 +26,8 @@ struct tyr_ctx {
 	ShadowQ shadow{};
 	DevCounters* dK = nullptr;
 	DevCounters* hK = nullptr; // pinned host mirror
+	DevCounters* hSnap[2] = { nullptr, nullptr }; // tyr_render one iteration ahead: where the counters of iteration i land (set i & 1)
+	hipEvent_t evSnap[2] = { nullptr, nullptr };
 	ConnectCounters* dKc = nullptr; // two sets, iteration i uses set i & 1
 	uint32_t iter = 0;
 
@@ -38,6 +40,10 @@ struct tyr_ctx {
 	// ride in the next iteration's trace launch, or in a connect of their own when the render ends)
 	bool shadowPending = false;
 	uint32_t shadowPendingMax = 0;
+	// tyr_render one iteration ahead: the last queued iteration turned out to be empty; once the stream is idle the device's
+	// counters get back what that iteration's set_wavefront_globals zeroed (the live and shadow counts of the last real one)
+	bool runAheadUndo = false;
+	uint32_t undoLive = 0, undoShadows = 0;
 	hipEvent_t evSide[2][2]{}; // TYR_FLAG_PROFILE: connect's start / stop on `side`, per set
 	bool evSideUsed[2]{};
 	unsigned long long* scanDesc = nullptr;
@@ -72,8 +78,8 @@ struct tyr_ctx {
 	LaunchCache launchCache{}; // occupancy answers of the persistent kernels, per ctx (not process-wide)
 	int numCUs = 256;
 
-	hipEvent_t ev[2 * TYR_K_COUNT]{};
-	bool evUsed[TYR_K_COUNT]{};
+	hipEvent_t ev[2][2 * TYR_K_COUNT]{}; // TYR_FLAG_PROFILE: start / stop per stage, two sets (iteration i uses set i & 1: two iterations may be queued)
+	bool evUsed[2][TYR_K_COUNT]{};
 	tyr_timings timings{};
 };
 

@@ -174,29 +174,34 @@ struct KernelTimer {
 	bool on;
 	KernelTimer(tyr_ctx* c_, int k_) : c(c_), k(k_), on((c_->cfg.flags & TYR_FLAG_PROFILE) != 0 && ((c_->tuning.profileMask >> k_) & 1) != 0) {
 		if (on)
-			(void)hipEventRecord(c->ev[2 * k], c->stream);
+			(void)hipEventRecord(c->ev[c->iter & 1u][2 * k], c->stream);
 	}
 	~KernelTimer() {
 		if (on) {
-			(void)hipEventRecord(c->ev[2 * k + 1], c->stream);
-			c->evUsed[k] = true;
+			(void)hipEventRecord(c->ev[c->iter & 1u][2 * k + 1], c->stream);
+			c->evUsed[c->iter & 1u][k] = true;
 		}
 	}
 };
-// after the stream went idle: fold the recorded event pairs into the running sums
-void collect_timings(tyr_ctx* c) {
+// fold the recorded event pairs of one set into the running sums (the stream must have passed them)
+void collect_timings_of(tyr_ctx* c, int set) {
 	if (!(c->cfg.flags & TYR_FLAG_PROFILE))
 		return;
 	for (int k = 0; k < TYR_K_COUNT; ++k) {
-		if (!c->evUsed[k])
+		if (!c->evUsed[set][k])
 			continue;
 		float ms = 0.0f;
-		if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) == hipSuccess) {
+		if (hipEventElapsedTime(&ms, c->ev[set][2 * k], c->ev[set][2 * k + 1]) == hipSuccess) {
 			c->timings.ms[k] += ms;
 			c->timings.launches[k] += 1;
 		}
-		c->evUsed[k] = false;
+		c->evUsed[set][k] = false;
 	}
+}
+// after the stream went idle
+void collect_timings(tyr_ctx* c) {
+	collect_timings_of(c, 0);
+	collect_timings_of(c, 1);
 }
 
 // connect launches timed on the side stream: fold the pairs that have finished (all of them when `wait`)
@@ -493,9 +498,17 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 	c->hK->budget_remaining = ~0ull;
 	if (hipMemcpy(c->dK, c->hK, sizeof(DevCounters), hipMemcpyHostToDevice) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
-	for (auto& e : c->ev)
-		if (hipEventCreate(&e) != hipSuccess)
+	for (auto& set : c->ev)
+		for (auto& e : set)
+			if (hipEventCreate(&e) != hipSuccess)
+				return fail(TYR_ERR_NO_DEVICE);
+	for (int s = 0; s < 2; ++s) {
+		if (hipHostMalloc(reinterpret_cast<void**>(&c->hSnap[s]), sizeof(DevCounters), hipHostMallocDefault) != hipSuccess)
+			return fail(TYR_ERR_OOM);
+		std::memset(c->hSnap[s], 0, sizeof(DevCounters));
+		if (hipEventCreateWithFlags(&c->evSnap[s], hipEventDisableTiming) != hipSuccess)
 			return fail(TYR_ERR_NO_DEVICE);
+	}
 	c->scene.rootRef = kRefDone;
 	*out = c;
 	return TYR_OK;
@@ -526,9 +539,16 @@ int tyr_destroy(tyr_ctx* c) {
 		dev_free(c->blit);
 	if (c->hK)
 		(void)hipHostFree(c->hK);
-	for (auto& e : c->ev)
-		if (e)
-			(void)hipEventDestroy(e);
+	for (auto& set : c->ev)
+		for (auto& e : set)
+			if (e)
+				(void)hipEventDestroy(e);
+	for (int s = 0; s < 2; ++s) {
+		if (c->hSnap[s])
+			(void)hipHostFree(c->hSnap[s]);
+		if (c->evSnap[s])
+			(void)hipEventDestroy(c->evSnap[s]);
+	}
 	for (auto& pair : c->evSide)
 		for (auto& e : pair)
 			if (e)
@@ -920,6 +940,115 @@ int tyr_launch_kernels(tyr_ctx* c) {
 	return launch_iteration(c, 0, false);
 }
 
+// ---- tyr_render, one iteration ahead of the counts (TYR_TUNE_RUN_AHEAD) -------------------------
+// Between shade(i) and the first kernel of iteration i + 1 the stream used to run dry for ~20 us: the counters travel
+// to the host, the host wakes up, sizes the grids and launches.  Nothing in iteration i + 1 needs the host for that:
+// k_primary and k_globals compute the top-up from the device's counters (kernel.cu:253, 227-244 do the same), the
+// persistent kernels read their item counts there, k_shade its tile count.  So the host queues iteration i + 1 right
+// behind iteration i, sizing every grid from upper bounds it can already compute -- survivors(i) <= live(i), shadow rays
+// (i) <= live(i), and live(i), the budget and the top-up of i + 1's predecessors follow exactly from the last counts that
+// DID arrive -- and waits for iteration i's counts afterwards, with iteration i + 1 already running or queued.
+// It learns one iteration late that the render has ended (no survivors, no budget): that last iteration has no rays of
+// its own and traces the final shadow rays -- the connect launch a merged render needs at its end anyway -- and the
+// host takes back its frame counter, queue swap and iteration parity, so that the ctx is where the reference's loop
+// would have left it (kernel.cu:735-745, main.cpp:169).
+struct IterationPlan {
+	uint32_t nNew, nLive, nSurvivors, carried; // exact values or upper bounds; carried: shadow rays of the iteration before (0: none to trace)
+};
+static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool begun) {
+	int rc = begun ? TYR_OK : stage_begin(c);
+	if (rc)
+		return rc;
+	const int set = static_cast<int>(c->iter & 1u);
+	FrameParams P = make_params(c);
+	enqueue_primary(c, P, p.nNew, p.nLive);
+	enqueue_trace(c, P, p.nLive, p.nSurvivors, p.carried);
+	if ((rc = join_connect(c)))
+		return rc;
+	enqueue_shade(c, P, p.nLive);
+	HIPCHK(hipMemcpyAsync(c->hSnap[set], c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipEventRecord(c->evSnap[set], c->stream));
+	HIPCHK(hipGetLastError());
+	stage_end(c);
+	return TYR_OK;
+}
+static bool run_ahead_eligible(const tyr_ctx* c) {
+#if defined(TYR_QUAD_STATS) || defined(TYR_LAUNCH_ANATOMY)
+	return false; // the instrumented builds print per-iteration records from the host mirror (launch_iteration)
+#else
+	const bool wanted = c->tuning.runAhead == 1 || (c->tuning.runAhead == 2 && c->cfg.queue_size <= kOverlapMaxLive);
+	return wanted && c->tuning.mergeTrace != 0 && c->tuning.traversalVariant == 4 && !(c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) &&
+	       c->scene.rootRef != kRefDone && c->blit != nullptr;
+#endif
+}
+static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
+	it = 0;
+	if (max_iterations == 0)
+		return TYR_OK;
+	int rc = flush_pending_shadow(c);
+	if (rc)
+		return rc;
+	if ((rc = stage_begin(c))) // may reset the accumulation and the survivor count (kernel.cu:712-718): before the plan is made
+		return rc;
+	const uint64_t N = c->cfg.queue_size;
+	// exact state in front of iteration 0 (hK is current: every entry point ends with sync_counters)
+	uint64_t s = c->hK->primary_ray_cnt, budget = c->hK->budget_remaining;
+	uint32_t nNew = static_cast<uint32_t>(std::min<uint64_t>(N - s, budget));
+	uint32_t live = static_cast<uint32_t>(s) + nNew; // live(enq - 1), exact
+	budget -= nNew;                                   // budget left behind iteration enq - 1, exact
+	const uint32_t iter0 = c->iter; // iteration j of this render is the ctx's iteration iter0 + j: its events and its counters use set (iter0 + j) & 1
+	if ((rc = enqueue_merged_iteration(c, IterationPlan{ nNew, live, static_cast<uint32_t>(s), 0u }, true)))
+		return rc;
+	uint32_t enq = 1;
+	for (;;) {
+		// iterations 0 .. enq - 1 are queued; the counts of 0 .. enq - 2 have arrived
+		bool ahead = false;
+		uint32_t frameBefore = c->frame;
+		if (enq < max_iterations) {
+			const uint32_t liveMax = static_cast<uint32_t>(std::min<uint64_t>(N, static_cast<uint64_t>(live) + budget));
+			const uint32_t newMax = static_cast<uint32_t>(std::min<uint64_t>(N, budget));
+			if ((rc = enqueue_merged_iteration(c, IterationPlan{ newMax, liveMax, live, live }, false)))
+				return rc;
+			ahead = true;
+		}
+		const int set = static_cast<int>((iter0 + enq - 1) & 1u);
+		HIPCHK(hipEventSynchronize(c->evSnap[set]));
+		std::memcpy(c->hK, c->hSnap[set], sizeof(DevCounters));
+		collect_timings_of(c, set);
+		it = enq;
+		s = c->hK->primary_ray_cnt; // survivors of iteration enq - 1
+		const uint32_t shadows = c->hK->shadow_ray_cnt;
+		if ((rc = check_device_error(c)))
+			return rc;
+		if (budget == 0 && s == 0) { // kernel loop of the reference's caller: nothing left to trace or to start
+			if (ahead) {
+				// iteration enq was queued for nothing but the shadow rays of iteration enq - 1: take the host state back
+				c->frame = frameBefore;
+				c->cur ^= 1;
+				c->iter--;
+				c->shadowPending = false;
+				c->runAheadUndo = true;
+				c->undoLive = live;
+				c->undoShadows = shadows;
+			} else {
+				c->shadowPending = shadows != 0;
+				c->shadowPendingMax = shadows;
+			}
+			return TYR_OK;
+		}
+		if (!ahead) { // max_iterations reached
+			c->shadowPending = shadows != 0;
+			c->shadowPendingMax = shadows;
+			return TYR_OK;
+		}
+		// iteration enq is real; what it does, exactly, now that its predecessor's survivors are known
+		nNew = static_cast<uint32_t>(std::min<uint64_t>(N - s, budget));
+		live = static_cast<uint32_t>(s) + nNew;
+		budget -= nNew;
+		++enq;
+	}
+}
+
 int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iterations_out) {
 	if (!c)
 		return TYR_ERR_INVALID;
@@ -930,12 +1059,18 @@ int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iter
 		return TYR_ERR_NO_SCENE;
 	const int overlap = c->tuning.overlapConnect;
 	uint32_t it = 0;
-	while (it < max_iterations) {
-		if ((rc = launch_iteration(c, overlap, true)))
-			break;
-		++it;
-		if (c->hK->budget_remaining == 0 && c->hK->primary_ray_cnt == 0)
-			break;
+	if (run_ahead_eligible(c)) {
+		if ((rc = use_device(c)))
+			return rc;
+		rc = render_run_ahead(c, max_iterations, it);
+	} else {
+		while (it < max_iterations) {
+			if ((rc = launch_iteration(c, overlap, true)))
+				break;
+			++it;
+			if (c->hK->budget_remaining == 0 && c->hK->primary_ray_cnt == 0)
+				break;
+		}
 	}
 	{
 		// the last connect: back onto `stream` if it ran beside it, counters refreshed (connect's included),
@@ -947,6 +1082,17 @@ int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iter
 		if (!rcj)
 			rcj = sync_counters(c);
 		collect_side_timings(c, true);
+		if (!rcj)
+			collect_timings(c); // (an iteration queued ahead may still have had its event pairs out)
+		if (c->runAheadUndo) {
+			// the empty iteration's set_wavefront_globals zeroed the live and shadow counts of the last real iteration
+			c->runAheadUndo = false;
+			if (!rcj) {
+				c->hK->n_live = c->undoLive;
+				c->hK->shadow_ray_cnt = c->undoShadows;
+				rcj = push_counters(c);
+			}
+		}
 		if (!rc)
 			rc = rcj ? rcj : check_device_error(c);
 	}
@@ -1238,6 +1384,11 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		if (value < 0 || value >= (1 << TYR_K_COUNT))
 			return TYR_ERR_INVALID;
 		c->tuning.profileMask = value;
+		return TYR_OK;
+	case TYR_TUNE_RUN_AHEAD:
+		if (value < 0 || value > 2)
+			return TYR_ERR_INVALID;
+		c->tuning.runAhead = value;
 		return TYR_OK;
 	case TYR_TUNE_STATIC_INTERLEAVE:
 		if (value < 0 || value > 1)
