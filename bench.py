@@ -94,6 +94,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-iterations", type=int, default=2)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearse the multi-rank path with every rank on ONE GPU (the combine then goes through host memory and torch)")
     ap.add_argument("--combine", default="gather", choices=["gather", "reduce"], help="N > 1: rank 0 gets the rows each rank owns (1/N of the frame per rank) or the sum of the full buffers")
+    ap.add_argument("--dist-preflight", action="store_true", help=argparse.SUPPRESS)  # internal: one rank of the native exchange's pre-flight check
+    ap.add_argument("--preflight-port", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--combine-impl", default="native", choices=["native", "torch"], help="native = tyr_dist_* (RCCL behind the C ABI, double-buffered); torch = torch.distributed collectives (always used with --backend gloo)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto: N = 1 and rocprofv3 present -> three --pmc child passes feed the roofline block")
     ap.add_argument("--save-pmc", default="", help="write the live PMC counters to this JSON file (copied to profiles/pmc_<workload>.json, the fallback when rocprofv3 cannot run beside the bench)")
@@ -310,10 +312,83 @@ def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_re
     return out
 
 
+PREFLIGHT_TIMEOUT_S = 150.0
+
+
+def dist_preflight(args) -> int:
+    """One rank of the pre-flight check of the native exchange (tyr_dist_*: RCCL behind the C ABI), run as a CHILD of the
+    bench rank of the same number before that rank has touched its GPU: a small frame, rows dealt y % world == rank, a
+    2-spp render per rank, GATHER and REDUCE onto rank 0, every pixel must hold exactly 2 finished paths.  The exchange
+    has only met one GPU per box before the driver's multi-GPU run; a hang, a crash or a wrong frame here costs this child,
+    not the measurement: the bench ranks then use torch.distributed for the combine.  Exit code 0 = verified on every rank."""
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    from tyrant_amd import binding, scenes
+
+    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("TYR_BENCH_PREFLIGHT_ONE_DEVICE"):
+        local_rank = 0  # rehearsal on a one-GPU box: RCCL refuses two ranks on one device, which is the failure path under test
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{args.preflight_port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    ok = 1
+    try:
+        torch.cuda.set_device(local_rank)
+        W, H, spp = 64, 8 * world, 2
+        sc = scenes.cornell_box()
+        nodes, prims = binding.bvh_build(sc.triangles)
+        r = binding.Renderer(W, H, 4096, device=local_rank, rank=rank, nranks=world)
+        r.load_scene(sc, nodes, prims)
+        ids = [binding.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = binding.Dist(r, ids[0], rank, world)
+        frame = torch.zeros(H * W * 4, dtype=torch.float32, device=f"cuda:{local_rank}") if rank == 0 else None
+        torch.cuda.synchronize()
+        for mode in (binding.TYR_DIST_GATHER, binding.TYR_DIST_REDUCE):
+            r.reset_accum()
+            r.render(spp)
+            comm.combine(frame.data_ptr() if frame is not None else None, mode=mode, root=0)
+            comm.wait()
+            torch.cuda.synchronize()
+            if rank == 0:
+                a = frame.view(H * W, 4)[:, 3]
+                if not (float(a.min()) == float(a.max()) == float(spp)):
+                    print(f"[bench preflight] mode {mode}: combined frame holds {float(a.min())}..{float(a.max())} paths per pixel, expected {spp}", file=sys.stderr)
+                    ok = 0
+                frame.zero_()
+        comm.close()
+        r.close()
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench preflight] rank {rank}: {e!r}", file=sys.stderr)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.destroy_process_group()
+    return 0 if int(flag.item()) == 1 else 1
+
+
+def run_dist_preflight() -> bool:
+    """spawn this rank's pre-flight child (this process has not initialised the GPU yet) and wait for it, bounded"""
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 17
+    cmd = [sys.executable, os.path.abspath(__file__), "--dist-preflight", "--preflight-port", str(port)]
+    # the children make their own rendezvous (rank 0's child hosts the store): without the launcher's TORCHELASTIC_* variables,
+    # which would tell them that an agent already hosts one at that port
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    try:
+        p = subprocess.run(cmd, timeout=PREFLIGHT_TIMEOUT_S, env=env, stdout=subprocess.DEVNULL)
+        return p.returncode == 0
+    except subprocess.TimeoutExpired:
+        print(f"[bench] rank {os.environ.get('RANK', '?')}: the native exchange's pre-flight did not finish in {PREFLIGHT_TIMEOUT_S:.0f} s", file=sys.stderr)
+        return False
+
+
 def main():
     args = parse_args()
     if args.pmc_child:
         sys.exit(pmc_child(args))
+    if args.dist_preflight:
+        sys.exit(dist_preflight(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 
@@ -332,6 +407,12 @@ def main():
                        "launches_averaged": pmc["launches_averaged"], "source": pmc["source"], "units": "per launch of the kernel, averaged over the launches of one warm render; FETCH_SIZE / WRITE_SIZE in KB"}, f, indent=1)
     if pmc is None and world == 1:
         pmc = committed_pmc(args.workload, N)
+
+    # the native exchange is checked by a child of every rank BEFORE this process initialises its GPU (see dist_preflight)
+    preflight_ok = True
+    want_native = world > 1 and args.combine_impl == "native" and (args.backend == "nccl" or bool(os.environ.get("TYR_BENCH_PREFLIGHT_ONE_DEVICE")))
+    if want_native:
+        preflight_ok = run_dist_preflight()
 
     import numpy as np  # noqa: F401
     import torch
@@ -354,6 +435,13 @@ def main():
     shard = tdist.shard_spec(rank, world, H)
     tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune)}
     native = world > 1 and args.combine_impl == "native" and args.backend == "nccl"
+    if native:
+        # every rank's child must have verified, or nobody uses the native path (the ranks have to branch alike)
+        flag = torch.tensor([1 if preflight_ok else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        native = bool(int(flag.item()))
+        if not native and rank == 0:
+            print("[bench] the native exchange did not pass its pre-flight: using torch.distributed for the combine", file=sys.stderr)
     mode = binding.TYR_DIST_GATHER if args.combine == "gather" else binding.TYR_DIST_REDUCE
     use_torch_gather = False
     if world > 1 and not native and args.combine == "gather":

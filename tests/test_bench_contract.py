@@ -133,6 +133,47 @@ def test_bench_launches_its_own_ranks():
     assert s["one_gpu_ms"] > 0 and s["speedup_vs_1gpu"] > 0 and abs(s["efficiency_vs_1gpu"] - s["speedup_vs_1gpu"] / 2) < 1e-3
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+@pytest.mark.gpu
+def test_native_exchange_preflight():
+    """bench.py checks the native exchange (tyr_dist_*) in a child of every rank before the rank touches its GPU, so that a
+    hang, a crash or a wrong frame costs the child and not the measurement.  One rank on one GPU: verified (exit 0).  Two
+    ranks on the one GPU of this box: RCCL refuses the second rank on a device -- the failure path: both children exit 1,
+    within their bounds."""
+    script = os.path.join(ROOT, "bench.py")
+    port = _free_port()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, script, "--dist-preflight", "--preflight-port", str(port)], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, script, "--dist-preflight", "--preflight-port", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
+                              env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", TYR_BENCH_PREFLIGHT_ONE_DEVICE="1")) for r in range(2)]
+    outs = [q.communicate(timeout=300) for q in procs]
+    assert [q.returncode for q in procs] == [1, 1], [o[1][-1500:] for o in outs]
+
+
+@pytest.mark.gpu
+def test_bench_ranks_run_the_preflight_and_fall_back():
+    """the whole path under the driver's launcher form: every rank spawns its pre-flight child first (forced here although the
+    backend is gloo: TYR_BENCH_PREFLIGHT_ONE_DEVICE), the children fail as two ranks on one device must, and the bench
+    still delivers its line over torch.distributed"""
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TYR_BENCH_PREFLIGHT_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo", "--workload", "c1", "--width", "320", "--height", "180", "--queue", "32768", "--spp", "4", "--no-reference-queue"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = _bench_line(p.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "torch.distributed" in d["config"]["sharding"]
+
+
 def test_bench_refuses_to_run_without_a_gpu():
     """the product path has no CPU fallback: on a box without a GPU bench.py says so instead of measuring something else"""
     import torch

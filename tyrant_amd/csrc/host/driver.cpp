@@ -409,7 +409,7 @@ const char* tyr_status_string(int status) {
 	case TYR_ERR_NO_SCENE: return "no scene uploaded";
 	case TYR_ERR_NO_BUFFER: return "no blit_buffer bound";
 	case TYR_ERR_OOM: return "out of device memory";
-	case TYR_ERR_DEVICE: return "device-side error (traversal stack overflow, compaction timeout or a stuck traversal wave)";
+	case TYR_ERR_DEVICE: return "device-side error (a render: traversal stack overflow, compaction timeout or a stuck traversal wave; tyr_dist_*: an RCCL call failed -- TYR_VERBOSE=1 prints which)";
 	case TYR_ERR_UNSUPPORTED: return "unsupported";
 	case TYR_ERR_IO: return "file I/O error";
 	default: return status > 0 ? hipGetErrorString(static_cast<hipError_t>(status)) : "unknown status";
