@@ -28,33 +28,33 @@ __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 
 	float sx, sy;
 	stratified_sample(seed, sx, sy);
-	const float rand_point_pixelX = (float)x - sx; // kernel.cu:268-269 (jitter is subtracted)
-	const float rand_point_pixelY = (float)y - sy;
-	const float normalized_i = (rand_point_pixelX / (float)P.W) - 0.5f;
-	const float normalized_j = (((float)P.H - rand_point_pixelY) / (float)P.H) - 0.5f;
+	const float jitteredX = (float)x - sx; // kernel.cu:268-269 (jitter is subtracted)
+	const float jitteredY = (float)y - sy;
+	const float ndcX = (jitteredX / (float)P.W) - 0.5f;
+	const float ndcY = (((float)P.H - jitteredY) / (float)P.H) - 0.5f;
 
-	const f3 O = ld3(P.camPos), camera_direction = ld3(P.camDir), camera_right = ld3(P.camRight), camera_up = ld3(P.camUp);
-	f3 directionToFocalPlane = camera_direction + normalized_i * camera_right + normalized_j * camera_up;
-	directionToFocalPlane = normalize(directionToFocalPlane);
-	const int ImGui_slider_hack = 3; // kernel.cu:286
-	const f3 convergencePoint = O + (P.focalDistance * (float)ImGui_slider_hack) * directionToFocalPlane;
+	const f3 O = ld3(P.camPos), camFwd = ld3(P.camDir), camRgt = ld3(P.camRight), camUpv = ld3(P.camUp);
+	f3 towardFocus = camFwd + ndcX * camRgt + ndcY * camUpv;
+	towardFocus = normalize(towardFocus);
+	const int kFocalScale = 3; // kernel.cu:286 (`ImGui_slider_hack`: the focal distance is always tripled)
+	const f3 focusPoint = O + (P.focalDistance * (float)kFocalScale) * towardFocus;
 
 	const float l0 = rng_float(seed);
 	const float l1 = rng_float(seed);
 	float dx, dy;
 	concentric_sample_disk(l0, l1, dx, dy);
 	const float pLx = P.lensRadius * dx, pLy = P.lensRadius * dy;
-	const f3 newOrigin = O + camera_right * pLx + camera_up * pLy;
-	const f3 direction = normalize(convergencePoint - newOrigin);
+	const f3 lensPoint = O + camRgt * pLx + camUpv * pLy;
+	const f3 direction = normalize(focusPoint - lensPoint);
 
 	// kernel.cu:295: {origin, direction, {1,1,1}, 0, 0, 0, pixel}; lastSpecular defaults to true (variables.h:33)
-	P.work.o_dx[slot] = make_float4(newOrigin.x, newOrigin.y, newOrigin.z, direction.x);
+	P.work.o_dx[slot] = make_float4(lensPoint.x, lensPoint.y, lensPoint.z, direction.x);
 	P.work.dyz[slot] = make_float2(direction.y, direction.z);
 	P.work.direct_ix[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(y * (int)P.W + x));
 	P.work.flags[slot] = 0u | (1u << 8);
 	// extend's sphere pre-pass for this ray, while it is in registers (k_extend_spheres then only has the
 	// survivors of the last iteration to do: nothing at all in a render's first, largest wavefront)
-	P.work.hit[slot] = sphere_hit_record(P, newOrigin, direction);
+	P.work.hit[slot] = sphere_hit_record(P, lensPoint, direction);
 }
 
 // ======================================================================================
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(kBlock) k_vecmath_probe(int op, const float* _
 	case 7: r = mk3(gclamp(A.x, B.x, B.y), gclamp(A.y, B.x, B.y), gclamp(A.z, B.x, B.y)); break;
 	case 8: r = gmix(A, B, Cc.x); break;
 	case 9: r.x = gsmoothstep(Cc.x, Cc.y, A.x); break;
-	case 10: // exponent 0.5 is the path's closed form sqrt (sunsky.hpp: pow(somethingElse * Fex, vec3(0.5)), sunsky.cu:66)
+	case 10: // exponent 0.5 is the path's closed form sqrt (sunsky.hpp: pow(inscatter * Fex, vec3(0.5)), sunsky.cu:66)
 		r = mk3(B.x == 0.5f ? sqrtf(A.x) : dm::powf_det(A.x, B.x), B.y == 0.5f ? sqrtf(A.y) : dm::powf_det(A.y, B.y), B.z == 0.5f ? sqrtf(A.z) : dm::powf_det(A.z, B.z));
 		break;
 	case 11: r = A / Cc.x; break;

@@ -21,8 +21,8 @@ struct ShadeOut {
 
 // NEE toward spheres[6], kernel.cu:419-447 / 559-590 (common part)
 struct LightSample {
-	f3 lightDir, lightVector;
-	float cosSurfaceToLight, cosLightToSurface;
+	f3 toLightUnit, toLight;
+	float cosAtSurface, cosAtLight;
 	bool valid;
 };
 __device__ __forceinline__ LightSample sample_sphere_light(const tyr_sphere& ls, uint32_t& seed, f3 origin, f3 normal) {
@@ -36,12 +36,12 @@ __device__ __forceinline__ LightSample sample_sphere_light(const tyr_sphere& ls,
 	const float y = ls.position[1] + ls.radius * cosPhi;
 	const float z = ls.position[2] + ls.radius * sinPhi * ct;
 	const f3 p = mk3(x, y, z);
-	L.lightVector = p - origin;
+	L.toLight = p - origin;
 	const f3 nL = normalize(p - ld3(ls.position));
-	L.lightDir = normalize(L.lightVector);
-	L.cosSurfaceToLight = dot(normal, L.lightDir);
-	L.cosLightToSurface = dot(nL, -L.lightDir);
-	L.valid = L.cosSurfaceToLight > 0 && L.cosLightToSurface > 0;
+	L.toLightUnit = normalize(L.toLight);
+	L.cosAtSurface = dot(normal, L.toLightUnit);
+	L.cosAtLight = dot(nL, -L.toLightUnit);
+	L.valid = L.cosAtSurface > 0 && L.cosAtLight > 0;
 	return L;
 }
 
@@ -87,12 +87,12 @@ __device__ __forceinline__ EmitterSample sample_emitter(const FrameParams& P, ui
 			const f3 e1 = mk3(t0.w, t1.x, t1.y), e2 = mk3(t1.z, t1.w, t2.x);
 			const f3 p = (mk3(t0.x, t0.y, t0.z) + e1 * b1) + e2 * b2;
 			const f3 cr = cross(e1, e2);
-			E.L.lightVector = p - origin;
+			E.L.toLight = p - origin;
 			const f3 nL = normalize(cr);
-			E.L.lightDir = normalize(E.L.lightVector);
-			E.L.cosSurfaceToLight = dot(normal, E.L.lightDir);
-			E.L.cosLightToSurface = dot(nL, -E.L.lightDir);
-			E.L.valid = E.L.cosSurfaceToLight > 0 && E.L.cosLightToSurface > 0;
+			E.L.toLightUnit = normalize(E.L.toLight);
+			E.L.cosAtSurface = dot(normal, E.L.toLightUnit);
+			E.L.cosAtLight = dot(nL, -E.L.toLightUnit);
+			E.L.valid = E.L.cosAtSurface > 0 && E.L.cosAtLight > 0;
 			E.emission = triangle_emission(P, t2) * pick;
 			E.area = 0.5f * length(cr);
 			return E;
@@ -131,9 +131,9 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 
 	int new_frame = 0;
 	f3 color = mk3(0.f, 0.f, 0.f);
-	f3 object_color = mk3(0.f, 0.f, 0.f);
+	f3 albedo = mk3(0.f, 0.f, 0.f);
 	uint32_t seed = (P.frame * (uint32_t)pixel * 147565741u) * 720898027u * slot; // kernel.cu:363
-	int reflection_type = TYR_DIFF;
+	int material = TYR_DIFF;
 	out.survive = false;
 	out.shadow = false;
 
@@ -148,28 +148,28 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 		if (ident & kHitSphere) {
 			const tyr_sphere& object = P.spheres[ident & 7u];
 			normal = (origin - ld3(object.position)) / object.radius;
-			reflection_type = object.refl;
-			if (reflection_type != TYR_REFR && reflection_type != TYR_LIGHT)
+			material = object.refl;
+			if (material != TYR_REFR && material != TYR_LIGHT)
 				direct = direct * ld3(object.color);
-			object_color = ld3(object.color);
+			albedo = ld3(object.color);
 		} else {
 			// kernel.cu:380-383: normal from e1 x e2, white DIFF
 			const float4 t0 = P.scene.tris[3 * ident + 0];
 			const float4 t1 = P.scene.tris[3 * ident + 1];
 			const float4 t2 = P.scene.tris[3 * ident + 2];
 			normal = normalize(cross(mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x)));
-			reflection_type = TYR_DIFF;
-			object_color = mk3(1.f, 1.f, 1.f);
+			material = TYR_DIFF;
+			albedo = mk3(1.f, 1.f, 1.f);
 			if (P.flags & TYR_FLAG_TRIANGLE_MATERIALS) {
 				const uint32_t m = __float_as_uint(t2.y);
-				reflection_type = m <= (uint32_t)(LIGHTS ? TYR_LIGHT : TYR_PHONG) ? (int)m : TYR_DIFF;
+				material = m <= (uint32_t)(LIGHTS ? TYR_LIGHT : TYR_PHONG) ? (int)m : TYR_DIFF;
 			}
 			if (P.flags & TYR_FLAG_TRIANGLE_COLORS) {
 				// Scene.cpp:44's `tempTriangle.color`, treated like a sphere's colour (kernel.cu:375-377)
 				const float4 c = P.palette[2u * (__float_as_uint(t2.z) & 255u)];
-				object_color = mk3(c.x, c.y, c.z);
-				if (reflection_type != TYR_REFR && reflection_type != TYR_LIGHT)
-					direct = direct * object_color;
+				albedo = mk3(c.x, c.y, c.z);
+				if (material != TYR_REFR && material != TYR_LIGHT)
+					direct = direct * albedo;
 				triEmit = triangle_emission(P, t2);
 			}
 		}
@@ -180,7 +180,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 		normal = outside ? normal : normal * -1.f;
 		origin = origin + normal * kEpsilon;
 
-		if (reflection_type == TYR_LIGHT) {
+		if (material == TYR_LIGHT) {
 			if (lastSpecular) {
 				if (LIGHTS && !(ident & kHitSphere))
 					color = direct * triEmit;
@@ -192,34 +192,34 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 			}
 		}
 		lastSpecular = false;
-		constexpr float phongexponent = 40.0f;
-		switch (reflection_type) {
+		constexpr float kPhongPower = 40.0f;
+		switch (material) {
 		case TYR_LIGHT:
 			break;
 		case TYR_DIFF: {
-			const f3 sunSampleDir = cone_sample(P.sun, seed);
-			const float sunLight = dot(normal, sunSampleDir);
+			const f3 toSun = cone_sample(P.sun, seed);
+			const float cosSun = dot(normal, toSun);
 			if (rng_float(seed) < 0.5f) {
-				if (sunLight > 0.f) {
+				if (cosSun > 0.f) {
 					out.shadow = true;
 					out.sOrigin = origin;
-					out.sDir = sunSampleDir;
-					out.sColor = 2.0f * direct; // x ((sun(sunSampleDir) * sunLight) * 1E-5f) below, kernel.cu:414
+					out.sDir = toSun;
+					out.sColor = 2.0f * direct; // x ((sun(toSun) * cosSun) * 1E-5f) below, kernel.cu:414
 					atmo = kAtmoSun;
-					atmoScale = sunLight;
+					atmoScale = cosSun;
 					out.sClosest = 1e20f; // variables.h:41
 				}
 			} else {
 				const EmitterSample E = sample_emitter<LIGHTS>(P, seed, origin, normal);
 				const LightSample& L = E.L;
 				if (L.valid) {
-					const float closestAllowed = length(L.lightVector);
-					const float solidAngle = (L.cosLightToSurface * E.area) / dot(L.lightVector, L.lightVector);
+					const float reach = length(L.toLight);
+					const float subtended = (L.cosAtLight * E.area) / dot(L.toLight, L.toLight);
 					out.shadow = true;
 					out.sOrigin = origin;
-					out.sDir = L.lightDir;
-					out.sColor = ((((E.emission * 2.0f) * direct) * solidAngle) * kInvPi) * L.cosSurfaceToLight;
-					out.sClosest = closestAllowed;
+					out.sDir = L.toLightUnit;
+					out.sColor = ((((E.emission * 2.0f) * direct) * subtended) * kInvPi) * L.cosAtSurface;
+					out.sClosest = reach;
 				}
 			}
 			if (bounces < kMaxBounces) {
@@ -264,7 +264,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 				direction = n * direction + (n * cosI - cosT) * normal;
 			}
 			if (!outside) {
-				const f3 e = (-object_color) * distance;
+				const f3 e = (-albedo) * distance;
 				direct = direct * mk3(dm::expf_det(e.x), dm::expf_det(e.y), dm::expf_det(e.z));
 			}
 			break;
@@ -274,30 +274,30 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 			do {
 				const float phi = 2 * kPi * rng_float(seed);
 				const float r2 = rng_float(seed);
-				const float cosTheta = dm::powf_det(1.0f - r2, 1.0f / (phongexponent + 1.0f));
-				const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+				const float cosLobe = dm::powf_det(1.0f - r2, 1.0f / (kPhongPower + 1.0f));
+				const float sinLobe = sqrtf(1.0f - cosLobe * cosLobe);
 				w = direction - (normal * 2.0f) * dot(normal, direction);
 				w = normalize(w);
 				orthonormal_basis_naive(w, u, v);
 				float sp, cp;
 				dm::sincosf_det(phi, sp, cp);
-				d = (u * cp) * sinTheta + (v * sp) * sinTheta + w * cosTheta;
+				d = (u * cp) * sinLobe + (v * sp) * sinLobe + w * cosLobe;
 				d = normalize(d);
 			} while (dot(d, normal) <= kEpsilon);
 
-			const f3 sunSampleDir = cone_sample(P.sun, seed);
-			float sunLight = dot(normal, sunSampleDir);
+			const f3 toSun = cone_sample(P.sun, seed);
+			float cosSun = dot(normal, toSun);
 			if (rng_float(seed) < 0.5f) {
-				if (sunLight > 0.f) {
-					const float phongCos = dot(sunSampleDir, w);
-					if (phongCos > kEpsilon) {
-						sunLight *= dm::powf_det(phongCos, phongexponent);
+				if (cosSun > 0.f) {
+					const float lobeCos = dot(toSun, w);
+					if (lobeCos > kEpsilon) {
+						cosSun *= dm::powf_det(lobeCos, kPhongPower);
 						out.shadow = true;
 						out.sOrigin = origin;
-						out.sDir = sunSampleDir;
-						out.sColor = (2.0f * direct) * ((phongexponent + 2) * 0.5f * kInvPi); // x ((sun(..) * sunLight) * 1E-5f) below
+						out.sDir = toSun;
+						out.sColor = (2.0f * direct) * ((kPhongPower + 2) * 0.5f * kInvPi); // x ((sun(..) * cosSun) * 1E-5f) below
 						atmo = kAtmoSun;
-						atmoScale = sunLight;
+						atmoScale = cosSun;
 						out.sClosest = 1e20f;
 					}
 				}
@@ -305,23 +305,23 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 				const EmitterSample E = sample_emitter<LIGHTS>(P, seed, origin, normal);
 				const LightSample& L = E.L;
 				if (L.valid) {
-					float phongCos = dot(L.lightDir, w);
-					if (phongCos > kEpsilon) {
-						phongCos = dm::powf_det(phongCos, phongexponent);
-						const float closestAllowed = length(L.lightVector);
-						const float solidAngle = (L.cosLightToSurface * E.area) / dot(L.lightVector, L.lightVector);
+					float lobeCos = dot(L.toLightUnit, w);
+					if (lobeCos > kEpsilon) {
+						lobeCos = dm::powf_det(lobeCos, kPhongPower);
+						const float reach = length(L.toLight);
+						const float subtended = (L.cosAtLight * E.area) / dot(L.toLight, L.toLight);
 						f3 sc = (E.emission * 2.0f) * direct;
-						sc = sc * solidAngle;
-						sc = sc * (phongexponent + 2);
+						sc = sc * subtended;
+						sc = sc * (kPhongPower + 2);
 						sc = sc * 0.5f;
 						sc = sc * kInvPi;
-						sc = sc * phongCos;
-						sc = sc * L.cosSurfaceToLight;
+						sc = sc * lobeCos;
+						sc = sc * L.cosAtSurface;
 						out.shadow = true;
 						out.sOrigin = origin;
-						out.sDir = L.lightDir;
+						out.sDir = L.toLightUnit;
 						out.sColor = sc;
-						out.sClosest = closestAllowed;
+						out.sClosest = reach;
 					}
 				}
 			}
@@ -336,7 +336,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 	}
 
 	// The atmosphere (sunsky.cu) is the most expensive thing a ray can ask for here, and three kinds of lanes ask:
-	// a diffuse or Phong hit whose next-event sample went to the sun (sun(sunSampleDir), kernel.cu:414 / 553), and a
+	// a diffuse or Phong hit whose next-event sample went to the sun (sun(toSun), kernel.cu:414 / 553), and a
 	// miss (sky / sunsky(direction), kernel.cu:613-617).  A ray asks at most once, nothing random is drawn in
 	// between, so all of them evaluate it HERE, in one pass of the wave, instead of one pass per place of call; every
 	// lane still performs exactly the operations the reference's order of evaluation prescribes.

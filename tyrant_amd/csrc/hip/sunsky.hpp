@@ -50,12 +50,12 @@ __device__ __forceinline__ Atmosphere atmosphere(const SunParams& S, f3 viewDir)
 	const f3 mieAtX = ld3(S.mieAtX);
 
 	const float cosViewSunAngle = dot(viewDir, sunDirection);
-	const float cosUpViewAngle = dot(up, viewDir);
-	const float zenithAngle = gmax(0.0f, cosUpViewAngle);
-	const float rayleighOpticalLength = kRayleighZenithLength / zenithAngle;
-	const float mieOpticalLength = kMieZenithLength / zenithAngle;
+	const float cosZenith = dot(up, viewDir);
+	const float cosZenithPos = gmax(0.0f, cosZenith);
+	const float pathRayleigh = kRayleighZenithLength / cosZenithPos;
+	const float pathMie = kMieZenithLength / cosZenithPos;
 
-	const f3 ext = rayleighAtX * rayleighOpticalLength + mieAtX * mieOpticalLength;
+	const f3 ext = rayleighAtX * pathRayleigh + mieAtX * pathMie;
 	const f3 Fex = mk3(dm::expf_det(-ext.x), dm::expf_det(-ext.y), dm::expf_det(-ext.z));
 
 	// RayleighPhase, sunsky.cu:10-12: (3.0 / (16.0 * pi)) * (1.0 + powf(c, 2.0))
@@ -67,12 +67,12 @@ __device__ __forceinline__ Atmosphere atmosphere(const SunParams& S, f3 viewDir)
 	const double hp = hb * sqrt(hb);
 	const float hg = (float)((1.0 / (4.0 * (double)kPi)) * ((1.0 - (double)g2) / hp));
 
-	const f3 lightFromXtoEye = rayleighAtX * rayleighPhase + mieAtX * hg;
-	const f3 somethingElse = S.sunE * (lightFromXtoEye / ld3(S.totalLightAtX));
+	const f3 phased = rayleighAtX * rayleighPhase + mieAtX * hg;
+	const f3 inscatter = S.sunE * (phased / ld3(S.totalLightAtX));
 
-	f3 sky = somethingElse * mk3(1.0f - Fex.x, 1.0f - Fex.y, 1.0f - Fex.z);
-	// mix(vec3(1), pow(somethingElse * Fex, vec3(0.5)), a) = 1 + a * (y - 1)  (func_common.inl:103-111)
-	const f3 sf = somethingElse * Fex;
+	f3 sky = inscatter * mk3(1.0f - Fex.x, 1.0f - Fex.y, 1.0f - Fex.z);
+	// mix(vec3(1), pow(inscatter * Fex, vec3(0.5)), a) = 1 + a * (y - 1)  (func_common.inl:103-111)
+	const f3 sf = inscatter * Fex;
 	sky = sky * gmix(mk3(1.0f, 1.0f, 1.0f), mk3(sqrtf(sf.x), sqrtf(sf.y), sqrtf(sf.z)), S.mixFactor);
 	return Atmosphere{ cosViewSunAngle, Fex, sky };
 }
