@@ -277,6 +277,7 @@ enum {
 	TYR_TUNE_MERGE_TRACE = 12,      /* tyr_render: 1 (default) = connect(i) shares the launch of extend(i + 1) -- both only depend on shade(i), and every traversal launch ends in a latency-bound drain as long as its longest ray (40-60 % of a launch at 1080p): one drain per iteration instead of two; the last iteration's shadow rays get a launch of their own.  0 = separate launches (with TYR_TUNE_OVERLAP_CONNECT deciding the stream).  Ignored by the counting build and by variants other than 4.  tyr_launch_kernels is always extend, shade, connect, done when it returns. */
 	TYR_TUNE_STATIC_INTERLEAVE = 13, /* variant 4: the fixed per-block part of the queue (TYR_TUNE_STATIC_SHARE) as interleaved 64-slot chunks -- block b owns chunks b, b + G, b + 2 G, ... -- (1, default) or as one contiguous range per block (0): contiguous ranges give single blocks whole regions of the frame (the queue is in scan-line order) and the launch ends on the block that drew the dense one */
 	TYR_TUNE_RUN_AHEAD = 14,        /* tyr_render with merged launches: 1 = iteration i + 1 is queued BEFORE the counts of iteration i have reached the host -- every kernel takes its counts from device memory, the host sizes grids from upper bounds (survivors(i) <= live(i)) and only learns one iteration late that the render has ended; that last, empty iteration traces the final shadow rays.  The stream never runs dry between iterations.  0 = wait for every iteration's counts; 2 (default) = run ahead when queue_size is at most 6 Mi slots: measured -1.2 % per render at the reference's 2 Mi slots (20 thin iterations), +0.5 % on a 16.6 M-slot queue, where the extra, empty iteration costs what six short waits save (profiles/r02_run_ahead_ab.txt).  Results do not depend on it. */
+	TYR_TUNE_WIDE_DRAIN = 15,       /* k_trace_flat: 1 (default) = once the queue is used up, a wave that holds at most 16 rays finishes them four lanes to a ray (one child box and one leaf primitive per lane, DPP exchange inside the group): a quarter of the instructions per step where the launch is bound by its last rays.  0 = the rays stay one to a lane.  Results do not depend on it. */
 	TYR_TUNE_RAYS_PER_BLOCK = 6     /* variants 2/3: queue slots owned by one 256-thread block and handed to its free lanes through LDS (256..65536, default 1024; halved automatically for thin queues) */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);

@@ -335,8 +335,8 @@ class Renderer:
         _check(self.L.tyr_get_timings(self.h, C.byref(t), int(reset)), "tyr_get_timings")
         return {n: {"ms": t.ms[i], "launches": int(t.launches[i])} for i, n in enumerate(KERNEL_NAMES)}
 
-    def set_tuning(self, traversal_variant=None, refill_min_idle=None, waves_per_simd=None, stack_lds_depth=None, min_traversing=None, ticket_chunk=None, rays_per_block=None, min_leaves=None, static_share=None, staged_nodes=None, overlap_connect=None, profile_mask=None, merge_trace=None, static_interleave=None, run_ahead=None):
-        for key, v in ((0, traversal_variant), (1, refill_min_idle), (2, waves_per_simd), (3, stack_lds_depth), (4, min_traversing), (5, ticket_chunk), (6, rays_per_block), (7, min_leaves), (8, static_share), (9, staged_nodes), (10, overlap_connect), (11, profile_mask), (12, merge_trace), (13, static_interleave), (14, run_ahead)):
+    def set_tuning(self, traversal_variant=None, refill_min_idle=None, waves_per_simd=None, stack_lds_depth=None, min_traversing=None, ticket_chunk=None, rays_per_block=None, min_leaves=None, static_share=None, staged_nodes=None, overlap_connect=None, profile_mask=None, merge_trace=None, static_interleave=None, run_ahead=None, wide_drain=None):
+        for key, v in ((0, traversal_variant), (1, refill_min_idle), (2, waves_per_simd), (3, stack_lds_depth), (4, min_traversing), (5, ticket_chunk), (6, rays_per_block), (7, min_leaves), (8, static_share), (9, staged_nodes), (10, overlap_connect), (11, profile_mask), (12, merge_trace), (13, static_interleave), (14, run_ahead), (15, wide_drain)):
             if v is not None:
                 _check(self.L.tyr_set_tuning(self.h, key, int(v)), "tyr_set_tuning")
 

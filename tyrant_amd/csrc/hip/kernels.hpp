@@ -102,6 +102,7 @@ struct FrameParams {
 	uint32_t staticShare;         // variant 4: sixteenths of the queue handed out as fixed per-block ranges
 	uint32_t traceShadow;         // k_trace_flat: the previous iteration's shadow rays ride in this launch (0: a render's first launch)
 	uint32_t staticInterleave;    // ... as 64-slot chunks b, b + G, ... (1) or as one contiguous range per block (0)
+	uint32_t wideDrain;           // k_trace_flat: finish a wave's last <= 16 rays four lanes to a ray
 	// TYR_FLAG_LIGHT_LIST (extension): emissive triangles, as indices into scene.tris in array order
 	const uint32_t* lights;
 	uint32_t nLights;
@@ -119,6 +120,7 @@ struct Tuning {
 	int raysPerBlock = 1024;
 	int staticShare = 12;     // sixteenths of the queue dealt out as fixed (interleaved) per-block chunks before the ticketed rest (4 with contiguous ranges in round 1; 12 measured best with interleaved ones: profiles/r02_knob_sweep_merged.txt)
 	int staticInterleave = 1; // the fixed per-block part of the queue in interleaved 64-slot chunks (every block the same mix of the frame)
+	int wideDrain = 1;        // k_trace_flat: the last rays of a wave four lanes to a ray (TYR_TUNE_WIDE_DRAIN)
 	int stagedNodes = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits

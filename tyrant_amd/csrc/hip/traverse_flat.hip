@@ -646,6 +646,193 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 	}
 }
 
+// LDS executes a wave's instructions in order; this only keeps the COMPILER from moving a lane's LDS read above another
+// lane's write of the same wave (no instruction is emitted)
+__device__ __forceinline__ void wave_lds_order() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// values of the other lanes of this lane's aligned group of four (DPP quad_perm: no LDS, no memory)
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) {
+	v |= quad_perm_u<0xB1>(v); // [1,0,3,2]
+	v |= quad_perm_u<0x4E>(v); // [2,3,0,1]
+	return v;
+}
+template <int K>
+__device__ __forceinline__ float quad_bcast_f(float v) { return __uint_as_float(quad_perm_u<K * 0x55>(__float_as_uint(v))); }
+constexpr uint32_t kWideRays = 16;        // a wave switches to four lanes per ray once it holds at most this many
+constexpr int kWideStackEntries = 4 * 12; // the four lanes' LDS columns of a group, as one stack
+
+// ==== the drain, four lanes to a ray ====
+		// Once the queue is used up a wave finishes its last rays a few lanes wide while every step still costs a full wave's
+	// instructions: ~330 per quad step (four box tests, ordering, up to three pushes, the leaf's primitives one trip each),
+	// five such waves to a SIMD -- the first third of a launch's drain is bound by exactly that.  Here the wave's (at most
+	// 16) rays are dealt one to each aligned group of four lanes: a lane tests ONE child box of the quad node (and one
+	// primitive of a leaf), the four answers meet through DPP quad_perm moves, every lane of the group derives the same
+	// visit order test_quad derives, and the group's stack is its four LDS columns taken as one.  Same boxes, same order,
+	// same accept rule, same answers -- at a quarter of the instructions per step.
+// (A function of its own, not inlined: inside k_trace_flat its scalar registers competed with the feed loop's -- 35 instead
+// of 16 spilled there, 2.5 % of a render whether or not a wave ever got here.)
+struct WideState {
+	float rox, roy, roz, rdx, rdy, rdz, rix, riy, riz, dist;
+	uint32_t ref, slot, flags; // flags: 1 regular, 2 hitTri, 4 isShadow, 8 occluded, 16 live
+	int prim, n;
+};
+template <int STACK_LDS>
+__device__ __attribute__((noinline)) uint32_t wide_drain(const float4* __restrict__ quads, const float4* __restrict__ tris, const float4* __restrict__ shadowColor, const float4* __restrict__ shadowDyzCdIx,
+                                                         float2* __restrict__ workHit, float4* __restrict__ blit, typename LdsStack<STACK_LDS, true>::entry_t* smem_, WideState w, uint32_t passes) {
+	const uint32_t lane = lane_id();
+	const unsigned long long below = (1ull << lane) - 1ull;
+	float rox = w.rox, roy = w.roy, roz = w.roz, rdx = w.rdx, rdy = w.rdy, rdz = w.rdz, rix = w.rix, riy = w.riy, riz = w.riz, dist = w.dist;
+	uint32_t ref = w.ref, slot = w.slot;
+	int prim = w.prim;
+	bool regular = (w.flags & 1u) != 0u, hitTri = (w.flags & 2u) != 0u, isShadow = (w.flags & 4u) != 0u, occluded = (w.flags & 8u) != 0u;
+	const bool live = (w.flags & 16u) != 0u;
+	uint32_t visible = 0;
+	struct { int n; } st = { w.n };
+	const uint32_t sub = lane & 3u, grp = lane >> 2;
+	const unsigned long long lm = __ballot(live);
+	const uint32_t nl = (uint32_t)__popcll(lm);
+	// the k-th live lane tells lane k its number (ds_permute: a scatter through the LDS crossbar, no LDS memory -- the
+	// block has none to spare: one more allocation granule and only four blocks fit a CU); idle lanes aim at lane 63,
+	// which no group asks (nl <= 16)
+	const uint32_t told = (uint32_t)__builtin_amdgcn_ds_permute(live ? (int)(__popcll(lm & below) << 2) : 63 * 4, (int)lane);
+	bool gActive = grp < nl;
+	const uint32_t asked = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(grp << 2), (int)told);
+	const uint32_t srcLane = gActive ? asked : lane;
+	const int pull = (int)(srcLane << 2);
+	auto pull_f = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)__float_as_uint(v))); };
+	auto pull_u = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v); };
+	rox = pull_f(rox), roy = pull_f(roy), roz = pull_f(roz);
+	rdx = pull_f(rdx), rdy = pull_f(rdy), rdz = pull_f(rdz);
+	rix = pull_f(rix), riy = pull_f(riy), riz = pull_f(riz);
+	dist = pull_f(dist);
+	ref = pull_u(ref);
+	slot = pull_u(slot);
+	prim = (int)pull_u((uint32_t)prim);
+	const uint32_t fl = pull_u((regular ? 1u : 0u) | (hitTri ? 2u : 0u) | (isShadow ? 4u : 0u) | (occluded ? 8u : 0u));
+	regular = (fl & 1u) != 0u, hitTri = (fl & 2u) != 0u, isShadow = (fl & 4u) != 0u, occluded = (fl & 8u) != 0u;
+	int n = (int)pull_u((uint32_t)st.n);
+	// the ray's stack (at most STACK_LDS entries, all in its old lane's LDS column) moves into the group's four columns:
+	// entry e at row e / 4 of lane e % 4
+	typedef typename LdsStack<STACK_LDS, true>::entry_t entry_t;
+	entry_t* const column0 = smem_ + (threadIdx.x & ~63u); // row 0 of this wave's lane 0
+	entry_t moved[STACK_LDS / 4];
+#pragma unroll
+	for (int row = 0; row < STACK_LDS / 4; ++row) {
+		const int e = 4 * row + (int)sub;
+		moved[row] = (gActive && e < n) ? column0[e * kBlock + srcLane] : entry_t{};
+	}
+	wave_lds_order();
+#pragma unroll
+	for (int row = 0; row < STACK_LDS / 4; ++row)
+		if (gActive && 4 * row + (int)sub < n)
+			column0[row * kBlock + lane] = moved[row];
+	wave_lds_order();
+	entry_t* const gstack = column0 + (lane & ~3u); // entry e: gstack[(e >> 2) * kBlock + (e & 3)]
+	const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 };
+	const uint32_t signBits = (r.nx ? 1u : 0u) | (r.ny ? 2u : 0u) | (r.nz ? 4u : 0u);
+	bool wideOverflow = false;
+	while (__ballot(gActive) != 0ull) {
+		if (kGuardPasses && ++passes > kMaxPasses)
+			break;
+		if (gActive && ref == kRefPop) {
+			if (n == 0) {
+				ref = kRefDone;
+			} else {
+				--n;
+				const entry_t e = gstack[(n >> 2) * kBlock + (n & 3)];
+				if (__uint_as_float(e.y) < dist) // the pop-time half of Bbox.h:61
+					ref = e.x;
+			}
+		}
+		if (gActive && (int)ref >= 0) {
+			// ---- one quad node: this lane's child box ----
+			const uint32_t idx = ref & kQuadIndexMask, meta = ref >> kQuadOrderShift;
+			const float* qf = reinterpret_cast<const float*>(quads + 8 * idx);
+			const uint32_t at = (sub >> 1) * 4u + (sub & 1u) * 2u;
+			const float2 bx = *reinterpret_cast<const float2*>(qf + at);
+			const float2 by = *reinterpret_cast<const float2*>(qf + 8 + at);
+			const float2 bz = *reinterpret_cast<const float2*>(qf + 16 + at);
+			const uint32_t cref = __float_as_uint(qf[24 + sub]);
+			float t;
+			bool h;
+			if (regular)
+				h = slab_fast(r, bx.x, bx.y, by.x, by.y, bz.x, bz.y, dist, t);
+			else
+				h = slab_test(r, r.nx ? bx.y : bx.x, r.nx ? bx.x : bx.y, r.ny ? by.y : by.x, r.ny ? by.x : by.y, r.nz ? bz.y : bz.x, r.nz ? bz.x : bz.y, dist, t);
+			// this slot's place in the reference's visit order (test_quad: near slot first inside each group, near group first)
+			const uint32_t aT = meta & 3u, aL = (meta >> 2) & 3u, aR = (meta >> 4) & 3u;
+			const uint32_t bT = (signBits >> aT) & 1u, bG = (signBits >> ((sub >> 1) ? aR : aL)) & 1u;
+			const uint32_t rank = 2u * ((sub >> 1) ^ bT) + ((sub & 1u) ^ bG);
+			const uint32_t hr = quad_or(h ? (1u << rank) : 0u); // the group's hits, in visit order
+			if (hr == 0u) {
+				ref = kRefPop;
+			} else {
+				const uint32_t first = (uint32_t)__ffs((int)hr) - 1u;
+				// the others go onto the stack farthest first, so that the nearest pops first (push3's order)
+				if (h && rank != first) {
+					const int e = n + (int)__popc(hr >> (rank + 1u));
+					if (e < kWideStackEntries)
+						gstack[(e >> 2) * kBlock + (e & 3)] = make_uint2(cref, __float_as_uint(t));
+				}
+				n += (int)__popc(hr) - 1;
+				if (n > kWideStackEntries) {
+					wideOverflow = true;
+					n = kWideStackEntries;
+				}
+				ref = quad_or(rank == first ? cref : 0u);
+			}
+		} else if (gActive && ref_is_leaf(ref)) {
+			// ---- a leaf: four primitives per trip, accepted in array order (bvh.h:129-140 / 229-238) ----
+			const uint32_t off = ref & (kMaxPrimOffset - 1);
+			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+			bool found = false;
+			for (uint32_t base = 0; base < cnt; base += 4u) {
+				const uint32_t i = base + sub;
+				float tm = 0.0f;
+				if (i < cnt)
+					tm = triangle_test(triangle_load(tris, off + i), r);
+				const float t0 = quad_bcast_f<0>(tm), t1 = quad_bcast_f<1>(tm), t2 = quad_bcast_f<2>(tm), t3 = quad_bcast_f<3>(tm);
+				const float tk[4] = { t0, t1, t2, t3 };
+#pragma unroll
+				for (uint32_t k = 0; k < 4u; ++k) {
+					const float t = tk[k];
+					if (base + k < cnt) {
+						if (isShadow) {
+							found = found || (t > kEpsilon && ((dist - t) > kEpsilon));
+						} else if (t > kEpsilon && t < dist && ((dist - t) > kEpsilon)) {
+							prim = (int)(off + base + k);
+							dist = t;
+							hitTri = true;
+						}
+					}
+				}
+			}
+			occluded = occluded || found;
+			ref = found ? kRefDone : kRefPop;
+		}
+		if (gActive && ref == kRefDone) {
+			if (sub == 0u) {
+				if (isShadow) {
+					if (!occluded) { // kernel.cu:640-644
+						const float4 c = shadowColor[slot];
+						accumulate_pixel(blit, __float_as_int(shadowDyzCdIx[slot].w), mk3(c.x, c.y, c.z), 0);
+						visible += 1;
+					}
+				} else if (hitTri) {
+					workHit[slot] = make_float2(dist, __uint_as_float((uint32_t)prim));
+				}
+			}
+			gActive = false;
+		}
+	}
+	return visible | (wideOverflow ? 0x80000000u : 0u) | (kGuardPasses && passes > kMaxPasses ? 0x40000000u : 0u);
+}
+
 // ======================================================================================
 // k_trace_flat: extend(i + 1) and connect(i) in ONE persistent launch (tyr_render only).
 //
@@ -714,6 +901,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		blockNext = blockBegin;
 	__syncthreads();
 	bool exhausted = nItems == 0;
+	bool wide = false;
+	const uint32_t wideLimit = P.wideDrain != 0u ? kWideRays : 0u;
 	uint32_t passes = 0;
 
 	for (;;) {
@@ -803,10 +992,16 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 				if (__ballot(live && ref == kRefDone) == 0ull)
 					continue; // mostly short rays (primary rays that end at the root box): top the wave up again first
 		}
-		if (__ballot(live) == 0ull) {
-			if (exhausted)
+		{
+			// one way out of the loop: the queue is used up and at most wideLimit rays are left (0: none) -- those are
+			// finished four lanes to a ray below
+			const uint32_t nLiveNow = (uint32_t)__popcll(__ballot(live));
+			if (exhausted && nLiveNow <= wideLimit && __ballot(live && st.n > STACK_LDS) == 0ull) {
+				wide = nLiveNow != 0u;
 				break;
-			continue;
+			}
+			if (nLiveNow == 0u)
+				continue;
 		}
 		allRegular = (__ballot(live && !regular) == 0ull);
 		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
@@ -901,6 +1096,17 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		}
 	}
 	flush_visible();
+	if (wide) {
+		WideState w;
+		w.rox = rox, w.roy = roy, w.roz = roz, w.rdx = rdx, w.rdy = rdy, w.rdz = rdz, w.rix = rix, w.riy = riy, w.riz = riz, w.dist = dist;
+		w.ref = ref, w.slot = slot, w.prim = prim, w.n = st.n;
+		w.flags = (regular ? 1u : 0u) | (hitTri ? 2u : 0u) | (isShadow ? 4u : 0u) | (occluded ? 8u : 0u) | (live ? 16u : 0u);
+		const uint32_t res = wide_drain<STACK_LDS>(sc.quads, sc.tris, P.shadow.color, P.shadow.dyz_cd_ix, P.work.hit, P.blit, smem_, w, passes);
+		visible += res & 0x3fffffffu;
+		overflow = overflow || (res & 0x80000000u) != 0u;
+		if (res & 0x40000000u)
+			passes = kMaxPasses + 1;
+	}
 	if (overflow)
 		atomicOr(&P.k->device_error, kErrStackOverflow);
 	if (kGuardPasses && passes > kMaxPasses)

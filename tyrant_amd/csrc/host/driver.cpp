@@ -161,6 +161,7 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.raysPerBlock = static_cast<uint32_t>(std::min(std::max(c->tuning.raysPerBlock, 256), 65536));
 	P.staticShare = static_cast<uint32_t>(std::min(std::max(c->tuning.staticShare, 0), 15));
 	P.staticInterleave = c->tuning.staticInterleave ? 1u : 0u;
+	P.wideDrain = c->tuning.wideDrain ? 1u : 0u;
 	P.lights = c->dLights;
 	P.nLights = c->nLights;
 	std::memcpy(P.triEmission, c->triEmission, 12);
@@ -1389,6 +1390,11 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		if (value < 0 || value > 2)
 			return TYR_ERR_INVALID;
 		c->tuning.runAhead = value;
+		return TYR_OK;
+	case TYR_TUNE_WIDE_DRAIN:
+		if (value < 0 || value > 1)
+			return TYR_ERR_INVALID;
+		c->tuning.wideDrain = value;
 		return TYR_OK;
 	case TYR_TUNE_STATIC_INTERLEAVE:
 		if (value < 0 || value > 1)
