@@ -34,7 +34,7 @@ for case in range(n_cases):
                         focalDistance=float(rng.uniform(1, 80)), lensRadius=float(rng.choice([0.0, 0.0, rng.uniform(0.1, 3.0)])))
     knobs = dict(traversal_variant=int(rng.choice([4, 4, 4, 3, 2, 1, 0])), stack_lds_depth=int(rng.choice([0, 8, 10, 12, 16, 24])), refill_min_idle=int(rng.integers(1, 65)),
                  min_traversing=int(rng.integers(1, 65)), ticket_chunk=int(rng.choice([64, 128, 1024])), static_share=int(rng.integers(0, 16)), staged_nodes=int(rng.integers(0, 65)),
-                 rays_per_block=int(rng.choice([256, 1024, 4096])), merge_trace=int(rng.integers(0, 2)), static_interleave=int(rng.integers(0, 2)), overlap_connect=int(rng.integers(0, 3)), run_ahead=int(rng.integers(0, 2)))
+                 rays_per_block=int(rng.choice([256, 1024, 4096])), merge_trace=int(rng.integers(0, 2)), static_interleave=int(rng.integers(0, 2)), overlap_connect=int(rng.integers(0, 3)), run_ahead=int(rng.integers(0, 2)), wide_drain=int(rng.integers(0, 2)))
     if knobs["traversal_variant"] == 4 and rng.random() < 0.15:
         knobs["traversal_variant"] = 5  # the ring-of-prepared-rays variant (diagnostics library)
         knobs["stack_lds_depth"] = 12

@@ -427,7 +427,7 @@ def test_render_with_and_without_the_deferred_connect(orc, hip, name, W, H, N, s
     g0.set_tuning(overlap_connect=0, merge_trace=0)
     g1.set_tuning(overlap_connect=1, merge_trace=0)
     g2.set_tuning(merge_trace=1)  # (the default) connect(i) inside the launch of extend(i + 1): k_trace_flat, iteration i + 1 queued ahead of iteration i's counts
-    g3.set_tuning(merge_trace=1, run_ahead=0)  # ... with the host waiting for every iteration's counts
+    g3.set_tuning(merge_trace=1, run_ahead=0, wide_drain=0)  # ... with the host waiting for every iteration's counts, and a wave's last rays left one to a lane
     from tyrant_amd import scenes
 
     sc, _, _ = built_scene(name)

@@ -682,7 +682,7 @@ struct WideState {
 	int prim, n;
 };
 template <int STACK_LDS>
-__device__ __attribute__((noinline)) uint32_t wide_drain(const float4* __restrict__ quads, const float4* __restrict__ tris, const float4* __restrict__ shadowColor, const float4* __restrict__ shadowDyzCdIx,
+__device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __restrict__ quads, const float4* __restrict__ tris, const float4* __restrict__ shadowColor, const float4* __restrict__ shadowDyzCdIx,
                                                          float2* __restrict__ workHit, float4* __restrict__ blit, typename LdsStack<STACK_LDS, true>::entry_t* smem_, WideState w, uint32_t passes) {
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
