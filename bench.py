@@ -244,8 +244,9 @@ def committed_pmc(workload: str, N: int):
 def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_render, kernel=EXTEND_KERNEL, con_ms=0.0, shadow_rays=0.0):
     """`bound` = the tightest of the measured resource fractions of the dominant kernel; the algorithmic-bytes figure of
     SURVEY.md 8d is a separate entry.  Merged launches (kernel = TRACE_KERNEL): the kernel traces this iteration's extend
-    rays and the previous iteration's shadow rays; ext_ms is the time of those launches, con_ms that of the connect launch
-    the last iteration's shadow rays get; the algorithmic figure then covers the whole traversal stage (all extend + all
+    rays and the previous iteration's shadow rays, and the launch that ends a render with the last iteration's shadow rays is
+    the same kernel: ext_ms / ext_launches are ALL its launches (main() adds the one timed as the connect stage; con_ms stays
+    for callers that time a connect launch apart); the algorithmic figure covers the whole traversal stage (all extend + all
     shadow rays over ext_ms + con_ms)."""
     avg_launch_s = ext_ms / max(ext_launches, 1) * 1e-3
     bytes_per_ext = 24 + 8 + 32 * visits["nodes_per_ext"] + 36 * visits["tris_per_ext"]
@@ -301,7 +302,7 @@ def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_re
         "frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
         "bytes_per_extend_ray": round(bytes_per_ext, 1),
         "bytes_per_launch": round(alg_bytes_per_launch),
-        "covers": "every extend and every shadow ray of the timed renders over the time of the trace launches + the last iteration's connect launch" if merged else "the extend launches",
+        "covers": "every extend and every shadow ray of the timed renders over the time of all trace launches (the one that ends a render with the last shadow rays included)" if merged else "the extend launches",
         "nodes_per_ray": round(visits["nodes_per_ext"], 2),
         "tris_per_ray": round(visits["tris_per_ext"], 3),
         "connect_nodes_per_ray": round(visits["nodes_per_con"], 2),
@@ -643,7 +644,11 @@ def main():
                     else {}
                 ),
             },
-            "roofline": roofline_block(pmc, tm["extend"]["ms"], tm["extend"]["launches"], m["ext"], m, m["kernel_ms_per_render"], kernel=dominant_kernel(args.tune), con_ms=tm["connect"]["ms"], shadow_rays=m["shd"]),
+            # merged renders: EVERY traversal launch is k_trace_flat -- the ones timed as the extend stage and the one that ends a
+            # render with the last iteration's shadow rays (timed as the connect stage): one kernel, one average
+            "roofline": (roofline_block(pmc, tm["extend"]["ms"] + tm["connect"]["ms"], tm["extend"]["launches"] + tm["connect"]["launches"], m["ext"], m, m["kernel_ms_per_render"], kernel=TRACE_KERNEL, con_ms=0.0, shadow_rays=m["shd"])
+                         if dominant_kernel(args.tune) == TRACE_KERNEL else
+                         roofline_block(pmc, tm["extend"]["ms"], tm["extend"]["launches"], m["ext"], m, m["kernel_ms_per_render"], kernel=EXTEND_KERNEL, con_ms=tm["connect"]["ms"], shadow_rays=m["shd"])),
         }
         if solo is not None:
             nsteps_solo = max(1, min(args.steps, 2))

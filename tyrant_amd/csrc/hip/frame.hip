@@ -116,6 +116,8 @@ __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P)
 	const uint32_t first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
 	if (first == 0)
 		P.kc->ticket = 0;
+	if (first < kTicketWords)
+		P.k->extend_chunks[first * 32] = 0; // k_trace_flat's tickets, when this pre-pass opens the launch that ends a render (no set_wavefront_globals in front of it)
 	const uint32_t n = P.kc->shadow_cnt;
 	for (uint32_t index = first; index < n; index += stride) {
 		const float4 a = P.shadow.o_dx[index];

@@ -100,7 +100,7 @@ struct FrameParams {
 	uint32_t ticketChunk;         // variants 1 / 4: queue slots a wave takes per draw from a device-wide ticket
 	uint32_t raysPerBlock;        // variants 2 / 3: queue slots owned by one 256-thread block
 	uint32_t staticShare;         // variant 4: sixteenths of the queue handed out as fixed per-block ranges
-	uint32_t traceShadow;         // k_trace_flat: the previous iteration's shadow rays ride in this launch (0: a render's first launch)
+	uint32_t traceShadow;         // k_trace_flat: the previous iteration's shadow rays ride in this launch (0: a render's first launch; 2: they are ALL of it -- the launch that ends a render)
 	uint32_t staticInterleave;    // ... as 64-slot chunks b, b + G, ... (1) or as one contiguous range per block (0)
 	uint32_t wideDrain;           // k_trace_flat: finish a wave's last <= 16 rays four lanes to a ray
 	// TYR_FLAG_LIGHT_LIST (extension): emissive triangles, as indices into scene.tris in array order

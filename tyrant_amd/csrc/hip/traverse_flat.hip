@@ -862,7 +862,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	}
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t nExt = P.k->n_live;
+	const uint32_t nExt = P.traceShadow == 2u ? 0u : P.k->n_live;
 	const uint32_t nItems = nExt + (P.traceShadow != 0u ? P.kcPrev->shadow_cnt : 0u); // (a render's first launch carries no shadow rays: kcPrev then holds an older render's count)
 	const DevScene& sc = P.scene;
 	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f;

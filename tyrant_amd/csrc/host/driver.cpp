@@ -350,8 +350,16 @@ int flush_pending_shadow(tyr_ctx* c) {
 		return TYR_OK;
 	c->shadowPending = false;
 	FrameParams P = make_params(c);
-	P.kc = P.kcPrev; // stage_end has advanced `iter`: the rays belong to the previous iteration's counter set
-	enqueue_connect(c, P, c->shadowPendingMax);
+	if (c->tuning.mergeTrace != 0 && c->tuning.traversalVariant == 4 && !(c->cfg.flags & TYR_FLAG_COUNT_VISITS)) {
+		// the same kernel as every other traversal launch of a merged render, with no extend rays: kcPrev (stage_end has
+		// advanced `iter`) is the set the rays belong to
+		P.traceShadow = 2u;
+		KernelTimer t(c, TYR_K_CONNECT);
+		launch_trace(P, 0u, 0u, c->shadowPendingMax, c->tuning, c->numCUs, c->launchCache, c->stream);
+	} else {
+		P.kc = P.kcPrev; // stage_end has advanced `iter`: the rays belong to the previous iteration's counter set
+		enqueue_connect(c, P, c->shadowPendingMax);
+	}
 	HIPCHK(hipGetLastError());
 	return TYR_OK;
 }
