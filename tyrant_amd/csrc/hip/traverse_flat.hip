@@ -853,6 +853,10 @@ template <int STACK_LDS>
 __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(const FrameParams P) {
 	constexpr bool COUNT = false; // (TYR_DBG)
 	TYR_DECLARE_FLAT_STACK(st, true)
+	// LDS: 24,576 B of stack + 7,168 B of staged nodes + 4 = 31,748 B per block, and five blocks per CU are 158,740 of its
+	// 163,840 B: ONE more allocation granule (a 256-byte array was enough) and the hardware places four while the occupancy
+	// query still answers five -- the fifth of the persistent grid's blocks then run after the others (+30 % per render,
+	// profiles/r02_wide_drain_ab.txt).  Nothing more fits here.
 	__shared__ float4 stagedNodes[7 * kStagedNodes];
 	__shared__ uint32_t blockNext;
 	const uint32_t nStaged = P.scene.nStaged;
