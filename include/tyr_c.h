@@ -240,7 +240,7 @@ typedef struct tyr_scene_info {
 	uint32_t n_prims, n_pair_nodes, n_quad_nodes, n_staged_nodes, n_lights;
 	uint32_t max_quad_nodes;   /* 1 << 25 */
 	uint32_t max_prim_offset;  /* 1 << 26 */
-	uint32_t reserved;
+	uint32_t quad_max_stack;   /* the most stack entries any traversal of this tree can need (the drain's four-lanes-to-a-ray form holds 48 and is used only below that) */
 	uint64_t device_bytes;     /* quad nodes + pair nodes + 48-byte triangles resident in HBM */
 } tyr_scene_info;
 int tyr_get_scene_info(tyr_ctx* ctx, tyr_scene_info* out);

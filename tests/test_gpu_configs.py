@@ -195,3 +195,48 @@ def test_product_builder_builds_c3_on_this_host(orc, hip):
     hip.set_build_threads(0)
     assert nodes.tobytes() == nodes_o.tobytes() and prims.tobytes() == prims_o.tobytes()
     assert nodes1.tobytes() == nodes_o.tobytes() and prims1.tobytes() == prims_o.tobytes()
+
+
+def test_stack_bound_of_the_tree_gates_the_wide_drain(orc, hip):
+    """The layout pass computes the most stack entries ANY traversal of the quad tree can need (tyr_scene_info.quad_max_stack);
+    the four-lanes-to-a-ray drain holds a ray's stack in 48 LDS entries and is entered only on trees that cannot need more.
+    The benchmark trees are far below; degenerate chains (triangles at geometrically growing distances: every SAH split
+    peels a few off) are above -- there the rays stay one to a lane (64 entries, as the reference's nodesToVisit[64],
+    bvh.h:124) and the render still equals the oracle's, with no overflow reported."""
+    from tyrant_amd import scenes
+
+    for name, lo, hi in (("mesh128", 8, 48), ("cornell_soup10k", 8, 48)):
+        sc, nodes, prims = built_scene(name)
+        g = hip.Renderer(64, 48, 4096, flags=1 if sc.triangle_materials else 0)
+        g.load_scene(sc, nodes, prims)
+        assert lo <= g.scene_info()["quad_max_stack"] <= hi, (name, g.scene_info())
+        g.close()
+    # six chains of triangles at +-2^1 .. +-2^40 along the three axes: every SAH split peels a few far ones off, the tree
+    # is 37 levels deep and a traversal could (for some ray) hold 55 entries -- more than the wide drain's 48, fewer than 64
+    n = 40
+    chains = []
+    for axis in range(3):
+        for sign in (1.0, -1.0):
+            v = np.zeros((n, 3), np.float32)
+            v[:, axis] = (2.0 ** np.arange(1, n + 1)).astype(np.float32) * np.float32(sign)
+            chains.append(v)
+    v0 = np.concatenate(chains)
+    tris = scenes.make_triangles(v0, v0 + np.float32([0.3, 0.9, 0.1]), v0 + np.float32([0.1, 0.4, 1.1]))
+    tris = np.concatenate([tris, scenes.make_triangles(v0, v0 + np.float32([0.1, 0.4, 1.1]), v0 + np.float32([0.3, 0.9, 0.1]))])  # both faces
+    nodes, prims = orc.bvh_build(tris, scenes.triangle_bboxes(tris))
+    sc = scenes.SceneData("chains", tris, scenes.cornell_spheres(), scenes.Camera(position=(-40.0, -30.0, 14.0), direction=(0.76, 0.57, -0.3), up=(0.0, 0.0, 1.0)))
+    W, H, N, spp = 96, 64, 6144, 3
+    o = orc.Oracle(W, H, N)
+    g = hip.Renderer(W, H, N)
+    for r in (o, g):
+        r.load_scene(sc, nodes, prims)
+    info = g.scene_info()
+    assert info["quad_max_stack"] > 48, info  # the wide drain is off for this tree
+    assert o.render(spp) == g.render(spp)
+    ko, kg = o.counters(), g.counters()
+    assert kg["device_error"] == 0
+    for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible"):
+        assert ko[f] == kg[f], f
+    bo, bg = o.blit_buffer(), g.blit_buffer()
+    assert np.array_equal(bo[:, 3], bg[:, 3]) and np.allclose(bg[:, :3], bo[:, :3], rtol=1e-5, atol=1e-6)
+    assert kg["total_extend_rays"] > W * H * spp  # (rays did reach the chains and bounce)

@@ -88,7 +88,7 @@ class Counters(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_prims", c_u32), ("n_pair_nodes", c_u32), ("n_quad_nodes", c_u32), ("n_staged_nodes", c_u32), ("n_lights", c_u32), ("max_quad_nodes", c_u32), ("max_prim_offset", c_u32),
-                ("reserved", c_u32), ("device_bytes", c_u64)]
+                ("quad_max_stack", c_u32), ("device_bytes", c_u64)]
 
 
 class Timings(C.Structure):

@@ -61,6 +61,7 @@ struct DevScene {
 	uint32_t quadRootRef;
 	uint32_t nQuads;
 	uint32_t nStaged;    // the first nStaged quad nodes are the top of the tree in breadth-first order (<= kStagedNodes)
+	uint32_t quadMaxStack; // upper bound of a traversal's stack depth on this tree, any ray (host/bvh_layout.cpp)
 	const float4* nodes; // PairNode array, 4 float4 each (the counting build and variants 0/1)
 	const float4* tris;  // 3 float4 each
 	float rootMin[3];

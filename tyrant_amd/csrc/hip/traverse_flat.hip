@@ -906,7 +906,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	__syncthreads();
 	bool exhausted = nItems == 0;
 	bool wide = false;
-	const uint32_t wideLimit = P.wideDrain != 0u ? kWideRays : 0u;
+	const uint32_t wideLimit = (P.wideDrain != 0u && P.scene.quadMaxStack <= (uint32_t)kWideStackEntries) ? kWideRays : 0u; // (a tree that could need more than the group's 48 entries keeps its rays one to a lane)
 	uint32_t passes = 0;
 
 	for (;;) {

@@ -297,6 +297,48 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 		L.quadRootRef = 0;
 	}
 	L.nQuads = static_cast<uint32_t>(L.quadNodes.size() / 32);
+	// The deepest a traversal's stack can get on this tree, for any ray and any visit order: inside the subtree of one child
+	// of a node, at most the node's other used slots wait on the stack -- need(q) = max over interior children c of
+	// (used slots of q - 1) + need(c), and (used slots - 1) for a node of leaves.  The kernels' four-lanes-to-a-ray drain
+	// keeps a ray's stack in 48 LDS entries and is only entered on trees that cannot need more.
+	L.quadMaxStack = 0;
+	if (L.nQuads > 0 && static_cast<int32_t>(L.quadRootRef) >= 0) {
+		auto ref_of = [&](uint32_t qi, int sidx) {
+			uint32_t r;
+			std::memcpy(&r, &L.quadNodes[static_cast<size_t>(qi) * 32 + 24 + sidx], 4);
+			return r;
+		};
+		std::vector<uint32_t> need(L.nQuads, 0);
+		std::vector<uint8_t> state(L.nQuads, 0); // 0 new, 1 children pushed, 2 done
+		std::vector<uint32_t> todo{ L.quadRootRef };
+		while (!todo.empty()) {
+			const uint32_t q = todo.back();
+			if (state[q] == 0) {
+				state[q] = 1;
+				for (int sidx = 0; sidx < 4; ++sidx) {
+					const uint32_t r = ref_of(q, sidx);
+					if (static_cast<int32_t>(r) >= 0 && r < L.nQuads && state[r] == 0)
+						todo.push_back(r);
+				}
+			} else {
+				todo.pop_back();
+				if (state[q] == 2)
+					continue;
+				state[q] = 2;
+				uint32_t used = 0, deepest = 0;
+				for (int sidx = 0; sidx < 4; ++sidx) {
+					const uint32_t r = ref_of(q, sidx);
+					if (r == kEmptyRef)
+						continue;
+					++used;
+					if (static_cast<int32_t>(r) >= 0 && r < L.nQuads)
+						deepest = std::max(deepest, need[r]);
+				}
+				need[q] = (used ? used - 1 : 0) + deepest;
+			}
+		}
+		L.quadMaxStack = need[L.quadRootRef];
+	}
 	// The top of the tree moves to the front of the array in breadth-first order: the persistent kernels keep the
 	// first kStagedNodes records in LDS (hip/traverse.hpp).  Everything else keeps its depth-first order.
 	L.nStaged = 0;

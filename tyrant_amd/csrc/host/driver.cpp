@@ -612,6 +612,7 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	c->scene.quadRootRef = L.quadRootRef;
 	c->scene.nQuads = L.nQuads;
 	c->scene.nStaged = L.nStaged;
+	c->scene.quadMaxStack = L.quadMaxStack;
 	HIPCHK(hipMemcpy(c->dTris, L.tris.data(), triFloats * sizeof(float), hipMemcpyHostToDevice));
 	c->scene.nodes = c->dNodes;
 	c->scene.tris = c->dTris;
@@ -1332,6 +1333,7 @@ int tyr_get_scene_info(tyr_ctx* c, tyr_scene_info* out) {
 	out->n_pair_nodes = c->scene.nPairs;
 	out->n_quad_nodes = c->scene.nQuads;
 	out->n_staged_nodes = c->scene.nStaged;
+	out->quad_max_stack = c->scene.quadMaxStack;
 	out->n_lights = c->nLights;
 	out->max_quad_nodes = 1u << kQuadOrderShift;
 	out->max_prim_offset = kMaxPrimOffset;

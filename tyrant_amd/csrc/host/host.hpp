@@ -27,6 +27,7 @@ struct DeviceLayout {
 	uint32_t quadRootRef = 0;
 	uint32_t nQuads = 0;
 	uint32_t nStaged = 0; // leading records that are the top of the tree in breadth-first order
+	uint32_t quadMaxStack = 0; // the most entries a traversal of the quad tree can ever have on its stack (whatever the ray)
 	std::vector<float> tris;      // 12 floats per triangle
 	float rootMin[3], rootMax[3];
 	uint32_t rootRef;
