@@ -97,6 +97,8 @@ def test_c5_ten_million_triangles_4k(orc, hip):
     leaves = nodes["primitiveCount"] > 0
     assert int((nodes["offset"][leaves].astype(np.int64) + nodes["primitiveCount"][leaves]).max()) <= info["max_prim_offset"] == 1 << 26, info  # 26-bit primitive offset
     assert info["n_pair_nodes"] == int((~leaves).sum())
+    assert 16 <= info["quad_max_stack"] <= 48, info  # no traversal of this tree can need more than the wide drain's 48 stack entries (nor the 64 of bvh.h:124)
+    print("C5 quad_max_stack", info["quad_max_stack"])
     o = orc.Oracle(W, H, N2M, flags=1)
     o.load_scene(sc, nodes, prims)
     # the scan-line cursor walks down the frame: the first 2 Mi slots are 546 rows of sky, the mesh comes into view in the
@@ -205,11 +207,12 @@ def test_stack_bound_of_the_tree_gates_the_wide_drain(orc, hip):
     bvh.h:124) and the render still equals the oracle's, with no overflow reported."""
     from tyrant_amd import scenes
 
-    for name, lo, hi in (("mesh128", 8, 48), ("cornell_soup10k", 8, 48)):
+    for name, lo, hi in (("mesh128", 8, 48), ("cornell_soup10k", 8, 48), ("mesh706", 16, 48)):
         sc, nodes, prims = built_scene(name)
         g = hip.Renderer(64, 48, 4096, flags=1 if sc.triangle_materials else 0)
         g.load_scene(sc, nodes, prims)
         assert lo <= g.scene_info()["quad_max_stack"] <= hi, (name, g.scene_info())
+        print(name, "quad_max_stack", g.scene_info()["quad_max_stack"])
         g.close()
     # six chains of triangles at +-2^1 .. +-2^40 along the three axes: every SAH split peels a few far ones off, the tree
     # is 37 levels deep and a traversal could (for some ray) hold 55 entries -- more than the wide drain's 48, fewer than 64
