@@ -252,6 +252,19 @@ int tyr_get_scene_info(tyr_ctx* ctx, tyr_scene_info* out);
  * device arithmetic to the vendored glm's own answers (tests/golden/ref_glm.npz).  op codes: oracle/ref_harness.cpp. */
 int tyr_vecmath_probe(int32_t device, int32_t op, const float* a, const float* b, const float* c, uint32_t n, float* out);
 
+/* The atmosphere as the shade kernel evaluates it (hip/sunsky.hpp, hip/device_common.hpp cone_sample), run ON THE DEVICE
+ * over host arrays, for the sun position (sun_x, sun_y) (variables.cpp:3; the constants of kernel.cu:683-709 come from
+ * the library's own host setup): the hook that pins the device arithmetic to the answers of the reference's own
+ * sunsky.cu compiled as C++ (tests/golden/ref_sunsky.npz, oracle/ref_host_harness.cpp).
+ *   which 0 sun(dir) sunsky.cu:32-74 | 1 sky(dir) 76-114 | 2 sunsky(dir) 116-161: dirs and out are n float3
+ *   which 3 getConeSample(sunDirection, 1 - sunAngularDiameterCos, seed) sunsky.cu:170-185 as kernel.cu:410 calls it:
+ *           n successive samples along ONE xorshift stream; dirs[0] carries the seed's bits in, out[3n] the state after */
+int tyr_sunsky_probe(int32_t device, float sun_x, float sun_y, int32_t which, const float* dirs, uint32_t n, float* out);
+/* the host half of the above (no GPU needed): the 25 floats of the per-sun-change constants -- sunDirection[3],
+ * sunAngularDiameterCos, sunE, rayleighAtX[3], mieAtX[3], totalLightAtX[3], mixFactor, coneDir[3], coneO1[3], coneO2[3],
+ * coneExtent (kernel.cu:683-684, 704-709; sunsky.cu:15-26, 66-67, 172-175) */
+int tyr_sun_setup(float sun_x, float sun_y, float* out25);
+
 /* ---- measurement ------------------------------------------------------------ */
 enum { TYR_K_PRIMARY = 0, TYR_K_EXTEND = 1, TYR_K_SHADE = 2, TYR_K_CONNECT = 3, TYR_K_RESOLVE = 4, TYR_K_COUNT = 5 };
 typedef struct tyr_timings {
@@ -325,6 +338,11 @@ int tyr_dist_scatter_rows(const void* slabs_device, void* frame_device, uint32_t
 /* class BVH, bvh.h:49-108 / bvh.cpp:3-225: binned-SAH build emitting the flat depth-first
  * node array; reorders `prims` in place (bvh.cpp:24).  bboxes: one per primitive (Scene.cpp:29-33).
  * nodes_out must hold 2*n-1 nodes.  algo: 1 = EqualCounts, 2 = SAH (bvh.h:45-47).
+ * SAH (what Scene.cpp:53 uses) is byte-pinned: nodes and reordered primitives equal the output of the reference's own
+ * bvh.cpp on every fixture scene incl. the 1.1 M-node C3 and 12.6 M-node C5 trees (tests/test_ref_pins.py).
+ * EqualCounts is NOT byte-pinned and cannot be: bvh.cpp:113-120 partitions with std::nth_element, whose permutation is
+ * implementation-defined (MSVC's STL in the original, libstdc++ in the reference as compiled here); this library's
+ * deterministic selection yields a valid median split with its own, thread-count-independent, bytes.
  * Returns the node count (>= 0) or a negative status. */
 int tyr_bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo);
 /* Threads tyr_bvh_build may use: the top of the tree fans out into tasks, the output is byte-identical

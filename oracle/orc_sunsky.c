@@ -51,12 +51,13 @@ static v3 ortho(v3 v) {
 
 void orc_sun_setup(const float sun_position[2], orc_sunparams* S) {
 	/* kernel.cu:683  float sun_angular = cos(sunSize * pi / 180.f); */
-	S->sunAngularDiameterCos = (float)cos((double)(sunSize * ORC_PI / 180.f));
+	S->sunAngularDiameterCos = cosf(sunSize * ORC_PI / 180.f); /* cos(float): the float overload, under nvcc and in the reference compiled as C++ (oracle/_ref) */
 	/* kernel.cu:708  normalize(fromSpherical((sun_position - vec2(0.0,0.5)) * vec2(6.28f,3.14f)))
-	 * sunsky.cu:28-30 fromSpherical: host cos/sin on float arguments */
+	 * sunsky.cu:28-30 fromSpherical: host cos/sin on float arguments = the float overloads, products in binary32
+	 * (pinned by tests/golden/ref_sunsky.npz: sun position (0.3, 0.12) tells this from a binary64 evaluation) */
 	float px = (sun_position[0] - 0.0f) * 6.28f;
 	float py = (sun_position[1] - 0.5f) * 3.14f;
-	v3 d = v3make((float)(cos((double)px) * sin((double)py)), (float)(sin((double)px) * sin((double)py)), (float)cos((double)py));
+	v3 d = v3make(cosf(px) * sinf(py), sinf(px) * sinf(py), cosf(py));
 	d = v3normalize(d);
 	v3store(S->sunDirection, d);
 

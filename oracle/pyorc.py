@@ -182,6 +182,16 @@ def ref() -> C.CDLL | None:
         if hasattr(R, "ref_glm"):
             R.ref_glm.restype = c_i
             R.ref_glm.argtypes = [c_i, P, P, P, c_i, P]
+        if hasattr(R, "ref_bvh_build"):  # the reference's bvh.cpp / Bbox.cpp / sunsky.cu (oracle/ref_host_harness.cpp)
+            R.ref_bvh_build.restype = c_i
+            R.ref_bvh_build.argtypes = [P, c_i, P, P, c_i]
+            R.ref_bbox_union.argtypes = [P, P, c_i, P]
+            R.ref_sun_setup.argtypes = [fp, fp]
+            R.ref_atmosphere.restype = c_i
+            R.ref_atmosphere.argtypes = [c_i, P, c_i, P]
+            R.ref_sun_helpers.argtypes = [P, c_i, P]
+            R.ref_mie_at_x.argtypes = [fp]
+            R.ref_cone_samples.argtypes = [C.POINTER(c_u32), c_i, P]
         _ref = R
     return _ref
 

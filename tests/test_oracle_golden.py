@@ -65,6 +65,34 @@ def test_cone_sample_known_answer(orc, golden):
     assert seed.value == k["seed_after"]
 
 
+def test_kat_values_rederive_from_the_reference(ref, golden):
+    """the sun / sky / cone known answers of kat.json (recorded during the survey) are what the reference's own sunsky.cu,
+    compiled unmodified into oracle/_ref, answers now (authoring container only)"""
+    if not hasattr(ref, "ref_atmosphere"):
+        pytest.skip("oracle/_ref predates the atmosphere exports")
+    setup = (C.c_float * 8)()
+    ref.ref_sun_setup((C.c_float * 2)(*golden["sun_position"]), setup)
+    assert _close9(setup[0:3], golden["sunDirection"]) and _close9([setup[3]], [golden["sunAngularDiameterCos"]])
+    n = _f(1) / np.sqrt(_f(3))
+
+    def run(which, d):
+        dirs = np.array([d], dtype=np.float32)
+        out = np.zeros((1, 3), dtype=np.float32)
+        assert ref.ref_atmosphere(which, dirs.ctypes.data, 1, out.ctypes.data) == 0
+        return out[0]
+
+    for e in golden["sky"]:
+        d = (n, n, n) if e["dir"] == "norm111" else e["dir"]
+        assert _close9(run(1, d), e["value"]), e
+    sd = setup[0:3]
+    assert _close9(run(0, sd), golden["sun_at_sunDirection"]) and _close9(run(2, sd), golden["sunsky_at_sunDirection"])
+    k = golden["cone_sample"]
+    seed = C.c_uint32(k["seed"])
+    out = np.zeros((1, 3), dtype=np.float32)
+    ref.ref_cone_samples(C.byref(seed), 1, out.ctypes.data)
+    assert _close9(out[0], k["value"]) and seed.value == k["seed_after"]
+
+
 def test_sunsky_quirks(orc):
     # sunsky() returns pure red when sunAngularDiameterCos == 1 (sunsky.cu:121-123)
     S = orc.sun_setup()

@@ -129,6 +129,8 @@ SYMBOLS = {
     "tyr_shadow_import": (C.c_int, [P, P, c_u32]),
     "tyr_get_scene_info": (C.c_int, [P, C.POINTER(SceneInfo)]),
     "tyr_vecmath_probe": (C.c_int, [c_i32, c_i32, P, P, P, c_u32, P]),
+    "tyr_sunsky_probe": (C.c_int, [c_i32, C.c_float, C.c_float, c_i32, P, c_u32, P]),
+    "tyr_sun_setup": (C.c_int, [C.c_float, C.c_float, P]),
     "tyr_get_timings": (C.c_int, [P, C.POINTER(Timings), C.c_int]),
     "tyr_set_tuning": (C.c_int, [P, C.c_int, C.c_int]),
     "tyr_bvh_build": (C.c_int, [P, c_i32, P, P, c_i32]),
@@ -386,6 +388,36 @@ def vecmath_probe(op: int, a: np.ndarray, b: np.ndarray, c: np.ndarray, device: 
 
 
 # ---- multi-GPU combine (RCCL behind the C ABI) --------------------------------------------------
+
+
+SUN_PARAM_FIELDS = (("sunDirection", 3), ("sunAngularDiameterCos", 1), ("sunE", 1), ("rayleighAtX", 3), ("mieAtX", 3), ("totalLightAtX", 3), ("mixFactor", 1), ("coneDir", 3), ("coneO1", 3), ("coneO2", 3), ("coneExtent", 1))
+
+
+def sun_setup(sun_x: float, sun_y: float) -> dict:
+    """the library's per-sun-change constants (host code; no GPU needed)"""
+    out = np.zeros(25, dtype=np.float32)
+    _check(lib().tyr_sun_setup(sun_x, sun_y, _ptr(out)), "tyr_sun_setup")
+    res, k = {}, 0
+    for name, n in SUN_PARAM_FIELDS:
+        res[name] = out[k : k + n].copy() if n > 1 else out[k]
+        k += n
+    return res
+
+
+def sunsky_probe(which: int, sun_position, dirs: np.ndarray, device: int = 0) -> np.ndarray:
+    """sun / sky / sunsky (which 0 / 1 / 2) of the device code over float3 directions"""
+    d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros_like(d)
+    _check(lib().tyr_sunsky_probe(device, float(sun_position[0]), float(sun_position[1]), which, _ptr(d), d.shape[0], _ptr(out)), "tyr_sunsky_probe")
+    return out
+
+
+def cone_probe(sun_position, seed: int, n: int, device: int = 0):
+    """n sun-cone samples of the device code along one xorshift stream; returns (samples[n][3], seed after)"""
+    inp = np.array([seed], dtype=np.uint32).view(np.float32)
+    out = np.zeros(3 * n + 1, dtype=np.float32)
+    _check(lib().tyr_sunsky_probe(device, float(sun_position[0]), float(sun_position[1]), 3, _ptr(inp), n, _ptr(out)), "tyr_sunsky_probe")
+    return out[: 3 * n].reshape(n, 3).copy(), int(out[3 * n : 3 * n + 1].view(np.uint32)[0])
 
 
 def dist_unique_id() -> bytes:

@@ -190,6 +190,41 @@ __global__ void __launch_bounds__(kBlock) k_vecmath_probe(int op, const float* _
 }
 
 // ======================================================================================
+// tyr_sunsky_probe: sun / sky / sunsky and the sun-cone sample exactly as k_shade evaluates them (one shared
+// atmosphere() block, then the radiance the ray asked for; shade.hip "The atmosphere ..."), over arrays, so that the
+// device arithmetic can be pinned to the reference's own sunsky.cu (tests/golden/ref_sunsky.npz).
+// ======================================================================================
+__global__ void __launch_bounds__(kBlock) k_sunsky_probe(const SunParams S, int which, const float* __restrict__ dirs, uint32_t n, float* __restrict__ out) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (which == 3) { // one stream, serial by definition: thread 0 draws the n samples in order
+		if (i != 0)
+			return;
+		uint32_t seed = __float_as_uint(dirs[0]);
+		for (uint32_t j = 0; j < n; ++j) {
+			const f3 r = cone_sample(S, seed);
+			out[3 * j + 0] = r.x;
+			out[3 * j + 1] = r.y;
+			out[3 * j + 2] = r.z;
+		}
+		out[3 * n] = __uint_as_float(seed);
+		return;
+	}
+	if (i >= n)
+		return;
+	const f3 viewDir = ld3(dirs + 3 * i);
+	f3 r;
+	if (which == 2 && S.sunAngularDiameterCos == 1.0f) {
+		r = mk3(1.0f, 0.0f, 0.0f); // sunsky.cu:118-119
+	} else {
+		const Atmosphere a = atmosphere(S, viewDir);
+		r = which == 0 ? sun_radiance(S, a) : which == 1 ? sky_radiance(a) : sunsky_radiance(S, a);
+	}
+	out[3 * i + 0] = r.x;
+	out[3 * i + 1] = r.y;
+	out[3 * i + 2] = r.z;
+}
+
+// ======================================================================================
 // extend_debug_BVH, kernel.cu:300-328 via intersect_scene_DEBUG (143-160) and CachedBVH::intersect_debug (bvh.h:164-209):
 // the reference's compile-time BVH_DEBUG picture of the traversal cost.  One thread per slot on the pair nodes with the
 // reference's counting rule (traversals = nodes visited - 1); a diagnostic, not a hot path.
@@ -242,6 +277,9 @@ void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream) {
 }
 void launch_vecmath_probe(int op, const float* a, const float* b, const float* c, uint32_t n, float* out, hipStream_t stream) {
 	hipLaunchKernelGGL(k_vecmath_probe, dim3(blocks_for(n ? n : 1)), dim3(kBlock), 0, stream, op, a, b, c, n, out);
+}
+void launch_sunsky_probe(const SunParams& S, int which, const float* dirs, uint32_t n, float* out, hipStream_t stream) {
+	hipLaunchKernelGGL(k_sunsky_probe, dim3(blocks_for(which == 3 ? 1 : n)), dim3(kBlock), 0, stream, S, which, dirs, n, out);
 }
 void launch_extend_debug(const FrameParams& P, uint32_t maxLive, hipStream_t stream) {
 	if (maxLive != 0)

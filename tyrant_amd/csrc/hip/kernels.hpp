@@ -161,5 +161,6 @@ void launch_connect_diag(const FrameParams& P, uint32_t maxShadow, bool countVis
 void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream);
 void launch_extend_debug(const FrameParams& P, uint32_t maxLive, hipStream_t stream); // TYR_FLAG_DEBUG_BVH
 void launch_vecmath_probe(int op, const float* a, const float* b, const float* c, uint32_t n, float* out, hipStream_t stream);
+void launch_sunsky_probe(const SunParams& S, int which, const float* dirs, uint32_t n, float* out, hipStream_t stream);
 
 } // namespace tyr

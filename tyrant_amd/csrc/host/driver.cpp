@@ -1323,6 +1323,46 @@ int tyr_vecmath_probe(int32_t device, int32_t op, const float* a, const float* b
 	return rc;
 }
 
+int tyr_sun_setup(float sun_x, float sun_y, float* out25) {
+	if (!out25)
+		return TYR_ERR_INVALID;
+	SunParams S;
+	sun_setup(sun_x, sun_y, S);
+	static_assert(sizeof(SunParams) == 25 * sizeof(float), "tyr_sun_setup hands out SunParams as 25 floats");
+	std::memcpy(out25, &S, sizeof S);
+	return TYR_OK;
+}
+
+int tyr_sunsky_probe(int32_t device, float sun_x, float sun_y, int32_t which, const float* dirs, uint32_t n, float* out) {
+	if (!dirs || !out || n == 0 || which < 0 || which > 3)
+		return TYR_ERR_INVALID;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+		return TYR_ERR_NO_DEVICE;
+	HIPCHK(hipSetDevice(device));
+	SunParams S;
+	sun_setup(sun_x, sun_y, S);
+	const size_t inBytes = (which == 3 ? 1 : static_cast<size_t>(n) * 3) * sizeof(float);
+	const size_t outBytes = (static_cast<size_t>(n) * 3 + (which == 3 ? 1 : 0)) * sizeof(float);
+	float *dIn = nullptr, *dOut = nullptr;
+	int rc = TYR_OK;
+	if (hipMalloc(reinterpret_cast<void**>(&dIn), inBytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&dOut), outBytes) != hipSuccess)
+		rc = TYR_ERR_OOM;
+	if (!rc && hipMemcpy(dIn, dirs, inBytes, hipMemcpyHostToDevice) != hipSuccess)
+		rc = TYR_ERR_DEVICE;
+	if (!rc) {
+		(void)hipGetLastError();
+		launch_sunsky_probe(S, which, dIn, n, dOut, nullptr);
+		if (hipGetLastError() != hipSuccess || hipMemcpy(out, dOut, outBytes, hipMemcpyDeviceToHost) != hipSuccess)
+			rc = TYR_ERR_DEVICE;
+	}
+	if (dIn)
+		(void)hipFree(dIn);
+	if (dOut)
+		(void)hipFree(dOut);
+	return rc;
+}
+
 int tyr_get_scene_info(tyr_ctx* c, tyr_scene_info* out) {
 	if (!c || !out)
 		return TYR_ERR_INVALID;

@@ -44,13 +44,14 @@ f3 ortho(f3 a) { return std::fabs(a.x) > std::fabs(a.z) ? mk3(-a.y, a.x, 0.0f) :
 
 void sun_setup(float sun_x, float sun_y, SunParams& S) {
 	// kernel.cu:683: float sun_angular = cos(sunSize * pi / 180.f)
-	S.sunAngularDiameterCos = static_cast<float>(std::cos(static_cast<double>(sunSize * kPi / 180.f)));
+	S.sunAngularDiameterCos = std::cos(sunSize * kPi / 180.f); // cos(float): the float overload
 
 	// kernel.cu:708: normalize(fromSpherical((sun_position - vec2(0.0, 0.5)) * vec2(6.28f, 3.14f))); sunsky.cu:28-30
 	const float px = (sun_x - 0.0f) * 6.28f;
 	const float py = (sun_y - 0.5f) * 3.14f;
-	const double dpx = px, dpy = py;
-	f3 d = mk3(static_cast<float>(std::cos(dpx) * std::sin(dpy)), static_cast<float>(std::sin(dpx) * std::sin(dpy)), static_cast<float>(std::cos(dpy)));
+	// float arguments pick the float overloads and the products are binary32 (tests/golden/ref_sunsky.npz, made by the
+	// reference's own fromSpherical, tells this from a binary64 evaluation at sun position (0.3, 0.12))
+	f3 d = mk3(std::cos(px) * std::sin(py), std::sin(px) * std::sin(py), std::cos(py));
 	d = normalize(d);
 	S.sunDirection[0] = d.x;
 	S.sunDirection[1] = d.y;
