@@ -243,3 +243,28 @@ def test_stack_bound_of_the_tree_gates_the_wide_drain(orc, hip):
     bo, bg = o.blit_buffer(), g.blit_buffer()
     assert np.array_equal(bo[:, 3], bg[:, 3]) and np.allclose(bg[:, :3], bo[:, :3], rtol=1e-5, atol=1e-6)
     assert kg["total_extend_rays"] > W * H * spp  # (rays did reach the chains and bounce)
+
+
+@pytest.mark.parametrize("N,spp", [(W1080 * H1080, 1), (N2M, 2)])
+def test_benchmarked_render_path_matches_oracle_at_full_size(orc, hip, N, spp):
+    """The code path bench.py times -- `tyr_render` with DEFAULT tuning: merged extend(i+1) + connect(i) launches
+    (`k_trace_flat`), run-ahead where the default enables it, the four-lanes-per-ray drain -- on C3 (996,882 triangles)
+    at 1920x1080 against `orc_render` (main.cpp:164-170 looping kernel.cu:664-748): same iteration count, every counter
+    equal, every pixel exactly `spp` finished paths, radiance within 1e-5 relative.  Once with the GPU-sized queue
+    (every primary ray of the render in flight, the bench's shape) and once at the reference's 2 Mi slots."""
+    from test_gpu_parity import assert_accum_close
+
+    sc, nodes, prims = built_scene("mesh706")
+    o = orc.Oracle(W1080, H1080, N, flags=1)
+    g = hip.Renderer(W1080, H1080, N, flags=1)
+    o.load_scene(sc, nodes, prims), g.load_scene(sc, nodes, prims)
+    it_o, it_g = o.render(spp), g.render(spp)
+    ko, kg = o.counters(), g.counters()
+    assert kg["device_error"] == 0
+    assert it_o == it_g, (it_o, it_g)
+    for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible", "start_position", "frame", "primary_ray_cnt", "shadow_ray_cnt"):
+        assert ko[f] == kg[f], (f, ko[f], kg[f])
+    assert ko["total_primary_rays"] == spp * W1080 * H1080
+    bo, bg = o.blit_buffer(), g.blit_buffer()
+    assert np.all(bg[:, 3] == spp)
+    assert_accum_close(bo, bg, f"C3 render, queue {N}, {spp} spp")
