@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TYR_ABI_VERSION 2 /* 2: tyr_counters grows (rays_in_tree_*, debug[16]), tyr_dist_*, per-triangle colours */
+#define TYR_ABI_VERSION 3 /* 2: tyr_counters grows (rays_in_tree_*, debug[16]), tyr_dist_*, per-triangle colours; 3: retired tuning keys removed, tyr_sunsky_probe / tyr_sun_setup */
 
 /* ---- record layouts (identical to the reference structs) ------------------ */
 
@@ -273,25 +273,22 @@ typedef struct tyr_timings {
 } tyr_timings;
 int tyr_get_timings(tyr_ctx* ctx, tyr_timings* out, int reset);
 
-/* Launch-shape knobs of the two traversal kernels (the reference's equivalents are the literals
- * `sm_cores * 8, 128` at kernel.cu:719-726).  They never change results. */
+/* Launch-shape knobs of the traversal kernel (the reference's equivalents are the literals `sm_cores * 8, 128` at
+ * kernel.cu:719-726).  They never change results; DESIGN.md section 4.4 has the measurements behind the defaults.
+ * (ABI 3 retired TRAVERSAL_VARIANT, STACK_LDS_DEPTH, RAYS_PER_BLOCK, MIN_LEAVES and OVERLAP_CONNECT with the kernels
+ * they selected; the remaining keys keep their numbers.) */
 enum {
-	TYR_TUNE_TRAVERSAL_VARIANT = 0, /* 0 = one thread per queue slot; 1 = persistent waves, finished lanes take new rays; 2 = 1 as a flat per-lane state machine; 3 = 2 on 128-byte quad nodes, each block owning a range of queue slots; 4 = 3 as a persistent grid whose waves draw chunks of slots from eight tickets; 5 = 4 with the refill off the critical path: every wave keeps a ring of prepared rays in LDS, topped up at full occupancy behind the leaf phases, and a lane that finishes takes the next one inside the descent loop -- measured and rejected, DESIGN.md 4.4 (the counting build always uses 2; libtyrant_hip.so has 4 only, the diagnostics build all) */
-	TYR_TUNE_REFILL_MIN_IDLE = 1,   /* variants 1-4: refill a wave when at least this many of its 64 lanes are free (1..64, default 16) */
-	TYR_TUNE_WAVES_PER_SIMD = 2,    /* variants 1 and 4 (persistent grids): resident 256-thread blocks per CU = waves per SIMD; 0 (default) = the occupancy query's answer */
-	TYR_TUNE_STACK_LDS_DEPTH = 3,   /* traversal-stack entries per lane held in LDS: 0, 8, 10, 12 (default), 16 or 24; deeper entries spill to scratch */
-	TYR_TUNE_MIN_TRAVERSING = 4,    /* variants 2-4: leave the descent loop when fewer lanes than this are descending and leaves / refills are pending (1..64, default 32) */
-	TYR_TUNE_TICKET_CHUNK = 5,      /* variants 1/4: queue slots a wave reserves per global atomic (64..65536, default 64) */
-	TYR_TUNE_MIN_LEAVES = 7,        /* retired (leaving the descent loop once this many lanes hold a leaf never paid): accepted, no effect */
-	TYR_TUNE_STATIC_SHARE = 8,      /* variant 4: sixteenths of the queue dealt to the blocks as fixed ranges before the ticketed chunks start (0..15, default 12) */
-	TYR_TUNE_STAGED_NODES = 9,      /* variant 4: top-of-tree quad nodes each block keeps in LDS (0..64, default 64) */
-	TYR_TUNE_OVERLAP_CONNECT = 10,  /* tyr_render: connect(i) on a second stream while the first already does primary / extend of iteration i + 1 (shade(i + 1) waits for it): 0 = never (one stream, kernel after kernel), 1 = always, 2 (default) = when queue_size is at most 6 Mi slots, where ramp and tail dominate a launch and the neighbour fills them; fixed per-block ranges are switched off beside a running connect.  tyr_launch_kernels is always one stream. */
-	TYR_TUNE_PROFILE_MASK = 11,     /* with TYR_FLAG_PROFILE: bit TYR_K_* set = that stage is bracketed by a hipEvent pair (default 31 = all five).  An event between two kernels costs ~10 us of idle GPU, ~2 % of a 1080p render with all of them on. */
-	TYR_TUNE_MERGE_TRACE = 12,      /* tyr_render: 1 (default) = connect(i) shares the launch of extend(i + 1) -- both only depend on shade(i), and every traversal launch ends in a latency-bound drain as long as its longest ray (40-60 % of a launch at 1080p): one drain per iteration instead of two; the last iteration's shadow rays get a launch of their own.  0 = separate launches (with TYR_TUNE_OVERLAP_CONNECT deciding the stream).  Ignored by the counting build and by variants other than 4.  tyr_launch_kernels is always extend, shade, connect, done when it returns. */
-	TYR_TUNE_STATIC_INTERLEAVE = 13, /* variant 4: the fixed per-block part of the queue (TYR_TUNE_STATIC_SHARE) as interleaved 64-slot chunks -- block b owns chunks b, b + G, b + 2 G, ... -- (1, default) or as one contiguous range per block (0): contiguous ranges give single blocks whole regions of the frame (the queue is in scan-line order) and the launch ends on the block that drew the dense one */
-	TYR_TUNE_RUN_AHEAD = 14,        /* tyr_render with merged launches: 1 = iteration i + 1 is queued BEFORE the counts of iteration i have reached the host -- every kernel takes its counts from device memory, the host sizes grids from upper bounds (survivors(i) <= live(i)) and only learns one iteration late that the render has ended; that last, empty iteration traces the final shadow rays.  The stream never runs dry between iterations.  0 = wait for every iteration's counts; 2 (default) = run ahead when queue_size is at most 6 Mi slots: measured -1.2 % per render at the reference's 2 Mi slots (20 thin iterations), +0.5 % on a 16.6 M-slot queue, where the extra, empty iteration costs what six short waits save (profiles/r02_run_ahead_ab.txt).  Results do not depend on it. */
-	TYR_TUNE_WIDE_DRAIN = 15,       /* k_trace_flat: 1 (default) = once the queue is used up, a wave that holds at most 16 rays finishes them four lanes to a ray (one child box and one leaf primitive per lane, DPP exchange inside the group): a quarter of the instructions per step where the launch is bound by its last rays.  0 = the rays stay one to a lane.  Results do not depend on it. */
-	TYR_TUNE_RAYS_PER_BLOCK = 6     /* variants 2/3: queue slots owned by one 256-thread block and handed to its free lanes through LDS (256..65536, default 1024; halved automatically for thin queues) */
+	TYR_TUNE_REFILL_MIN_IDLE = 1,    /* refill a wave when at least this many of its 64 lanes are free (1..64, default 16) */
+	TYR_TUNE_WAVES_PER_SIMD = 2,     /* resident 256-thread blocks per CU of the persistent grid; 0 (default) = the occupancy query's answer */
+	TYR_TUNE_MIN_TRAVERSING = 4,     /* leave the descent loop below this many descending lanes when leaves / refills are pending (1..64, default 32) */
+	TYR_TUNE_TICKET_CHUNK = 5,       /* queue slots a wave reserves per draw from a ticket (64..65536, default 64) */
+	TYR_TUNE_STATIC_SHARE = 8,       /* sixteenths of the queue dealt to the blocks as fixed chunks before the ticketed rest (0..15, default 12) */
+	TYR_TUNE_STAGED_NODES = 9,       /* top-of-tree quad nodes each block keeps in LDS (0..64, default 64) */
+	TYR_TUNE_PROFILE_MASK = 11,      /* with TYR_FLAG_PROFILE: bit TYR_K_* set = that stage gets a hipEvent pair (default 31 = all five; a pair costs ~10 us of idle GPU) */
+	TYR_TUNE_MERGE_TRACE = 12,       /* tyr_render: 1 (default) = connect(i) shares the launch of extend(i + 1); 0 = launch_kernels' order, iteration by iteration */
+	TYR_TUNE_STATIC_INTERLEAVE = 13, /* the fixed per-block part as interleaved 64-slot chunks (1, default) or one contiguous range per block (0) */
+	TYR_TUNE_RUN_AHEAD = 14,         /* tyr_render: queue iteration i + 1 before iteration i's counts reach the host: 0 never, 1 always, 2 (default) for queues of at most 6 Mi slots */
+	TYR_TUNE_WIDE_DRAIN = 15         /* 1 (default) = a wave's last <= 16 rays are finished four lanes to a ray */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);
 

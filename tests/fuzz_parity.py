@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tests/fuzz_parity.py [n] [seed] -- randomised end-to-end parity: random scenes (triangle soups and height-field meshes of
 random size, with and without per-triangle materials, emissive triangles and colour palettes), random resolutions, pixel shards (rank / nranks), queue sizes, cameras and
-launch-shape knobs (merged / separate / side-stream traversal launches, every traversal variant);
+launch-shape knobs (merged / separate traversal launches, run-ahead, work distribution);
 each render is compared with the oracle's: identical iteration and ray counts, queues of the last iteration bit-exact,
 radiance within 1e-5 relative.  A checker like the tests (it is the only other place that drives the oracle), not collected by pytest (run time grows with n); prints one line per case."""
 import os
@@ -32,12 +32,9 @@ for case in range(n_cases):
     spp = int(rng.integers(1, 4))
     cam = scenes.Camera(position=tuple(np.array(sc.camera.position) + rng.normal(0, 3, 3)), direction=sc.camera.direction, up=sc.camera.up,
                         focalDistance=float(rng.uniform(1, 80)), lensRadius=float(rng.choice([0.0, 0.0, rng.uniform(0.1, 3.0)])))
-    knobs = dict(traversal_variant=int(rng.choice([4, 4, 4, 3, 2, 1, 0])), stack_lds_depth=int(rng.choice([0, 8, 10, 12, 16, 24])), refill_min_idle=int(rng.integers(1, 65)),
-                 min_traversing=int(rng.integers(1, 65)), ticket_chunk=int(rng.choice([64, 128, 1024])), static_share=int(rng.integers(0, 16)), staged_nodes=int(rng.integers(0, 65)),
-                 rays_per_block=int(rng.choice([256, 1024, 4096])), merge_trace=int(rng.integers(0, 2)), static_interleave=int(rng.integers(0, 2)), overlap_connect=int(rng.integers(0, 3)), run_ahead=int(rng.integers(0, 2)), wide_drain=int(rng.integers(0, 2)))
-    if knobs["traversal_variant"] == 4 and rng.random() < 0.15:
-        knobs["traversal_variant"] = 5  # the ring-of-prepared-rays variant (diagnostics library)
-        knobs["stack_lds_depth"] = 12
+    knobs = dict(refill_min_idle=int(rng.integers(1, 65)), min_traversing=int(rng.integers(1, 65)), ticket_chunk=int(rng.choice([64, 128, 1024])), static_share=int(rng.integers(0, 16)),
+                 staged_nodes=int(rng.integers(0, 65)), merge_trace=int(rng.integers(0, 2)), static_interleave=int(rng.integers(0, 2)), run_ahead=int(rng.integers(0, 3)), wide_drain=int(rng.integers(0, 2)),
+                 waves_per_simd=int(rng.choice([0, 0, 1, 3])))
     if sc.triangle_materials and rng.random() < 0.5:  # emissive triangles + light list (TYR_FLAG_LIGHT_LIST)
         lit = rng.choice(len(sc.triangles), size=int(rng.integers(1, min(40, len(sc.triangles)))), replace=False)
         sc.triangles["materialType"][lit] = scenes.LIGHT
@@ -53,7 +50,7 @@ for case in range(n_cases):
     bb = scenes.triangle_bboxes(sc.triangles)
     nodes, prims = pyorc.bvh_build(sc.triangles, bb)
     o = pyorc.Oracle(W, H, N, rank=rank, nranks=nranks, flags=flags)
-    g = binding.Renderer(W, H, N, rank=rank, nranks=nranks, flags=flags, diag=True)  # every variant and stack depth: libtyrant_hip_diag.so
+    g = binding.Renderer(W, H, N, rank=rank, nranks=nranks, flags=flags)
     for r in (o, g):
         r.load_scene(sc, nodes, prims)
         r.set_camera(cam)

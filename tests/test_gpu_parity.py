@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 LIVE_FIELDS = ("origin", "direction", "direct")
 
 
-def pair(orc, hip, name, W, H, N, flags=0, rank=0, nranks=1, diag=False):
+def pair(orc, hip, name, W, H, N, flags=0, rank=0, nranks=1):
     sc, nodes, prims = built_scene(name)
     if sc.triangle_materials:
         flags |= 1
@@ -26,7 +26,7 @@ def pair(orc, hip, name, W, H, N, flags=0, rank=0, nranks=1, diag=False):
         flags |= 16
     o = orc.Oracle(W, H, N, rank=rank, nranks=nranks, flags=flags & 25)
     o.load_scene(sc, nodes, prims)
-    g = hip.Renderer(W, H, N, rank=rank, nranks=nranks, flags=flags, diag=diag)  # diag: libtyrant_hip_diag.so (variants 0-3)
+    g = hip.Renderer(W, H, N, rank=rank, nranks=nranks, flags=flags)
     g.load_scene(sc, nodes, prims)
     return o, g
 
@@ -134,11 +134,12 @@ def test_reference_traversal_fixture_through_the_abi(orc, hip):
         assert np.array_equal(q["identifier"][hit], z["identifier"][hit]), name
 
 
-@pytest.mark.parametrize("variant", [5, 4, 3, 2, 0])
-def test_axis_aligned_rays_and_long_leaves(orc, hip, variant):
+@pytest.mark.parametrize("flags", [0, 4])
+def test_axis_aligned_rays_and_long_leaves(orc, hip, flags):
     """rays with zero direction components (1/d infinite: the generic box test, not the packed one) through a scene
     whose leaves are longer than the device layout's inline limit (the quad layout's chains of -inf..+inf boxes) and
-    through an ordinary mesh: extend answers bit for bit, for mixed waves (regular and axis-aligned rays side by side)"""
+    through an ordinary mesh: extend answers bit for bit, for mixed waves (regular and axis-aligned rays side by side);
+    flags = 4 is the counting build (pair nodes, TYR_FLAG_COUNT_VISITS)"""
     from tyrant_amd import scenes
 
     rng = np.random.default_rng(5)
@@ -165,8 +166,7 @@ def test_axis_aligned_rays_and_long_leaves(orc, hip, variant):
     s["position"] = np.array([0.0, 1e6, -1e6], dtype=np.float32)  # only the BVH answers
     s["radius"] = 1.0
     o = orc.Oracle(64, 64, n)
-    g = hip.Renderer(64, 64, n, diag=variant != 4)
-    g.set_tuning(traversal_variant=variant)
+    g = hip.Renderer(64, 64, n, flags=flags)
     for r in (o, g):
         r.upload(nodes, prims)
         r.set_spheres(s)
@@ -367,40 +367,17 @@ def test_cpp_host_api_example(hip):
     assert os.path.getsize(out) > 640 * 360 * 3
 
 
-@pytest.mark.parametrize("variant,lds", [(0, 0), (0, 8), (1, 0), (1, 16), (2, 12), (2, 0), (3, 12), (3, 0), (3, 24), (4, 12), (4, 0), (4, 8), (5, 12)])
-def test_every_traversal_variant_is_bit_exact(orc, hip, variant, lds):
-    """launch shape / node layout / stack placement never change results: each traversal variant reproduces
-    the oracle's queues bit for bit over several iterations (bounce rays included)"""
-    for name, W, H, N in (("cornell_soup2k", 80, 48, 4096), ("tyrant_default", 96, 64, 5000)):
-        o, g = pair(orc, hip, name, W, H, N, diag=True)
-        g.set_tuning(traversal_variant=variant, stack_lds_depth=lds, refill_min_idle=8, min_traversing=24, ticket_chunk=64)
-        for it in range(4):
-            o.launch_kernels(), g.launch_kernels()
-            ko, kg = o.counters(), g.counters()
-            assert kg["device_error"] == 0
-            for f in ("primary_ray_cnt", "shadow_ray_cnt", "n_shadow_visible", "total_shadow_rays", "n_survive"):
-                assert ko[f] == kg[f], (name, variant, it, f)
-            ns, nh = ko["primary_ray_cnt"], ko["shadow_ray_cnt"]
-            assert_state_equal(o.ray_queue(0, ns), g.ray_queue(0, ns), f"{name} variant {variant} iteration {it}")
-            so, sg = o.shadow_queue(nh), g.shadow_queue(nh)
-            assert so.tobytes() == sg.tobytes()
-        assert_accum_close(o.blit_buffer(), g.blit_buffer(), f"{name} variant {variant}")
-
-
-
 @pytest.mark.parametrize("knobs", [
     dict(static_share=0, ticket_chunk=64), dict(static_share=15, ticket_chunk=4096), dict(static_share=8, ticket_chunk=256, staged_nodes=0),
-    dict(staged_nodes=1), dict(staged_nodes=21, stack_lds_depth=10), dict(refill_min_idle=1, min_traversing=1), dict(refill_min_idle=64, min_traversing=64, min_leaves=1),
-    dict(traversal_variant=3, rays_per_block=256), dict(traversal_variant=3, rays_per_block=65536),
-    dict(traversal_variant=5), dict(traversal_variant=5, static_share=0, ticket_chunk=64, min_traversing=1), dict(traversal_variant=5, static_share=15, ticket_chunk=4096, min_traversing=64),
-    dict(traversal_variant=5, staged_nodes=0, min_traversing=16),
+    dict(staged_nodes=1), dict(staged_nodes=21), dict(refill_min_idle=1, min_traversing=1), dict(refill_min_idle=64, min_traversing=64),
+    dict(static_interleave=0, static_share=4), dict(wide_drain=0), dict(waves_per_simd=2),
 ])
 def test_work_distribution_knobs_never_change_results(orc, hip, knobs):
     """every launch-shape knob of tyr_set_tuning -- how queue slots reach the waves, how much of the tree sits in LDS,
     when the descent loop is left -- at its extremes: queues stay bit-identical to the oracle's, on a scene whose
     tree is deeper than the LDS stack and on a queue that is not a multiple of anything"""
     for name, W, H, N in (("mesh128", 72, 40, 2999), ("cornell_soup2k", 50, 30, 777)):
-        o, g = pair(orc, hip, name, W, H, N, diag=knobs.get("traversal_variant", 4) != 4 or "stack_lds_depth" in knobs)
+        o, g = pair(orc, hip, name, W, H, N)
         g.set_tuning(**knobs)
         for it in range(3):
             o.launch_kernels(), g.launch_kernels()
@@ -415,17 +392,16 @@ def test_work_distribution_knobs_never_change_results(orc, hip, knobs):
 
 
 @pytest.mark.parametrize("name,W,H,N,spp", [("cornell_soup2k", 160, 90, 9000, 5), ("mesh128", 128, 72, 20000, 3), ("cornell_area_light", 96, 64, 3000, 4)])
-def test_render_with_and_without_the_deferred_connect(orc, hip, name, W, H, N, spp):
-    """tyr_render can run connect(i) on a second stream next to primary / extend of iteration i + 1
-    (TYR_TUNE_OVERLAP_CONNECT): same iteration count, same counters -- connect's included, which arrive with the final join -- and the same
-    radiance as the one-stream order and as the oracle; a render, a camera move (reset of the accumulation buffer while
+def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
+    """tyr_render in launch_kernels' order (merge_trace = 0), with connect(i) inside the launch of extend(i + 1), and one
+    iteration ahead of the counts: same iteration count, same counters and the same radiance as the oracle; a render, a camera move (reset of the accumulation buffer while
     nothing may be in flight) and a second render back to back"""
     o, g1 = pair(orc, hip, name, W, H, N)
     _, g0 = pair(orc, hip, name, W, H, N)
     _, g2 = pair(orc, hip, name, W, H, N)
     _, g3 = pair(orc, hip, name, W, H, N)
-    g0.set_tuning(overlap_connect=0, merge_trace=0)
-    g1.set_tuning(overlap_connect=1, merge_trace=0)
+    g0.set_tuning(merge_trace=0)
+    g1.set_tuning(merge_trace=1, run_ahead=1)
     g2.set_tuning(merge_trace=1)  # (the default) connect(i) inside the launch of extend(i + 1): k_trace_flat, iteration i + 1 queued ahead of iteration i's counts
     g3.set_tuning(merge_trace=1, run_ahead=0, wide_drain=0)  # ... with the host waiting for every iteration's counts, and a wave's last rays left one to a lane
     from tyrant_amd import scenes
@@ -444,7 +420,7 @@ def test_render_with_and_without_the_deferred_connect(orc, hip, name, W, H, N, s
             assert ko[f] == k0[f] == k1[f] == k2[f] == k3[f], (name, f)
         assert_accum_close(o.blit_buffer(), g3.blit_buffer(), name + " merged trace launches, no run-ahead")
         assert_accum_close(o.blit_buffer(), g0.blit_buffer(), name + " one stream")
-        assert_accum_close(o.blit_buffer(), g1.blit_buffer(), name + " deferred connect")
+        assert_accum_close(o.blit_buffer(), g1.blit_buffer(), name + " merged, always one iteration ahead")
         assert_accum_close(o.blit_buffer(), g2.blit_buffer(), name + " merged trace launches")
     # stage by stage right after a render with deferred / merged connects: nothing is left in flight or owed
     for st in ("begin", "primary", "extend", "shade", "connect", "end"):
@@ -494,44 +470,6 @@ def test_bench_two_ranks_on_one_gpu(hip):
     assert d["n_gpus"] == 2 and d["config"]["spp_total"] == 4 and d["scaling"] == "weak" and d["value"] > 0
 
 
-def test_feed_variant_at_full_size(orc, hip):
-    """traversal variant 5 (rings of prepared rays, refill inside the descent loop) on BASELINE config C3 at 1080p: the first
-    wavefront's queues bit-exact against the oracle, and a whole GPU-sized render with exactly the ray totals of variant 4
-    (which ray a lane traces never changes an answer: every result goes to its own slot)"""
-    W, H, N = 1920, 1080, 2097152
-    sc, nodes, prims = built_scene("mesh706")
-    o = orc.Oracle(W, H, N, flags=1)
-    g = hip.Renderer(W, H, N, flags=1, diag=True)
-    g.set_tuning(traversal_variant=5)
-    o.load_scene(sc, nodes, prims), g.load_scene(sc, nodes, prims)
-    for r in (o, g):
-        r.stage("begin"), r.stage("primary"), r.stage("extend")
-    qo, qg = o.ray_queue(0), g.ray_queue(0)
-    assert g.counters()["device_error"] == 0
-    assert np.array_equal(bits(qo["distance"]), bits(qg["distance"]))
-    hit = qo["distance"] < 1e20
-    assert np.array_equal(qo["identifier"][hit], qg["identifier"][hit]) and np.array_equal(qo["geometry_type"][hit], qg["geometry_type"][hit])
-    o.stage("shade"), g.stage("shade")
-    ko, kg = o.counters(), g.counters()
-    assert ko["primary_ray_cnt"] == kg["primary_ray_cnt"] and ko["shadow_ray_cnt"] == kg["shadow_ray_cnt"]
-    assert o.shadow_queue(ko["shadow_ray_cnt"]).tobytes() == g.shadow_queue(kg["shadow_ray_cnt"]).tobytes()
-    o.stage("connect"), g.stage("connect")
-    assert o.counters()["n_shadow_visible"] == g.counters()["n_shadow_visible"]
-    o.close(), g.close()
-    totals = []
-    for variant in (4, 5):
-        g = hip.Renderer(W, H, W * H * 4, flags=1, diag=True)
-        g.set_tuning(traversal_variant=variant)
-        g.load_scene(sc, nodes, prims)
-        g.render(4)
-        k = g.counters()
-        assert k["device_error"] == 0 and k["total_primary_rays"] == 4 * W * H
-        totals.append(({f: k[f] for f in ("total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible")}, g.blit_buffer()))
-        g.close()
-    assert totals[0][0] == totals[1][0], totals
-    assert np.array_equal(totals[0][1][:, 3], totals[1][1][:, 3]) and np.allclose(totals[0][1], totals[1][1], rtol=1e-5, atol=1e-6)
-
-
 def test_triangle_colors_defaults_and_errors(orc, hip):
     """TYR_FLAG_TRIANGLE_COLORS (per-triangle colour / emission, the reference's commented-out Scene.cpp:44): needs
     TRIANGLE_MATERIALS; with the default palette (white, (3,3,3)) it is the run without the flag, bit for bit in the
@@ -550,9 +488,10 @@ def test_triangle_colors_defaults_and_errors(orc, hip):
         for _ in range(3):
             g.launch_kernels()
         k = g.counters()
-        runs.append((k, g.ray_queue(0, k["primary_ray_cnt"]).tobytes(), g.shadow_queue(k["shadow_ray_cnt"]).tobytes(), g.blit_buffer()))
+        runs.append((k, g.ray_queue(0, k["primary_ray_cnt"]), g.shadow_queue(k["shadow_ray_cnt"]).tobytes(), g.blit_buffer()))
         if not flags & 16:
             with pytest.raises(hip.TyrError):
                 g.set_triangle_palette(np.ones((256, 3), dtype=np.float32))
-    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+    assert_state_equal(runs[0][1], runs[1][1], "survivors with and without the palette")  # (distance / identifier of a survivor are stale until extend: quirk 18)
+    assert runs[0][2] == runs[1][2]
     assert np.allclose(runs[0][3], runs[1][3], rtol=1e-5, atol=1e-6)

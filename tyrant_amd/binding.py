@@ -15,9 +15,6 @@ from . import scenes
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TYRANT_HIP_LIBRARY: load another build of the same ABI (diagnostic builds made by tools/*.sh); never a CPU path
 LIB_PATH = os.environ.get("TYRANT_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libtyrant_hip.so")
-# the same ABI built with -DTYR_DIAG (make -C tyrant_amd/csrc diag): traversal variants 0-3 and the other LDS stack
-# depths behind tyr_set_tuning.  Loaded by tools/ and the variant parity tests only (Renderer(..., diag=True)).
-DIAG_LIB_PATH = os.path.join(_HERE, "lib", "libtyrant_hip_diag.so")
 
 TYR_FLAG_TRIANGLE_MATERIALS = 1
 TYR_FLAG_PROFILE = 2
@@ -157,11 +154,11 @@ SYMBOLS = {
 _libs: dict = {}
 
 
-def lib(diag: bool = False) -> C.CDLL:
+def lib() -> C.CDLL:
     """Load order matters when PyTorch shares the process: its wheels carry their own HIP runtime in the global symbol
     scope.  Import torch BEFORE the first call of this function (then this library's HIP calls bind to that one runtime);
     the other order leaves two runtimes in the process and the one that initialises second reports no device."""
-    path = DIAG_LIB_PATH if diag else LIB_PATH
+    path = LIB_PATH
     if path not in _libs:
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: build it with `python __graft_entry__.py build` (there is no fallback path)")
@@ -256,8 +253,8 @@ def default_spheres() -> np.ndarray:
 class Renderer:
     """one tyr_ctx"""
 
-    def __init__(self, width, height, queue_size, device=0, rank=0, nranks=1, flags=0, stream=None, blit_buffer=None, diag=False):
-        self.L = lib(diag)
+    def __init__(self, width, height, queue_size, device=0, rank=0, nranks=1, flags=0, stream=None, blit_buffer=None):
+        self.L = lib()
         self.W, self.H, self.N = width, height, queue_size
         cfg = Config(width, height, queue_size, device, rank, nranks, flags, stream)
         h = P()
@@ -337,10 +334,12 @@ class Renderer:
         _check(self.L.tyr_get_timings(self.h, C.byref(t), int(reset)), "tyr_get_timings")
         return {n: {"ms": t.ms[i], "launches": int(t.launches[i])} for i, n in enumerate(KERNEL_NAMES)}
 
-    def set_tuning(self, traversal_variant=None, refill_min_idle=None, waves_per_simd=None, stack_lds_depth=None, min_traversing=None, ticket_chunk=None, rays_per_block=None, min_leaves=None, static_share=None, staged_nodes=None, overlap_connect=None, profile_mask=None, merge_trace=None, static_interleave=None, run_ahead=None, wide_drain=None):
-        for key, v in ((0, traversal_variant), (1, refill_min_idle), (2, waves_per_simd), (3, stack_lds_depth), (4, min_traversing), (5, ticket_chunk), (6, rays_per_block), (7, min_leaves), (8, static_share), (9, staged_nodes), (10, overlap_connect), (11, profile_mask), (12, merge_trace), (13, static_interleave), (14, run_ahead), (15, wide_drain)):
+    TUNING_KEYS = {"refill_min_idle": 1, "waves_per_simd": 2, "min_traversing": 4, "ticket_chunk": 5, "static_share": 8, "staged_nodes": 9, "profile_mask": 11, "merge_trace": 12, "static_interleave": 13, "run_ahead": 14, "wide_drain": 15}
+
+    def set_tuning(self, **knobs):
+        for name, v in knobs.items():
             if v is not None:
-                _check(self.L.tyr_set_tuning(self.h, key, int(v)), "tyr_set_tuning")
+                _check(self.L.tyr_set_tuning(self.h, self.TUNING_KEYS[name], int(v)), "tyr_set_tuning")
 
     def reset_accum(self):
         _check(self.L.tyr_reset_accum(self.h), "tyr_reset_accum")

@@ -1,5 +1,5 @@
 // device_common.hpp -- small device helpers shared by the kernel translation units (frame.hip, shade.hip,
-// traverse_flat.hip, traverse_diag.hip): the reference's RNG and sampling routines (kernel.cu:23-65, 181-208,
+// traverse_flat.hip): the reference's RNG and sampling routines (kernel.cu:23-65, 181-208,
 // sunsky.cu:170-185), Sphere::intersect (kernel.cu:83-105), wave-level helpers.
 #pragma once
 
@@ -91,6 +91,42 @@ __device__ __forceinline__ float sphere_intersect(const tyr_sphere& sp, f3 origi
 		return 0;
 	disc = sqrtf(disc);
 	return (t = b - disc) > kEpsilon ? t : ((t = b + disc) > kEpsilon ? t : 0);
+}
+
+// ---- segmented queues (kernels.hpp "Queues") -------------------------------------------------------------------------
+// physical slot of record j of segment seg
+__device__ __forceinline__ uint32_t seg_phys(uint32_t seg, uint32_t j) { return ((((j >> 6) * kSegs) + seg) << 6) | (j & 63u); }
+// slots [0, extent) cover every record of the queue (a multiple of 512; wave-uniform: eight scalar loads)
+__device__ __forceinline__ uint32_t queue_extent(const uint32_t* cnt) {
+	uint32_t m = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < kSegs; ++w) {
+		const uint32_t c = cnt[w * kSegStride];
+		m = c > m ? c : m;
+	}
+	return ((m + 63u) >> 6) * (kSegs * 64u);
+}
+__device__ __forceinline__ uint32_t queue_records(const uint32_t* cnt) {
+	uint32_t n = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < kSegs; ++w)
+		n += cnt[w * kSegStride];
+	return n;
+}
+// does physical slot s hold a record?  (per lane: one 4-byte load, eight distinct addresses)
+__device__ __forceinline__ bool slot_valid(const uint32_t* cnt, uint32_t s) { return (((s >> 9) << 6) | (s & 63u)) < cnt[((s >> 6) & (kSegs - 1u)) * kSegStride]; }
+// records in the 64-slot chunk that starts at slot s0 (s0 % 64 == 0; wave-uniform when s0 is)
+__device__ __forceinline__ uint32_t chunk_valid(const uint32_t* cnt, uint32_t s0) {
+	const uint32_t c = cnt[((s0 >> 6) & (kSegs - 1u)) * kSegStride], first = (s0 >> 9) << 6;
+	return c > first ? (c - first < 64u ? c - first : 64u) : 0u;
+}
+// this iteration's virtual slot of a ray from its key
+__device__ __forceinline__ uint32_t v_lookup(const VTable& T, uint32_t key) {
+	const uint32_t v = key & kKeyMask;
+	if (!(key & kKeyIndirect))
+		return v;
+	const uint32_t e = v >> 6;
+	return T.blk[e >> 8] + T.pre[e] + (uint32_t)__popcll(T.word[e] & ((1ull << (v & 63u)) - 1ull));
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

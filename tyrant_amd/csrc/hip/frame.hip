@@ -9,14 +9,31 @@ namespace tyr {
 // primary_rays, kernel.cu:247-297.  One thread per new queue slot.
 // ======================================================================================
 __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
+	__shared__ uint32_t baseSh;
 	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t cnt = P.k->primary_ray_cnt; // survivors already in the buffer (kernel.cu:253)
 	const unsigned long long room = (unsigned long long)(P.N - cnt);
 	const unsigned long long budget = P.k->budget_remaining;
 	const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
-	if (index >= nNew)
+	const uint32_t firstOfBlock = blockIdx.x * kBlock;
+	if (firstOfBlock >= nNew)
+		return; // (the whole block)
+	// the block's rays go to segment blockIdx % 8 of the work queue, behind whatever it holds: one atomic per block
+	const uint32_t nHere = nNew - firstOfBlock < (uint32_t)kBlock ? nNew - firstOfBlock : (uint32_t)kBlock;
+	const uint32_t seg = blockIdx.x & (kSegs - 1u);
+	if (threadIdx.x == 0) {
+		uint32_t base = atomicAdd(&P.segWork[seg * kSegStride], nHere);
+		if (base + nHere > P.segCap) {
+			atomicOr(&P.k->device_error, kErrQueueOverflow);
+			base = 0xffffffffu;
+		}
+		baseSh = base;
+	}
+	__syncthreads();
+	if (index >= nNew || baseSh == 0xffffffffu)
 		return;
-	const uint32_t slot = index + cnt;
+	const uint32_t slot = seg_phys(seg, baseSh + threadIdx.x);
+	const uint32_t vslot = index + cnt; // the slot the serial order gives this ray (kernel.cu:254): what seeds its shading
 	// kernel.cu:258 seeds by the ticket `index`; with pixel sharding (nranks > 1) the ranks' tickets are interleaved so that
 	// rows y = yl * R + r, r = 0..R-1, do not share their jitter and lens samples (nranks == 1: the reference's expression)
 	uint32_t seed = (P.frame * 147565741u) * 720898027u * (index * P.nranks + P.rank);
@@ -55,19 +72,21 @@ __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 	// extend's sphere pre-pass for this ray, while it is in registers (k_extend_spheres then only has the
 	// survivors of the last iteration to do: nothing at all in a render's first, largest wavefront)
 	P.work.hit[slot] = sphere_hit_record(P, lensPoint, direction);
+	P.work.key[slot] = vslot | kKeySphereDone;
 }
 
 // ======================================================================================
 // set_wavefront_globals, kernel.cu:227-244 (+ reset of the compaction descriptors)
 // ======================================================================================
-__global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_t nDesc) {
+__global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	if (i < nDesc)
-		P.scanDesc[i] = 0ull;
 	if (i < kTicketWords) {
 		P.k->extend_chunks[i * 32] = 0;
 		P.kc->chunks[i * 32] = 0;
 		P.k->shade_tiles[i * 32] = 0;
+		// what this iteration's shade appends to: the next ray queue and this iteration's shadow queue
+		P.segNext[i * kSegStride] = 0;
+		P.kc->seg[i * kSegStride] = 0;
 	}
 	if (i == 0) {
 		DevCounters* k = P.k;
@@ -78,6 +97,7 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 		k->start_position = (uint32_t)(((unsigned long long)k->start_position + nNew) % P.localPixels);
 		k->n_live = cnt + nNew;
 		k->first_fresh = cnt;
+		k->shade_blocks_done = 0;
 		k->shadow_ray_cnt = 0;
 		k->primary_ray_cnt = 0;
 		k->extend_ticket = 0;
@@ -100,9 +120,13 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P, uint32_
 __global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) {
 	const uint32_t first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
 	if (first == 0)
-		P.k->extend_ticket = 0; // the persistent kernel that follows on the stream starts from slot 0
-	const uint32_t n = P.k->first_fresh; // slots from there to n_live are this iteration's primary rays: k_primary has done them
+		P.k->extend_ticket = 0;
+	const uint32_t n = queue_extent(P.segWork);
 	for (uint32_t slot = first; slot < n; slot += stride) {
+		if (!slot_valid(P.segWork, slot))
+			continue;
+		if (P.work.key[slot] & kKeySphereDone) // this iteration's primary rays: k_primary has done them
+			continue;
 		const float4 a = P.work.o_dx[slot];
 		const float2 b = P.work.dyz[slot];
 		P.work.hit[slot] = sphere_hit_record(P, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
@@ -118,8 +142,10 @@ __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P)
 		P.kc->ticket = 0;
 	if (first < kTicketWords)
 		P.k->extend_chunks[first * 32] = 0; // k_trace_flat's tickets, when this pre-pass opens the launch that ends a render (no set_wavefront_globals in front of it)
-	const uint32_t n = P.kc->shadow_cnt;
+	const uint32_t n = queue_extent(P.kc->seg);
 	for (uint32_t index = first; index < n; index += stride) {
+		if (!slot_valid(P.kc->seg, index))
+			continue;
 		const float4 a = P.shadow.o_dx[index];
 		const float4 b = P.shadow.dyz_cd_ix[index];
 		const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
@@ -131,6 +157,96 @@ __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P)
 			occluded = occluded || (t && (t + kEpsilon) < closest);
 		}
 		reinterpret_cast<float*>(&P.shadow.color[index])[3] = occluded ? 1.0f : 0.0f;
+	}
+}
+
+// ======================================================================================
+// The serial order, recovered as numbers (kernels.hpp "Queues"): shade wrote one byte per ray at its virtual slot --
+// survived or not; rank(v) = survivors below v is the survivor's slot in the next iteration by the reference's serial
+// ticket order (kernel.cu:607 with the atomics in slot order).  k_scan_words packs 64 bytes into one word and scans the
+// words' counts inside 16384-slot blocks; k_scan_blocks scans the blocks' totals.  v_lookup() adds the three parts.
+// ======================================================================================
+constexpr uint32_t kScanBlockSlots = 64u * kBlock;
+__global__ void __launch_bounds__(kBlock) k_scan_words(const FrameParams P) {
+	__shared__ uint32_t waveSum[kBlock / 64];
+	const uint32_t n = P.k->n_live;
+	const uint32_t e = blockIdx.x * kBlock + threadIdx.x, first = e * 64u;
+	if (blockIdx.x * kScanBlockSlots >= n)
+		return; // (the whole block: the host sized the grid from an upper bound)
+	unsigned long long word = 0ull;
+	if (first < n) {
+		const uint4* p = reinterpret_cast<const uint4*>(P.survFlag + first);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint4 q = p[k];
+			const uint32_t x[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { // four bytes, each 0 or 1 -> four bits
+				const uint32_t b = (x[j] & 1u) | ((x[j] >> 7) & 2u) | ((x[j] >> 14) & 4u) | ((x[j] >> 21) & 8u);
+				word |= (unsigned long long)b << (16 * k + 4 * j);
+			}
+		}
+		if (n - first < 64u)
+			word &= (1ull << (n - first)) - 1ull; // bytes past the queue's end were never written
+	}
+	const uint32_t c = (uint32_t)__popcll(word);
+	uint32_t incl = c;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t v = __shfl_up(incl, o, 64);
+		if (lane >= (uint32_t)o)
+			incl += v;
+	}
+	if (lane == 63u)
+		waveSum[wave] = incl;
+	__syncthreads();
+	uint32_t before = 0, total = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < kBlock / 64; ++w) {
+		if (w < wave)
+			before += waveSum[w];
+		total += waveSum[w];
+	}
+	P.vWordOut[e] = word;
+	P.vPreOut[e] = before + incl - c;
+	if (threadIdx.x == 0)
+		P.vBlkOut[blockIdx.x] = total; // raw; k_scan_blocks turns the totals into exclusive prefixes
+}
+__global__ void __launch_bounds__(1024) k_scan_blocks(const FrameParams P) {
+	__shared__ uint32_t waveSum[16];
+	__shared__ uint32_t carrySh;
+	const uint32_t n = P.k->n_live;
+	const uint32_t nBlocks = (n + kScanBlockSlots - 1) / kScanBlockSlots;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0)
+		carrySh = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < nBlocks; base += 1024u) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t c = i < nBlocks ? P.vBlkOut[i] : 0u;
+		uint32_t incl = c;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t v = __shfl_up(incl, o, 64);
+			if (lane >= (uint32_t)o)
+				incl += v;
+		}
+		if (lane == 63u)
+			waveSum[wave] = incl;
+		__syncthreads();
+		uint32_t before = carrySh, total = 0;
+		for (uint32_t w = 0; w < 16; ++w) {
+			if (w < wave)
+				before += waveSum[w];
+			total += waveSum[w];
+		}
+		if (i < nBlocks)
+			P.vBlkOut[i] = before + incl - c;
+		__syncthreads();
+		if (threadIdx.x == 0)
+			carrySh += total;
+		__syncthreads();
 	}
 }
 
@@ -236,7 +352,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_debug(const FrameParams P) {
 	st.bind(nullptr, refs, ts);
 	st.reset();
 	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-	if (slot >= P.k->n_live)
+	if (slot >= queue_extent(P.segWork) || !slot_valid(P.segWork, slot))
 		return;
 	const float4 a = P.work.o_dx[slot];
 	const float2 b = P.work.dyz[slot];
@@ -272,8 +388,12 @@ void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
 		return;
 	hipLaunchKernelGGL(k_primary, dim3(blocks_for(maxNew)), dim3(kBlock), 0, stream, P);
 }
-void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream) {
-	hipLaunchKernelGGL(k_globals, dim3(blocks_for(nDesc ? nDesc : 1)), dim3(kBlock), 0, stream, P, nDesc);
+void launch_globals(const FrameParams& P, hipStream_t stream) { hipLaunchKernelGGL(k_globals, dim3(1), dim3(kBlock), 0, stream, P); }
+void launch_scan(const FrameParams& P, uint32_t maxLive, hipStream_t stream) {
+	if (maxLive == 0)
+		return;
+	hipLaunchKernelGGL(k_scan_words, dim3((maxLive + kScanBlockSlots - 1) / kScanBlockSlots), dim3(kBlock), 0, stream, P);
+	hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, P);
 }
 void launch_vecmath_probe(int op, const float* a, const float* b, const float* c, uint32_t n, float* out, hipStream_t stream) {
 	hipLaunchKernelGGL(k_vecmath_probe, dim3(blocks_for(n ? n : 1)), dim3(kBlock), 0, stream, op, a, b, c, n, out);

@@ -24,14 +24,43 @@ struct RayQ {
 	float4* direct_ix;   // direct.rgb (path throughput), pixel index (int bits)     variables.h:27,31
 	uint32_t* flags;     // bounces | lastSpecular << 8                               variables.h:30,33
 	float2* hit;         // distance, identifier (int bits; bit 31 = sphere)         variables.h:28,29,32
+	uint32_t* key;       // the ray's VIRTUAL slot (see "Queues" below): bit 31 = kKeyIndirect, bit 30 = kKeySphereDone
 };
 constexpr uint32_t kHitSphere = 0x80000000u;
+
+// ---- Queues: physically unordered, virtually in the serial ticket order ---------------------------------------------
+// The reference appends survivors with atomicAdd(&primary_ray_cnt, 1) (kernel.cu:607) and seeds a ray's random numbers
+// with its SLOT (kernel.cu:363), so "fixed seed" is only defined against one serial order; rounds 1-2 reproduced that
+// order physically (a stable device-wide compaction with a decoupled look-back inside k_shade).  That made every
+// tile's output position depend on every earlier tile -- shade could not start before the last straggler of the
+// traversal launch had finished.  Since round 3 only the NUMBER is kept: every ray carries its virtual slot (the slot
+// the serial order gives it), the RNG is seeded from it, and where the record physically lies is free:
+//   * a queue is eight segments; segment w owns the 64-slot chunks w, w + 8, w + 16, ... of the arrays, filled in
+//     order (record j of segment w lies at slot ((j / 64) * 8 + w) * 64 + j % 64).  A producer block appends its tile's
+//     records to segment (tile % 8) with ONE atomic on that segment's counter (eight counters, 128 bytes apart: a single
+//     word serves only ~88 returning atomics per microsecond);
+//   * consumers walk physical slots [0, extent) and skip the few holes at the segments' ends (slot_valid);
+//   * shade(i) writes one byte per ray at its virtual slot v: survived or not.  A scan of those bytes (k_scan_*) gives
+//     rank(v) = survivors with a lower virtual slot = the survivor's slot in iteration i + 1 by the serial order.  The
+//     survivor's record carries v | kKeyIndirect; shade(i + 1) looks rank(v) up in the scan's tables (v_lookup).
+//     Fresh primary rays carry their slot directly (survivors + ticket, kernel.cu:254).
+constexpr uint32_t kKeyIndirect = 0x80000000u;   // the low bits are the slot of the PREVIOUS iteration: look the rank up
+constexpr uint32_t kKeySphereDone = 0x40000000u; // the producer (k_primary) has already written the sphere half of the hit record
+constexpr uint32_t kKeyMask = 0x3fffffffu;
+constexpr uint32_t kSegs = 8;                    // = kTicketWords (k_trace_flat's ticket word w draws the chunks of segment w)
+constexpr uint32_t kSegStride = 32;              // uint32 words between two segment counters (128 bytes)
+struct VTable {                                  // scan of one iteration's survive bytes, 64 virtual slots per entry
+	const unsigned long long* word;              // bit b of word[e]: slot 64 e + b survived
+	const uint32_t* pre;                         // survivors in front of word e inside its 16384-slot block
+	const uint32_t* blk;                         // survivors in front of block (e / 256)
+};
 
 // ShadowQueue (variables.h:36-42), 44 B -> 32 B read by every connect ray + 16 B only when visible
 struct ShadowQ {
 	float4* o_dx;        // origin.xyz, direction.x
 	float4* dyz_cd_ix;   // direction.y, direction.z, closestDistance, buffer_index (int bits)
-	float4* color;       // color.rgb, unused
+	float4* color;       // color.rgb, occluded-by-a-sphere flag of the connect pre-pass
+	uint32_t* key;       // virtual slot of the ray that emitted it (tyr_shadow_export sorts by it; the kernels never read it)
 };
 
 // kernel.cu:211-224 device counters + the extensions (budget, totals, visit counters)
@@ -62,6 +91,9 @@ struct DevCounters {
 	uint32_t extend_chunks[kTicketWords * 32];
 	uint32_t reserved2[kTicketWords * 32]; // (connect's chunk tickets live in ConnectCounters)
 	uint32_t shade_tiles[kTicketWords * 32]; // k_shade: word w hands out tiles w, w + 8, w + 16, ...
+	uint32_t seg[2][kSegs * kSegStride];      // records in segment w of ray queue q: seg[q][w * kSegStride]
+	uint32_t shade_blocks_done;               // k_shade: blocks that have finished (the last one folds the segment counters into the totals)
+	uint32_t reserved3[31];
 };
 // What connect reads and draws from, apart from the shadow queue.  Two of them, used by alternate iterations:
 // inside tyr_render connect(i) runs on a second stream next to primary / extend of iteration i + 1, whose
@@ -71,10 +103,12 @@ struct ConnectCounters {
 	uint32_t ticket;                    // variant 1: next shadow-queue slot
 	uint32_t pad[30];
 	uint32_t chunks[kTicketWords * 32]; // variant 4: chunk tickets, one word per 128 bytes like extend_chunks
+	uint32_t seg[kSegs * kSegStride];   // records in segment w of this iteration's shadow queue
 };
 constexpr uint32_t kErrStackOverflow = 1u;
 constexpr uint32_t kErrScanTimeout = 2u;
 constexpr uint32_t kErrNoProgress = 4u; // -DTYR_GUARD_PASSES builds: a wave of a flat traversal kernel ran out of passes (kMaxPasses)
+constexpr uint32_t kErrQueueOverflow = 8u; // a queue segment ran out of room (the records beyond it were dropped)
 
 struct FrameParams {
 	uint32_t W, H, N;
@@ -94,7 +128,15 @@ struct FrameParams {
 	DevCounters* k;
 	ConnectCounters* kc;     // this iteration's set
 	ConnectCounters* kcPrev; // the previous iteration's set (k_trace_flat: its shadow rays are traced beside this iteration's extend)
-	unsigned long long* scanDesc; // one look-back descriptor per shade block
+	uint32_t* segWork;            // segment counters of `work` / `next` (DevCounters.seg[...]); the shadow queue's are kc->seg / kcPrev->seg
+	uint32_t* segNext;
+	uint32_t segCap;              // records one segment has room for
+	uint8_t* survFlag;            // [N] shade writes 1 / 0 at the ray's virtual slot
+	VTable vPrev;                 // the scan of the previous iteration's survive bytes (what kKeyIndirect keys are looked up in)
+	unsigned long long* vWordOut; // ... and where the scan of this iteration's goes
+	uint32_t* vPreOut;
+	uint32_t* vBlkOut;
+	uint32_t shadeBlocks;         // k_shade: blocks of all of this iteration's shade launches together (the last one to finish finalises)
 	uint32_t refillMinIdle;       // persistent traversal: refill a wave once this many lanes are free
 	uint32_t minTraversing;       // flat traversal: leave the descent loop below this many descending lanes
 	uint32_t ticketChunk;         // variants 1 / 4: queue slots a wave takes per draw from a device-wide ticket
@@ -111,40 +153,36 @@ struct FrameParams {
 	const float4* palette;
 };
 
-// traversal kernel structure (tyr_set_tuning)
+// launch shape of the traversal kernel (tyr_set_tuning; DESIGN.md section 4.4 has the measurements behind the defaults)
 struct Tuning {
-	int traversalVariant = 4; // 0 = one thread per queue slot, 1 = persistent waves with lane refill, 2 = 1 + flat state machine, 3 = 2 on quad nodes,
-	                          // 4 = 3 on a persistent grid fed by block-owned ranges + ticketed chunks, top of the tree in LDS (production)
 	int minTraversing = 32;
 	int ticketChunk = 64;
-	int raysPerBlock = 1024;
-	int staticShare = 12;     // sixteenths of the queue dealt out as fixed (interleaved) per-block chunks before the ticketed rest (4 with contiguous ranges in round 1; 12 measured best with interleaved ones: profiles/r02_knob_sweep_merged.txt)
-	int staticInterleave = 1; // the fixed per-block part of the queue in interleaved 64-slot chunks (every block the same mix of the frame)
-	int wideDrain = 1;        // k_trace_flat: the last rays of a wave four lanes to a ray (TYR_TUNE_WIDE_DRAIN)
+	int staticShare = 12;     // sixteenths of the queue dealt out as fixed (interleaved) per-block chunks before the ticketed rest
+	int staticInterleave = 1;
+	int wideDrain = 1;        // the last rays of a wave four lanes to a ray
 	int stagedNodes = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
-	int runAhead = 2;         // tyr_render (merged launches): queue iteration i + 1 before iteration i's counts are on the host: 0 never, 1 always, 2 for queues of at most 6 Mi slots
-	int mergeTrace = 1;       // tyr_render: connect(i) rides in the launch of extend(i + 1) (k_trace_flat): one drain per iteration instead of two
-	int overlapConnect = 2;   // tyr_render: connect(i) on a second stream next to primary / extend of iteration i + 1: 0 never, 1 always, 2 for thin wavefronts
-	int profileMask = 31;     // TYR_FLAG_PROFILE: which stages (bit TYR_K_*) get a hipEvent pair; every pair is ~10 us of idle GPU
-	int stackLdsDepth = 12;   // traversal-stack entries per lane kept in LDS (0, 8, 10, 12, 16, 24); the rest spill to scratch
+	int runAhead = 2;         // tyr_render: queue iteration i + 1 before iteration i's counts are on the host: 0 never, 1 always, 2 for queues of at most 6 Mi slots
+	int mergeTrace = 1;       // tyr_render: connect(i) rides in the launch of extend(i + 1)
+	int profileMask = 31;     // TYR_FLAG_PROFILE: which stages (bit TYR_K_*) get a hipEvent pair
 };
+constexpr uint32_t kCountRaysPerBlock = 1024; // the counting build's kernels: queue slots owned by one 256-thread block
 
 constexpr int kBlock = 256; // 4 wave64 per workgroup
 
 // Per-context cache of the occupancy queries that size the persistent grids (a slow host call: asked once per
 // kernel, not once per launch).  Lives in tyr_ctx -- one ctx per device, no process-wide statics.
-enum { kLcExtend = 0, kLcConnect, kLcShade, kLcTrace, kLcExtendFeed, kLcConnectFeed, kLcDiagExtend, kLcDiagConnect, kLcDiagExtendCount, kLcDiagConnectCount, kLcKinds };
+enum { kLcShade = 0, kLcTrace, kLcKinds };
 struct LaunchCache {
 	int perCU[kLcKinds][6] = {};
 };
-constexpr int stack_slot(int stackLds) { return stackLds == 0 ? 0 : stackLds == 8 ? 1 : stackLds == 10 ? 2 : stackLds == 12 ? 3 : stackLds == 16 ? 4 : 5; }
 
 // launches (all on `stream`); grids are sized by the host from upper bounds, kernels bound-check
 // against the device counters
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream);
-void launch_globals(const FrameParams& P, uint32_t nDesc, hipStream_t stream);
+void launch_globals(const FrameParams& P, hipStream_t stream);
+void launch_scan(const FrameParams& P, uint32_t maxLive, hipStream_t stream); // the survive bytes of this iteration -> vWordOut / vPreOut / vBlkOut
 // nSurvivors: upper bound of the slots the sphere pre-pass still has to do (primary rays get theirs in k_primary)
 void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
 void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCache& lc, hipStream_t stream);
@@ -153,11 +191,6 @@ void launch_trace(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, u
 // the sphere pre-passes of extend / connect (frame.hip), launched by the traversal launchers
 void launch_extend_spheres(const FrameParams& P, uint32_t nSurvivors, hipStream_t stream);
 void launch_connect_spheres(const FrameParams& P, uint32_t maxShadow, hipStream_t stream);
-#ifdef TYR_DIAG
-// libtyrant_hip_diag.so only: traversal variants 0 and 1 (traverse_diag.hip)
-void launch_extend_diag(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
-void launch_connect_diag(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
-#endif
 void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream);
 void launch_extend_debug(const FrameParams& P, uint32_t maxLive, hipStream_t stream); // TYR_FLAG_DEBUG_BVH
 void launch_vecmath_probe(int op, const float* a, const float* b, const float* c, uint32_t n, float* out, hipStream_t stream);

@@ -1,7 +1,8 @@
-// shade.hip -- shade (kernel.cu:347-627) with a STABLE device-wide compaction of survivors and shadow rays
-// (wave ballot + popcount, LDS across the four waves, decoupled look-back across tiles) in place of
-// atomicAdd(&primary_ray_cnt, 1) (kernel.cu:607): slot order equals the serial ticket order, which makes a
-// fixed-seed render reproducible (the RNG seed depends on the slot, kernel.cu:363).
+// shade.hip -- shade (kernel.cu:347-627).  A ray's random numbers are seeded from its VIRTUAL slot -- the slot the
+// reference's serial ticket order gives it (kernel.cu:363, 607) -- which every record carries (kernels.hpp "Queues");
+// survivors and shadow rays are appended a tile at a time to one of eight queue segments (one atomic per tile and
+// queue), in whatever order the tiles finish.  Rounds 1-2 kept the serial order physically (a stable compaction with a
+// decoupled look-back); that chained every tile to all tiles before it.
 #include "device_common.hpp"
 
 namespace tyr {
@@ -110,11 +111,12 @@ __device__ __forceinline__ EmitterSample sample_emitter(const FrameParams& P, ui
 // Lanes past the end of the queue come along with valid = false (they load nothing and produce nothing) so that
 // afterLoads is reached by the whole wave.
 template <bool LIGHTS, class AfterLoads>
-__device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, bool valid, ShadeOut& out, AfterLoads&& afterLoads) {
+__device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, bool valid, ShadeOut& out, uint32_t& vslotOut, AfterLoads&& afterLoads) {
 	float4 a = make_float4(0.f, 0.f, 0.f, 0.f), dq = a;
 	float2 b = make_float2(0.f, 0.f), h = make_float2(kVeryFar, 0.f);
-	uint32_t fl = 0;
+	uint32_t fl = 0, key = 0;
 	if (valid) {
+		key = P.work.key[slot];
 		a = P.work.o_dx[slot];
 		b = P.work.dyz[slot];
 		h = P.work.hit[slot];
@@ -132,7 +134,9 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 	int new_frame = 0;
 	f3 color = mk3(0.f, 0.f, 0.f);
 	f3 albedo = mk3(0.f, 0.f, 0.f);
-	uint32_t seed = (P.frame * (uint32_t)pixel * 147565741u) * 720898027u * slot; // kernel.cu:363
+	const uint32_t vslot = valid ? v_lookup(P.vPrev, key) : 0u; // the ray's slot by the serial order
+	vslotOut = vslot;
+	uint32_t seed = (P.frame * (uint32_t)pixel * 147565741u) * 720898027u * vslot; // kernel.cu:363
 	int material = TYR_DIFF;
 	out.survive = false;
 	out.shadow = false;
@@ -376,153 +380,44 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 	out.newFrame = new_frame;
 }
 
-constexpr unsigned long long kScanTimeoutTicks = 200000000ull; // 2 s of s_memrealtime (100 MHz)
-// look-back descriptor: [63:62] status, [61:31] survivors, [30:0] shadow rays
-constexpr unsigned long long kDescAggregate = 1ull << 62;
-constexpr unsigned long long kDescInclusive = 2ull << 62;
-__device__ __forceinline__ unsigned long long desc_pack(uint32_t s, uint32_t h) { return ((unsigned long long)s << 31) | (unsigned long long)h; }
-__device__ __forceinline__ uint32_t desc_s(unsigned long long d) { return (uint32_t)((d >> 31) & 0x7fffffffull); }
-__device__ __forceinline__ uint32_t desc_h(unsigned long long d) { return (uint32_t)(d & 0x7fffffffull); }
-
-// Tile order without a ticket.  The stable compaction needs every tile's predecessors to be running
-// (or done) while it looks back.  The first version drew a virtual tile id from an atomic counter at
-// block start -- 8192 returning atomics on one word per launch, ~0.2 ms of a 0.3 ms kernel (one word
-// serves ~88 of them per microsecond; measured by replacing the ticket: 0.30 -> 0.096 ms per launch).
-// Now the grid is small enough to be entirely co-resident (at most 4 blocks of 256 threads per CU) and
-// block b shades tiles b, b + G, b + 2G, ...: the predecessor of any tile belongs to a block that is
-// resident, whatever order the hardware dispatched them in, so the look-back cannot starve.
-//
-// Deferred look-back.  With "shade tile i, look back for tile i, write tile i" every block waited, tile after
-// tile, for the SLOWEST of its predecessors to publish an aggregate (all resident blocks shade the same
-// generation of tiles at the same time and shading time has a long tail): an s_memtime build showed two thirds
-// of a tile's time inside the look-back, and fetching more descriptors per round trip did not help.  Now the
-// tile's compacted records wait in LDS (survivors and shadow rays at their rank inside the tile) and the
-// look-back for tile i runs AFTER tile i+G has been shaded: by then every predecessor has long published, the
-// look-back is pure round trips (kWindows x 64 descriptors each), and the records leave LDS as coalesced stores
-// (thread t writes record t).
-struct ShadeStage { // one tile's compacted output, 23 KB
+struct ShadeStage { // one tile's output, waiting for the tile's place in the queues: 25 KB
 	float4 sv_o_dx[kBlock];
 	float2 sv_dyz[kBlock];
 	float4 sv_direct_ix[kBlock];
 	uint32_t sv_flags[kBlock];
+	uint32_t sv_key[kBlock];
 	float4 sh_o_dx[kBlock];
 	float4 sh_dyz_cd_ix[kBlock];
 	float4 sh_color[kBlock];
+	uint32_t sh_key[kBlock];
 };
 
-// Exclusive prefix of tile vb over all lower tiles, computed by the whole block; publishes the tile's inclusive
-// prefix.  Wave w inspects descriptors vb-1-512w ... vb-512(w+1) (kWindows x 64, lane i of window k reads one), so
-// one memory round trip covers 2048 predecessors -- more than the distance to the nearest inclusive prefix, which
-// is one to two generations of resident tiles (<= 1024 each) because the look-back is deferred by one tile.
-// With wave 0 alone and 512 descriptors per step it took three steps, 36 % of a tile's time.
-__device__ __forceinline__ void shade_lookback(const FrameParams& P, uint32_t vb, uint32_t totS, uint32_t totH, uint32_t tid, uint32_t nTiles, uint32_t* sh, uint32_t& esOut, uint32_t& ehOut) {
-	constexpr int kWindows = 2;
-	constexpr int kPerWave = 64 * kWindows, kPerStep = kPerWave * (int)(kBlock / 64);
-	const uint32_t lane = tid & 63u, wave = tid >> 6;
-	uint32_t es = 0, eh = 0;
-	if (vb > 0) { // block-uniform
-		int base = (int)vb - 1; // nearest predecessor of this step
-		for (;;) {
-			const int first = base - kPerWave * (int)wave; // nearest descriptor of this wave's share
-			unsigned long long d[kWindows];
-#pragma unroll
-			for (int k = 0; k < kWindows; ++k) {
-				const int idx = first - 64 * k - (int)lane;
-				d[k] = kDescInclusive; // below tile 0: an inclusive prefix of zero
-				if (idx >= 0)
-					d[k] = __hip_atomic_load(&P.scanDesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			bool found = false, timeout = false;
-			uint32_t ps = 0, ph = 0;
-#pragma unroll
-			for (int k = 0; k < kWindows; ++k) {
-				if (found)
-					continue; // (wave-uniform) an inclusive prefix was found in a nearer window
-				const int idx = first - 64 * k - (int)lane;
-				const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime(); // 100 MHz, independent of the shader clock
-				while (!(d[k] >> 62)) { // not published yet: poll this one
-					// every wait is bounded by wall time (2 s; a launch is milliseconds): report, never hang.  The zero
-					// prefix written on that path only lets the block finish -- the launch is reported as failed
-					// (kErrScanTimeout -> TYR_ERR_DEVICE) and its queues are not to be used.
-					if (__builtin_amdgcn_s_memrealtime() - t0_ > kScanTimeoutTicks) {
-						timeout = true;
-						d[k] = kDescInclusive;
-						// what timed out, for TYR_VERBOSE's report (host/driver.cpp check_device_error)
-						P.k->debug[0] = vb;
-						P.k->debug[1] = (unsigned long long)idx;
-						P.k->debug[2] = blockIdx.x;
-						P.k->debug[3] = gridDim.x;
-						P.k->debug[4] = __builtin_amdgcn_s_memrealtime() - t0_; // 100 MHz ticks
-						break;
-					}
-					__builtin_amdgcn_s_sleep(1);
-					d[k] = __hip_atomic_load(&P.scanDesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-				const unsigned long long inclMask = __ballot((d[k] >> 62) == 2ull);
-				// lanes up to and including the nearest inclusive descriptor contribute
-				const uint32_t stop = inclMask ? (uint32_t)__ffsll((long long)inclMask) - 1u : 63u;
-				unsigned long long v = (lane <= stop) ? (d[k] & ~(3ull << 62)) : 0ull;
-#pragma unroll
-				for (int o = 32; o > 0; o >>= 1)
-					v += __shfl_xor(v, o, 64);
-				ps += desc_s(v);
-				ph += desc_h(v);
-				found = (inclMask != 0ull);
-			}
-			if (__ballot(timeout) != 0ull && lane == 0)
-				atomicOr(&P.k->device_error, kErrScanTimeout);
-			if (lane == 0) {
-				sh[16 + 3 * wave + 0] = ps;
-				sh[16 + 3 * wave + 1] = ph;
-				sh[16 + 3 * wave + 2] = found ? 1u : 0u;
-			}
-			__syncthreads();
-			bool any = false;
-#pragma unroll
-			for (uint32_t w = 0; w < kBlock / 64; ++w) {
-				if (!any) {
-					es += sh[16 + 3 * w + 0];
-					eh += sh[16 + 3 * w + 1];
-					any = sh[16 + 3 * w + 2] != 0u;
-				}
-			}
-			__syncthreads(); // sh[16..] may be rewritten by another step
-			if (any)
-				break;
-			base -= kPerStep;
-		}
-	}
-	if (tid == 0) {
-		__hip_atomic_store(&P.scanDesc[vb], kDescInclusive | desc_pack(es + totS, eh + totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (vb == nTiles - 1) {
-			// kernel.cu:607 / 416: the totals the next top-up and connect read
-			P.k->primary_ray_cnt = es + totS;
-			P.k->shadow_ray_cnt = eh + totH;
-			P.kc->shadow_cnt = eh + totH;
-			P.k->total_shadow_rays += eh + totH;
-			P.k->n_survive += es + totS;
-		}
-	}
-	esOut = es;
-	ehOut = eh;
-}
-
 #ifndef TYR_SHADE_BLOCKS_PER_CU
-#define TYR_SHADE_BLOCKS_PER_CU 4 // tiles in flight per CU: 128 vector registers each (a what-if build may ask for 5 or 6 and take the spills)
+#define TYR_SHADE_BLOCKS_PER_CU 4 // tiles in flight per CU: 128 vector registers each
 #endif
+// One tile = 256 consecutive physical slots of the work queue = four 64-slot chunks (one per wave), each the tail or
+// the middle of one segment: a wave's valid lanes are the first chunk_valid() of its chunk.
+//
+// Tiles are drawn from eight tickets (word w hands out tiles w, w + 8, ...; a block starts at word blockIdx % 8 and
+// moves on when a word is used up): one word per tile id would be a single ticket (88 draws/us: 0.74 ms for the 64.8 k
+// tiles of a full queue).  Nothing waits for anything here: any grid size is safe.
+//
+// A tile's survivors (kernel.cu:607-608) and shadow rays (kernel.cu:416-417 ...) get their place with ONE atomic per
+// queue on the counter of segment (tile % 8), issued as soon as the tile's counts are known; the records wait in LDS at
+// their rank inside the tile and leave as coalesced stores (thread t writes record t) AFTER the next tile has been
+// shaded -- by then the atomics have long returned.
 template <bool LIGHTS>
 __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const FrameParams P) {
 	__shared__ uint32_t sh[32];
 	__shared__ ShadeStage stage;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u, wave = tid >> 6;
-	const uint32_t nLive = P.k->n_live;
-	const uint32_t nTiles = (nLive + kBlock - 1) / kBlock; // from the device's count: the host may have sized the grid from an upper bound (tyr_render runs one iteration ahead of the counts)
+	const uint32_t extent = queue_extent(P.segWork);
+	const uint32_t nTiles = extent / kBlock; // from the device's counts: the host may have sized the grid from an upper bound
 	const unsigned long long below = (1ull << lane) - 1ull;
 #ifdef TYR_SHADE_TIMING
 	// diagnostic build: where a tile's time goes, in s_memtime ticks summed over this block's tiles (thread 0;
-	// debug[0] shade, [1] ranks + barrier, [2] look-back, [3] barrier after it, [4] copy out + barrier, [5] stage +
-	// pixel atomics, [7] tiles)
+	// debug[0] shade, [1] ranks + barrier, [2] place, [4] copy out + barrier, [5] stage + pixel atomics, [7] tiles)
 	unsigned long long tacc_[6] = { 0, 0, 0, 0, 0, 0 }, t_ = __builtin_amdgcn_s_memtime(), ntiles_ = 0;
 #define TYR_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc_[i] += now_ - t_; t_ = now_; }
 #else
@@ -532,47 +427,39 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	uint32_t pendPixel = 0;           // this lane's pixel contribution of that tile, not yet added
 	int pendNew = 0;
 	f3 pendColor = mk3(0.f, 0.f, 0.f);
-	uint32_t prevVb = 0, prevS = 0, prevH = 0;
+	uint32_t prevSeg = 0, prevS = 0, prevH = 0;
+	uint32_t mySurvivors = 0, myShadows = 0; // thread 0: what this block appended
 
-	// finish the waiting tile: look back, then move its records from LDS to their slots (kernel.cu:607-608, 416-417)
+	// finish the waiting tile: its places have arrived (sh[12], sh[13]); move its records from LDS to the queues
 	auto flush_prev = [&]() {
-		uint32_t es, eh;
-		shade_lookback(P, prevVb, prevS, prevH, tid, nTiles, sh, es, eh);
+		const uint32_t baseS = sh[12], baseH = sh[13];
 		TYR_STAMP(2)
-		// one array at a time (the compiler barrier keeps it from loading all seven records first): this copy is where
-		// the kernel's register count peaks
-		if (tid < prevS) {
-			P.next.o_dx[es + tid] = stage.sv_o_dx[tid];
+		// one array at a time (the compiler barrier keeps it from loading all records first): this copy is where the
+		// kernel's register count peaks
+		if (tid < prevS && baseS != 0xffffffffu) {
+			const uint32_t d = seg_phys(prevSeg, baseS + tid);
+			P.next.o_dx[d] = stage.sv_o_dx[tid];
 			__asm__ volatile("" ::: "memory");
-			P.next.direct_ix[es + tid] = stage.sv_direct_ix[tid];
+			P.next.direct_ix[d] = stage.sv_direct_ix[tid];
 			__asm__ volatile("" ::: "memory");
-			P.next.dyz[es + tid] = stage.sv_dyz[tid];
-			P.next.flags[es + tid] = stage.sv_flags[tid];
+			P.next.dyz[d] = stage.sv_dyz[tid];
+			P.next.flags[d] = stage.sv_flags[tid];
+			P.next.key[d] = stage.sv_key[tid];
 		}
 		__asm__ volatile("" ::: "memory");
-		if (tid < prevH) {
-			P.shadow.o_dx[eh + tid] = stage.sh_o_dx[tid];
+		if (tid < prevH && baseH != 0xffffffffu) {
+			const uint32_t d = seg_phys(prevSeg, baseH + tid);
+			P.shadow.o_dx[d] = stage.sh_o_dx[tid];
 			__asm__ volatile("" ::: "memory");
-			P.shadow.dyz_cd_ix[eh + tid] = stage.sh_dyz_cd_ix[tid];
+			P.shadow.dyz_cd_ix[d] = stage.sh_dyz_cd_ix[tid];
 			__asm__ volatile("" ::: "memory");
-			P.shadow.color[eh + tid] = stage.sh_color[tid];
+			P.shadow.color[d] = stage.sh_color[tid];
+			P.shadow.key[d] = stage.sh_key[tid];
 		}
 		__syncthreads(); // `stage` and sh[] are free again
 		TYR_STAMP(4)
 	};
 
-	// Tiles are drawn from eight tickets (word w hands out tiles w, w + 8, ...; a block starts at word
-	// blockIdx % 8 and moves on when a word is used up).  A tile is only ever started after every lower tile of
-	// its word.  Liveness: let T be the lowest tile not yet drawn, w = T % 8.  The block that drew the latest tile of
-	// word w holds only tiles below T, every tile below T has been drawn (and a drawn tile publishes its aggregate
-	// without waiting for anybody), so that block's look-back completes and its next draw is T.  This needs every word
-	// to have a RESIDENT block serving it: blocks are dispatched in index order, so any eight resident blocks cover the
-	// eight words, and launch_shade never launches fewer than eight blocks when there are eight tiles (a device that
-	// keeps fewer than eight 256-thread blocks resident -- under four CUs -- cannot run this kernel: the bounded wait
-	// below then reports kErrScanTimeout instead of hanging).
-	// Unlike the fixed assignment b, b + G, ... a slow block simply shades fewer tiles instead of holding up every
-	// look-back of its generation; one word per tile id would be a single ticket again (88 draws/us: 0.74 ms for
-	// the 64.8 k tiles of a full queue).
 	uint32_t word = blockIdx.x % kTicketWords, tried = 0;
 	auto draw_tile = [&]() -> uint32_t { // block-uniform; nTiles when nothing is left
 		uint32_t vbNext = nTiles;
@@ -594,10 +481,10 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		__syncthreads();
 		return vbNext;
 	};
-	for (uint32_t vb = draw_tile(); vb < nTiles; vb = draw_tile()) { // vb = tile id = queue order
+	for (uint32_t vb = draw_tile(); vb < nTiles; vb = draw_tile()) { // vb = tile id = 256 physical slots
 		const uint32_t slot = vb * kBlock + tid;
 		ShadeOut out = {};
-		uint32_t pixelBits = 0;
+		uint32_t pixelBits = 0, vslot = 0;
 		// kernel.cu:622-625 for the tile BEFORE this one.  vmcnt retires loads and atomics in issue order, and an
 		// atomic that has to reach the memory side takes thousands of cycles under load: issued at the end of a
 		// tile they sat in front of the next tile's ray loads (0.34 ms of a render's 1.77 ms of shade, measured by
@@ -608,13 +495,15 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			pendColor = mk3(0.f, 0.f, 0.f);
 			pendNew = 0;
 		};
-		const bool valid = slot < nLive;
+		const bool valid = lane < chunk_valid(P.segWork, slot & ~63u);
 		if (valid)
 			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
-		shade_ray<LIGHTS>(P, slot, valid, out, flush_pixels);
+		shade_ray<LIGHTS>(P, slot, valid, out, vslot, flush_pixels);
+		if (valid)
+			P.survFlag[vslot] = out.survive ? 1 : 0; // what k_scan_words turns into next iteration's slots
 		TYR_STAMP(0)
 
-		// ---- stable compaction of survivors and shadow rays: ranks inside the tile ----
+		// ---- ranks inside the tile ----
 		const unsigned long long bs = __ballot(out.survive);
 		const unsigned long long bh = __ballot(out.shadow);
 		const uint32_t rs = __popcll(bs & below), rh = __popcll(bh & below);
@@ -636,32 +525,49 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		}
 		totS = (uint32_t)__builtin_amdgcn_readfirstlane((int)totS); // block-uniform: keep them out of the vector registers
 		totH = (uint32_t)__builtin_amdgcn_readfirstlane((int)totH);
-		// the aggregate goes out at once: later tiles can add it up long before this tile knows its own prefix.
-		// Descriptor = 8 bytes {status, survivors, shadows} written by one relaxed agent-scope store: payload and
-		// flag travel together, no fence needed.  Tile 0 publishes one too: its inclusive prefix only appears when its
-		// deferred look-back runs, and every look-back of the first generation would sit waiting for it.
-		if (tid == 0)
-			__hip_atomic_store(&P.scanDesc[vb], kDescAggregate | desc_pack(totS, totH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		TYR_STAMP(1)
 		if (havePrev)
-			flush_prev(); // ends with a barrier: sh[4..11] have been read by every thread
+			flush_prev(); // ends with a barrier: sh[4..13] have been read by every thread
 		else
 			__syncthreads();
+		const uint32_t seg = vb & (kSegs - 1u);
+		if (tid == 0) {
+			// this tile's places: consumed by flush_prev one tile later
+			uint32_t bS = 0, bH = 0;
+			if (totS) {
+				bS = atomicAdd(&P.segNext[seg * kSegStride], totS);
+				if (bS + totS > P.segCap)
+					bS = 0xffffffffu;
+			}
+			if (totH) {
+				bH = atomicAdd(&P.kc->seg[seg * kSegStride], totH);
+				if (bH + totH > P.segCap)
+					bH = 0xffffffffu;
+			}
+			if (bS == 0xffffffffu || bH == 0xffffffffu)
+				atomicOr(&P.k->device_error, kErrQueueOverflow);
+			sh[12] = bS;
+			sh[13] = bH;
+			mySurvivors += bS == 0xffffffffu ? 0u : totS;
+			myShadows += bH == 0xffffffffu ? 0u : totH;
+		}
 		if (out.survive) {
 			const uint32_t k = ws + rs;
 			stage.sv_o_dx[k] = make_float4(out.origin.x, out.origin.y, out.origin.z, out.direction.x);
 			stage.sv_dyz[k] = make_float2(out.direction.y, out.direction.z);
 			stage.sv_direct_ix[k] = make_float4(out.direct.x, out.direct.y, out.direct.z, __uint_as_float(pixelBits));
 			stage.sv_flags[k] = out.flags;
+			stage.sv_key[k] = vslot | kKeyIndirect; // next iteration's slot = rank of vslot among this iteration's survivors
 		}
 		if (out.shadow) {
 			const uint32_t k = wh + rh;
 			stage.sh_o_dx[k] = make_float4(out.sOrigin.x, out.sOrigin.y, out.sOrigin.z, out.sDir.x);
 			stage.sh_dyz_cd_ix[k] = make_float4(out.sDir.y, out.sDir.z, out.sClosest, __uint_as_float(pixelBits));
 			stage.sh_color[k] = make_float4(out.sColor.x, out.sColor.y, out.sColor.z, 0.0f);
+			stage.sh_key[k] = vslot;
 		}
 		havePrev = true;
-		prevVb = vb;
+		prevSeg = seg;
 		prevS = totS;
 		prevH = totH;
 		// goes to the pixel under the next tile's arithmetic (or after the loop); zeros for lanes past the end
@@ -679,6 +585,23 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		__syncthreads();
 		flush_prev();
 	}
+	// kernel.cu:607 / 416: the totals the next top-up and connect read.  Every block adds what it appended; the block
+	// that finishes last (of ALL of this iteration's shade launches: P.shadeBlocks) publishes the per-iteration figures.
+	if (tid == 0) {
+		if (mySurvivors)
+			atomicAdd(&P.k->primary_ray_cnt, mySurvivors);
+		if (myShadows)
+			atomicAdd(&P.kc->shadow_cnt, myShadows);
+		__threadfence();
+		if (atomicAdd(&P.k->shade_blocks_done, 1u) + 1u == P.shadeBlocks) {
+			__threadfence();
+			const uint32_t s = __hip_atomic_load(&P.k->primary_ray_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t h = __hip_atomic_load(&P.kc->shadow_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			P.k->shadow_ray_cnt = h;
+			P.k->total_shadow_rays += h;
+			P.k->n_survive += s;
+		}
+	}
 #ifdef TYR_SHADE_TIMING
 	if (tid == 0) {
 		for (int i = 0; i < 6; ++i)
@@ -689,11 +612,9 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 #undef TYR_STAMP
 }
 
-
-void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCache& lc, hipStream_t stream) {
-	if (maxLive == 0)
-		return;
-	const uint32_t nTiles = blocks_for(maxLive); // an upper bound is fine: the kernel takes the tile count from the device
+// blocks of a shade launch over (at most) maxSlots physical slots
+uint32_t shade_grid(const FrameParams& P, uint32_t maxSlots, int numCUs, LaunchCache& lc) {
+	const uint32_t nTiles = blocks_for(maxSlots); // an upper bound is fine: the kernel takes the tile count from the device
 	// A persistent grid: as many blocks as stay resident (more would only wait for a slot and then find no tile
 	// left; the tile tickets make any grid size safe).  Asked once: the occupancy query is a slow host call.
 	const bool lights = (P.flags & TYR_FLAG_LIGHT_LIST) != 0; // its own instantiation: the default kernel keeps its registers
@@ -706,11 +627,15 @@ void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCach
 		perCU[lights] = q > 6 ? 6 : q;
 	}
 	const uint32_t resident = (uint32_t)perCU[lights] * (uint32_t)numCUs;
-	const dim3 grid(nTiles < resident ? nTiles : resident);
-	if (lights)
-		hipLaunchKernelGGL(k_shade<true>, grid, dim3(kBlock), 0, stream, P);
+	return nTiles < resident ? (nTiles ? nTiles : 1u) : resident;
+}
+void launch_shade(const FrameParams& P0, uint32_t maxSlots, int numCUs, LaunchCache& lc, hipStream_t stream) {
+	FrameParams P = P0;
+	P.shadeBlocks = shade_grid(P, maxSlots, numCUs, lc);
+	if (P.flags & TYR_FLAG_LIGHT_LIST)
+		hipLaunchKernelGGL(k_shade<true>, dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
 	else
-		hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), 0, stream, P);
+		hipLaunchKernelGGL(k_shade<false>, dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
 }
 
 } // namespace tyr

@@ -1,8 +1,7 @@
 // traverse_flat.hip -- extend (kernel.cu:331-343 via intersect_scene, kernel.cu:125-142) and connect
 // (kernel.cu:630-646 via intersect_scene_simple, kernel.cu:162-174) as flat per-lane state machines on persistent
 // waves.  Production = quad nodes on a persistent grid (variant 4); the counting build (TYR_FLAG_COUNT_VISITS) = the
-// same state machine on pair nodes, which reproduces the reference's visit counts (bvh.h:164-209).  Variants 0-3 and
-// the other stack depths live in traverse_diag.hip / the -DTYR_DIAG build (libtyrant_hip_diag.so).
+// same state machine on pair nodes, which reproduces the reference's visit counts (bvh.h:164-209).  
 #include "device_common.hpp"
 
 namespace tyr {
@@ -161,7 +160,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 	}
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t nLive = P.k->n_live;
+	const uint32_t nLive = queue_extent(P.segWork); // physical slots; the few that hold no record are skipped (slot_valid)
 	const DevScene& sc = P.scene;
 	// the ray of this lane as plain scalars: kept as one RayConst object across the refill branch, its first 16
 	// bytes (origin + direction.x) stayed in a private-memory slot that every descent and leaf phase re-read
@@ -256,6 +255,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 				fed = !live && rank < take;
 			}
 			{
+				if (fed)
+					fed = slot_valid(P.segWork, s);
 				if (fed) {
 					TYR_DBG(6)
 					const float4 a = P.work.o_dx[s];
@@ -427,7 +428,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 	}
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t nRays = P.kc->shadow_cnt;
+	const uint32_t nRays = queue_extent(P.kc->seg); // physical slots of the shadow queue
 	const DevScene& sc = P.scene;
 	const bool haveBvh = (sc.rootRef != kRefDone);
 	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f; // see k_extend_flat
@@ -522,6 +523,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 			if (__ballot(pendIdx != kNoPending) != 0ull)
 				flush_visible();
 			{
+				if (fed)
+					fed = slot_valid(P.kc->seg, s);
 				if (fed) {
 					const float4 a = P.shadow.o_dx[s];
 					const float4 b = P.shadow.dyz_cd_ix[s];
@@ -866,8 +869,10 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	}
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t nExt = P.traceShadow == 2u ? 0u : P.k->n_live;
-	const uint32_t nItems = nExt + (P.traceShadow != 0u ? P.kcPrev->shadow_cnt : 0u); // (a render's first launch carries no shadow rays: kcPrev then holds an older render's count)
+	// items = physical slots: the work queue's [0, nExt), then the shadow queue's; the few slots at the segments' ends that
+	// hold no record are handed out like the others and dropped at the refill (slot_valid)
+	const uint32_t nExt = P.traceShadow == 2u ? 0u : queue_extent(P.segWork);
+	const uint32_t nItems = nExt + (P.traceShadow != 0u ? queue_extent(P.kcPrev->seg) : 0u); // (a render's first launch carries no shadow rays: kcPrev then holds an older render's count)
 	const DevScene& sc = P.scene;
 	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f;
 	bool regular = true, allRegular = true;
@@ -958,7 +963,9 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 				float4 a;
 				float by, bz, bound;
 				bool blocked = false;
+				bool holds; // the slot holds a record (loaded beside the record, not in front of it: one round trip)
 				if (s < nExt) { // a ray of the work queue: closest hit
+					holds = slot_valid(P.segWork, s);
 					a = P.work.o_dx[s];
 					const float2 b = P.work.dyz[s];
 					const float2 h = P.work.hit[s];
@@ -967,6 +974,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 					isShadow = false;
 				} else { // a shadow ray of the previous iteration: any hit within closestDistance
 					const uint32_t idx = s - nExt;
+					holds = slot_valid(P.kcPrev->seg, idx);
 					a = P.shadow.o_dx[idx];
 					const float4 b = P.shadow.dyz_cd_ix[idx];
 					blocked = reinterpret_cast<const float*>(&P.shadow.color[idx])[3] != 0.0f; // the sphere pre-pass's verdict
@@ -974,6 +982,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 					slot = idx;
 					isShadow = true;
 				}
+				blocked = blocked || !holds;
 				const RayConst nr = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, by, bz));
 				rox = nr.o.x, roy = nr.o.y, roz = nr.o.z, rdx = nr.d.x, rdy = nr.d.y, rdz = nr.d.z, rix = nr.inv.x, riy = nr.inv.y, riz = nr.inv.z;
 				regular = ray_is_regular(nr);
@@ -986,7 +995,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 					ref = sc.quadRootRef;
 				// an extend ray that misses the root box is finished here (the pre-pass's answer stands, nothing to write); a
 				// shadow ray a sphere blocks likewise; a shadow ray that misses the tree is visible: it retires below
-				live = (ref != kRefDone) || (isShadow && !blocked);
+				live = holds && ((ref != kRefDone) || (isShadow && !blocked));
 #ifdef TYR_RAY_STEPS
 				if (!live && s < P.N)
 					P.next.hit[s] = make_float2(0.0f, isShadow ? 1.0f : 0.0f); // never entered the tree
@@ -1138,618 +1147,57 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	}
 }
 
-#ifdef TYR_DIAG // variant 5 was measured and lost to variant 4: diagnostics build only
-// ======================================================================================
-// Variant 5 ("feed"): the flat state machine of variant 4 with the REFILL taken off the critical path.
-//
-// What the lane-state census of variant 4 showed (tools/loop_occupancy.py production=1 on a -DTYR_QUAD_STATS build,
-// C3 at 1080p, profiles/r02_loop_census_c3.txt): in the average descent trip 50 % of the lanes test a node, 10 % hold a
-// leaf and wait for the descent to end, 5 % have just popped a stale entry -- and 27 % have NO RAY, 5 % more a finished
-// one.  A refill is a wave-wide affair there (leave the descent loop, draw slots, load 32 bytes per new ray, wait for
-// them, three divisions and the root-box test under a partial mask), so it is only worth starting once many lanes are
-// free (refill_min_idle = 16 measured best), and until then the free lanes ride along empty.
-//
-// Here every wave keeps a small ring of PREPARED rays in LDS (origin, direction, 1 / direction, bound, slot: 48 bytes):
-//   * top-up: up to 64 queue slots at a time, one per lane whatever the lane is doing -- coalesced loads, the divisions
-//     and the root-box test at full occupancy; rays that miss the root box (three primary rays in four on C3) end
-//     there and never cost a traversing lane anything; the others are compacted into the ring (ballot ranks).  The
-//     loads are issued in FRONT of a leaf phase and consumed BEHIND it: vmcnt retires in order, so by the time the
-//     triangle records of that phase have arrived the rays have too, and the top-up costs its arithmetic only;
-//   * pop: a lane that finishes its ray takes the next prepared one inside the descent loop -- three ds_read_b128 --
-//     in the same trip.
-// Results do not depend on which lane traces which ray (every answer goes to its own slot), so this is bit-exact like
-// every other launch shape (tests: the variant / knob parity tests run variant 5 as well).
-// ======================================================================================
-#ifndef TYR_FEED_STACK
-#define TYR_FEED_STACK 8     // LDS stack entries per lane (the ring needs LDS too: 8 + 64 staged nodes + a 32-entry ring = 29.7 KB per block, 5 blocks per CU)
-#endif
-#ifndef TYR_FEED_FIFO
-#define TYR_FEED_FIFO 32     // prepared rays per wave (power of two)
-#endif
-#ifndef TYR_FEED_STAGED
-#define TYR_FEED_STAGED 64   // top-of-tree quad nodes in LDS (<= kStagedNodes)
-#endif
-#ifndef TYR_FEED_WAVES_PER_EU
-#define TYR_FEED_WAVES_PER_EU 5
-#endif
-#ifndef TYR_FEED_POP_MIN
-#define TYR_FEED_POP_MIN 1   // free lanes needed before a pop is worth its scalar bookkeeping
-#endif
-
-template <int FIFO>
-struct RayRing { // one per wave; entry e = plane[0][e], plane[1][e], plane[2][e]: consecutive entries are consecutive 16-byte words of a plane (no bank conflicts)
-	float4 plane[3][FIFO];
-};
-__device__ __forceinline__ void wave_lds_fence() {
-	// LDS executes a wave's instructions in order; this only keeps the COMPILER from moving a lane's ring read above
-	// another lane's ring write (no instruction is emitted)
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// where a wave's next queue slots come from: the block's fixed range first (an LDS counter), then ticketed chunks
-struct SlotSource {
-	ChunkFeed feed;
-	uint32_t blockEnd, dynBase, nItems;
-	bool staticDone;
-	__device__ __forceinline__ void init(uint32_t nItems_, uint32_t staticShare, uint32_t ticketChunk, uint32_t* blockNext) {
-		nItems = nItems_;
-		const uint32_t perBlock = static_range(nItems, staticShare);
-		dynBase = perBlock * gridDim.x;
-		const uint32_t blockBegin = blockIdx.x * perBlock;
-		blockEnd = blockBegin + perBlock;
-		feed.init(nItems - dynBase, ticketChunk);
-		staticDone = (perBlock == 0);
-		if (threadIdx.x == 0)
-			*blockNext = blockBegin;
-	}
-	// up to `want` consecutive slots starting at `base`; 0 = the queue is used up (all wave-uniform)
-	__device__ __forceinline__ uint32_t acquire(uint32_t want, uint32_t& base, uint32_t* blockNext, uint32_t* tickets, uint32_t lane) {
-		if (!staticDone) {
-			uint32_t b = 0;
-			if (lane == 0)
-				b = atomicAdd(blockNext, want); // LDS
-			b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-			const uint32_t avail = b < blockEnd ? blockEnd - b : 0u;
-			staticDone = (b + want >= blockEnd);
-			if (avail != 0u) {
-				base = b;
-				return avail < want ? avail : want;
-			}
-		}
-		if (!feed.refill(tickets, nItems - dynBase, lane))
-			return 0u;
-		const uint32_t avail = feed.end - feed.next;
-		const uint32_t take = avail < want ? avail : want;
-		base = dynBase + feed.next;
-		feed.next += take;
-		return take;
-	}
-};
-
-template <int STACK_LDS, int FIFO, int STAGED>
-__global__ void __launch_bounds__(kBlock, TYR_FEED_WAVES_PER_EU) k_extend_feed(const FrameParams P) {
-	static_assert((FIFO & (FIFO - 1)) == 0 && FIFO >= 16 && FIFO <= 64, "ring size");
-	constexpr bool COUNT = false; // (TYR_DBG)
-	TYR_DECLARE_FLAT_STACK(st, true)
-	__shared__ float4 stagedNodes[7 * STAGED];
-	__shared__ RayRing<FIFO> rings[kBlock / 64];
-	__shared__ uint32_t blockNext;
-	const uint32_t nStaged = P.scene.nStaged < (uint32_t)STAGED ? P.scene.nStaged : (uint32_t)STAGED;
-	for (uint32_t i = threadIdx.x; i < 7 * nStaged; i += kBlock) {
-		const uint32_t v = i / nStaged, n = i - v * nStaged;
-		stagedNodes[v * STAGED + n] = P.scene.quads[8 * n + v];
-	}
-	const uint32_t lane = lane_id();
-	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t nLive = P.k->n_live;
-	const DevScene& sc = P.scene;
-	RayRing<FIFO>& ring = rings[threadIdx.x >> 6];
-	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f;
-	bool regular = true, allRegular = true;
-	float dist = 0.0f;
-	uint32_t ref = kRefDone, slot = 0;
-	int prim = 0;
-	bool hitTri = false, live = false, overflow = false;
-	uint32_t dbg[16] = {};
-	uint32_t head = 0, count = 0; // the ring: wave-uniform
-	SlotSource src;
-	src.init(nLive, P.staticShare, P.ticketChunk, &blockNext);
-	__syncthreads();
-	bool exhausted = (sc.rootRef == kRefDone) || nLive == 0;
-	uint32_t passes = 0;
-
-	// ---- top-up, first half: draw slots and ISSUE the loads (every lane takes part, whatever its own ray is doing).
-	// The loaded record lives in a TopUp object local to ONE pass of the outer loop: declared outside it, the nine
-	// registers would be carried around the whole loop (the compiler cannot see that `got` is zero at the back edge). ----
-	struct TopUp {
-		uint32_t got = 0, slot = 0;
-		float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-		float2 b = make_float2(0.f, 0.f), h = make_float2(0.f, 0.f);
-	};
-	auto top_up_issue = [&](TopUp& tu) {
-		const uint32_t room = (uint32_t)FIFO - count;
-		uint32_t base = 0;
-		tu.got = src.acquire(room < 64u ? room : 64u, base, &blockNext, P.k->extend_chunks, lane);
-		if (tu.got == 0u) {
-			exhausted = true;
-			return;
-		}
-		if (lane < tu.got) {
-			tu.slot = base + lane;
-			tu.a = P.work.o_dx[tu.slot];
-			tu.b = P.work.dyz[tu.slot];
-			tu.h = P.work.hit[tu.slot];
-		}
-	};
-	// ---- second half: 1 / d, the root box, compaction into the ring ----
-	auto top_up_consume = [&](const TopUp& tu) {
-		if (tu.got == 0u)
-			return;
-		bool pass = false;
-		float4 e1 = make_float4(0.f, 0.f, 0.f, 0.f), e2 = e1;
-		if (lane < tu.got) {
-			TYR_DBG(6)
-			const RayConst nr = make_ray(mk3(tu.a.x, tu.a.y, tu.a.z), mk3(tu.a.w, tu.b.x, tu.b.y));
-			// a ray that misses the root box (or is already stopped short of it by a sphere) is finished here: the
-			// pre-pass's answer stands, nothing to write
-			pass = root_ref(sc, nr, tu.h.x) != kRefDone;
-			e1 = make_float4(tu.b.x, tu.b.y, nr.inv.x, nr.inv.y);
-			e2 = make_float4(nr.inv.z, tu.h.x, __uint_as_float(tu.slot), 0.0f);
-		}
-		const unsigned long long m = __ballot(pass);
-		if (pass) {
-			const uint32_t e = (head + count + (uint32_t)__popcll(m & below)) & (uint32_t)(FIFO - 1);
-			ring.plane[0][e] = tu.a;
-			ring.plane[1][e] = e1;
-			ring.plane[2][e] = e2;
-		}
-		count += (uint32_t)__popcll(m);
-		wave_lds_fence();
-	};
-	// ---- retire finished rays, hand prepared ones to the free lanes (inside the descent loop) ----
-	auto retire_and_pop = [&]() {
-		if (live && ref == kRefDone) {
-			// a triangle hit replaces the sphere answer of the pre-pass (kernel.cu:138-140)
-			if (hitTri)
-				P.work.hit[slot] = make_float2(dist, __uint_as_float((uint32_t)prim));
-			overflow = overflow || st.overflow;
-			live = false;
-		}
-		if (count != 0u) {
-			const unsigned long long idleMask = __ballot(!live);
-			const uint32_t nIdle = (uint32_t)__popcll(idleMask);
-			if (nIdle >= (uint32_t)TYR_FEED_POP_MIN) {
-				const uint32_t take = nIdle < count ? nIdle : count;
-				const uint32_t rank = (uint32_t)__popcll(idleMask & below);
-				if (!live && rank < take) {
-					const uint32_t e = (head + rank) & (uint32_t)(FIFO - 1);
-					const float4 a = ring.plane[0][e], b = ring.plane[1][e], c = ring.plane[2][e];
-					rox = a.x, roy = a.y, roz = a.z, rdx = a.w, rdy = b.x, rdz = b.y, rix = b.z, riy = b.w, riz = c.x;
-					dist = c.y;
-					slot = __float_as_uint(c.z);
-					regular = (fabsf(rix) < __builtin_inff()) && (fabsf(riy) < __builtin_inff()) && (fabsf(riz) < __builtin_inff());
-					hitTri = false;
-					st.reset();
-					ref = sc.quadRootRef;
-					live = true;
-				}
-				head = (head + take) & (uint32_t)(FIFO - 1);
-				count -= take;
-				allRegular = (__ballot(live && !regular) == 0ull);
-			}
-		}
-	};
-
-	for (;;) {
-		if (kGuardPasses && ++passes > kMaxPasses)
-			break;
-		// nothing prepared and lanes to feed: a blocking top-up (the start of the launch, and launches whose rays mostly
-		// end at the root box).  Otherwise top-ups ride on the leaf phases below.
-		while (!exhausted && count == 0u) {
-			TopUp tu;
-			top_up_issue(tu);
-			top_up_consume(tu);
-		}
-		retire_and_pop();
-		if (__ballot(live) == 0ull) {
-			if (exhausted && count == 0u)
-				break;
-			continue;
-		}
-		// ---- descent: one pop attempt + one quad test per lane per trip; free lanes are refilled in the same trip ----
-		for (;;) {
-			retire_and_pop();
-			const uint32_t nTrav = (uint32_t)__popcll(lanes_traversing(ref));
-			if (nTrav == 0u)
-				break;
-			// leave for the leaf phase once few lanes are still descending (the others hold leaves: with the refill
-			// inline, a lane is descending, at a leaf, or -- only when the ring is empty -- free)
-			if (nTrav < P.minTraversing && (lanes_at_leaf(ref) != 0ull || (count == 0u && !exhausted)))
-				break;
-			if (kLoopStats) {
-				const unsigned long long mLeaf = lanes_at_leaf(ref), mIdle = __ballot(!live), mDone = __ballot(live && ref == kRefDone);
-				if (lane == 0) {
-					dbg[8] += 1;
-					dbg[9] += __popcll(mLeaf);
-					dbg[10] += __popcll(mIdle);
-					dbg[11] += __popcll(mDone);
-				}
-			}
-			const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
-			if (ref == kRefPop) {
-				TYR_DBG(2)
-				uint32_t pr;
-				float pt;
-				if (st.pop(pr, pt)) {
-					if (pt < dist) // the pop-time half of Bbox.h:61
-						ref = pr;
-					else if (kLoopStats)
-						dbg[12] += 1;
-				} else {
-					ref = kRefDone;
-				}
-			}
-			if ((int)ref >= 0) {
-				TYR_DBG(0)
-				const QuadHits q = allRegular ? test_quad<true, true, true, STAGED>(sc.quads, ref, r, dist, stagedNodes, nStaged) : test_quad<false, true, true, STAGED>(sc.quads, ref, r, dist, stagedNodes, nStaged);
-				const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
-				st.push3(q.hit[3] & any012, q.ref[3], q.t[3], q.hit[2] & any01, q.ref[2], q.t[2], q.hit[1] & q.hit[0], q.ref[1], q.t[1]);
-				ref = lane_in(q.hit[0]) ? q.ref[0] : lane_in(q.hit[1]) ? q.ref[1] : lane_in(q.hit[2]) ? q.ref[2] : lane_in(q.hit[3]) ? q.ref[3] : kRefPop;
-			}
-		}
-		// ---- leaves (bvh.h:129-140), with the next top-up's loads in flight behind the triangle loads ----
-		TopUp tu;
-		if (!exhausted && count <= (uint32_t)(FIFO / 2))
-			top_up_issue(tu);
-		if (ref_is_leaf(ref)) {
-			const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 };
-			const uint32_t off = ref & (kMaxPrimOffset - 1);
-			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
-			TriData tri = triangle_load(sc.tris, off);
-			for (uint32_t i = 0; i < cnt; ++i) {
-				TYR_DBG(4)
-				const TriData cur = tri; // the next primitive of the leaf is on its way while this one is tested
-				if (i + 1 < cnt)
-					tri = triangle_load(sc.tris, off + i + 1);
-				const float t = triangle_test(cur, r);
-				if (t > kEpsilon && t < dist && ((dist - t) > kEpsilon)) {
-					prim = (int)(off + i);
-					dist = t;
-					hitTri = true;
-				}
-			}
-			ref = kRefPop;
-		}
-		top_up_consume(tu);
-	}
-	if (overflow)
-		atomicOr(&P.k->device_error, kErrStackOverflow);
-	if (kGuardPasses && passes > kMaxPasses)
-		atomicOr(&P.k->device_error, kErrNoProgress);
-	if (kLoopStats) {
-		for (int i = 0; i < 16; ++i)
-			wave_add_u64(&P.k->debug[i], dbg[i]);
-	}
-}
-
-template <int STACK_LDS, int FIFO, int STAGED>
-__global__ void __launch_bounds__(kBlock, TYR_FEED_WAVES_PER_EU) k_connect_feed(const FrameParams P) {
-	static_assert((FIFO & (FIFO - 1)) == 0 && FIFO >= 16 && FIFO <= 64, "ring size");
-	TYR_DECLARE_FLAT_STACK(st, false) // any-hit: the bound never shrinks, entries are the reference alone
-	__shared__ float4 stagedNodes[7 * STAGED];
-	__shared__ RayRing<FIFO> rings[kBlock / 64];
-	__shared__ uint32_t blockNext;
-	const uint32_t nStaged = P.scene.nStaged < (uint32_t)STAGED ? P.scene.nStaged : (uint32_t)STAGED;
-	for (uint32_t i = threadIdx.x; i < 7 * nStaged; i += kBlock) {
-		const uint32_t v = i / nStaged, n = i - v * nStaged;
-		stagedNodes[v * STAGED + n] = P.scene.quads[8 * n + v];
-	}
-	const uint32_t lane = lane_id();
-	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t nRays = P.kc->shadow_cnt;
-	const DevScene& sc = P.scene;
-	const bool haveBvh = (sc.rootRef != kRefDone);
-	RayRing<FIFO>& ring = rings[threadIdx.x >> 6];
-	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f;
-	bool regular = true, allRegular = true;
-	float closest = 0.0f;
-	uint32_t ref = kRefDone, index = 0;
-	bool live = false, occluded = false, overflow = false;
-	uint32_t visible = 0;
-	uint32_t head = 0, count = 0;
-	SlotSource src;
-	src.init(nRays, P.staticShare, P.ticketChunk, &blockNext);
-	__syncthreads();
-	bool exhausted = nRays == 0;
-	uint32_t passes = 0;
-	// kernel.cu:640-644, deferred: a lane whose ray came through unoccluded notes the slot; the wave adds all such
-	// colours to their pixels together (loads batched, atomics transposed: accumulate_pixels_wave)
-	constexpr uint32_t kNoPending = 0xffffffffu;
-	uint32_t pendIdx = kNoPending;
-	auto flush_visible = [&]() {
-		float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-		int px = 0;
-		if (pendIdx != kNoPending) {
-			c = P.shadow.color[pendIdx];
-			px = __float_as_int(P.shadow.dyz_cd_ix[pendIdx].w);
-		}
-		accumulate_pixels_wave(P.blit, px, mk3(c.x, c.y, c.z), 0);
-		pendIdx = kNoPending;
-	};
-
-	struct TopUp { // local to one pass of the outer loop (see k_extend_feed)
-		uint32_t got = 0, index = 0;
-		float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
-		float occ = 0.0f;
-	};
-	auto top_up_issue = [&](TopUp& tu) {
-		const uint32_t room = (uint32_t)FIFO - count;
-		uint32_t base = 0;
-		tu.got = src.acquire(room < 64u ? room : 64u, base, &blockNext, P.kc->chunks, lane);
-		if (tu.got == 0u) {
-			exhausted = true;
-			return;
-		}
-		if (lane < tu.got) {
-			tu.index = base + lane;
-			tu.a = P.shadow.o_dx[tu.index];
-			tu.b = P.shadow.dyz_cd_ix[tu.index];
-			tu.occ = reinterpret_cast<const float*>(&P.shadow.color[tu.index])[3]; // the sphere pre-pass's verdict
-		}
-	};
-	auto top_up_consume = [&](const TopUp& tu) {
-		if (tu.got == 0u)
-			return;
-		bool keep = false;
-		float4 e1 = make_float4(0.f, 0.f, 0.f, 0.f), e2 = e1;
-		if (lane < tu.got && tu.occ == 0.0f) { // a ray a sphere already blocks is finished: nothing to add, nothing to trace
-			const RayConst nr = make_ray(mk3(tu.a.x, tu.a.y, tu.a.z), mk3(tu.a.w, tu.b.x, tu.b.y));
-			// misses the tree altogether: unoccluded; goes through the ring with "done" as its first reference so that the
-			// one place that books visible rays stays the retire step
-			const uint32_t start = haveBvh ? (root_ref(sc, nr, tu.b.z) != kRefDone ? sc.quadRootRef : kRefDone) : kRefDone;
-			keep = true;
-			e1 = make_float4(tu.b.x, tu.b.y, nr.inv.x, nr.inv.y);
-			e2 = make_float4(nr.inv.z, tu.b.z, __uint_as_float(tu.index), __uint_as_float(start));
-		}
-		const unsigned long long m = __ballot(keep);
-		if (keep) {
-			const uint32_t e = (head + count + (uint32_t)__popcll(m & below)) & (uint32_t)(FIFO - 1);
-			ring.plane[0][e] = tu.a;
-			ring.plane[1][e] = e1;
-			ring.plane[2][e] = e2;
-		}
-		count += (uint32_t)__popcll(m);
-		wave_lds_fence();
-	};
-	auto retire_and_pop = [&]() {
-		const bool done = live && ref == kRefDone;
-		if (__ballot(done && !occluded && pendIdx != kNoPending) != 0ull)
-			flush_visible(); // some lane's note is still unpaid: settle all of them (wave-wide) before it takes another
-		if (done) {
-			if (!occluded) {
-				pendIdx = index;
-				visible += 1;
-			}
-			overflow = overflow || st.overflow;
-			live = false;
-		}
-		if (count != 0u) {
-			const unsigned long long idleMask = __ballot(!live);
-			const uint32_t nIdle = (uint32_t)__popcll(idleMask);
-			if (nIdle >= (uint32_t)TYR_FEED_POP_MIN) {
-				const uint32_t take = nIdle < count ? nIdle : count;
-				const uint32_t rank = (uint32_t)__popcll(idleMask & below);
-				if (!live && rank < take) {
-					const uint32_t e = (head + rank) & (uint32_t)(FIFO - 1);
-					const float4 a = ring.plane[0][e], b = ring.plane[1][e], c = ring.plane[2][e];
-					rox = a.x, roy = a.y, roz = a.z, rdx = a.w, rdy = b.x, rdz = b.y, rix = b.z, riy = b.w, riz = c.x;
-					closest = c.y;
-					index = __float_as_uint(c.z);
-					regular = (fabsf(rix) < __builtin_inff()) && (fabsf(riy) < __builtin_inff()) && (fabsf(riz) < __builtin_inff());
-					occluded = false;
-					st.reset();
-					ref = __float_as_uint(c.w);
-					live = true;
-				}
-				head = (head + take) & (uint32_t)(FIFO - 1);
-				count -= take;
-				allRegular = (__ballot(live && !regular) == 0ull);
-			}
-		}
-	};
-
-	for (;;) {
-		if (kGuardPasses && ++passes > kMaxPasses)
-			break;
-		while (!exhausted && count == 0u) {
-			TopUp tu;
-			top_up_issue(tu);
-			top_up_consume(tu);
-		}
-		retire_and_pop();
-		if (__ballot(live) == 0ull) {
-			if (exhausted && count == 0u)
-				break;
-			continue;
-		}
-		for (;;) {
-			retire_and_pop();
-			const uint32_t nTrav = (uint32_t)__popcll(lanes_traversing(ref));
-			if (nTrav == 0u)
-				break;
-			if (nTrav < P.minTraversing && (lanes_at_leaf(ref) != 0ull || (count == 0u && !exhausted)))
-				break;
-			const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 };
-			if (ref == kRefPop) {
-				uint32_t pr;
-				float pt;
-				if (st.pop(pr, pt))
-					ref = pr; // (entries carry no distance: the bound of an any-hit query never shrinks)
-				else
-					ref = kRefDone;
-			}
-			if ((int)ref >= 0) {
-				const QuadHits q = allRegular ? test_quad<true, TYR_CONNECT_ORDERED, true, STAGED>(sc.quads, ref, r, closest, stagedNodes, nStaged) : test_quad<false, TYR_CONNECT_ORDERED, true, STAGED>(sc.quads, ref, r, closest, stagedNodes, nStaged);
-				const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
-				st.push3(q.hit[3] & any012, q.ref[3], q.t[3], q.hit[2] & any01, q.ref[2], q.t[2], q.hit[1] & q.hit[0], q.ref[1], q.t[1]);
-				ref = lane_in(q.hit[0]) ? q.ref[0] : lane_in(q.hit[1]) ? q.ref[1] : lane_in(q.hit[2]) ? q.ref[2] : lane_in(q.hit[3]) ? q.ref[3] : kRefPop;
-			}
-		}
-		TopUp tu;
-		if (!exhausted && count <= (uint32_t)(FIFO / 2))
-			top_up_issue(tu);
-		if (ref_is_leaf(ref)) {
-			const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 };
-			const uint32_t off = ref & (kMaxPrimOffset - 1);
-			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
-			bool found = false;
-			TriData tri = triangle_load(sc.tris, off);
-			for (uint32_t i = 0; i < cnt && !found; ++i) {
-				const TriData cur = tri;
-				if (i + 1 < cnt)
-					tri = triangle_load(sc.tris, off + i + 1);
-				const float t = triangle_test(cur, r);
-				found = (t > kEpsilon && ((closest - t) > kEpsilon)); // bvh.h:232-236
-			}
-			if (found) {
-				occluded = true;
-				ref = kRefDone;
-			} else {
-				ref = kRefPop;
-			}
-		}
-		top_up_consume(tu);
-	}
-	flush_visible();
-	if (overflow)
-		atomicOr(&P.k->device_error, kErrStackOverflow);
-	if (kGuardPasses && passes > kMaxPasses)
-		atomicOr(&P.k->device_error, kErrNoProgress);
-	wave_add_u64(&P.k->n_shadow_visible, visible);
-}
-#endif // TYR_DIAG (variant 5)
 #undef TYR_DBG
 
 
-template <bool COUNT, int STACK_LDS>
-static void launch_extend_t(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
-	launch_extend_spheres(P, nSurvivors, stream);
-	const uint32_t flatBlocks = (maxLive + P.raysPerBlock - 1) / P.raysPerBlock;
-	if (COUNT) {
-		// pair nodes: the only layout that reproduces the reference's visit counts (bvh.h:164-209)
-		hipLaunchKernelGGL((k_extend_flat<true, STACK_LDS, false, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
-		return;
-	}
-#ifdef TYR_DIAG
-	if (t.traversalVariant == 3) {
-		hipLaunchKernelGGL((k_extend_flat<false, STACK_LDS, true, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
-		return;
-	}
-	if (t.traversalVariant == 2) {
-		hipLaunchKernelGGL((k_extend_flat<false, STACK_LDS, false, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
-		return;
-	}
-#endif
-#ifdef TYR_DIAG
-	if (t.traversalVariant == 5) {
-		hipLaunchKernelGGL((k_extend_feed<TYR_FEED_STACK, TYR_FEED_FIFO, TYR_FEED_STAGED>), dim3(persistent_blocks(k_extend_feed<TYR_FEED_STACK, TYR_FEED_FIFO, TYR_FEED_STAGED>, maxLive, t, numCUs, lc.perCU[kLcExtendFeed][0])),
-			dim3(kBlock), 0, stream, P);
-		return;
-	}
-#endif
-	hipLaunchKernelGGL((k_extend_flat<false, STACK_LDS, true, true>), dim3(persistent_blocks(k_extend_flat<false, STACK_LDS, true, true>, maxLive, t, numCUs, lc.perCU[kLcExtend][stack_slot(STACK_LDS)])), dim3(kBlock), 0, stream, P);
-}
-template <bool COUNT, int STACK_LDS>
-static void launch_connect_t(const FrameParams& P, uint32_t maxShadow, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
-	launch_connect_spheres(P, maxShadow, stream);
-	const uint32_t flatBlocks = (maxShadow + P.raysPerBlock - 1) / P.raysPerBlock;
-	if (COUNT) {
-		hipLaunchKernelGGL((k_connect_flat<true, STACK_LDS, false, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
-		return;
-	}
-#ifdef TYR_DIAG
-	if (t.traversalVariant == 3) {
-		hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, true, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
-		return;
-	}
-	if (t.traversalVariant == 2) {
-		hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, false, false>), dim3(flatBlocks), dim3(kBlock), 0, stream, P);
-		return;
-	}
-#endif
-#ifdef TYR_DIAG
-	if (t.traversalVariant == 5) {
-		hipLaunchKernelGGL((k_connect_feed<TYR_FEED_STACK, TYR_FEED_FIFO, TYR_FEED_STAGED>), dim3(persistent_blocks(k_connect_feed<TYR_FEED_STACK, TYR_FEED_FIFO, TYR_FEED_STAGED>, maxShadow, t, numCUs, lc.perCU[kLcConnectFeed][0])),
-			dim3(kBlock), 0, stream, P);
-		return;
-	}
-#endif
-	hipLaunchKernelGGL((k_connect_flat<false, STACK_LDS, true, true>), dim3(persistent_blocks(k_connect_flat<false, STACK_LDS, true, true>, maxShadow, t, numCUs, lc.perCU[kLcConnect][stack_slot(STACK_LDS)])), dim3(kBlock), 0, stream, P);
-}
-
-// The stack depths that are compiled in.  The shipped library has the production depth only (12 entries per lane in
-// LDS, the rest in scratch); the diagnostics build keeps the others selectable (TYR_TUNE_STACK_LDS_DEPTH).
-#ifdef TYR_DIAG
-#define TYR_DISPATCH_STACK(FN, COUNT, ...)          \
-	switch (t.stackLdsDepth) {                      \
-	case 0: FN<COUNT, 0>(__VA_ARGS__); break;       \
-	case 8: FN<COUNT, 8>(__VA_ARGS__); break;       \
-	case 10: FN<COUNT, 10>(__VA_ARGS__); break;     \
-	case 16: FN<COUNT, 16>(__VA_ARGS__); break;     \
-	case 24: FN<COUNT, 24>(__VA_ARGS__); break;     \
-	default: FN<COUNT, 12>(__VA_ARGS__); break;     \
-	}
-#else
-#define TYR_DISPATCH_STACK(FN, COUNT, ...) FN<COUNT, 12>(__VA_ARGS__);
-#endif
-
-// extend of this iteration + connect of the previous one in one launch (tyr_render; production traversal only).
-// P.kc must be this iteration's set, P.kcPrev the previous iteration's (its shadow rays are still in the shadow queue).
+// extend of this iteration + connect of the previous one in one launch.  P.kc must be this iteration's set, P.kcPrev the
+// set of the iteration whose shadow rays ride along (P.traceShadow: 0 none, 1 beside the extend rays, 2 they are all of it).
 #ifndef TYR_TRACE_STACK
 #define TYR_TRACE_STACK 12 // LDS stack entries per lane of k_trace_flat (a what-if build may pair 8 with TYR_FLAT_WAVES_PER_EU=6)
 #endif
 void launch_trace(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, uint32_t maxShadowPrev, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
-	launch_extend_spheres(P, nSurvivors, stream);
+	if (P.traceShadow != 2u)
+		launch_extend_spheres(P, nSurvivors, stream);
 	if (maxShadowPrev != 0) {
 		FrameParams Pc = P;
-		Pc.kc = P.kcPrev; // the sphere pre-pass of the shadow rays reads its count there
+		Pc.kc = P.kcPrev; // the sphere pre-pass of the shadow rays reads its counts there
 		launch_connect_spheres(Pc, maxShadowPrev, stream);
 	}
 	const uint32_t items = maxLive + maxShadowPrev;
 	hipLaunchKernelGGL((k_trace_flat<TYR_TRACE_STACK>), dim3(persistent_blocks(k_trace_flat<TYR_TRACE_STACK>, items, t, numCUs, lc.perCU[kLcTrace][0])), dim3(kBlock), 0, stream, P);
 }
 
-void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
+// extend / connect as launches of their own (the stage API, tyr_launch_kernels): the same kernel with one kind of ray;
+// the counting build (TYR_FLAG_COUNT_VISITS) traverses pair nodes, the only layout that reproduces the reference's
+// visit counts (bvh.h:164-209), one block per kCountRaysPerBlock slots of the queue's capacity.
+void launch_extend(const FrameParams& P0, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
 	if (maxLive == 0)
 		return;
-#ifdef TYR_DIAG
-	if (t.traversalVariant <= 1) {
-		launch_extend_diag(P, maxLive, nSurvivors, countVisits, t, numCUs, lc, stream);
+	FrameParams P = P0;
+	if (countVisits) {
+		launch_extend_spheres(P, nSurvivors, stream);
+		P.raysPerBlock = kCountRaysPerBlock;
+		const uint32_t blocks = (P.segCap * kSegs + kCountRaysPerBlock - 1) / kCountRaysPerBlock; // every physical slot a record could lie in
+		hipLaunchKernelGGL((k_extend_flat<true, 12, false, false>), dim3(blocks), dim3(kBlock), 0, stream, P);
 		return;
 	}
-#endif
-	if (countVisits) {
-		TYR_DISPATCH_STACK(launch_extend_t, true, P, maxLive, nSurvivors, t, numCUs, lc, stream)
-	} else {
-		TYR_DISPATCH_STACK(launch_extend_t, false, P, maxLive, nSurvivors, t, numCUs, lc, stream)
-	}
+	P.traceShadow = 0u;
+	launch_trace(P, maxLive, nSurvivors, 0u, t, numCUs, lc, stream);
 }
-void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
+void launch_connect(const FrameParams& P0, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
 	if (maxShadow == 0)
 		return;
-#ifdef TYR_DIAG
-	if (t.traversalVariant <= 1) {
-		launch_connect_diag(P, maxShadow, countVisits, t, numCUs, lc, stream);
+	FrameParams P = P0;
+	if (countVisits) {
+		launch_connect_spheres(P, maxShadow, stream);
+		P.raysPerBlock = kCountRaysPerBlock;
+		const uint32_t blocks = (P.segCap * kSegs + kCountRaysPerBlock - 1) / kCountRaysPerBlock;
+		hipLaunchKernelGGL((k_connect_flat<true, 12, false, false>), dim3(blocks), dim3(kBlock), 0, stream, P);
 		return;
 	}
-#endif
-	if (countVisits) {
-		TYR_DISPATCH_STACK(launch_connect_t, true, P, maxShadow, t, numCUs, lc, stream)
-	} else {
-		TYR_DISPATCH_STACK(launch_connect_t, false, P, maxShadow, t, numCUs, lc, stream)
-	}
+	P.kcPrev = P.kc; // the rays of THIS iteration's shadow queue
+	P.traceShadow = 2u;
+	launch_trace(P, 0u, 0u, maxShadow, t, numCUs, lc, stream);
 }
 
 } // namespace tyr

@@ -30,12 +30,10 @@ struct tyr_ctx {
 	hipEvent_t evSnap[2] = { nullptr, nullptr };
 	ConnectCounters* dKc = nullptr; // two sets, iteration i uses set i & 1
 	uint32_t iter = 0;
+	uint32_t shadowSet = 0; // which of the two sets holds the counts of the shadow queue's current content (tyr_shadow_export)
 
-	// tyr_render only: connect(i) runs on `side` while the host already reads shade(i)'s counts and `stream` runs
-	// primary / extend of iteration i + 1; shade(i + 1) waits for it (it rewrites the shadow queue)
-	hipStream_t side = nullptr;
-	hipEvent_t evShadeDone = nullptr, evConnectDone = nullptr, evSnapshot = nullptr;
-	bool connectPending = false;
+	hipStream_t side = nullptr; // second stream of a ctx (shade launches that run beside the traversal)
+	hipEvent_t evSnapshot = nullptr;
 	// tyr_render with TYR_TUNE_MERGE_TRACE: the shadow rays of the last shaded iteration have not been traced yet (they
 	// ride in the next iteration's trace launch, or in a connect of their own when the render ends)
 	bool shadowPending = false;
@@ -44,10 +42,12 @@ struct tyr_ctx {
 	// counters get back what that iteration's set_wavefront_globals zeroed (the live and shadow counts of the last real one)
 	bool runAheadUndo = false;
 	uint32_t undoLive = 0, undoShadows = 0;
-	hipEvent_t evSide[2][2]{}; // TYR_FLAG_PROFILE: connect's start / stop on `side`, per set
-	bool evSideUsed[2]{};
-	unsigned long long* scanDesc = nullptr;
-	uint32_t nDescCap = 0;
+	// hip/kernels.hpp "Queues": room per queue segment, the survive bytes and the two sets of scan tables
+	uint32_t segCap = 0;
+	uint8_t* survFlag = nullptr;
+	unsigned long long* vWord[2] = { nullptr, nullptr };
+	uint32_t* vPre[2] = { nullptr, nullptr };
+	uint32_t* vBlk[2] = { nullptr, nullptr };
 	float4* blit = nullptr;
 	bool ownBlit = false;
 

@@ -63,6 +63,8 @@ int alloc_rayq(RayQ& q, size_t n) {
 		return rc;
 	if ((rc = dev_alloc(q.hit, n)))
 		return rc;
+	if ((rc = dev_alloc(q.key, n)))
+		return rc;
 	return TYR_OK;
 }
 void free_rayq(RayQ& q) {
@@ -71,6 +73,7 @@ void free_rayq(RayQ& q) {
 	dev_free(q.direct_ix);
 	dev_free(q.flags);
 	dev_free(q.hit);
+	dev_free(q.key);
 }
 
 void default_spheres(tyr_sphere* s) {
@@ -114,17 +117,7 @@ int push_counters(tyr_ctx* c) {
 	return TYR_OK;
 }
 
-// rays owned by one block of the flat traversal kernels: the tuned value while that still gives every CU
-// several blocks, smaller (down to one wave-load per wave) for the thin queues of the drain iterations
-uint32_t rays_per_block_for(const tyr_ctx* c, uint32_t nRays) {
-	uint32_t rpb = static_cast<uint32_t>(std::min(std::max(c->tuning.raysPerBlock, 256), 65536));
-	const uint64_t wanted = static_cast<uint64_t>(c->numCUs) * 8; // blocks needed to keep every CU busy with latency hidden
-	while (rpb > 256 && (nRays + rpb - 1) / rpb < wanted)
-		rpb /= 2;
-	return std::max<uint32_t>(rpb, 256);
-}
-
-constexpr uint32_t kOverlapMaxLive = 6u << 20; // TYR_TUNE_OVERLAP_CONNECT = 2: queues of up to this many slots run connect on the side stream
+constexpr uint32_t kRunAheadMaxLive = 6u << 20; // TYR_TUNE_RUN_AHEAD = 2: queues of up to this many slots run one iteration ahead of the counts
 
 FrameParams make_params(const tyr_ctx* c) {
 	FrameParams P{};
@@ -154,11 +147,21 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.k = c->dK;
 	P.kc = c->dKc + (c->iter & 1u);
 	P.kcPrev = c->dKc + ((c->iter ^ 1u) & 1u);
-	P.scanDesc = c->scanDesc;
+	P.segWork = &c->dK->seg[c->cur][0];
+	P.segNext = &c->dK->seg[c->cur ^ 1][0];
+	P.segCap = c->segCap;
+	P.survFlag = c->survFlag;
+	{
+		const int out = static_cast<int>(c->iter & 1u), prev = out ^ 1;
+		P.vPrev = tyr::VTable{ c->vWord[prev], c->vPre[prev], c->vBlk[prev] };
+		P.vWordOut = c->vWord[out];
+		P.vPreOut = c->vPre[out];
+		P.vBlkOut = c->vBlk[out];
+	}
 	P.refillMinIdle = static_cast<uint32_t>(std::min(std::max(c->tuning.refillMinIdle, 1), 64));
 	P.minTraversing = static_cast<uint32_t>(std::min(std::max(c->tuning.minTraversing, 1), 64));
 	P.ticketChunk = static_cast<uint32_t>(std::min(std::max(c->tuning.ticketChunk, 64), 65536));
-	P.raysPerBlock = static_cast<uint32_t>(std::min(std::max(c->tuning.raysPerBlock, 256), 65536));
+	P.raysPerBlock = tyr::kCountRaysPerBlock;
 	P.staticShare = static_cast<uint32_t>(std::min(std::max(c->tuning.staticShare, 0), 15));
 	P.staticInterleave = c->tuning.staticInterleave ? 1u : 0u;
 	P.wideDrain = c->tuning.wideDrain ? 1u : 0u;
@@ -205,33 +208,6 @@ void collect_timings(tyr_ctx* c) {
 	collect_timings_of(c, 1);
 }
 
-// connect launches timed on the side stream: fold the pairs that have finished (all of them when `wait`)
-void collect_side_timings(tyr_ctx* c, bool wait) {
-	for (int p = 0; p < 2; ++p) {
-		if (!c->evSideUsed[p])
-			continue;
-		if (wait)
-			(void)hipEventSynchronize(c->evSide[p][1]);
-		else if (hipEventQuery(c->evSide[p][1]) != hipSuccess)
-			continue;
-		float ms = 0.0f;
-		if (hipEventElapsedTime(&ms, c->evSide[p][0], c->evSide[p][1]) == hipSuccess) {
-			c->timings.ms[TYR_K_CONNECT] += ms;
-			c->timings.launches[TYR_K_CONNECT] += 1;
-		}
-		c->evSideUsed[p] = false;
-	}
-}
-
-// `stream` takes over again: whatever follows on it sees the deferred connect's results
-int join_connect(tyr_ctx* c) {
-	if (c->connectPending) {
-		HIPCHK(hipStreamWaitEvent(c->stream, c->evConnectDone, 0));
-		c->connectPending = false;
-	}
-	return TYR_OK;
-}
-
 uint32_t planned_new(const tyr_ctx* c) {
 	const uint64_t room = c->cfg.queue_size - c->hK->primary_ray_cnt;
 	const uint64_t budget = c->hK->budget_remaining;
@@ -264,34 +240,33 @@ int stage_begin(tyr_ctx* c) {
 		sun_setup(c->sunPos[0], c->sunPos[1], c->sun);
 	}
 	if (reset) { // kernel.cu:712-718
-		int rcj = join_connect(c);
-		if (rcj)
-			return rcj;
 		HIPCHK(hipMemsetAsync(c->blit, 0, sizeof(float4) * static_cast<size_t>(c->cfg.width) * c->cfg.height, c->stream));
 		c->hK->primary_ray_cnt = 0;
 		HIPCHK(hipMemcpyAsync(&c->dK->primary_ray_cnt, &c->hK->primary_ray_cnt, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		// ... and with it the survivors in the work queue (the next top-up regenerates all N slots, quirk 16)
+		std::memset(&c->hK->seg[c->cur][0], 0, sizeof c->hK->seg[0]);
+		HIPCHK(hipMemsetAsync(&c->dK->seg[c->cur][0], 0, sizeof c->dK->seg[0], c->stream));
 	}
 	return TYR_OK;
 }
 
-// enqueue one stage; the host mirror hK must be current for the sizes used here
-void enqueue_primary(tyr_ctx* c, const FrameParams& P, uint32_t nNew, uint32_t nLive) {
+// enqueue one stage; the host mirror hK must be current for the sizes used here (upper bounds will do: every kernel takes
+// its counts from the device)
+void enqueue_primary(tyr_ctx* c, const FrameParams& P, uint32_t nNew) {
 	{
 		KernelTimer t(c, TYR_K_PRIMARY);
 		launch_primary(P, nNew, c->stream);
 	}
-	launch_globals(P, std::min<uint32_t>(c->nDescCap, (nLive + kBlock - 1) / kBlock + 8), c->stream);
+	launch_globals(P, c->stream);
 }
-// nSurvivors: how many of the nLive slots were in the queue before this iteration's primary rays (they still need
-// their sphere pre-pass; an upper bound is fine, the kernel checks against the device's count)
-void enqueue_extend(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t nSurvivors) {
+// nSurvivors: how many of the nLive rays were in the queue before this iteration's primary rays (they still need their
+// sphere pre-pass)
+void enqueue_extend(tyr_ctx* c, const FrameParams& P, uint32_t nLive, uint32_t nSurvivors) {
 	KernelTimer t(c, TYR_K_EXTEND);
 	if (c->cfg.flags & TYR_FLAG_DEBUG_BVH) { // the reference's BVH_DEBUG build: kernel.cu:721-722
-		launch_extend_debug(P0, nLive, c->stream);
+		launch_extend_debug(P, c->segCap * tyr::kSegs, c->stream);
 		return;
 	}
-	FrameParams P = P0;
-	P.raysPerBlock = rays_per_block_for(c, nLive);
 	launch_extend(P, nLive, nSurvivors, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, c->stream);
 }
 // extend of this iteration and connect of the previous one in one launch (tyr_render, TYR_TUNE_MERGE_TRACE)
@@ -301,65 +276,28 @@ void enqueue_trace(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t n
 	KernelTimer t(c, TYR_K_EXTEND);
 	launch_trace(P, nLive, nSurvivors, maxShadowPrev, c->tuning, c->numCUs, c->launchCache, c->stream);
 }
+// shade, then the scan that turns its survive bytes into the next iteration's slots
 void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
+	c->shadowSet = c->iter & 1u;
 	KernelTimer t(c, TYR_K_SHADE);
 	launch_shade(P, nLive, c->numCUs, c->launchCache, c->stream);
+	launch_scan(P, nLive, c->stream);
 }
-void enqueue_connect(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow) {
+void enqueue_connect(tyr_ctx* c, const FrameParams& P, uint32_t maxShadow) {
 	KernelTimer t(c, TYR_K_CONNECT);
-	FrameParams P = P0;
-	P.raysPerBlock = rays_per_block_for(c, maxShadow);
 	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, c->stream);
 }
-// Inside tyr_render the host does not wait for connect: shade's counts are all it needs to launch the next
-// iteration (connect only adds to pixels), so connect goes out either on the side stream (onSide: beside the next
-// iteration's primary / extend) or on `stream` behind a snapshot of the counters -- the host reads the snapshot and
-// queues iteration i + 1 while connect(i) runs, and the stream never runs dry (45 us per iteration otherwise).
-// Its hipEvent pair alternates between two sets, folded into the timings once they have completed.
-int enqueue_connect_unwaited(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow, bool onSide) {
-	hipStream_t s = onSide ? c->side : c->stream;
-	if (onSide) {
-		HIPCHK(hipEventRecord(c->evShadeDone, c->stream));
-		HIPCHK(hipStreamWaitEvent(c->side, c->evShadeDone, 0));
-	}
-	const bool timed = (c->cfg.flags & TYR_FLAG_PROFILE) != 0 && ((c->tuning.profileMask >> TYR_K_CONNECT) & 1) != 0;
-	const int set = static_cast<int>(c->iter & 1u);
-	if (timed) {
-		if (c->evSideUsed[set]) // connect(i - 2): shade(i - 1) ran after it and the host has seen shade(i - 1)'s counts
-			collect_side_timings(c, true);
-		HIPCHK(hipEventRecord(c->evSide[set][0], s));
-	}
-	FrameParams P = P0;
-	P.raysPerBlock = rays_per_block_for(c, maxShadow);
-	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, s);
-	if (timed) {
-		HIPCHK(hipEventRecord(c->evSide[set][1], s));
-		c->evSideUsed[set] = true;
-	}
-	if (onSide) {
-		HIPCHK(hipEventRecord(c->evConnectDone, c->side));
-		c->connectPending = true;
-	}
-	return TYR_OK;
-}
 
-void enqueue_connect(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow);
-// the shadow rays a merged render still owes (those of the last shaded iteration): a connect launch of their own
+bool merged_render(const tyr_ctx* c) { return c->tuning.mergeTrace != 0 && !(c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) && c->scene.rootRef != tyr::kRefDone; }
+
+// the shadow rays a merged render still owes (those of the last shaded iteration): a launch of their own
 int flush_pending_shadow(tyr_ctx* c) {
 	if (!c->shadowPending)
 		return TYR_OK;
 	c->shadowPending = false;
 	FrameParams P = make_params(c);
-	if (c->tuning.mergeTrace != 0 && c->tuning.traversalVariant == 4 && !(c->cfg.flags & TYR_FLAG_COUNT_VISITS)) {
-		// the same kernel as every other traversal launch of a merged render, with no extend rays: kcPrev (stage_end has
-		// advanced `iter`) is the set the rays belong to
-		P.traceShadow = 2u;
-		KernelTimer t(c, TYR_K_CONNECT);
-		launch_trace(P, 0u, 0u, c->shadowPendingMax, c->tuning, c->numCUs, c->launchCache, c->stream);
-	} else {
-		P.kc = P.kcPrev; // stage_end has advanced `iter`: the rays belong to the previous iteration's counter set
-		enqueue_connect(c, P, c->shadowPendingMax);
-	}
+	P.kc = P.kcPrev; // stage_end has advanced `iter`: the rays belong to the previous iteration's counter set
+	enqueue_connect(c, P, c->shadowPendingMax);
 	HIPCHK(hipGetLastError());
 	return TYR_OK;
 }
@@ -380,32 +318,46 @@ void stage_end(tyr_ctx* c) {
 int check_device_error(const tyr_ctx* c) {
 	if (!c->hK->device_error)
 		return TYR_OK;
-	if (std::getenv("TYR_VERBOSE")) {
-		std::fprintf(stderr, "[tyrant] device_error bits 0x%x (1 = traversal stack overflow, 2 = compaction look-back timeout, 4 = a traversal wave made no progress); n_live %u\n", c->hK->device_error, c->hK->n_live);
-		// state of the compaction descriptors of the failed launch
-		std::vector<unsigned long long> d(c->nDescCap);
-		DevCounters k;
-		if (hipMemcpy(d.data(), c->scanDesc, d.size() * 8, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(&k, c->dK, sizeof k, hipMemcpyDeviceToHost) == hipSuccess) {
-			const uint32_t nTiles = (c->hK->n_live + kBlock - 1) / kBlock;
-			uint32_t cnt[4] = { 0, 0, 0, 0 };
-			int firstEmpty = -1, firstAgg = -1;
-			for (uint32_t i = 0; i < nTiles && i < d.size(); ++i) {
-				const uint32_t st = static_cast<uint32_t>(d[i] >> 62);
-				++cnt[st];
-				if (st == 0 && firstEmpty < 0)
-					firstEmpty = static_cast<int>(i);
-				if (st == 1 && firstAgg < 0)
-					firstAgg = static_cast<int>(i);
-			}
-			std::fprintf(stderr, "[tyrant] %u tiles: %u unpublished, %u aggregate only, %u inclusive; first unpublished %d, first aggregate-only %d; tile tickets", nTiles, cnt[0], cnt[1], cnt[2], firstEmpty, firstAgg);
-			for (uint32_t w = 0; w < kTicketWords; ++w)
-				std::fprintf(stderr, " %u", k.shade_tiles[w * 32]);
-			std::fprintf(stderr, "\n[tyrant] last timed-out wait: tile %llu waited for tile %llu (block %llu of %llu) for %.3f ms\n", k.debug[0], k.debug[1], k.debug[2], k.debug[3], k.debug[4] / 1e5);
-		}
-	}
+	if (std::getenv("TYR_VERBOSE"))
+		std::fprintf(stderr, "[tyrant] device_error bits 0x%x (1 = traversal stack overflow, 4 = a traversal wave made no progress, 8 = a queue segment overflowed); n_live %u\n", c->hK->device_error, c->hK->n_live);
 	return TYR_ERR_DEVICE;
 }
 
+} // namespace
+
+namespace {
+// physical slots that hold a record, per segment counter array `seg` (device pointer)
+int valid_slots(const uint32_t* dSeg, std::vector<uint32_t>& slots, uint32_t* total = nullptr) {
+	uint32_t cnt[tyr::kSegs * tyr::kSegStride];
+	HIPCHK(hipMemcpy(cnt, dSeg, sizeof cnt, hipMemcpyDeviceToHost));
+	slots.clear();
+	uint32_t n = 0;
+	for (uint32_t w = 0; w < tyr::kSegs; ++w) {
+		const uint32_t c = cnt[w * tyr::kSegStride];
+		n += c;
+		for (uint32_t j = 0; j < c; ++j)
+			slots.push_back(((((j >> 6) * tyr::kSegs) + w) << 6) | (j & 63u));
+	}
+	if (total)
+		*total = n;
+	return TYR_OK;
+}
+// dense layout of n records: record i in physical slot i (chunk i / 64 belongs to segment (i / 64) % 8)
+void dense_counts(uint32_t n, uint32_t* cnt /* [kSegs * kSegStride] */) {
+	std::memset(cnt, 0, sizeof(uint32_t) * tyr::kSegs * tyr::kSegStride);
+	for (uint32_t chunk = 0; chunk * 64u < n; ++chunk)
+		cnt[(chunk % tyr::kSegs) * tyr::kSegStride] += std::min<uint32_t>(64u, n - chunk * 64u);
+}
+template <class T>
+int gather(const T* dev, const std::vector<uint32_t>& slots, uint32_t extent, std::vector<T>& out) {
+	std::vector<T> all(extent);
+	if (extent)
+		HIPCHK(hipMemcpy(all.data(), dev, extent * sizeof(T), hipMemcpyDeviceToHost));
+	out.resize(slots.size());
+	for (size_t i = 0; i < slots.size(); ++i)
+		out[i] = all[slots[i]];
+	return TYR_OK;
+}
 } // namespace
 
 extern "C" {
@@ -418,7 +370,7 @@ const char* tyr_status_string(int status) {
 	case TYR_ERR_NO_SCENE: return "no scene uploaded";
 	case TYR_ERR_NO_BUFFER: return "no blit_buffer bound";
 	case TYR_ERR_OOM: return "out of device memory";
-	case TYR_ERR_DEVICE: return "device-side error (a render: traversal stack overflow, compaction timeout or a stuck traversal wave; tyr_dist_*: an RCCL call failed -- TYR_VERBOSE=1 prints which)";
+	case TYR_ERR_DEVICE: return "device-side error (a render: traversal stack overflow, a queue segment out of room or a stuck traversal wave; tyr_dist_*: an RCCL call failed -- TYR_VERBOSE=1 prints which)";
 	case TYR_ERR_UNSUPPORTED: return "unsupported";
 	case TYR_ERR_IO: return "file I/O error";
 	default: return status > 0 ? hipGetErrorString(static_cast<hipError_t>(status)) : "unknown status";
@@ -433,7 +385,7 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 	*out = nullptr;
 	if (cfg->width == 0 || cfg->height == 0 || cfg->queue_size == 0 || cfg->nranks == 0 || cfg->rank >= cfg->nranks || (cfg->height % cfg->nranks) != 0)
 		return TYR_ERR_INVALID;
-	if (static_cast<uint64_t>(cfg->width) * cfg->height >= (1ull << 31) || cfg->queue_size >= (1u << 31))
+	if (static_cast<uint64_t>(cfg->width) * cfg->height >= (1ull << 31) || cfg->queue_size >= (1u << 30))
 		return TYR_ERR_INVALID;
 	if ((cfg->flags & (TYR_FLAG_LIGHT_LIST | TYR_FLAG_TRIANGLE_COLORS)) && !(cfg->flags & TYR_FLAG_TRIANGLE_MATERIALS))
 		return TYR_ERR_INVALID; // an emissive or coloured triangle is a triangle material
@@ -471,12 +423,26 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		c->ownStream = true;
 	}
 	const size_t N = cfg->queue_size;
-	if ((rc = alloc_rayq(c->q[0], N)) || (rc = alloc_rayq(c->q[1], N)))
+	// a queue is eight segments (hip/kernels.hpp "Queues"): tiles are dealt to them round-robin, so each holds an eighth of
+	// the records give or take the tiles' luck; half as much again is room no render has come near (a segment that does
+	// run out reports kErrQueueOverflow, it never writes past its end)
+	c->segCap = static_cast<uint32_t>(((N / 8 + N / 16 + 2048) + 63) & ~size_t(63));
+	const size_t cap = static_cast<size_t>(c->segCap) * tyr::kSegs;
+	if ((rc = alloc_rayq(c->q[0], cap)) || (rc = alloc_rayq(c->q[1], cap)))
 		return fail(rc);
-	if ((rc = dev_alloc(c->shadow.o_dx, N)) || (rc = dev_alloc(c->shadow.dyz_cd_ix, N)) || (rc = dev_alloc(c->shadow.color, N)))
+	if ((rc = dev_alloc(c->shadow.o_dx, cap)) || (rc = dev_alloc(c->shadow.dyz_cd_ix, cap)) || (rc = dev_alloc(c->shadow.color, cap)) || (rc = dev_alloc(c->shadow.key, cap)))
 		return fail(rc);
-	c->nDescCap = static_cast<uint32_t>((N + kBlock - 1) / kBlock) + 8; // k_shade rounds the tile count up to its group size
-	if ((rc = dev_alloc(c->scanDesc, c->nDescCap)) || (rc = dev_alloc(c->dK, 1)) || (rc = dev_alloc(c->dKc, 2)))
+	// one survive byte per virtual slot, and the two sets of scan tables made from them (iteration i writes set i & 1)
+	const size_t entries = (N + 63) / 64 + kBlock, blocks = (N + 16383) / 16384 + 1;
+	if ((rc = dev_alloc(c->survFlag, N + 64)))
+		return fail(rc);
+	for (int t = 0; t < 2; ++t) {
+		if ((rc = dev_alloc(c->vWord[t], entries)) || (rc = dev_alloc(c->vPre[t], entries)) || (rc = dev_alloc(c->vBlk[t], blocks)))
+			return fail(rc);
+		if (hipMemset(c->vWord[t], 0, entries * 8) != hipSuccess || hipMemset(c->vPre[t], 0, entries * 4) != hipSuccess || hipMemset(c->vBlk[t], 0, blocks * 4) != hipSuccess)
+			return fail(TYR_ERR_NO_DEVICE);
+	}
+	if ((rc = dev_alloc(c->dK, 1)) || (rc = dev_alloc(c->dKc, 2)))
 		return fail(rc);
 	if (hipMemset(c->dKc, 0, 2 * sizeof(ConnectCounters)) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
@@ -494,13 +460,8 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		if (hipMemcpy(c->dPalette, pal.data(), pal.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
 			return fail(TYR_ERR_NO_DEVICE);
 	}
-	if (hipEventCreateWithFlags(&c->evShadeDone, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evConnectDone, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&c->evSnapshot, hipEventDisableTiming) != hipSuccess)
+	if (hipEventCreateWithFlags(&c->evSnapshot, hipEventDisableTiming) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
-	for (auto& pair : c->evSide)
-		for (auto& e : pair)
-			if (hipEventCreate(&e) != hipSuccess)
-				return fail(TYR_ERR_NO_DEVICE);
 	if (hipHostMalloc(reinterpret_cast<void**>(&c->hK), sizeof(DevCounters), hipHostMallocDefault) != hipSuccess)
 		return fail(TYR_ERR_OOM);
 	std::memset(c->hK, 0, sizeof(DevCounters));
@@ -536,7 +497,13 @@ int tyr_destroy(tyr_ctx* c) {
 	dev_free(c->shadow.o_dx);
 	dev_free(c->shadow.dyz_cd_ix);
 	dev_free(c->shadow.color);
-	dev_free(c->scanDesc);
+	dev_free(c->shadow.key);
+	dev_free(c->survFlag);
+	for (int t = 0; t < 2; ++t) {
+		dev_free(c->vWord[t]);
+		dev_free(c->vPre[t]);
+		dev_free(c->vBlk[t]);
+	}
 	dev_free(c->dK);
 	dev_free(c->dKc);
 	dev_free(c->dNodes);
@@ -558,14 +525,6 @@ int tyr_destroy(tyr_ctx* c) {
 		if (c->evSnap[s])
 			(void)hipEventDestroy(c->evSnap[s]);
 	}
-	for (auto& pair : c->evSide)
-		for (auto& e : pair)
-			if (e)
-				(void)hipEventDestroy(e);
-	if (c->evShadeDone)
-		(void)hipEventDestroy(c->evShadeDone);
-	if (c->evConnectDone)
-		(void)hipEventDestroy(c->evConnectDone);
 	if (c->evSnapshot)
 		(void)hipEventDestroy(c->evSnapshot);
 	if (c->side)
@@ -651,8 +610,6 @@ int tyr_set_triangle_palette(tyr_ctx* c, const float* color_rgb256, const float*
 		return TYR_ERR_UNSUPPORTED; // the ctx was created without TYR_FLAG_TRIANGLE_COLORS
 	int rc = use_device(c);
 	if (rc)
-		return rc;
-	if ((rc = join_connect(c)))
 		return rc;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	std::vector<float4> pal(512);
@@ -789,7 +746,8 @@ int tyr_stage_primary(tyr_ctx* c) {
 	if ((rc = sync_counters(c)))
 		return rc;
 	const uint32_t nNew = planned_new(c), nLive = c->hK->primary_ray_cnt + nNew;
-	enqueue_primary(c, make_params(c), nNew, nLive);
+	(void)nLive;
+	enqueue_primary(c, make_params(c), nNew);
 	HIPCHK(hipGetLastError());
 	rc = sync_counters(c);
 	collect_timings(c);
@@ -853,36 +811,29 @@ int tyr_sync(tyr_ctx* c) {
 }
 
 // ---- the per-frame entry point --------------------------------------------------------------
-// One wavefront iteration.  overlap = 0, pipelined = false is launch_kernels as the reference has it: everything on
-// one stream, done when it returns (kernel.cu:733).  Inside tyr_render (pipelined) the call returns as soon as shade's
-// counts are on the host, with connect still queued or running -- on `stream`, or on the side stream beside the
-// next iteration's primary and extend (overlap); the caller syncs at the end.
-static int launch_iteration(tyr_ctx* c, int overlap, bool pipelined) {
+// One wavefront iteration.  pipelined = false is launch_kernels as the reference has it: primary, extend, shade, connect on
+// one stream, done when it returns (kernel.cu:719-733).  Inside tyr_render (pipelined, merged launches) connect(i) rides in
+// the traversal launch of iteration i + 1 and the call returns as soon as shade's counts are on the host.
+static int launch_iteration(tyr_ctx* c, bool pipelined) {
 	// hK is current: every entry point that enqueues work ends with sync_counters
 	int rc = stage_begin(c);
 	if (rc)
 		return rc;
 	const uint32_t nNew = planned_new(c), nLive = c->hK->primary_ray_cnt + nNew;
-	// overlap 2 = by queue size: a thin wavefront is mostly ramp and tail on a 256-CU part, and that is what the
-	// neighbouring kernel fills (N = 2 Mi: +8 % C2, +13 % C3; from ~8 M rays up the two grids only stretch each other;
-	// deciding per iteration by nLive instead was neutral on a 16.6 M queue: profiles/r01_deferred_connect_ab.txt)
-	// merged traversal launches (k_trace_flat): connect(i) waits for the launch of extend(i + 1)
+	FrameParams P = make_params(c);
 	if (c->cfg.flags & TYR_FLAG_DEBUG_BVH) {
 		// kernel.cu:720-722 under BVH_DEBUG: primary_rays, set_wavefront_globals, extend_debug_BVH -- no shade, no connect
 		// (nothing survives: the next call regenerates the whole queue from the cursor)
-		FrameParams Pd = make_params(c);
-		enqueue_primary(c, Pd, nNew, nLive);
-		enqueue_extend(c, Pd, nLive, nLive - nNew);
+		enqueue_primary(c, P, nNew);
+		enqueue_extend(c, P, nLive, nLive - nNew);
 		HIPCHK(hipGetLastError());
 		rc = sync_counters(c);
 		collect_timings(c);
 		stage_end(c);
 		return rc ? rc : check_device_error(c);
 	}
-	const bool merge = pipelined && c->tuning.mergeTrace != 0 && c->tuning.traversalVariant == 4 && !(c->cfg.flags & TYR_FLAG_COUNT_VISITS) && c->scene.rootRef != kRefDone;
-	const bool deferConnect = !merge && (overlap == 1 || (overlap == 2 && c->cfg.queue_size <= kOverlapMaxLive));
-	FrameParams P = make_params(c);
-	enqueue_primary(c, P, nNew, nLive);
+	const bool merge = pipelined && merged_render(c);
+	enqueue_primary(c, P, nNew);
 	if (merge) { // every traversal launch of a merged render is k_trace_flat; the first one has no shadow rays to carry yet
 		const uint32_t carried = c->shadowPending ? c->shadowPendingMax : 0u;
 		c->shadowPending = false;
@@ -890,14 +841,8 @@ static int launch_iteration(tyr_ctx* c, int overlap, bool pipelined) {
 	} else {
 		if ((rc = flush_pending_shadow(c))) // (a render whose merge setting changed between iterations: never, but cheap)
 			return rc;
-		// next to a connect that is still running, blocks become resident late: no fixed per-block ranges then
-		FrameParams Pe = P;
-		if (overlap == 2 && c->connectPending)
-			Pe.staticShare = 0;
-		enqueue_extend(c, Pe, nLive, nLive - nNew);
+		enqueue_extend(c, P, nLive, nLive - nNew);
 	}
-	if ((rc = join_connect(c))) // shade rewrites the shadow queue connect(i - 1) reads
-		return rc;
 	enqueue_shade(c, P, nLive);
 	if (merge) {
 		// everything the host needs to launch iteration i + 1 (survivors, budget, the shadow-ray count) is final here
@@ -919,16 +864,6 @@ static int launch_iteration(tyr_ctx* c, int overlap, bool pipelined) {
 			std::fprintf(stderr, "\n");
 		}
 #endif
-	} else if (deferConnect || pipelined) {
-		if (deferConnect && overlap == 2)
-			P.staticShare = 0;
-		// the counters as shade left them, on their way to the host before connect starts
-		HIPCHK(hipMemcpyAsync(c->hK, c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(hipEventRecord(c->evSnapshot, c->stream));
-		if ((rc = enqueue_connect_unwaited(c, P, nLive, deferConnect)))
-			return rc;
-		HIPCHK(hipGetLastError());
-		HIPCHK(hipEventSynchronize(c->evSnapshot));
 	} else {
 		enqueue_connect(c, P, nLive); // at most one shadow ray per live ray
 		HIPCHK(hipGetLastError());
@@ -947,7 +882,7 @@ int tyr_launch_kernels(tyr_ctx* c) {
 	int rc = use_device(c);
 	if (rc)
 		return rc;
-	return launch_iteration(c, 0, false);
+	return launch_iteration(c, false);
 }
 
 // ---- tyr_render, one iteration ahead of the counts (TYR_TUNE_RUN_AHEAD) -------------------------
@@ -971,10 +906,8 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 		return rc;
 	const int set = static_cast<int>(c->iter & 1u);
 	FrameParams P = make_params(c);
-	enqueue_primary(c, P, p.nNew, p.nLive);
+	enqueue_primary(c, P, p.nNew);
 	enqueue_trace(c, P, p.nLive, p.nSurvivors, p.carried);
-	if ((rc = join_connect(c)))
-		return rc;
 	enqueue_shade(c, P, p.nLive);
 	HIPCHK(hipMemcpyAsync(c->hSnap[set], c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipEventRecord(c->evSnap[set], c->stream));
@@ -986,9 +919,8 @@ static bool run_ahead_eligible(const tyr_ctx* c) {
 #if defined(TYR_QUAD_STATS) || defined(TYR_LAUNCH_ANATOMY)
 	return false; // the instrumented builds print per-iteration records from the host mirror (launch_iteration)
 #else
-	const bool wanted = c->tuning.runAhead == 1 || (c->tuning.runAhead == 2 && c->cfg.queue_size <= kOverlapMaxLive);
-	return wanted && c->tuning.mergeTrace != 0 && c->tuning.traversalVariant == 4 && !(c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) &&
-	       c->scene.rootRef != kRefDone && c->blit != nullptr;
+	const bool wanted = c->tuning.runAhead == 1 || (c->tuning.runAhead == 2 && c->cfg.queue_size <= kRunAheadMaxLive);
+	return wanted && merged_render(c) && c->blit != nullptr;
 #endif
 }
 static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
@@ -1067,7 +999,6 @@ int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iter
 		return rc;
 	if (!c->haveScene)
 		return TYR_ERR_NO_SCENE;
-	const int overlap = c->tuning.overlapConnect;
 	uint32_t it = 0;
 	if (run_ahead_eligible(c)) {
 		if ((rc = use_device(c)))
@@ -1075,7 +1006,7 @@ int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iter
 		rc = render_run_ahead(c, max_iterations, it);
 	} else {
 		while (it < max_iterations) {
-			if ((rc = launch_iteration(c, overlap, true)))
+			if ((rc = launch_iteration(c, true)))
 				break;
 			++it;
 			if (c->hK->budget_remaining == 0 && c->hK->primary_ray_cnt == 0)
@@ -1083,15 +1014,11 @@ int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iter
 		}
 	}
 	{
-		// the last connect: back onto `stream` if it ran beside it, counters refreshed (connect's included),
-		// nothing in flight when this returns
+		// the last shadow rays; counters refreshed (connect's included), nothing in flight when this returns
 		int rcj = rc ? TYR_OK : flush_pending_shadow(c);
 		c->shadowPending = false;
 		if (!rcj)
-			rcj = join_connect(c);
-		if (!rcj)
 			rcj = sync_counters(c);
-		collect_side_timings(c, true);
 		if (!rcj)
 			collect_timings(c); // (an iteration queued ahead may still have had its event pairs out)
 		if (c->runAheadUndo) {
@@ -1141,6 +1068,7 @@ int tyr_reset_accum(tyr_ctx* c) {
 		return rc;
 	HIPCHK(hipMemsetAsync(c->blit, 0, sizeof(float4) * static_cast<size_t>(c->cfg.width) * c->cfg.height, c->stream));
 	c->hK->primary_ray_cnt = 0;
+	std::memset(&c->hK->seg[c->cur][0], 0, sizeof c->hK->seg[0]);
 	return push_counters(c);
 }
 
@@ -1158,6 +1086,10 @@ int tyr_read_accum(tyr_ctx* c, float* host_float4) {
 }
 
 // ---- AoS import / export (fixtures, parity tests) -------------------------------------------
+// The device's queues are physically unordered (hip/kernels.hpp "Queues"); the ABI's queues are the reference's: record i
+// is the ray in slot i of the serial order.  Export gathers the records the segments hold and sorts them by virtual slot
+// (survivors of the previous iteration first, in the order of the slots they had there -- their rank -- then this
+// iteration's primary rays by ticket); import lays the records down in order, slot = position.
 int tyr_queue_export(tyr_ctx* c, int which, tyr_ray_queue* host, uint32_t count) {
 	if (!c || !host || (which != 0 && which != 1) || count > c->cfg.queue_size)
 		return TYR_ERR_INVALID;
@@ -1165,20 +1097,29 @@ int tyr_queue_export(tyr_ctx* c, int which, tyr_ray_queue* host, uint32_t count)
 	if (rc)
 		return rc;
 	HIPCHK(hipStreamSynchronize(c->stream));
-	const RayQ& q = c->q[which == 0 ? c->cur : (c->cur ^ 1)];
-	std::vector<float4> a(count), d(count);
-	std::vector<float2> b(count), h(count);
-	std::vector<uint32_t> f(count);
-	if (count) {
-		HIPCHK(hipMemcpy(a.data(), q.o_dx, count * sizeof(float4), hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(b.data(), q.dyz, count * sizeof(float2), hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(d.data(), q.direct_ix, count * sizeof(float4), hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(f.data(), q.flags, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(h.data(), q.hit, count * sizeof(float2), hipMemcpyDeviceToHost));
-	}
-	for (uint32_t i = 0; i < count; ++i) {
-		tyr_ray_queue& r = host[i];
-		std::memset(&r, 0, sizeof(r));
+	const int qi = which == 0 ? c->cur : (c->cur ^ 1);
+	const RayQ& q = c->q[qi];
+	std::vector<uint32_t> slots;
+	if ((rc = valid_slots(&c->dK->seg[qi][0], slots)))
+		return rc;
+	uint32_t extent = 0;
+	for (uint32_t s : slots)
+		extent = std::max(extent, s + 1);
+	std::vector<float4> a, d;
+	std::vector<float2> b, h;
+	std::vector<uint32_t> f, key;
+	if ((rc = gather(q.o_dx, slots, extent, a)) || (rc = gather(q.dyz, slots, extent, b)) || (rc = gather(q.direct_ix, slots, extent, d)) || (rc = gather(q.flags, slots, extent, f)) ||
+	    (rc = gather(q.hit, slots, extent, h)) || (rc = gather(q.key, slots, extent, key)))
+		return rc;
+	std::vector<uint32_t> order(slots.size());
+	for (uint32_t i = 0; i < order.size(); ++i)
+		order[i] = i;
+	auto rankOf = [&](uint32_t i) { return (static_cast<uint64_t>((key[i] & tyr::kKeyIndirect) ? 0u : 1u) << 32) | (key[i] & tyr::kKeyMask); };
+	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return rankOf(x) < rankOf(y); });
+	std::memset(host, 0, sizeof(tyr_ray_queue) * count);
+	for (uint32_t k = 0; k < count && k < order.size(); ++k) {
+		const uint32_t i = order[k];
+		tyr_ray_queue& r = host[k];
 		r.origin[0] = a[i].x;
 		r.origin[1] = a[i].y;
 		r.origin[2] = a[i].z;
@@ -1211,7 +1152,7 @@ int tyr_queue_import(tyr_ctx* c, const tyr_ray_queue* host, uint32_t n) {
 	const RayQ& q = c->q[c->cur];
 	std::vector<float4> a(n), d(n);
 	std::vector<float2> b(n), h(n);
-	std::vector<uint32_t> f(n);
+	std::vector<uint32_t> f(n), key(n);
 	for (uint32_t i = 0; i < n; ++i) {
 		const tyr_ray_queue& r = host[i];
 		a[i] = make_float4(r.origin[0], r.origin[1], r.origin[2], r.direction[0]);
@@ -1224,6 +1165,7 @@ int tyr_queue_import(tyr_ctx* c, const tyr_ray_queue* host, uint32_t n) {
 		float idf;
 		std::memcpy(&idf, &id, 4);
 		h[i] = make_float2(r.distance, idf);
+		key[i] = i; // slot = position; no kKeySphereDone: extend's pre-pass computes the sphere half as for any survivor
 	}
 	if (n) {
 		HIPCHK(hipMemcpy(q.o_dx, a.data(), n * sizeof(float4), hipMemcpyHostToDevice));
@@ -1231,8 +1173,10 @@ int tyr_queue_import(tyr_ctx* c, const tyr_ray_queue* host, uint32_t n) {
 		HIPCHK(hipMemcpy(q.direct_ix, d.data(), n * sizeof(float4), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(q.flags, f.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(q.hit, h.data(), n * sizeof(float2), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(q.key, key.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
 	c->hK->primary_ray_cnt = n;
+	dense_counts(n, &c->hK->seg[c->cur][0]);
 	return push_counters(c);
 }
 
@@ -1243,14 +1187,24 @@ int tyr_shadow_export(tyr_ctx* c, tyr_shadow_queue* host, uint32_t count) {
 	if (rc)
 		return rc;
 	HIPCHK(hipStreamSynchronize(c->stream));
-	std::vector<float4> a(count), b(count), col(count);
-	if (count) {
-		HIPCHK(hipMemcpy(a.data(), c->shadow.o_dx, count * sizeof(float4), hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(b.data(), c->shadow.dyz_cd_ix, count * sizeof(float4), hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(col.data(), c->shadow.color, count * sizeof(float4), hipMemcpyDeviceToHost));
-	}
-	for (uint32_t i = 0; i < count; ++i) {
-		tyr_shadow_queue& s = host[i];
+	std::vector<uint32_t> slots;
+	if ((rc = valid_slots(&(c->dKc + c->shadowSet)->seg[0], slots))) // the set of the iteration that was shaded last
+		return rc;
+	uint32_t extent = 0;
+	for (uint32_t s : slots)
+		extent = std::max(extent, s + 1);
+	std::vector<float4> a, b, col;
+	std::vector<uint32_t> key;
+	if ((rc = gather(c->shadow.o_dx, slots, extent, a)) || (rc = gather(c->shadow.dyz_cd_ix, slots, extent, b)) || (rc = gather(c->shadow.color, slots, extent, col)) || (rc = gather(c->shadow.key, slots, extent, key)))
+		return rc;
+	std::vector<uint32_t> order(slots.size());
+	for (uint32_t i = 0; i < order.size(); ++i)
+		order[i] = i;
+	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; }); // the emitting rays' slots: the serial order
+	std::memset(host, 0, sizeof(tyr_shadow_queue) * count);
+	for (uint32_t k = 0; k < count && k < order.size(); ++k) {
+		const uint32_t i = order[k];
+		tyr_shadow_queue& s = host[k];
 		s.origin[0] = a[i].x;
 		s.origin[1] = a[i].y;
 		s.origin[2] = a[i].z;
@@ -1272,9 +1226,10 @@ int tyr_shadow_import(tyr_ctx* c, const tyr_shadow_queue* host, uint32_t n) {
 	int rc = use_device(c);
 	if (rc)
 		return rc;
-	if ((rc = join_connect(c)) || (rc = sync_counters(c)))
+	if ((rc = sync_counters(c)))
 		return rc;
 	std::vector<float4> a(n), b(n), col(n);
+	std::vector<uint32_t> key(n);
 	for (uint32_t i = 0; i < n; ++i) {
 		const tyr_shadow_queue& s = host[i];
 		float ix;
@@ -1282,15 +1237,22 @@ int tyr_shadow_import(tyr_ctx* c, const tyr_shadow_queue* host, uint32_t n) {
 		a[i] = make_float4(s.origin[0], s.origin[1], s.origin[2], s.direction[0]);
 		b[i] = make_float4(s.direction[1], s.direction[2], s.closestDistance, ix);
 		col[i] = make_float4(s.color[0], s.color[1], s.color[2], 0.0f);
+		key[i] = i;
 	}
 	if (n) {
 		HIPCHK(hipMemcpy(c->shadow.o_dx, a.data(), n * sizeof(float4), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(c->shadow.dyz_cd_ix, b.data(), n * sizeof(float4), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(c->shadow.color, col.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(c->shadow.key, key.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
-	// what shade's last tile writes (kernel.cu:416-417): the count connect reads, in this iteration's set
+	// what shade leaves behind (kernel.cu:416-417): the counts connect reads, in this iteration's set
 	c->hK->shadow_ray_cnt = n;
-	HIPCHK(hipMemcpy(&(c->dKc + (c->iter & 1u))->shadow_cnt, &n, sizeof(uint32_t), hipMemcpyHostToDevice));
+	c->shadowSet = c->iter & 1u;
+	ConnectCounters* kc = c->dKc + (c->iter & 1u);
+	uint32_t cnt[tyr::kSegs * tyr::kSegStride];
+	dense_counts(n, cnt);
+	HIPCHK(hipMemcpy(&kc->shadow_cnt, &n, sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(&kc->seg[0], cnt, sizeof cnt, hipMemcpyHostToDevice));
 	return push_counters(c);
 }
 
@@ -1384,95 +1346,32 @@ int tyr_get_scene_info(tyr_ctx* c, tyr_scene_info* out) {
 int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 	if (!c)
 		return TYR_ERR_INVALID;
-	switch (key) {
-	case TYR_TUNE_TRAVERSAL_VARIANT:
-		if (value < 0 || value > 5)
+	struct Knob {
+		int key, lo, hi;
+		int Tuning::*field;
+	};
+	static const Knob knobs[] = {
+		{ TYR_TUNE_REFILL_MIN_IDLE, 1, 64, &Tuning::refillMinIdle },
+		{ TYR_TUNE_WAVES_PER_SIMD, 0, 8, &Tuning::wavesPerSimd },
+		{ TYR_TUNE_MIN_TRAVERSING, 1, 64, &Tuning::minTraversing },
+		{ TYR_TUNE_TICKET_CHUNK, 64, 65536, &Tuning::ticketChunk },
+		{ TYR_TUNE_STATIC_SHARE, 0, 15, &Tuning::staticShare },
+		{ TYR_TUNE_STAGED_NODES, 0, static_cast<int>(kStagedNodes), &Tuning::stagedNodes },
+		{ TYR_TUNE_PROFILE_MASK, 0, (1 << TYR_K_COUNT) - 1, &Tuning::profileMask },
+		{ TYR_TUNE_MERGE_TRACE, 0, 1, &Tuning::mergeTrace },
+		{ TYR_TUNE_STATIC_INTERLEAVE, 0, 1, &Tuning::staticInterleave },
+		{ TYR_TUNE_RUN_AHEAD, 0, 2, &Tuning::runAhead },
+		{ TYR_TUNE_WIDE_DRAIN, 0, 1, &Tuning::wideDrain },
+	};
+	for (const Knob& k : knobs) {
+		if (k.key != key)
+			continue;
+		if (value < k.lo || value > k.hi)
 			return TYR_ERR_INVALID;
-#ifndef TYR_DIAG
-		if (value != 4)
-			return TYR_ERR_UNSUPPORTED; // variants 0-3 and 5 live in libtyrant_hip_diag.so (make diag)
-#endif
-		c->tuning.traversalVariant = value;
+		c->tuning.*(k.field) = value;
 		return TYR_OK;
-	case TYR_TUNE_REFILL_MIN_IDLE:
-		if (value < 1 || value > 64)
-			return TYR_ERR_INVALID;
-		c->tuning.refillMinIdle = value;
-		return TYR_OK;
-	case TYR_TUNE_WAVES_PER_SIMD:
-		if (value < 0 || value > 8)
-			return TYR_ERR_INVALID;
-		c->tuning.wavesPerSimd = value;
-		return TYR_OK;
-	case TYR_TUNE_MIN_TRAVERSING:
-		if (value < 1 || value > 64)
-			return TYR_ERR_INVALID;
-		c->tuning.minTraversing = value;
-		return TYR_OK;
-	case TYR_TUNE_RAYS_PER_BLOCK:
-		if (value < 256 || value > 65536)
-			return TYR_ERR_INVALID;
-		c->tuning.raysPerBlock = value;
-		return TYR_OK;
-	case TYR_TUNE_MIN_LEAVES:
-		return (value < 1 || value > 64) ? TYR_ERR_INVALID : TYR_OK; // retired knob: accepted, no effect
-	case TYR_TUNE_STAGED_NODES:
-		if (value < 0 || value > static_cast<int>(kStagedNodes))
-			return TYR_ERR_INVALID;
-		c->tuning.stagedNodes = value;
-		return TYR_OK;
-	case TYR_TUNE_STATIC_SHARE:
-		if (value < 0 || value > 15)
-			return TYR_ERR_INVALID;
-		c->tuning.staticShare = value;
-		return TYR_OK;
-	case TYR_TUNE_TICKET_CHUNK:
-		if (value < 64 || value > 65536)
-			return TYR_ERR_INVALID;
-		c->tuning.ticketChunk = value;
-		return TYR_OK;
-	case TYR_TUNE_PROFILE_MASK:
-		if (value < 0 || value >= (1 << TYR_K_COUNT))
-			return TYR_ERR_INVALID;
-		c->tuning.profileMask = value;
-		return TYR_OK;
-	case TYR_TUNE_RUN_AHEAD:
-		if (value < 0 || value > 2)
-			return TYR_ERR_INVALID;
-		c->tuning.runAhead = value;
-		return TYR_OK;
-	case TYR_TUNE_WIDE_DRAIN:
-		if (value < 0 || value > 1)
-			return TYR_ERR_INVALID;
-		c->tuning.wideDrain = value;
-		return TYR_OK;
-	case TYR_TUNE_STATIC_INTERLEAVE:
-		if (value < 0 || value > 1)
-			return TYR_ERR_INVALID;
-		c->tuning.staticInterleave = value;
-		return TYR_OK;
-	case TYR_TUNE_MERGE_TRACE:
-		if (value < 0 || value > 1)
-			return TYR_ERR_INVALID;
-		c->tuning.mergeTrace = value;
-		return TYR_OK;
-	case TYR_TUNE_OVERLAP_CONNECT:
-		if (value < 0 || value > 2)
-			return TYR_ERR_INVALID;
-		c->tuning.overlapConnect = value;
-		return TYR_OK;
-	case TYR_TUNE_STACK_LDS_DEPTH:
-		if (value != 0 && value != 8 && value != 10 && value != 12 && value != 16 && value != 24)
-			return TYR_ERR_INVALID;
-#ifndef TYR_DIAG
-		if (value != 12)
-			return TYR_ERR_UNSUPPORTED; // the other depths are compiled into libtyrant_hip_diag.so only
-#endif
-		c->tuning.stackLdsDepth = value;
-		return TYR_OK;
-	default:
-		return TYR_ERR_INVALID;
 	}
+	return TYR_ERR_INVALID;
 }
 
 int tyr_get_timings(tyr_ctx* c, tyr_timings* out, int reset) {
