@@ -393,8 +393,9 @@ def test_work_distribution_knobs_never_change_results(orc, hip, knobs):
 
 @pytest.mark.parametrize("name,W,H,N,spp", [("cornell_soup2k", 160, 90, 9000, 5), ("mesh128", 128, 72, 20000, 3), ("cornell_area_light", 96, 64, 3000, 4)])
 def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
-    """tyr_render in launch_kernels' order (merge_trace = 0), with connect(i) inside the launch of extend(i + 1), and one
-    iteration ahead of the counts: same iteration count, same counters and the same radiance as the oracle; a render, a camera move (reset of the accumulation buffer while
+    """tyr_render in launch_kernels' order (merge_trace = 0), with connect(i) inside the launch of extend(i + 1) and the
+    rays that miss the tree shaded beside that launch (the default), one iteration ahead of the counts, and merged without
+    the overlapped shade: same iteration count, same counters and the same radiance as the oracle; a render, a camera move (reset of the accumulation buffer while
     nothing may be in flight) and a second render back to back"""
     o, g1 = pair(orc, hip, name, W, H, N)
     _, g0 = pair(orc, hip, name, W, H, N)
@@ -403,7 +404,7 @@ def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
     g0.set_tuning(merge_trace=0)
     g1.set_tuning(merge_trace=1, run_ahead=1)
     g2.set_tuning(merge_trace=1)  # (the default) connect(i) inside the launch of extend(i + 1): k_trace_flat, iteration i + 1 queued ahead of iteration i's counts
-    g3.set_tuning(merge_trace=1, run_ahead=0, wide_drain=0)  # ... with the host waiting for every iteration's counts, and a wave's last rays left one to a lane
+    g3.set_tuning(merge_trace=1, run_ahead=0, wide_drain=0, shade_overlap=0)  # ... with the host waiting for every iteration's counts, and a wave's last rays left one to a lane
     from tyrant_amd import scenes
 
     sc, _, _ = built_scene(name)

@@ -120,6 +120,38 @@ __device__ __forceinline__ uint32_t chunk_valid(const uint32_t* cnt, uint32_t s0
 	const uint32_t c = cnt[((s0 >> 6) & (kSegs - 1u)) * kSegStride], first = (s0 >> 9) << 6;
 	return c > first ? (c - first < 64u ? c - first : 64u) : 0u;
 }
+// the eight counts in registers, for kernels that test many slots (one load each at kernel start, then selects)
+struct SegCounts {
+	uint32_t c[kSegs];
+	__device__ __forceinline__ void load(const uint32_t* cnt) {
+#pragma unroll
+		for (uint32_t w = 0; w < kSegs; ++w)
+			c[w] = cnt[w * kSegStride];
+	}
+	__device__ __forceinline__ uint32_t extent() const {
+		uint32_t m = 0;
+#pragma unroll
+		for (uint32_t w = 0; w < kSegs; ++w)
+			m = c[w] > m ? c[w] : m;
+		return ((m + 63u) >> 6) * (kSegs * 64u);
+	}
+	__device__ __forceinline__ bool valid(uint32_t s) const {
+		const uint32_t seg = (s >> 6) & (kSegs - 1u);
+		uint32_t lim = c[0];
+#pragma unroll
+		for (uint32_t w = 1; w < kSegs; ++w)
+			lim = seg == w ? c[w] : lim;
+		return (((s >> 9) << 6) | (s & 63u)) < lim;
+	}
+};
+// what a slot that holds no record looks like to the traversal kernel: a ray that cannot enter any box (the pre-passes
+// and k_primary write it into the holes at the segments' ends, so that k_trace_flat hands out slots without asking)
+__device__ __forceinline__ void write_dead_ray(const RayQ& q, uint32_t slot) {
+	q.o_dx[slot] = make_float4(3e38f, 3e38f, 3e38f, 1.0f);
+	q.dyz[slot] = make_float2(0.0f, 0.0f);
+	q.hit[slot] = make_float2(0.0f, 0.0f);
+}
+
 // this iteration's virtual slot of a ray from its key
 __device__ __forceinline__ uint32_t v_lookup(const VTable& T, uint32_t key) {
 	const uint32_t v = key & kKeyMask;
@@ -141,6 +173,13 @@ __device__ __forceinline__ void wave_add_u64(unsigned long long* p, uint32_t v) 
 		atomicAdd(p, sum);
 }
 
+__device__ __forceinline__ uint32_t root_ref(const DevScene& sc, const RayConst& r, float bound) {
+	float t0;
+	const bool ok = slab_test(r, r.nx ? sc.rootMax[0] : sc.rootMin[0], r.nx ? sc.rootMin[0] : sc.rootMax[0], r.ny ? sc.rootMax[1] : sc.rootMin[1], r.ny ? sc.rootMin[1] : sc.rootMax[1],
+		r.nz ? sc.rootMax[2] : sc.rootMin[2], r.nz ? sc.rootMin[2] : sc.rootMax[2], bound, t0);
+	return ok ? sc.rootRef : kRefDone;
+}
+
 // the sphere half of intersect_scene (kernel.cu:127-136): closest of the seven spheres, or VERY_FAR
 __device__ __forceinline__ float2 sphere_hit_record(const FrameParams& P, f3 o, f3 d) {
 	float dist = kVeryFar;
@@ -153,15 +192,13 @@ __device__ __forceinline__ float2 sphere_hit_record(const FrameParams& P, f3 o, 
 			id = kHitSphere | (uint32_t)i;
 		}
 	}
+	// the traversal's own first test (root_ref at the refill of k_trace_flat: same function, same bound, same answer):
+	// a ray that fails it is finished with this record
+	if (P.scene.rootRef != kRefDone && root_ref(P.scene, make_ray(o, d), dist) != kRefDone)
+		id |= kHitPending;
 	return make_float2(dist, __uint_as_float(id));
 }
 
-__device__ __forceinline__ uint32_t root_ref(const DevScene& sc, const RayConst& r, float bound) {
-	float t0;
-	const bool ok = slab_test(r, r.nx ? sc.rootMax[0] : sc.rootMin[0], r.nx ? sc.rootMin[0] : sc.rootMax[0], r.ny ? sc.rootMax[1] : sc.rootMin[1], r.ny ? sc.rootMin[1] : sc.rootMax[1],
-		r.nz ? sc.rootMax[2] : sc.rootMin[2], r.nz ? sc.rootMin[2] : sc.rootMax[2], bound, t0);
-	return ok ? sc.rootRef : kRefDone;
-}
 
 // kernel.cu:622-625.  Adding +0 leaves the pixel unchanged, so zero terms are skipped (the reference's
 // own TODO at kernel.cu:621).  One lane, one pixel: used by the per-slot and first persistent kernels (variants

@@ -16,23 +16,38 @@ __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 	const unsigned long long budget = P.k->budget_remaining;
 	const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
 	const uint32_t firstOfBlock = blockIdx.x * kBlock;
-	if (firstOfBlock >= nNew)
-		return; // (the whole block)
-	// the block's rays go to segment blockIdx % 8 of the work queue, behind whatever it holds: one atomic per block
-	const uint32_t nHere = nNew - firstOfBlock < (uint32_t)kBlock ? nNew - firstOfBlock : (uint32_t)kBlock;
-	const uint32_t seg = blockIdx.x & (kSegs - 1u);
-	if (threadIdx.x == 0) {
-		uint32_t base = atomicAdd(&P.segWork[seg * kSegStride], nHere);
-		if (base + nHere > P.segCap) {
-			atomicOr(&P.k->device_error, kErrQueueOverflow);
-			base = 0xffffffffu;
+	uint32_t slot;
+	if (cnt == 0) {
+		// nothing in the queue (a render's first wavefront, the whole queue after a reset): the rays are laid down densely,
+		// ray i in slot i -- chunk i / 64 of segment (i / 64) % 8, the counts follow arithmetically (k_globals) -- and the
+		// slots between nNew and the end of its group of eight chunks become holes the traversal can skip by itself
+		const uint32_t padded = (nNew + 511u) & ~511u;
+		if (index >= padded)
+			return;
+		slot = index;
+		if (index >= nNew) {
+			write_dead_ray(P.work, slot);
+			return;
 		}
-		baseSh = base;
+	} else {
+		if (firstOfBlock >= nNew)
+			return; // (the whole block)
+		// the block's rays go to segment blockIdx % 8 of the work queue, behind what it holds: one atomic per block
+		const uint32_t nHere = nNew - firstOfBlock < (uint32_t)kBlock ? nNew - firstOfBlock : (uint32_t)kBlock;
+		const uint32_t seg = blockIdx.x & (kSegs - 1u);
+		if (threadIdx.x == 0) {
+			uint32_t base = atomicAdd(&P.segWork[seg * kSegStride], nHere);
+			if (base + nHere > P.segCap) {
+				atomicOr(&P.k->device_error, kErrQueueOverflow);
+				base = 0xffffffffu;
+			}
+			baseSh = base;
+		}
+		__syncthreads();
+		if (index >= nNew || baseSh == 0xffffffffu)
+			return;
+		slot = seg_phys(seg, baseSh + threadIdx.x);
 	}
-	__syncthreads();
-	if (index >= nNew || baseSh == 0xffffffffu)
-		return;
-	const uint32_t slot = seg_phys(seg, baseSh + threadIdx.x);
 	const uint32_t vslot = index + cnt; // the slot the serial order gives this ray (kernel.cu:254): what seeds its shading
 	// kernel.cu:258 seeds by the ticket `index`; with pixel sharding (nranks > 1) the ranks' tickets are interleaved so that
 	// rows y = yl * R + r, r = 0..R-1, do not share their jitter and lens samples (nranks == 1: the reference's expression)
@@ -84,10 +99,20 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P) {
 		P.k->extend_chunks[i * 32] = 0;
 		P.kc->chunks[i * 32] = 0;
 		P.k->shade_tiles[i * 32] = 0;
+		P.k->shade_tiles_late[i * 32] = 0;
 		// what this iteration's shade appends to: the next ray queue and this iteration's shadow queue
 		P.segNext[i * kSegStride] = 0;
 		P.kc->seg[i * kSegStride] = 0;
+		// k_primary laid its rays down densely when the queue was empty: the counts that go with that
+		const uint32_t cnt0 = P.k->primary_ray_cnt;
+		if (cnt0 == 0) {
+			const unsigned long long room = (unsigned long long)P.N, budget = P.k->budget_remaining;
+			const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
+			const uint32_t rem = nNew & 511u, part = rem > 64u * i ? (rem - 64u * i < 64u ? rem - 64u * i : 64u) : 0u;
+			P.segWork[i * kSegStride] = (nNew >> 9) * 64u + part;
+		}
 	}
+	__syncthreads(); // thread 0 below changes primary_ray_cnt and the budget the lines above have read
 	if (i == 0) {
 		DevCounters* k = P.k;
 		const uint32_t cnt = k->primary_ray_cnt;
@@ -98,6 +123,8 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P) {
 		k->n_live = cnt + nNew;
 		k->first_fresh = cnt;
 		k->shade_blocks_done = 0;
+		k->late_tiles = 0;
+		k->feed_done = 0;
 		k->shadow_ray_cnt = 0;
 		k->primary_ray_cnt = 0;
 		k->extend_ticket = 0;
@@ -121,10 +148,14 @@ __global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) 
 	const uint32_t first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
 	if (first == 0)
 		P.k->extend_ticket = 0;
-	const uint32_t n = queue_extent(P.segWork);
+	SegCounts sc;
+	sc.load(P.segWork);
+	const uint32_t n = sc.extent();
 	for (uint32_t slot = first; slot < n; slot += stride) {
-		if (!slot_valid(P.segWork, slot))
+		if (!sc.valid(slot)) {
+			write_dead_ray(P.work, slot); // a hole at a segment's end
 			continue;
+		}
 		if (P.work.key[slot] & kKeySphereDone) // this iteration's primary rays: k_primary has done them
 			continue;
 		const float4 a = P.work.o_dx[slot];
@@ -142,10 +173,14 @@ __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P)
 		P.kc->ticket = 0;
 	if (first < kTicketWords)
 		P.k->extend_chunks[first * 32] = 0; // k_trace_flat's tickets, when this pre-pass opens the launch that ends a render (no set_wavefront_globals in front of it)
-	const uint32_t n = queue_extent(P.kc->seg);
+	SegCounts sc;
+	sc.load(P.kc->seg);
+	const uint32_t n = sc.extent();
 	for (uint32_t index = first; index < n; index += stride) {
-		if (!slot_valid(P.kc->seg, index))
+		if (!sc.valid(index)) {
+			reinterpret_cast<float*>(&P.shadow.color[index])[3] = 1.0f; // a hole: "occluded" retires it at the traversal's refill
 			continue;
+		}
 		const float4 a = P.shadow.o_dx[index];
 		const float4 b = P.shadow.dyz_cd_ix[index];
 		const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
@@ -386,7 +421,7 @@ constexpr uint32_t kPrepassMaxBlocks = 8192; // 8 waves of 256 threads per SIMD 
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
 	if (maxNew == 0)
 		return;
-	hipLaunchKernelGGL(k_primary, dim3(blocks_for(maxNew)), dim3(kBlock), 0, stream, P);
+	hipLaunchKernelGGL(k_primary, dim3(blocks_for((maxNew + 511u) & ~511u)), dim3(kBlock), 0, stream, P);
 }
 void launch_globals(const FrameParams& P, hipStream_t stream) { hipLaunchKernelGGL(k_globals, dim3(1), dim3(kBlock), 0, stream, P); }
 void launch_scan(const FrameParams& P, uint32_t maxLive, hipStream_t stream) {

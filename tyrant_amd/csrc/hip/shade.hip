@@ -111,7 +111,7 @@ __device__ __forceinline__ EmitterSample sample_emitter(const FrameParams& P, ui
 // Lanes past the end of the queue come along with valid = false (they load nothing and produce nothing) so that
 // afterLoads is reached by the whole wave.
 template <bool LIGHTS, class AfterLoads>
-__device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, bool valid, ShadeOut& out, uint32_t& vslotOut, AfterLoads&& afterLoads) {
+__device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, bool valid, float2 hitRecord, ShadeOut& out, uint32_t& vslotOut, AfterLoads&& afterLoads) {
 	float4 a = make_float4(0.f, 0.f, 0.f, 0.f), dq = a;
 	float2 b = make_float2(0.f, 0.f), h = make_float2(kVeryFar, 0.f);
 	uint32_t fl = 0, key = 0;
@@ -119,7 +119,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 		key = P.work.key[slot];
 		a = P.work.o_dx[slot];
 		b = P.work.dyz[slot];
-		h = P.work.hit[slot];
+		h = hitRecord; // loaded by the caller (an early launch reads it past the caches, once)
 		dq = P.work.direct_ix[slot];
 		fl = P.work.flags[slot];
 	}
@@ -413,7 +413,9 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u, wave = tid >> 6;
 	const uint32_t extent = queue_extent(P.segWork);
-	const uint32_t nTiles = extent / kBlock; // from the device's counts: the host may have sized the grid from an upper bound
+	// from the device's counts: the host may have sized the grid from an upper bound.  The launch behind the traversal
+	// (phase 2) only visits the tiles the early launch listed
+	const uint32_t nTiles = P.shadePhase == 2u ? P.k->late_tiles : extent / kBlock;
 	const unsigned long long below = (1ull << lane) - 1ull;
 #ifdef TYR_SHADE_TIMING
 	// diagnostic build: where a tile's time goes, in s_memtime ticks summed over this block's tiles (thread 0;
@@ -461,11 +463,12 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	};
 
 	uint32_t word = blockIdx.x % kTicketWords, tried = 0;
+	uint32_t* const tickets = P.shadePhase == 2u ? P.k->shade_tiles_late : P.k->shade_tiles; // every launch sweeps all tiles
 	auto draw_tile = [&]() -> uint32_t { // block-uniform; nTiles when nothing is left
 		uint32_t vbNext = nTiles;
 		if (tid == 0) {
 			while (tried < kTicketWords) {
-				const uint32_t t = atomicAdd(&P.k->shade_tiles[word * 32], 1u);
+				const uint32_t t = atomicAdd(&tickets[word * 32], 1u);
 				const unsigned long long cand = (unsigned long long)t * kTicketWords + word;
 				if (cand < nTiles) {
 					vbNext = (uint32_t)cand;
@@ -481,7 +484,8 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		__syncthreads();
 		return vbNext;
 	};
-	for (uint32_t vb = draw_tile(); vb < nTiles; vb = draw_tile()) { // vb = tile id = 256 physical slots
+	for (uint32_t ticket = draw_tile(); ticket < nTiles; ticket = draw_tile()) {
+		const uint32_t vb = P.shadePhase == 2u ? P.lateList[ticket] : ticket; // vb = tile id = 256 physical slots
 		const uint32_t slot = vb * kBlock + tid;
 		ShadeOut out = {};
 		uint32_t pixelBits = 0, vslot = 0;
@@ -495,10 +499,43 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			pendColor = mk3(0.f, 0.f, 0.f);
 			pendNew = 0;
 		};
-		const bool valid = lane < chunk_valid(P.segWork, slot & ~63u);
+		bool valid = lane < chunk_valid(P.segWork, slot & ~63u);
+		float2 hitRecord = make_float2(kVeryFar, 0.f);
+		if (P.shadePhase == 1u) {
+			// beside the traversal launch: only the rays whose hit record is final -- never entered the tree, or the
+			// traversal has already answered (ONE agent-scope look, past the caches, whose value is the one that gets
+			// shaded; a record still pending is left to the late launch)
+			union {
+				unsigned long long u;
+				float2 f;
+			} v;
+			v.u = (unsigned long long)kHitPending << 32;
+			if (valid)
+				v.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&P.work.hit[slot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			hitRecord = v.f;
+			const bool pending = valid && (__float_as_uint(v.f.y) & kHitPending);
+			valid = valid && !pending;
+			const bool anyPending = __syncthreads_or(pending ? 1 : 0) != 0; // (the result is a truth value, not the OR of the arguments)
+			const bool anyReady = __syncthreads_or(valid ? 1 : 0) != 0;
+			if (anyPending && tid == 0)
+				P.lateList[atomicAdd(&P.k->late_tiles, 1u)] = vb; // the launch behind the traversal comes back for the rest
+			if (!anyReady)
+				continue; // nothing ready in this tile (block-uniform)
+			if (valid)
+				P.work.flags[slot] |= kFlagShaded;
+		} else {
+			if (P.shadePhase == 2u) {
+				if (valid)
+					valid = !(P.work.flags[slot] & kFlagShaded);
+				if (__syncthreads_or(valid) == 0)
+					continue; // the early launch has done the whole tile
+			}
+			if (valid)
+				hitRecord = P.work.hit[slot];
+		}
 		if (valid)
 			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
-		shade_ray<LIGHTS>(P, slot, valid, out, vslot, flush_pixels);
+		shade_ray<LIGHTS>(P, slot, valid, hitRecord, out, vslot, flush_pixels);
 		if (valid)
 			P.survFlag[vslot] = out.survive ? 1 : 0; // what k_scan_words turns into next iteration's slots
 		TYR_STAMP(0)
@@ -629,8 +666,18 @@ uint32_t shade_grid(const FrameParams& P, uint32_t maxSlots, int numCUs, LaunchC
 	const uint32_t resident = (uint32_t)perCU[lights] * (uint32_t)numCUs;
 	return nTiles < resident ? (nTiles ? nTiles : 1u) : resident;
 }
+void launch_shade_phase(const FrameParams& P0, uint32_t phase, uint32_t blocks, uint32_t blocksOfBothPhases, hipStream_t stream) {
+	FrameParams P = P0;
+	P.shadePhase = phase;
+	P.shadeBlocks = blocksOfBothPhases;
+	if (P.flags & TYR_FLAG_LIGHT_LIST)
+		hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(kBlock), 0, stream, P);
+	else
+		hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(kBlock), 0, stream, P);
+}
 void launch_shade(const FrameParams& P0, uint32_t maxSlots, int numCUs, LaunchCache& lc, hipStream_t stream) {
 	FrameParams P = P0;
+	P.shadePhase = 0u;
 	P.shadeBlocks = shade_grid(P, maxSlots, numCUs, lc);
 	if (P.flags & TYR_FLAG_LIGHT_LIST)
 		hipLaunchKernelGGL(k_shade<true>, dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);

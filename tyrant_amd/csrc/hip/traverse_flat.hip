@@ -124,6 +124,22 @@ struct ChunkFeed {
 	}
 };
 
+// A closest-hit ray is finished: a triangle hit replaces the sphere answer of the pre-pass (kernel.cu:138-140); either
+// way the record loses kHitPending.  Agent-scope writes: an early shade launch on another XCD may be looking
+// (it only ever acts on records WITHOUT the bit, so a stale look costs it nothing but the wait for the late launch).
+__device__ __forceinline__ void finish_extend_ray(float2* hit, uint32_t slot, bool hitTri, float dist, int prim) {
+	if (hitTri) {
+		union {
+			float2 f;
+			unsigned long long u;
+		} v;
+		v.f = make_float2(dist, __uint_as_float((uint32_t)prim));
+		__hip_atomic_store(reinterpret_cast<unsigned long long*>(&hit[slot]), v.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	} else {
+		atomicAnd(reinterpret_cast<uint32_t*>(&hit[slot]) + 1, ~kHitPending);
+	}
+}
+
 // slots of the queue that each block of a persistent grid owns outright (a multiple of 64; 0 for thin queues)
 __device__ __forceinline__ uint32_t static_range(uint32_t nItems, uint32_t sixteenths) {
 	const unsigned long long share = (unsigned long long)nItems * sixteenths / 16ull;
@@ -382,8 +398,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 		// (Holding the record back until the wave's next refill, one store for all lanes that finished in between,
 		// was measured: +1 %.) ----
 		if (live && ref == kRefDone) {
-			if (hitTri)
-				P.work.hit[slot] = make_float2(dist, __uint_as_float((uint32_t)prim));
+			finish_extend_ray(P.work.hit, slot, hitTri, dist, prim);
 			overflow = overflow || st.overflow;
 			live = false;
 		}
@@ -826,8 +841,8 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 						accumulate_pixel(blit, __float_as_int(shadowDyzCdIx[slot].w), mk3(c.x, c.y, c.z), 0);
 						visible += 1;
 					}
-				} else if (hitTri) {
-					workHit[slot] = make_float2(dist, __uint_as_float((uint32_t)prim));
+				} else {
+					finish_extend_ray(workHit, slot, hitTri, dist, prim);
 				}
 			}
 			gActive = false;
@@ -870,7 +885,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 	// items = physical slots: the work queue's [0, nExt), then the shadow queue's; the few slots at the segments' ends that
-	// hold no record are handed out like the others and dropped at the refill (slot_valid)
+	// hold no record are handed out like the others: the pre-passes (and k_primary) have made them rays that enter nothing
 	const uint32_t nExt = P.traceShadow == 2u ? 0u : queue_extent(P.segWork);
 	const uint32_t nItems = nExt + (P.traceShadow != 0u ? queue_extent(P.kcPrev->seg) : 0u); // (a render's first launch carries no shadow rays: kcPrev then holds an older render's count)
 	const DevScene& sc = P.scene;
@@ -894,8 +909,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
 		int px = 0;
 		if (pendIdx != kNoPending) {
-			c = P.shadow.color[pendIdx];
-			px = __float_as_int(P.shadow.dyz_cd_ix[pendIdx].w);
+			c = P.shadowPrev.color[pendIdx];
+			px = __float_as_int(P.shadowPrev.dyz_cd_ix[pendIdx].w);
 		}
 		accumulate_pixels_wave(P.blit, px, mk3(c.x, c.y, c.z), 0);
 		pendIdx = kNoPending;
@@ -941,6 +956,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 			while (staticDone && got < nIdle) {
 				if (!feed.refill(P.k->extend_chunks, nItems - dynBase, lane)) {
 					exhausted = true;
+					if (P.feedDoneHost != nullptr && lane == 0 && atomicExch(&P.k->feed_done, 1u) == 0u) // the first wave to run dry tells the host
+						__hip_atomic_store(const_cast<uint32_t*>(P.feedDoneHost), P.feedDoneTag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 					if (kAnatomy && tExhausted == 0ull) {
 						tExhausted = __builtin_amdgcn_s_memrealtime();
 						liveAtExhaustion = (uint32_t)__popcll(__ballot(live)) + got;
@@ -963,9 +980,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 				float4 a;
 				float by, bz, bound;
 				bool blocked = false;
-				bool holds; // the slot holds a record (loaded beside the record, not in front of it: one round trip)
 				if (s < nExt) { // a ray of the work queue: closest hit
-					holds = slot_valid(P.segWork, s);
 					a = P.work.o_dx[s];
 					const float2 b = P.work.dyz[s];
 					const float2 h = P.work.hit[s];
@@ -974,15 +989,13 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 					isShadow = false;
 				} else { // a shadow ray of the previous iteration: any hit within closestDistance
 					const uint32_t idx = s - nExt;
-					holds = slot_valid(P.kcPrev->seg, idx);
-					a = P.shadow.o_dx[idx];
-					const float4 b = P.shadow.dyz_cd_ix[idx];
-					blocked = reinterpret_cast<const float*>(&P.shadow.color[idx])[3] != 0.0f; // the sphere pre-pass's verdict
+					a = P.shadowPrev.o_dx[idx];
+					const float4 b = P.shadowPrev.dyz_cd_ix[idx];
+					blocked = reinterpret_cast<const float*>(&P.shadowPrev.color[idx])[3] != 0.0f; // the sphere pre-pass's verdict
 					by = b.x, bz = b.y, bound = b.z;
 					slot = idx;
 					isShadow = true;
 				}
-				blocked = blocked || !holds;
 				const RayConst nr = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, by, bz));
 				rox = nr.o.x, roy = nr.o.y, roz = nr.o.z, rdx = nr.d.x, rdy = nr.d.y, rdz = nr.d.z, rix = nr.inv.x, riy = nr.inv.y, riz = nr.inv.z;
 				regular = ray_is_regular(nr);
@@ -995,7 +1008,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 					ref = sc.quadRootRef;
 				// an extend ray that misses the root box is finished here (the pre-pass's answer stands, nothing to write); a
 				// shadow ray a sphere blocks likewise; a shadow ray that misses the tree is visible: it retires below
-				live = holds && ((ref != kRefDone) || (isShadow && !blocked));
+				live = (ref != kRefDone) || (isShadow && !blocked);
 #ifdef TYR_RAY_STEPS
 				if (!live && s < P.N)
 					P.next.hit[s] = make_float2(0.0f, isShadow ? 1.0f : 0.0f); // never entered the tree
@@ -1080,9 +1093,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 					pendIdx = slot;
 					visible += 1;
 				}
-			} else if (hitTri) {
-				// a triangle hit replaces the sphere answer of the pre-pass (kernel.cu:138-140)
-				P.work.hit[slot] = make_float2(dist, __uint_as_float((uint32_t)prim));
+			} else {
+				finish_extend_ray(P.work.hit, slot, hitTri, dist, prim);
 			}
 			overflow = overflow || st.overflow;
 			live = false;
@@ -1114,7 +1126,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		w.rox = rox, w.roy = roy, w.roz = roz, w.rdx = rdx, w.rdy = rdy, w.rdz = rdz, w.rix = rix, w.riy = riy, w.riz = riz, w.dist = dist;
 		w.ref = ref, w.slot = slot, w.prim = prim, w.n = st.n;
 		w.flags = (regular ? 1u : 0u) | (hitTri ? 2u : 0u) | (isShadow ? 4u : 0u) | (occluded ? 8u : 0u) | (live ? 16u : 0u);
-		const uint32_t res = wide_drain<STACK_LDS>(sc.quads, sc.tris, P.shadow.color, P.shadow.dyz_cd_ix, P.work.hit, P.blit, smem_, w, passes);
+		const uint32_t res = wide_drain<STACK_LDS>(sc.quads, sc.tris, P.shadowPrev.color, P.shadowPrev.dyz_cd_ix, P.work.hit, P.blit, smem_, w, passes);
 		visible += res & 0x3fffffffu;
 		overflow = overflow || (res & 0x80000000u) != 0u;
 		if (res & 0x40000000u)
@@ -1155,16 +1167,23 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 #ifndef TYR_TRACE_STACK
 #define TYR_TRACE_STACK 12 // LDS stack entries per lane of k_trace_flat (a what-if build may pair 8 with TYR_FLAT_WAVES_PER_EU=6)
 #endif
+void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream);
 void launch_trace(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, uint32_t maxShadowPrev, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
+	launch_trace_prepasses(P, nSurvivors, maxShadowPrev, stream); // (the shadow rays' pre-pass reads its counts in kcPrev)
+	launch_trace_kernel(P, maxLive + maxShadowPrev, t, numCUs, lc, stream);
+}
+void launch_trace_kernel(const FrameParams& P, uint32_t items, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
+	hipLaunchKernelGGL((k_trace_flat<TYR_TRACE_STACK>), dim3(persistent_blocks(k_trace_flat<TYR_TRACE_STACK>, items, t, numCUs, lc.perCU[kLcTrace][0])), dim3(kBlock), 0, stream, P);
+}
+void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream) {
 	if (P.traceShadow != 2u)
 		launch_extend_spheres(P, nSurvivors, stream);
 	if (maxShadowPrev != 0) {
 		FrameParams Pc = P;
-		Pc.kc = P.kcPrev; // the sphere pre-pass of the shadow rays reads its counts there
+		Pc.kc = P.kcPrev;
+		Pc.shadow = P.shadowPrev;
 		launch_connect_spheres(Pc, maxShadowPrev, stream);
 	}
-	const uint32_t items = maxLive + maxShadowPrev;
-	hipLaunchKernelGGL((k_trace_flat<TYR_TRACE_STACK>), dim3(persistent_blocks(k_trace_flat<TYR_TRACE_STACK>, items, t, numCUs, lc.perCU[kLcTrace][0])), dim3(kBlock), 0, stream, P);
 }
 
 // extend / connect as launches of their own (the stage API, tyr_launch_kernels): the same kernel with one kind of ray;
@@ -1196,6 +1215,7 @@ void launch_connect(const FrameParams& P0, uint32_t maxShadow, bool countVisits,
 		return;
 	}
 	P.kcPrev = P.kc; // the rays of THIS iteration's shadow queue
+	P.shadowPrev = P.shadow;
 	P.traceShadow = 2u;
 	launch_trace(P, 0u, 0u, maxShadow, t, numCUs, lc, stream);
 }

@@ -6,6 +6,7 @@
 // argument block (FrameParams) instead of cudaMemcpyToSymbol (kernel.cu:681-684, 707-709).
 // There is no CPU fallback: without a HIP device tyr_create fails with TYR_ERR_NO_DEVICE.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -142,7 +143,8 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.scene.nStaged = std::min(c->scene.nStaged, static_cast<uint32_t>(std::max(c->tuning.stagedNodes, 0)));
 	P.work = c->q[c->cur];
 	P.next = c->q[c->cur ^ 1];
-	P.shadow = c->shadow;
+	P.shadow = c->shadow[c->iter & 1u];
+	P.shadowPrev = c->shadow[(c->iter ^ 1u) & 1u];
 	P.blit = c->blit;
 	P.k = c->dK;
 	P.kc = c->dKc + (c->iter & 1u);
@@ -151,6 +153,8 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.segNext = &c->dK->seg[c->cur ^ 1][0];
 	P.segCap = c->segCap;
 	P.survFlag = c->survFlag;
+	P.lateList = c->lateList;
+	P.feedDoneHost = nullptr;
 	{
 		const int out = static_cast<int>(c->iter & 1u), prev = out ^ 1;
 		P.vPrev = tyr::VTable{ c->vWord[prev], c->vPre[prev], c->vBlk[prev] };
@@ -283,6 +287,59 @@ void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	launch_shade(P, nLive, c->numCUs, c->launchCache, c->stream);
 	launch_scan(P, nLive, c->stream);
 }
+// The traversal launch and shade of one merged iteration, overlapped (TYR_TUNE_SHADE_OVERLAP): every ray whose hit record
+// is final before the traversal starts -- it misses the root box: sky, ground sphere, the other spheres; 61 % of the
+// extend rays of a C3 render -- is shaded on the side stream BESIDE the traversal launch (k_shade phase 1), which also
+// picks up whatever the traversal has already answered when it gets to a tile; the launch behind the traversal (phase 2)
+// shades the rest.  Nothing orders the two launches' appends: the queues are unordered (hip/kernels.hpp "Queues").
+// The traversal grid fills the CUs (five blocks: all of the LDS) and the side stream has the lowest priority: the early
+// launch's blocks move in as traversal blocks retire, i.e. into the launch's drain.
+int enqueue_trace_and_shade(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t nSurvivors, uint32_t maxShadowPrev) {
+	if (!c->tuning.shadeOverlap || nLive == 0) {
+		enqueue_trace(c, P0, nLive, nSurvivors, maxShadowPrev);
+		enqueue_shade(c, P0, nLive);
+		return TYR_OK;
+	}
+	c->shadowSet = c->iter & 1u;
+	FrameParams P = P0;
+	P.traceShadow = maxShadowPrev != 0 ? 1u : 0u;
+	const uint32_t blocks = shade_grid(P, nLive, c->numCUs, c->launchCache);
+	// the traversal tells the host when its queue is used up (a pinned word), and only then does the early shade launch go
+	// out: its blocks move into the slots that retiring traversal blocks free -- the launch's drain -- instead of
+	// competing with its feed (launched together the two stretched each other by what they overlapped:
+	// profiles/r03_timeline_shade_overlap_first.txt)
+	P.feedDoneHost = c->feedDoneDev;
+	P.feedDoneTag = ++c->feedDoneTag;
+	{
+		KernelTimer timer(c, TYR_K_EXTEND);
+		launch_trace_prepasses(P, nSurvivors, maxShadowPrev, c->stream);
+		launch_trace_kernel(P, nLive + maxShadowPrev, c->tuning, c->numCUs, c->launchCache, c->stream);
+		HIPCHK(hipEventRecord(c->evPrepass, c->stream)); // (here: the traversal launch has finished)
+	}
+	HIPCHK(hipGetLastError());
+	{
+		// bounded: the launch's end ends the wait too (an empty queue never runs dry), and so does a second of wall time
+		const auto t0 = std::chrono::steady_clock::now();
+		unsigned spins = 0;
+		while (*c->feedDoneHost != P.feedDoneTag) {
+			if ((++spins & 255u) == 0u) {
+				if (hipEventQuery(c->evPrepass) != hipErrorNotReady)
+					break;
+				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1))
+					break;
+			}
+		}
+	}
+	launch_shade_phase(P, 1u, blocks, 2u * blocks, c->side);
+	HIPCHK(hipEventRecord(c->evEarlyShade, c->side));
+	HIPCHK(hipStreamWaitEvent(c->stream, c->evEarlyShade, 0));
+	{
+		KernelTimer timer(c, TYR_K_SHADE);
+		launch_shade_phase(P, 2u, blocks, 2u * blocks, c->stream);
+		launch_scan(P, nLive, c->stream);
+	}
+	return TYR_OK;
+}
 void enqueue_connect(tyr_ctx* c, const FrameParams& P, uint32_t maxShadow) {
 	KernelTimer t(c, TYR_K_CONNECT);
 	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, c->stream);
@@ -296,7 +353,8 @@ int flush_pending_shadow(tyr_ctx* c) {
 		return TYR_OK;
 	c->shadowPending = false;
 	FrameParams P = make_params(c);
-	P.kc = P.kcPrev; // stage_end has advanced `iter`: the rays belong to the previous iteration's counter set
+	P.kc = P.kcPrev; // stage_end has advanced `iter`: the rays belong to the previous iteration's counter set and shadow queue
+	P.shadow = P.shadowPrev;
 	enqueue_connect(c, P, c->shadowPendingMax);
 	HIPCHK(hipGetLastError());
 	return TYR_OK;
@@ -418,7 +476,9 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 	if (cfg->stream) {
 		c->stream = static_cast<hipStream_t>(cfg->stream);
 	} else {
-		if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) != hipSuccess)
 			return fail(TYR_ERR_NO_DEVICE);
 		c->ownStream = true;
 	}
@@ -430,8 +490,9 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 	const size_t cap = static_cast<size_t>(c->segCap) * tyr::kSegs;
 	if ((rc = alloc_rayq(c->q[0], cap)) || (rc = alloc_rayq(c->q[1], cap)))
 		return fail(rc);
-	if ((rc = dev_alloc(c->shadow.o_dx, cap)) || (rc = dev_alloc(c->shadow.dyz_cd_ix, cap)) || (rc = dev_alloc(c->shadow.color, cap)) || (rc = dev_alloc(c->shadow.key, cap)))
-		return fail(rc);
+	for (auto& sq : c->shadow) // two: shade(i) fills one while the traversal launch of iteration i still reads shade(i - 1)'s
+		if ((rc = dev_alloc(sq.o_dx, cap)) || (rc = dev_alloc(sq.dyz_cd_ix, cap)) || (rc = dev_alloc(sq.color, cap)) || (rc = dev_alloc(sq.key, cap)))
+			return fail(rc);
 	// one survive byte per virtual slot, and the two sets of scan tables made from them (iteration i writes set i & 1)
 	const size_t entries = (N + 63) / 64 + kBlock, blocks = (N + 16383) / 16384 + 1;
 	if ((rc = dev_alloc(c->survFlag, N + 64)))
@@ -442,12 +503,25 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		if (hipMemset(c->vWord[t], 0, entries * 8) != hipSuccess || hipMemset(c->vPre[t], 0, entries * 4) != hipSuccess || hipMemset(c->vBlk[t], 0, blocks * 4) != hipSuccess)
 			return fail(TYR_ERR_NO_DEVICE);
 	}
+	if ((rc = dev_alloc(c->lateList, cap / kBlock + 8)))
+		return fail(rc);
+	if (hipHostMalloc(reinterpret_cast<void**>(const_cast<uint32_t**>(&c->feedDoneHost)), 64, hipHostMallocMapped) != hipSuccess)
+		return fail(TYR_ERR_OOM);
+	*c->feedDoneHost = 0;
+	if (hipHostGetDevicePointer(reinterpret_cast<void**>(const_cast<uint32_t**>(&c->feedDoneDev)), const_cast<uint32_t*>(c->feedDoneHost), 0) != hipSuccess)
+		return fail(TYR_ERR_NO_DEVICE);
 	if ((rc = dev_alloc(c->dK, 1)) || (rc = dev_alloc(c->dKc, 2)))
 		return fail(rc);
 	if (hipMemset(c->dKc, 0, 2 * sizeof(ConnectCounters)) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
-	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess)
-		return fail(TYR_ERR_NO_DEVICE);
+	{
+		// the side stream carries the shade launch that runs BESIDE a traversal launch: lowest priority, so that its blocks
+		// only take what the traversal grid leaves free (nothing until traversal blocks retire) instead of displacing it
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess)
+			return fail(TYR_ERR_NO_DEVICE);
+	}
 	if (cfg->flags & TYR_FLAG_TRIANGLE_COLORS) {
 		// the palette's defaults are the reference's constants: white triangles (kernel.cu:383), emission (3,3,3) (kernel.cu:680)
 		if ((rc = dev_alloc(c->dPalette, 512)))
@@ -460,7 +534,8 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		if (hipMemcpy(c->dPalette, pal.data(), pal.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
 			return fail(TYR_ERR_NO_DEVICE);
 	}
-	if (hipEventCreateWithFlags(&c->evSnapshot, hipEventDisableTiming) != hipSuccess)
+	if (hipEventCreateWithFlags(&c->evSnapshot, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evPrepass, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->evEarlyShade, hipEventDisableTiming) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
 	if (hipHostMalloc(reinterpret_cast<void**>(&c->hK), sizeof(DevCounters), hipHostMallocDefault) != hipSuccess)
 		return fail(TYR_ERR_OOM);
@@ -494,11 +569,16 @@ int tyr_destroy(tyr_ctx* c) {
 		(void)hipStreamSynchronize(c->stream);
 	free_rayq(c->q[0]);
 	free_rayq(c->q[1]);
-	dev_free(c->shadow.o_dx);
-	dev_free(c->shadow.dyz_cd_ix);
-	dev_free(c->shadow.color);
-	dev_free(c->shadow.key);
+	for (auto& sq : c->shadow) {
+		dev_free(sq.o_dx);
+		dev_free(sq.dyz_cd_ix);
+		dev_free(sq.color);
+		dev_free(sq.key);
+	}
 	dev_free(c->survFlag);
+	dev_free(c->lateList);
+	if (c->feedDoneHost)
+		(void)hipHostFree(const_cast<uint32_t*>(c->feedDoneHost));
 	for (int t = 0; t < 2; ++t) {
 		dev_free(c->vWord[t]);
 		dev_free(c->vPre[t]);
@@ -527,6 +607,10 @@ int tyr_destroy(tyr_ctx* c) {
 	}
 	if (c->evSnapshot)
 		(void)hipEventDestroy(c->evSnapshot);
+	if (c->evPrepass)
+		(void)hipEventDestroy(c->evPrepass);
+	if (c->evEarlyShade)
+		(void)hipEventDestroy(c->evEarlyShade);
 	if (c->side)
 		(void)hipStreamDestroy(c->side);
 	if (c->ownStream && c->stream)
@@ -837,13 +921,14 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 	if (merge) { // every traversal launch of a merged render is k_trace_flat; the first one has no shadow rays to carry yet
 		const uint32_t carried = c->shadowPending ? c->shadowPendingMax : 0u;
 		c->shadowPending = false;
-		enqueue_trace(c, P, nLive, nLive - nNew, carried);
+		if ((rc = enqueue_trace_and_shade(c, P, nLive, nLive - nNew, carried)))
+			return rc;
 	} else {
 		if ((rc = flush_pending_shadow(c))) // (a render whose merge setting changed between iterations: never, but cheap)
 			return rc;
 		enqueue_extend(c, P, nLive, nLive - nNew);
+		enqueue_shade(c, P, nLive);
 	}
-	enqueue_shade(c, P, nLive);
 	if (merge) {
 		// everything the host needs to launch iteration i + 1 (survivors, budget, the shadow-ray count) is final here
 		HIPCHK(hipMemcpyAsync(c->hK, c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
@@ -907,8 +992,8 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 	const int set = static_cast<int>(c->iter & 1u);
 	FrameParams P = make_params(c);
 	enqueue_primary(c, P, p.nNew);
-	enqueue_trace(c, P, p.nLive, p.nSurvivors, p.carried);
-	enqueue_shade(c, P, p.nLive);
+	if ((rc = enqueue_trace_and_shade(c, P, p.nLive, p.nSurvivors, p.carried)))
+		return rc;
 	HIPCHK(hipMemcpyAsync(c->hSnap[set], c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipEventRecord(c->evSnap[set], c->stream));
 	HIPCHK(hipGetLastError());
@@ -1136,7 +1221,7 @@ int tyr_queue_export(tyr_ctx* c, int which, tyr_ray_queue* host, uint32_t count)
 		uint32_t id;
 		std::memcpy(&id, &h[i].y, 4);
 		r.geometry_type = (id & kHitSphere) ? 0 : 1;
-		r.identifier = static_cast<int32_t>(id & ~kHitSphere);
+		r.identifier = static_cast<int32_t>(id & ~(kHitSphere | tyr::kHitPending));
 	}
 	return TYR_OK;
 }
@@ -1195,7 +1280,8 @@ int tyr_shadow_export(tyr_ctx* c, tyr_shadow_queue* host, uint32_t count) {
 		extent = std::max(extent, s + 1);
 	std::vector<float4> a, b, col;
 	std::vector<uint32_t> key;
-	if ((rc = gather(c->shadow.o_dx, slots, extent, a)) || (rc = gather(c->shadow.dyz_cd_ix, slots, extent, b)) || (rc = gather(c->shadow.color, slots, extent, col)) || (rc = gather(c->shadow.key, slots, extent, key)))
+	const ShadowQ& sq = c->shadow[c->shadowSet];
+	if ((rc = gather(sq.o_dx, slots, extent, a)) || (rc = gather(sq.dyz_cd_ix, slots, extent, b)) || (rc = gather(sq.color, slots, extent, col)) || (rc = gather(sq.key, slots, extent, key)))
 		return rc;
 	std::vector<uint32_t> order(slots.size());
 	for (uint32_t i = 0; i < order.size(); ++i)
@@ -1240,10 +1326,11 @@ int tyr_shadow_import(tyr_ctx* c, const tyr_shadow_queue* host, uint32_t n) {
 		key[i] = i;
 	}
 	if (n) {
-		HIPCHK(hipMemcpy(c->shadow.o_dx, a.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-		HIPCHK(hipMemcpy(c->shadow.dyz_cd_ix, b.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-		HIPCHK(hipMemcpy(c->shadow.color, col.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-		HIPCHK(hipMemcpy(c->shadow.key, key.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+		const ShadowQ& sq = c->shadow[c->iter & 1u];
+		HIPCHK(hipMemcpy(sq.o_dx, a.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(sq.dyz_cd_ix, b.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(sq.color, col.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(sq.key, key.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
 	// what shade leaves behind (kernel.cu:416-417): the counts connect reads, in this iteration's set
 	c->hK->shadow_ray_cnt = n;
@@ -1362,6 +1449,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_STATIC_INTERLEAVE, 0, 1, &Tuning::staticInterleave },
 		{ TYR_TUNE_RUN_AHEAD, 0, 2, &Tuning::runAhead },
 		{ TYR_TUNE_WIDE_DRAIN, 0, 1, &Tuning::wideDrain },
+		{ TYR_TUNE_SHADE_OVERLAP, 0, 1, &Tuning::shadeOverlap },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)
