@@ -192,10 +192,6 @@ __device__ __forceinline__ float2 sphere_hit_record(const FrameParams& P, f3 o, 
 			id = kHitSphere | (uint32_t)i;
 		}
 	}
-	// the traversal's own first test (root_ref at the refill of k_trace_flat: same function, same bound, same answer):
-	// a ray that fails it is finished with this record
-	if (P.scene.rootRef != kRefDone && root_ref(P.scene, make_ray(o, d), dist) != kRefDone)
-		id |= kHitPending;
 	return make_float2(dist, __uint_as_float(id));
 }
 

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 	// extend's sphere pre-pass for this ray, while it is in registers (k_extend_spheres then only has the
 	// survivors of the last iteration to do: nothing at all in a render's first, largest wavefront)
 	P.work.hit[slot] = sphere_hit_record(P, lensPoint, direction);
-	P.work.key[slot] = vslot | kKeySphereDone;
+	P.work.key[slot] = vslot;
 }
 
 // ======================================================================================
@@ -99,7 +99,6 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P) {
 		P.k->extend_chunks[i * 32] = 0;
 		P.kc->chunks[i * 32] = 0;
 		P.k->shade_tiles[i * 32] = 0;
-		P.k->shade_tiles_late[i * 32] = 0;
 		// what this iteration's shade appends to: the next ray queue and this iteration's shadow queue
 		P.segNext[i * kSegStride] = 0;
 		P.kc->seg[i * kSegStride] = 0;
@@ -123,8 +122,6 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P) {
 		k->n_live = cnt + nNew;
 		k->first_fresh = cnt;
 		k->shade_blocks_done = 0;
-		k->late_tiles = 0;
-		k->feed_done = 0;
 		k->shadow_ray_cnt = 0;
 		k->primary_ray_cnt = 0;
 		k->extend_ticket = 0;
@@ -150,14 +147,26 @@ __global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) 
 		P.k->extend_ticket = 0;
 	SegCounts sc;
 	sc.load(P.segWork);
+	uint32_t surv[kSegs];
+#pragma unroll
+	for (uint32_t w = 0; w < kSegs; ++w)
+		surv[w] = P.k->segSurv[w];
 	const uint32_t n = sc.extent();
 	for (uint32_t slot = first; slot < n; slot += stride) {
 		if (!sc.valid(slot)) {
 			write_dead_ray(P.work, slot); // a hole at a segment's end
 			continue;
 		}
-		if (P.work.key[slot] & kKeySphereDone) // this iteration's primary rays: k_primary has done them
-			continue;
+		// the records a top-up appended behind the survivors are this iteration's primary rays: k_primary has done them
+		{
+			const uint32_t seg = (slot >> 6) & (kSegs - 1u);
+			uint32_t lim = surv[0];
+#pragma unroll
+			for (uint32_t w = 1; w < kSegs; ++w)
+				lim = seg == w ? surv[w] : lim;
+			if ((((slot >> 9) << 6) | (slot & 63u)) >= lim)
+				continue;
+		}
 		const float4 a = P.work.o_dx[slot];
 		const float2 b = P.work.dyz[slot];
 		P.work.hit[slot] = sphere_hit_record(P, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));

@@ -24,15 +24,9 @@ struct RayQ {
 	float4* direct_ix;   // direct.rgb (path throughput), pixel index (int bits)     variables.h:27,31
 	uint32_t* flags;     // bounces | lastSpecular << 8                               variables.h:30,33
 	float2* hit;         // distance, identifier (int bits; bit 31 = sphere)         variables.h:28,29,32
-	uint32_t* key;       // the ray's VIRTUAL slot (see "Queues" below): bit 31 = kKeyIndirect, bit 30 = kKeySphereDone
+	uint32_t* key;       // the ray's VIRTUAL slot (see "Queues" below): bit 31 = kKeyIndirect
 };
 constexpr uint32_t kHitSphere = 0x80000000u;
-// bit 30 of the identifier: the ray enters the root box, so the traversal kernel still owes this record its answer.  Set by
-// whoever writes the sphere half (k_primary, k_extend_spheres), cleared by the traversal kernel when the ray is finished:
-// a record without it is FINAL, which is what lets k_shade work on a queue whose traversal launch is still running.
-constexpr uint32_t kHitPending = 0x40000000u;
-constexpr uint32_t kFlagShaded = 0x10000u; // RayQ.flags: an early shade launch (P.shadePhase 1) has dealt with this ray
-
 // ---- Queues: physically unordered, virtually in the serial ticket order ---------------------------------------------
 // The reference appends survivors with atomicAdd(&primary_ray_cnt, 1) (kernel.cu:607) and seeds a ray's random numbers
 // with its SLOT (kernel.cu:363), so "fixed seed" is only defined against one serial order; rounds 1-2 reproduced that
@@ -50,7 +44,6 @@ constexpr uint32_t kFlagShaded = 0x10000u; // RayQ.flags: an early shade launch 
 //     survivor's record carries v | kKeyIndirect; shade(i + 1) looks rank(v) up in the scan's tables (v_lookup).
 //     Fresh primary rays carry their slot directly (survivors + ticket, kernel.cu:254).
 constexpr uint32_t kKeyIndirect = 0x80000000u;   // the low bits are the slot of the PREVIOUS iteration: look the rank up
-constexpr uint32_t kKeySphereDone = 0x40000000u; // the producer (k_primary) has already written the sphere half of the hit record
 constexpr uint32_t kKeyMask = 0x3fffffffu;
 constexpr uint32_t kSegs = 8;                    // = kTicketWords (k_trace_flat's ticket word w draws the chunks of segment w)
 constexpr uint32_t kSegStride = 32;              // uint32 words between two segment counters (128 bytes)
@@ -99,10 +92,8 @@ struct DevCounters {
 	uint32_t seg[2][kSegs * kSegStride];      // records in segment w of ray queue q: seg[q][w * kSegStride]
 	uint32_t shade_blocks_done;               // k_shade: blocks that have finished (the last one folds the segment counters into the totals)
 	uint32_t reserved3[31];
-	uint32_t shade_tiles_late[kTicketWords * 32]; // the tile tickets of the launch behind the traversal (P.shadePhase 2)
-	uint32_t late_tiles;                      // tiles the early shade launch left rays in (P.lateList holds their ids)
-	uint32_t feed_done;                       // k_trace_flat: a wave has found the queue used up (the first one tells the host: P.feedDoneHost)
-	uint32_t reserved4[30];
+	uint32_t segSurv[kSegs];                  // seg[next] as shade left it: the records in front of the primary rays a top-up appends (the sphere pre-pass's share)
+	uint32_t reserved4[24];
 };
 // What connect reads and draws from, apart from the shadow queue.  Two of them, used by alternate iterations:
 // inside tyr_render connect(i) runs on a second stream next to primary / extend of iteration i + 1, whose
@@ -147,10 +138,6 @@ struct FrameParams {
 	uint32_t* vPreOut;
 	uint32_t* vBlkOut;
 	uint32_t shadeBlocks;         // k_shade: blocks of all of this iteration's shade launches together (the last one to finish finalises)
-	uint32_t* lateList;           // k_shade phase 1 -> 2: ids of the tiles that still hold unshaded rays
-	volatile uint32_t* feedDoneHost; // pinned host word: k_trace_flat stores feedDoneTag there when its queue is used up (the host then launches the early shade: it should fill the launch's drain, not compete with its feed); may be null
-	uint32_t feedDoneTag;
-	uint32_t shadePhase;          // k_shade: 0 = every ray; 1 = beside the traversal launch: the rays whose hit record is final (marks them kFlagShaded); 2 = the rest
 	uint32_t refillMinIdle;       // persistent traversal: refill a wave once this many lanes are free
 	uint32_t minTraversing;       // flat traversal: leave the descent loop below this many descending lanes
 	uint32_t ticketChunk;         // variants 1 / 4: queue slots a wave takes per draw from a device-wide ticket
@@ -180,7 +167,6 @@ struct Tuning {
 	int runAhead = 2;         // tyr_render: queue iteration i + 1 before iteration i's counts are on the host: 0 never, 1 always, 2 for queues of at most 6 Mi slots
 	int mergeTrace = 1;       // tyr_render: connect(i) rides in the launch of extend(i + 1)
 	int profileMask = 31;     // TYR_FLAG_PROFILE: which stages (bit TYR_K_*) get a hipEvent pair
-	int shadeOverlap = 1;     // tyr_render: shade the rays that never enter the tree on a second stream BESIDE the traversal launch
 };
 constexpr uint32_t kCountRaysPerBlock = 1024; // the counting build's kernels: queue slots owned by one 256-thread block
 
@@ -201,9 +187,6 @@ void launch_scan(const FrameParams& P, uint32_t maxLive, hipStream_t stream); //
 // nSurvivors: upper bound of the slots the sphere pre-pass still has to do (primary rays get theirs in k_primary)
 void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
 void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCache& lc, hipStream_t stream);
-// one iteration's shade as two launches: phase 1 on `early` (beside the traversal), phase 2 on `late` (behind it)
-uint32_t shade_grid(const FrameParams& P, uint32_t maxSlots, int numCUs, LaunchCache& lc);
-void launch_shade_phase(const FrameParams& P, uint32_t phase, uint32_t blocks, uint32_t blocksOfBothPhases, hipStream_t stream);
 void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream);
 void launch_trace_kernel(const FrameParams& P, uint32_t items, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream); // k_trace_flat alone (launch_trace = pre-passes + this)
 void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);

@@ -134,7 +134,11 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 	int new_frame = 0;
 	f3 color = mk3(0.f, 0.f, 0.f);
 	f3 albedo = mk3(0.f, 0.f, 0.f);
+#ifdef TYR_WHATIF_NO_LOOKUP
+	const uint32_t vslot = key & kKeyMask;
+#else
 	const uint32_t vslot = valid ? v_lookup(P.vPrev, key) : 0u; // the ray's slot by the serial order
+#endif
 	vslotOut = vslot;
 	uint32_t seed = (P.frame * (uint32_t)pixel * 147565741u) * 720898027u * vslot; // kernel.cu:363
 	int material = TYR_DIFF;
@@ -413,9 +417,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u, wave = tid >> 6;
 	const uint32_t extent = queue_extent(P.segWork);
-	// from the device's counts: the host may have sized the grid from an upper bound.  The launch behind the traversal
-	// (phase 2) only visits the tiles the early launch listed
-	const uint32_t nTiles = P.shadePhase == 2u ? P.k->late_tiles : extent / kBlock;
+	const uint32_t nTiles = extent / kBlock; // from the device's counts: the host may have sized the grid from an upper bound
 	const unsigned long long below = (1ull << lane) - 1ull;
 #ifdef TYR_SHADE_TIMING
 	// diagnostic build: where a tile's time goes, in s_memtime ticks summed over this block's tiles (thread 0;
@@ -463,7 +465,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	};
 
 	uint32_t word = blockIdx.x % kTicketWords, tried = 0;
-	uint32_t* const tickets = P.shadePhase == 2u ? P.k->shade_tiles_late : P.k->shade_tiles; // every launch sweeps all tiles
+	uint32_t* const tickets = P.k->shade_tiles;
 	auto draw_tile = [&]() -> uint32_t { // block-uniform; nTiles when nothing is left
 		uint32_t vbNext = nTiles;
 		if (tid == 0) {
@@ -484,8 +486,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		__syncthreads();
 		return vbNext;
 	};
-	for (uint32_t ticket = draw_tile(); ticket < nTiles; ticket = draw_tile()) {
-		const uint32_t vb = P.shadePhase == 2u ? P.lateList[ticket] : ticket; // vb = tile id = 256 physical slots
+	for (uint32_t vb = draw_tile(); vb < nTiles; vb = draw_tile()) { // vb = tile id = 256 physical slots
 		const uint32_t slot = vb * kBlock + tid;
 		ShadeOut out = {};
 		uint32_t pixelBits = 0, vslot = 0;
@@ -499,45 +500,17 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			pendColor = mk3(0.f, 0.f, 0.f);
 			pendNew = 0;
 		};
-		bool valid = lane < chunk_valid(P.segWork, slot & ~63u);
+		const bool valid = lane < chunk_valid(P.segWork, slot & ~63u);
 		float2 hitRecord = make_float2(kVeryFar, 0.f);
-		if (P.shadePhase == 1u) {
-			// beside the traversal launch: only the rays whose hit record is final -- never entered the tree, or the
-			// traversal has already answered (ONE agent-scope look, past the caches, whose value is the one that gets
-			// shaded; a record still pending is left to the late launch)
-			union {
-				unsigned long long u;
-				float2 f;
-			} v;
-			v.u = (unsigned long long)kHitPending << 32;
-			if (valid)
-				v.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&P.work.hit[slot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			hitRecord = v.f;
-			const bool pending = valid && (__float_as_uint(v.f.y) & kHitPending);
-			valid = valid && !pending;
-			const bool anyPending = __syncthreads_or(pending ? 1 : 0) != 0; // (the result is a truth value, not the OR of the arguments)
-			const bool anyReady = __syncthreads_or(valid ? 1 : 0) != 0;
-			if (anyPending && tid == 0)
-				P.lateList[atomicAdd(&P.k->late_tiles, 1u)] = vb; // the launch behind the traversal comes back for the rest
-			if (!anyReady)
-				continue; // nothing ready in this tile (block-uniform)
-			if (valid)
-				P.work.flags[slot] |= kFlagShaded;
-		} else {
-			if (P.shadePhase == 2u) {
-				if (valid)
-					valid = !(P.work.flags[slot] & kFlagShaded);
-				if (__syncthreads_or(valid) == 0)
-					continue; // the early launch has done the whole tile
-			}
-			if (valid)
-				hitRecord = P.work.hit[slot];
-		}
+		if (valid)
+			hitRecord = P.work.hit[slot];
 		if (valid)
 			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
 		shade_ray<LIGHTS>(P, slot, valid, hitRecord, out, vslot, flush_pixels);
+#ifndef TYR_WHATIF_NO_SURVFLAG
 		if (valid)
 			P.survFlag[vslot] = out.survive ? 1 : 0; // what k_scan_words turns into next iteration's slots
+#endif
 		TYR_STAMP(0)
 
 		// ---- ranks inside the tile ----
@@ -623,7 +596,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		flush_prev();
 	}
 	// kernel.cu:607 / 416: the totals the next top-up and connect read.  Every block adds what it appended; the block
-	// that finishes last (of ALL of this iteration's shade launches: P.shadeBlocks) publishes the per-iteration figures.
+	// that finishes last publishes the per-iteration figures.
 	if (tid == 0) {
 		if (mySurvivors)
 			atomicAdd(&P.k->primary_ray_cnt, mySurvivors);
@@ -637,6 +610,8 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			P.k->shadow_ray_cnt = h;
 			P.k->total_shadow_rays += h;
 			P.k->n_survive += s;
+			for (uint32_t w = 0; w < kSegs; ++w) // what the next iteration's sphere pre-pass has to do (a top-up appends behind it)
+				P.k->segSurv[w] = __hip_atomic_load(&P.segNext[w * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 #ifdef TYR_SHADE_TIMING
@@ -666,18 +641,8 @@ uint32_t shade_grid(const FrameParams& P, uint32_t maxSlots, int numCUs, LaunchC
 	const uint32_t resident = (uint32_t)perCU[lights] * (uint32_t)numCUs;
 	return nTiles < resident ? (nTiles ? nTiles : 1u) : resident;
 }
-void launch_shade_phase(const FrameParams& P0, uint32_t phase, uint32_t blocks, uint32_t blocksOfBothPhases, hipStream_t stream) {
-	FrameParams P = P0;
-	P.shadePhase = phase;
-	P.shadeBlocks = blocksOfBothPhases;
-	if (P.flags & TYR_FLAG_LIGHT_LIST)
-		hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(kBlock), 0, stream, P);
-	else
-		hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(kBlock), 0, stream, P);
-}
 void launch_shade(const FrameParams& P0, uint32_t maxSlots, int numCUs, LaunchCache& lc, hipStream_t stream) {
 	FrameParams P = P0;
-	P.shadePhase = 0u;
 	P.shadeBlocks = shade_grid(P, maxSlots, numCUs, lc);
 	if (P.flags & TYR_FLAG_LIGHT_LIST)
 		hipLaunchKernelGGL(k_shade<true>, dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);

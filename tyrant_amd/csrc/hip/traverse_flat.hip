@@ -124,20 +124,10 @@ struct ChunkFeed {
 	}
 };
 
-// A closest-hit ray is finished: a triangle hit replaces the sphere answer of the pre-pass (kernel.cu:138-140); either
-// way the record loses kHitPending.  Agent-scope writes: an early shade launch on another XCD may be looking
-// (it only ever acts on records WITHOUT the bit, so a stale look costs it nothing but the wait for the late launch).
+// a closest-hit ray is finished: a triangle hit replaces the sphere answer of the pre-pass (kernel.cu:138-140)
 __device__ __forceinline__ void finish_extend_ray(float2* hit, uint32_t slot, bool hitTri, float dist, int prim) {
-	if (hitTri) {
-		union {
-			float2 f;
-			unsigned long long u;
-		} v;
-		v.f = make_float2(dist, __uint_as_float((uint32_t)prim));
-		__hip_atomic_store(reinterpret_cast<unsigned long long*>(&hit[slot]), v.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	} else {
-		atomicAnd(reinterpret_cast<uint32_t*>(&hit[slot]) + 1, ~kHitPending);
-	}
+	if (hitTri)
+		hit[slot] = make_float2(dist, __uint_as_float((uint32_t)prim));
 }
 
 // slots of the queue that each block of a persistent grid owns outright (a multiple of 64; 0 for thin queues)
@@ -956,8 +946,6 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 			while (staticDone && got < nIdle) {
 				if (!feed.refill(P.k->extend_chunks, nItems - dynBase, lane)) {
 					exhausted = true;
-					if (P.feedDoneHost != nullptr && lane == 0 && atomicExch(&P.k->feed_done, 1u) == 0u) // the first wave to run dry tells the host
-						__hip_atomic_store(const_cast<uint32_t*>(P.feedDoneHost), P.feedDoneTag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 					if (kAnatomy && tExhausted == 0ull) {
 						tExhausted = __builtin_amdgcn_s_memrealtime();
 						liveAtExhaustion = (uint32_t)__popcll(__ballot(live)) + got;

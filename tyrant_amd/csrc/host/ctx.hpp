@@ -34,7 +34,7 @@ struct tyr_ctx {
 
 	hipStream_t side = nullptr; // second stream of a ctx (shade launches that run beside the traversal)
 	hipEvent_t evSnapshot = nullptr;
-	hipEvent_t evPrepass = nullptr, evEarlyShade = nullptr; // TYR_TUNE_SHADE_OVERLAP: pre-passes done (stream -> side), early shade done (side -> stream)
+	hipEvent_t evScan = nullptr; // the side stream's numbering pass of an iteration has finished (stream waits for it in front of the next shade)
 	// tyr_render with TYR_TUNE_MERGE_TRACE: the shadow rays of the last shaded iteration have not been traced yet (they
 	// ride in the next iteration's trace launch, or in a connect of their own when the render ends)
 	bool shadowPending = false;
@@ -46,10 +46,6 @@ struct tyr_ctx {
 	// hip/kernels.hpp "Queues": room per queue segment, the survive bytes and the two sets of scan tables
 	uint32_t segCap = 0;
 	uint8_t* survFlag = nullptr;
-	uint32_t* lateList = nullptr;              // tiles an early shade launch left rays in
-	volatile uint32_t* feedDoneHost = nullptr; // pinned: the traversal launch's "queue used up" word, and its device alias
-	volatile uint32_t* feedDoneDev = nullptr;
-	uint32_t feedDoneTag = 0;
 	unsigned long long* vWord[2] = { nullptr, nullptr };
 	uint32_t* vPre[2] = { nullptr, nullptr };
 	uint32_t* vBlk[2] = { nullptr, nullptr };

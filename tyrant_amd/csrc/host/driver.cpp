@@ -6,7 +6,6 @@
 // argument block (FrameParams) instead of cudaMemcpyToSymbol (kernel.cu:681-684, 707-709).
 // There is no CPU fallback: without a HIP device tyr_create fails with TYR_ERR_NO_DEVICE.
 #include <algorithm>
-#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -153,8 +152,6 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.segNext = &c->dK->seg[c->cur ^ 1][0];
 	P.segCap = c->segCap;
 	P.survFlag = c->survFlag;
-	P.lateList = c->lateList;
-	P.feedDoneHost = nullptr;
 	{
 		const int out = static_cast<int>(c->iter & 1u), prev = out ^ 1;
 		P.vPrev = tyr::VTable{ c->vWord[prev], c->vPre[prev], c->vBlk[prev] };
@@ -249,7 +246,9 @@ int stage_begin(tyr_ctx* c) {
 		HIPCHK(hipMemcpyAsync(&c->dK->primary_ray_cnt, &c->hK->primary_ray_cnt, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 		// ... and with it the survivors in the work queue (the next top-up regenerates all N slots, quirk 16)
 		std::memset(&c->hK->seg[c->cur][0], 0, sizeof c->hK->seg[0]);
+		std::memset(c->hK->segSurv, 0, sizeof c->hK->segSurv);
 		HIPCHK(hipMemsetAsync(&c->dK->seg[c->cur][0], 0, sizeof c->dK->seg[0], c->stream));
+		HIPCHK(hipMemsetAsync(c->dK->segSurv, 0, sizeof c->dK->segSurv, c->stream));
 	}
 	return TYR_OK;
 }
@@ -286,59 +285,6 @@ void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	KernelTimer t(c, TYR_K_SHADE);
 	launch_shade(P, nLive, c->numCUs, c->launchCache, c->stream);
 	launch_scan(P, nLive, c->stream);
-}
-// The traversal launch and shade of one merged iteration, overlapped (TYR_TUNE_SHADE_OVERLAP): every ray whose hit record
-// is final before the traversal starts -- it misses the root box: sky, ground sphere, the other spheres; 61 % of the
-// extend rays of a C3 render -- is shaded on the side stream BESIDE the traversal launch (k_shade phase 1), which also
-// picks up whatever the traversal has already answered when it gets to a tile; the launch behind the traversal (phase 2)
-// shades the rest.  Nothing orders the two launches' appends: the queues are unordered (hip/kernels.hpp "Queues").
-// The traversal grid fills the CUs (five blocks: all of the LDS) and the side stream has the lowest priority: the early
-// launch's blocks move in as traversal blocks retire, i.e. into the launch's drain.
-int enqueue_trace_and_shade(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t nSurvivors, uint32_t maxShadowPrev) {
-	if (!c->tuning.shadeOverlap || nLive == 0) {
-		enqueue_trace(c, P0, nLive, nSurvivors, maxShadowPrev);
-		enqueue_shade(c, P0, nLive);
-		return TYR_OK;
-	}
-	c->shadowSet = c->iter & 1u;
-	FrameParams P = P0;
-	P.traceShadow = maxShadowPrev != 0 ? 1u : 0u;
-	const uint32_t blocks = shade_grid(P, nLive, c->numCUs, c->launchCache);
-	// the traversal tells the host when its queue is used up (a pinned word), and only then does the early shade launch go
-	// out: its blocks move into the slots that retiring traversal blocks free -- the launch's drain -- instead of
-	// competing with its feed (launched together the two stretched each other by what they overlapped:
-	// profiles/r03_timeline_shade_overlap_first.txt)
-	P.feedDoneHost = c->feedDoneDev;
-	P.feedDoneTag = ++c->feedDoneTag;
-	{
-		KernelTimer timer(c, TYR_K_EXTEND);
-		launch_trace_prepasses(P, nSurvivors, maxShadowPrev, c->stream);
-		launch_trace_kernel(P, nLive + maxShadowPrev, c->tuning, c->numCUs, c->launchCache, c->stream);
-		HIPCHK(hipEventRecord(c->evPrepass, c->stream)); // (here: the traversal launch has finished)
-	}
-	HIPCHK(hipGetLastError());
-	{
-		// bounded: the launch's end ends the wait too (an empty queue never runs dry), and so does a second of wall time
-		const auto t0 = std::chrono::steady_clock::now();
-		unsigned spins = 0;
-		while (*c->feedDoneHost != P.feedDoneTag) {
-			if ((++spins & 255u) == 0u) {
-				if (hipEventQuery(c->evPrepass) != hipErrorNotReady)
-					break;
-				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1))
-					break;
-			}
-		}
-	}
-	launch_shade_phase(P, 1u, blocks, 2u * blocks, c->side);
-	HIPCHK(hipEventRecord(c->evEarlyShade, c->side));
-	HIPCHK(hipStreamWaitEvent(c->stream, c->evEarlyShade, 0));
-	{
-		KernelTimer timer(c, TYR_K_SHADE);
-		launch_shade_phase(P, 2u, blocks, 2u * blocks, c->stream);
-		launch_scan(P, nLive, c->stream);
-	}
-	return TYR_OK;
 }
 void enqueue_connect(tyr_ctx* c, const FrameParams& P, uint32_t maxShadow) {
 	KernelTimer t(c, TYR_K_CONNECT);
@@ -503,13 +449,6 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		if (hipMemset(c->vWord[t], 0, entries * 8) != hipSuccess || hipMemset(c->vPre[t], 0, entries * 4) != hipSuccess || hipMemset(c->vBlk[t], 0, blocks * 4) != hipSuccess)
 			return fail(TYR_ERR_NO_DEVICE);
 	}
-	if ((rc = dev_alloc(c->lateList, cap / kBlock + 8)))
-		return fail(rc);
-	if (hipHostMalloc(reinterpret_cast<void**>(const_cast<uint32_t**>(&c->feedDoneHost)), 64, hipHostMallocMapped) != hipSuccess)
-		return fail(TYR_ERR_OOM);
-	*c->feedDoneHost = 0;
-	if (hipHostGetDevicePointer(reinterpret_cast<void**>(const_cast<uint32_t**>(&c->feedDoneDev)), const_cast<uint32_t*>(c->feedDoneHost), 0) != hipSuccess)
-		return fail(TYR_ERR_NO_DEVICE);
 	if ((rc = dev_alloc(c->dK, 1)) || (rc = dev_alloc(c->dKc, 2)))
 		return fail(rc);
 	if (hipMemset(c->dKc, 0, 2 * sizeof(ConnectCounters)) != hipSuccess)
@@ -534,8 +473,7 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		if (hipMemcpy(c->dPalette, pal.data(), pal.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
 			return fail(TYR_ERR_NO_DEVICE);
 	}
-	if (hipEventCreateWithFlags(&c->evSnapshot, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evPrepass, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&c->evEarlyShade, hipEventDisableTiming) != hipSuccess)
+	if (hipEventCreateWithFlags(&c->evSnapshot, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evScan, hipEventDisableTiming) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
 	if (hipHostMalloc(reinterpret_cast<void**>(&c->hK), sizeof(DevCounters), hipHostMallocDefault) != hipSuccess)
 		return fail(TYR_ERR_OOM);
@@ -576,9 +514,6 @@ int tyr_destroy(tyr_ctx* c) {
 		dev_free(sq.key);
 	}
 	dev_free(c->survFlag);
-	dev_free(c->lateList);
-	if (c->feedDoneHost)
-		(void)hipHostFree(const_cast<uint32_t*>(c->feedDoneHost));
 	for (int t = 0; t < 2; ++t) {
 		dev_free(c->vWord[t]);
 		dev_free(c->vPre[t]);
@@ -607,10 +542,8 @@ int tyr_destroy(tyr_ctx* c) {
 	}
 	if (c->evSnapshot)
 		(void)hipEventDestroy(c->evSnapshot);
-	if (c->evPrepass)
-		(void)hipEventDestroy(c->evPrepass);
-	if (c->evEarlyShade)
-		(void)hipEventDestroy(c->evEarlyShade);
+	if (c->evScan)
+		(void)hipEventDestroy(c->evScan);
 	if (c->side)
 		(void)hipStreamDestroy(c->side);
 	if (c->ownStream && c->stream)
@@ -921,8 +854,8 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 	if (merge) { // every traversal launch of a merged render is k_trace_flat; the first one has no shadow rays to carry yet
 		const uint32_t carried = c->shadowPending ? c->shadowPendingMax : 0u;
 		c->shadowPending = false;
-		if ((rc = enqueue_trace_and_shade(c, P, nLive, nLive - nNew, carried)))
-			return rc;
+		enqueue_trace(c, P, nLive, nLive - nNew, carried);
+		enqueue_shade(c, P, nLive);
 	} else {
 		if ((rc = flush_pending_shadow(c))) // (a render whose merge setting changed between iterations: never, but cheap)
 			return rc;
@@ -992,8 +925,8 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 	const int set = static_cast<int>(c->iter & 1u);
 	FrameParams P = make_params(c);
 	enqueue_primary(c, P, p.nNew);
-	if ((rc = enqueue_trace_and_shade(c, P, p.nLive, p.nSurvivors, p.carried)))
-		return rc;
+	enqueue_trace(c, P, p.nLive, p.nSurvivors, p.carried);
+	enqueue_shade(c, P, p.nLive);
 	HIPCHK(hipMemcpyAsync(c->hSnap[set], c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipEventRecord(c->evSnap[set], c->stream));
 	HIPCHK(hipGetLastError());
@@ -1154,6 +1087,7 @@ int tyr_reset_accum(tyr_ctx* c) {
 	HIPCHK(hipMemsetAsync(c->blit, 0, sizeof(float4) * static_cast<size_t>(c->cfg.width) * c->cfg.height, c->stream));
 	c->hK->primary_ray_cnt = 0;
 	std::memset(&c->hK->seg[c->cur][0], 0, sizeof c->hK->seg[0]);
+	std::memset(c->hK->segSurv, 0, sizeof c->hK->segSurv);
 	return push_counters(c);
 }
 
@@ -1221,7 +1155,7 @@ int tyr_queue_export(tyr_ctx* c, int which, tyr_ray_queue* host, uint32_t count)
 		uint32_t id;
 		std::memcpy(&id, &h[i].y, 4);
 		r.geometry_type = (id & kHitSphere) ? 0 : 1;
-		r.identifier = static_cast<int32_t>(id & ~(kHitSphere | tyr::kHitPending));
+		r.identifier = static_cast<int32_t>(id & ~kHitSphere);
 	}
 	return TYR_OK;
 }
@@ -1262,6 +1196,8 @@ int tyr_queue_import(tyr_ctx* c, const tyr_ray_queue* host, uint32_t n) {
 	}
 	c->hK->primary_ray_cnt = n;
 	dense_counts(n, &c->hK->seg[c->cur][0]);
+	for (uint32_t w = 0; w < tyr::kSegs; ++w)
+		c->hK->segSurv[w] = c->hK->seg[c->cur][w * tyr::kSegStride];
 	return push_counters(c);
 }
 
@@ -1449,7 +1385,6 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_STATIC_INTERLEAVE, 0, 1, &Tuning::staticInterleave },
 		{ TYR_TUNE_RUN_AHEAD, 0, 2, &Tuning::runAhead },
 		{ TYR_TUNE_WIDE_DRAIN, 0, 1, &Tuning::wideDrain },
-		{ TYR_TUNE_SHADE_OVERLAP, 0, 1, &Tuning::shadeOverlap },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)
