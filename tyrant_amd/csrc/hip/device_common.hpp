@@ -144,8 +144,8 @@ struct SegCounts {
 		return (((s >> 9) << 6) | (s & 63u)) < lim;
 	}
 };
-// what a slot that holds no record looks like to the traversal kernel: a ray that cannot enter any box (the pre-passes
-// and k_primary write it into the holes at the segments' ends, so that k_trace_flat hands out slots without asking)
+// what a slot that holds no record looks like to the traversal kernel: a ray that cannot enter any box (k_pad_holes
+// writes it into the holes at the segments' ends, so that k_trace_flat hands out slots without asking)
 __device__ __forceinline__ void write_dead_ray(const RayQ& q, uint32_t slot) {
 	q.o_dx[slot] = make_float4(3e38f, 3e38f, 3e38f, 1.0f);
 	q.dyz[slot] = make_float2(0.0f, 0.0f);

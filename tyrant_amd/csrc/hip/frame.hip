@@ -9,45 +9,16 @@ namespace tyr {
 // primary_rays, kernel.cu:247-297.  One thread per new queue slot.
 // ======================================================================================
 __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
-	__shared__ uint32_t baseSh;
+	__shared__ uint32_t baseSh[kClasses], cntSh[8];
 	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t cnt = P.k->primary_ray_cnt; // survivors already in the buffer (kernel.cu:253)
 	const unsigned long long room = (unsigned long long)(P.N - cnt);
 	const unsigned long long budget = P.k->budget_remaining;
 	const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
 	const uint32_t firstOfBlock = blockIdx.x * kBlock;
-	uint32_t slot;
-	if (cnt == 0) {
-		// nothing in the queue (a render's first wavefront, the whole queue after a reset): the rays are laid down densely,
-		// ray i in slot i -- chunk i / 64 of segment (i / 64) % 8, the counts follow arithmetically (k_globals) -- and the
-		// slots between nNew and the end of its group of eight chunks become holes the traversal can skip by itself
-		const uint32_t padded = (nNew + 511u) & ~511u;
-		if (index >= padded)
-			return;
-		slot = index;
-		if (index >= nNew) {
-			write_dead_ray(P.work, slot);
-			return;
-		}
-	} else {
-		if (firstOfBlock >= nNew)
-			return; // (the whole block)
-		// the block's rays go to segment blockIdx % 8 of the work queue, behind what it holds: one atomic per block
-		const uint32_t nHere = nNew - firstOfBlock < (uint32_t)kBlock ? nNew - firstOfBlock : (uint32_t)kBlock;
-		const uint32_t seg = blockIdx.x & (kSegs - 1u);
-		if (threadIdx.x == 0) {
-			uint32_t base = atomicAdd(&P.segWork[seg * kSegStride], nHere);
-			if (base + nHere > P.segCap) {
-				atomicOr(&P.k->device_error, kErrQueueOverflow);
-				base = 0xffffffffu;
-			}
-			baseSh = base;
-		}
-		__syncthreads();
-		if (index >= nNew || baseSh == 0xffffffffu)
-			return;
-		slot = seg_phys(seg, baseSh + threadIdx.x);
-	}
+	if (firstOfBlock >= nNew)
+		return; // (the whole block)
+	const bool mine = index < nNew;
 	const uint32_t vslot = index + cnt; // the slot the serial order gives this ray (kernel.cu:254): what seeds its shading
 	// kernel.cu:258 seeds by the ticket `index`; with pixel sharding (nranks > 1) the ranks' tickets are interleaved so that
 	// rows y = yl * R + r, r = 0..R-1, do not share their jitter and lens samples (nranks == 1: the reference's expression)
@@ -79,14 +50,56 @@ __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 	const f3 lensPoint = O + camRgt * pLx + camUpv * pLy;
 	const f3 direction = normalize(focusPoint - lensPoint);
 
+	// extend's sphere half for this ray, while it is in registers (k_extend_spheres then only has the survivors of the
+	// last iteration to do), and the traversal's own first test (root_ref at the refill of k_trace_flat: same function,
+	// same bound, same answer): a ray that fails it goes to class 1 and is finished with this record
+	const float2 hitRecord = sphere_hit_record(P, lensPoint, direction);
+	const bool tree = mine && P.scene.rootRef != kRefDone && root_ref(P.scene, make_ray(lensPoint, direction), hitRecord.x) != kRefDone;
+	// the block's rays of either class go to segment blockIdx % 8 of that class, behind what it holds: one atomic each
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const unsigned long long bt = __ballot(tree), bsky = __ballot(mine && !tree), below = (1ull << lane) - 1ull;
+	if (lane == 0) {
+		cntSh[wave] = (uint32_t)__popcll(bt);
+		cntSh[4 + wave] = (uint32_t)__popcll(bsky);
+	}
+	__syncthreads();
+	uint32_t before[2] = { 0, 0 }, total[2] = { 0, 0 };
+#pragma unroll
+	for (uint32_t w = 0; w < kBlock / 64; ++w) {
+		if (w < wave) {
+			before[0] += cntSh[w];
+			before[1] += cntSh[4 + w];
+		}
+		total[0] += cntSh[w];
+		total[1] += cntSh[4 + w];
+	}
+	const uint32_t seg = blockIdx.x & (kSegs - 1u);
+	if (threadIdx.x < kClasses) {
+		const uint32_t c = threadIdx.x, n = total[c];
+		uint32_t base = 0;
+		if (n) {
+			base = atomicAdd(&P.segWork[c * kClassWords + seg * kSegStride], n);
+			if (base + n > P.segCap) {
+				atomicOr(&P.k->device_error, kErrQueueOverflow);
+				base = 0xffffffffu;
+			}
+		}
+		baseSh[c] = base;
+	}
+	__syncthreads();
+	if (!mine)
+		return;
+	const uint32_t cls = tree ? 0u : 1u;
+	if (baseSh[cls] == 0xffffffffu)
+		return;
+	const uint32_t rank = before[cls] + (uint32_t)__popcll((tree ? bt : bsky) & below);
+	const uint32_t slot = cls * P.classStride + seg_phys(seg, baseSh[cls] + rank);
 	// kernel.cu:295: {origin, direction, {1,1,1}, 0, 0, 0, pixel}; lastSpecular defaults to true (variables.h:33)
 	P.work.o_dx[slot] = make_float4(lensPoint.x, lensPoint.y, lensPoint.z, direction.x);
 	P.work.dyz[slot] = make_float2(direction.y, direction.z);
 	P.work.direct_ix[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(y * (int)P.W + x));
 	P.work.flags[slot] = 0u | (1u << 8);
-	// extend's sphere pre-pass for this ray, while it is in registers (k_extend_spheres then only has the
-	// survivors of the last iteration to do: nothing at all in a render's first, largest wavefront)
-	P.work.hit[slot] = sphere_hit_record(P, lensPoint, direction);
+	P.work.hit[slot] = hitRecord;
 	P.work.key[slot] = vslot;
 }
 
@@ -101,17 +114,9 @@ __global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P) {
 		P.k->shade_tiles[i * 32] = 0;
 		// what this iteration's shade appends to: the next ray queue and this iteration's shadow queue
 		P.segNext[i * kSegStride] = 0;
+		P.segNext[kClassWords + i * kSegStride] = 0;
 		P.kc->seg[i * kSegStride] = 0;
-		// k_primary laid its rays down densely when the queue was empty: the counts that go with that
-		const uint32_t cnt0 = P.k->primary_ray_cnt;
-		if (cnt0 == 0) {
-			const unsigned long long room = (unsigned long long)P.N, budget = P.k->budget_remaining;
-			const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
-			const uint32_t rem = nNew & 511u, part = rem > 64u * i ? (rem - 64u * i < 64u ? rem - 64u * i : 64u) : 0u;
-			P.segWork[i * kSegStride] = (nNew >> 9) * 64u + part;
-		}
 	}
-	__syncthreads(); // thread 0 below changes primary_ray_cnt and the budget the lines above have read
 	if (i == 0) {
 		DevCounters* k = P.k;
 		const uint32_t cnt = k->primary_ray_cnt;
@@ -145,31 +150,40 @@ __global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) 
 	const uint32_t first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
 	if (first == 0)
 		P.k->extend_ticket = 0;
-	SegCounts sc;
-	sc.load(P.segWork);
-	uint32_t surv[kSegs];
+	// the survivors of the last iteration, both classes: the records in front of what a top-up appended (k_primary has done
+	// its own rays).  Class 0: the distance bounds the BVH search; class 1: the record is the ray's answer.
+	for (uint32_t c = 0; c < kClasses; ++c) {
+		SegCounts sc;
 #pragma unroll
-	for (uint32_t w = 0; w < kSegs; ++w)
-		surv[w] = P.k->segSurv[w];
-	const uint32_t n = sc.extent();
-	for (uint32_t slot = first; slot < n; slot += stride) {
-		if (!sc.valid(slot)) {
-			write_dead_ray(P.work, slot); // a hole at a segment's end
-			continue;
-		}
-		// the records a top-up appended behind the survivors are this iteration's primary rays: k_primary has done them
-		{
-			const uint32_t seg = (slot >> 6) & (kSegs - 1u);
-			uint32_t lim = surv[0];
-#pragma unroll
-			for (uint32_t w = 1; w < kSegs; ++w)
-				lim = seg == w ? surv[w] : lim;
-			if ((((slot >> 9) << 6) | (slot & 63u)) >= lim)
+		for (uint32_t w = 0; w < kSegs; ++w)
+			sc.c[w] = P.k->segSurv[c][w];
+		const uint32_t n = sc.extent(), base = c * P.classStride;
+		for (uint32_t j = first; j < n; j += stride) {
+			if (!sc.valid(j))
 				continue;
+			const uint32_t slot = base + j;
+			const float4 a = P.work.o_dx[slot];
+			const float2 b = P.work.dyz[slot];
+			P.work.hit[slot] = sphere_hit_record(P, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
 		}
-		const float4 a = P.work.o_dx[slot];
-		const float2 b = P.work.dyz[slot];
-		P.work.hit[slot] = sphere_hit_record(P, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+	}
+}
+
+// The slots at the ends of the eight segments that hold no record (a segment is a few records shorter than the longest)
+// become rays that enter nothing / shadow rays that are "occluded": k_trace_flat hands out slots [0, extent) without
+// asking which of them hold a record.  Block w does segment w; what == 0: class 0 of the work queue, 1: the shadow queue.
+__global__ void __launch_bounds__(kBlock) k_pad_holes(const FrameParams P, uint32_t workQueue, uint32_t shadowQueue) {
+	const uint32_t w = blockIdx.x & (kSegs - 1u), what = blockIdx.x / kSegs;
+	if ((what == 0 && !workQueue) || (what == 1 && !shadowQueue))
+		return;
+	const uint32_t* cnt = what == 0 ? P.segWork : P.kc->seg;
+	const uint32_t mine = cnt[w * kSegStride], ext = queue_extent(cnt) / kSegs; // records per segment up to the extent
+	for (uint32_t j = mine + threadIdx.x; j < ext; j += kBlock) {
+		const uint32_t slot = seg_phys(w, j);
+		if (what == 0)
+			write_dead_ray(P.work, slot);
+		else
+			reinterpret_cast<float*>(&P.shadow.color[slot])[3] = 1.0f;
 	}
 }
 
@@ -186,10 +200,8 @@ __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P)
 	sc.load(P.kc->seg);
 	const uint32_t n = sc.extent();
 	for (uint32_t index = first; index < n; index += stride) {
-		if (!sc.valid(index)) {
-			reinterpret_cast<float*>(&P.shadow.color[index])[3] = 1.0f; // a hole: "occluded" retires it at the traversal's refill
-			continue;
-		}
+		if (!sc.valid(index))
+			continue; // (a hole: k_pad_holes marks it)
 		const float4 a = P.shadow.o_dx[index];
 		const float4 b = P.shadow.dyz_cd_ix[index];
 		const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
@@ -395,9 +407,13 @@ __global__ void __launch_bounds__(kBlock) k_extend_debug(const FrameParams P) {
 	TravStack<0> st;
 	st.bind(nullptr, refs, ts);
 	st.reset();
-	const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-	if (slot >= queue_extent(P.segWork) || !slot_valid(P.segWork, slot))
-		return;
+	uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+	{
+		const uint32_t c = slot >= P.classStride ? 1u : 0u, j = slot - c * P.classStride;
+		const uint32_t* cnt = P.segWork + c * kClassWords;
+		if (c >= kClasses || j >= queue_extent(cnt) || !slot_valid(cnt, j))
+			return;
+	}
 	const float4 a = P.work.o_dx[slot];
 	const float2 b = P.work.dyz[slot];
 	float dist = kVeryFar; // kernel.cu:145; the spheres are commented out there (147-155)
@@ -427,10 +443,13 @@ __global__ void __launch_bounds__(kBlock) k_extend_debug(const FrameParams P) {
 // ---- launch wrappers ---------------------------------------------------------------------
 
 constexpr uint32_t kPrepassMaxBlocks = 8192; // 8 waves of 256 threads per SIMD of a 256-CU part: enough to stream at full rate
+void launch_pad_holes(const FrameParams& P, bool workQueue, bool shadowQueue, hipStream_t stream) {
+	hipLaunchKernelGGL(k_pad_holes, dim3(2 * kSegs), dim3(kBlock), 0, stream, P, workQueue ? 1u : 0u, shadowQueue ? 1u : 0u);
+}
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
 	if (maxNew == 0)
 		return;
-	hipLaunchKernelGGL(k_primary, dim3(blocks_for((maxNew + 511u) & ~511u)), dim3(kBlock), 0, stream, P);
+	hipLaunchKernelGGL(k_primary, dim3(blocks_for(maxNew)), dim3(kBlock), 0, stream, P);
 }
 void launch_globals(const FrameParams& P, hipStream_t stream) { hipLaunchKernelGGL(k_globals, dim3(1), dim3(kBlock), 0, stream, P); }
 void launch_scan(const FrameParams& P, uint32_t maxLive, hipStream_t stream) {

@@ -43,10 +43,17 @@ constexpr uint32_t kHitSphere = 0x80000000u;
 //     rank(v) = survivors with a lower virtual slot = the survivor's slot in iteration i + 1 by the serial order.  The
 //     survivor's record carries v | kKeyIndirect; shade(i + 1) looks rank(v) up in the scan's tables (v_lookup).
 //     Fresh primary rays carry their slot directly (survivors + ticket, kernel.cu:254).
+//   * a RAY queue is two such sets of segments, one per CLASS: class 0 holds the rays that may enter the tree (they pass
+//     the root box), class 1 the rays that cannot (sky, ground sphere, the other spheres: 61 % of the extend rays of a C3
+//     render).  Whoever makes a ray knows which it is -- k_primary and k_shade have origin and direction in registers --
+//     and the traversal kernel is only ever handed class 0; the sphere pre-pass and shade walk both.  Class c's records lie
+//     at slots [c * classStride, ...) of the same arrays.
 constexpr uint32_t kKeyIndirect = 0x80000000u;   // the low bits are the slot of the PREVIOUS iteration: look the rank up
 constexpr uint32_t kKeyMask = 0x3fffffffu;
 constexpr uint32_t kSegs = 8;                    // = kTicketWords (k_trace_flat's ticket word w draws the chunks of segment w)
 constexpr uint32_t kSegStride = 32;              // uint32 words between two segment counters (128 bytes)
+constexpr uint32_t kClasses = 2;                 // ray queues: 0 = may enter the tree, 1 = cannot
+constexpr uint32_t kClassWords = kSegs * kSegStride; // uint32 words between the counters of class 0 and class 1
 struct VTable {                                  // scan of one iteration's survive bytes, 64 virtual slots per entry
 	const unsigned long long* word;              // bit b of word[e]: slot 64 e + b survived
 	const uint32_t* pre;                         // survivors in front of word e inside its 16384-slot block
@@ -89,11 +96,11 @@ struct DevCounters {
 	uint32_t extend_chunks[kTicketWords * 32];
 	uint32_t reserved2[kTicketWords * 32]; // (connect's chunk tickets live in ConnectCounters)
 	uint32_t shade_tiles[kTicketWords * 32]; // k_shade: word w hands out tiles w, w + 8, w + 16, ...
-	uint32_t seg[2][kSegs * kSegStride];      // records in segment w of ray queue q: seg[q][w * kSegStride]
+	uint32_t seg[2][kClasses][kSegs * kSegStride]; // records in segment w of class c of ray queue q: seg[q][c][w * kSegStride]
 	uint32_t shade_blocks_done;               // k_shade: blocks that have finished (the last one folds the segment counters into the totals)
 	uint32_t reserved3[31];
-	uint32_t segSurv[kSegs];                  // seg[next] as shade left it: the records in front of the primary rays a top-up appends (the sphere pre-pass's share)
-	uint32_t reserved4[24];
+	uint32_t segSurv[kClasses][kSegs];        // seg[next] as shade left it: the records in front of the primary rays a top-up appends (the sphere pre-pass's share)
+	uint32_t reserved4[16];
 };
 // What connect reads and draws from, apart from the shadow queue.  Two of them, used by alternate iterations:
 // inside tyr_render connect(i) runs on a second stream next to primary / extend of iteration i + 1, whose
@@ -129,9 +136,10 @@ struct FrameParams {
 	DevCounters* k;
 	ConnectCounters* kc;     // this iteration's set
 	ConnectCounters* kcPrev; // the previous iteration's set (k_trace_flat: its shadow rays are traced beside this iteration's extend)
-	uint32_t* segWork;            // segment counters of `work` / `next` (DevCounters.seg[...]); the shadow queue's are kc->seg / kcPrev->seg
+	uint32_t* segWork;            // segment counters of `work` / `next`, class 0 (class 1: + kClassWords); the shadow queue's are kc->seg / kcPrev->seg
 	uint32_t* segNext;
 	uint32_t segCap;              // records one segment has room for
+	uint32_t classStride;         // first slot of class 1 in the ray queues' arrays (= kSegs * segCap)
 	uint8_t* survFlag;            // [N] shade writes 1 / 0 at the ray's virtual slot
 	VTable vPrev;                 // the scan of the previous iteration's survive bytes (what kKeyIndirect keys are looked up in)
 	unsigned long long* vWordOut; // ... and where the scan of this iteration's goes
@@ -183,6 +191,7 @@ struct LaunchCache {
 // against the device counters
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream);
 void launch_globals(const FrameParams& P, hipStream_t stream);
+void launch_pad_holes(const FrameParams& P, bool workQueue, bool shadowQueue, hipStream_t stream); // the slots at the segments' ends that hold no record become rays that enter nothing
 void launch_scan(const FrameParams& P, uint32_t maxLive, hipStream_t stream); // the survive bytes of this iteration -> vWordOut / vPreOut / vBlkOut
 // nSurvivors: upper bound of the slots the sphere pre-pass still has to do (primary rays get theirs in k_primary)
 void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);

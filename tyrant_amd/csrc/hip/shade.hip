@@ -12,6 +12,7 @@ namespace tyr {
 // ======================================================================================
 struct ShadeOut {
 	bool survive, shadow;
+	bool tree; // a survivor that may enter the tree (class 0 of the next queue)
 	f3 origin, direction, direct; // survivor state
 	uint32_t flags;
 	f3 sOrigin, sDir, sColor;      // shadow ray
@@ -369,6 +370,9 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 			bounces++;
 			direct = direct * (1.0f / p);
 			out.survive = true;
+			// the traversal's own first test on the new ray, without the sphere bound it does not have yet (a bound only
+			// takes rays away): a ray that fails it can never enter the tree and goes to class 1
+			out.tree = P.scene.rootRef != kRefDone && root_ref(P.scene, make_ray(origin, direction), kVeryFar) != kRefDone;
 			out.origin = origin;
 			out.direction = direction;
 			out.direct = direct;
@@ -416,8 +420,9 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	__shared__ ShadeStage stage;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u, wave = tid >> 6;
-	const uint32_t extent = queue_extent(P.segWork);
-	const uint32_t nTiles = extent / kBlock; // from the device's counts: the host may have sized the grid from an upper bound
+	// class 0's tiles, then class 1's (from the device's counts: the host may have sized the grid from an upper bound)
+	const uint32_t tiles0 = queue_extent(P.segWork) / kBlock;
+	const uint32_t nTiles = tiles0 + queue_extent(P.segWork + kClassWords) / kBlock;
 	const unsigned long long below = (1ull << lane) - 1ull;
 #ifdef TYR_SHADE_TIMING
 	// diagnostic build: where a tile's time goes, in s_memtime ticks summed over this block's tiles (thread 0;
@@ -431,24 +436,28 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	uint32_t pendPixel = 0;           // this lane's pixel contribution of that tile, not yet added
 	int pendNew = 0;
 	f3 pendColor = mk3(0.f, 0.f, 0.f);
-	uint32_t prevSeg = 0, prevS = 0, prevH = 0;
+	uint32_t prevSeg = 0, prevS = 0, prevT = 0, prevH = 0;
 	uint32_t mySurvivors = 0, myShadows = 0; // thread 0: what this block appended
 
 	// finish the waiting tile: its places have arrived (sh[12], sh[13]); move its records from LDS to the queues
 	auto flush_prev = [&]() {
-		const uint32_t baseS = sh[12], baseH = sh[13];
+		const uint32_t baseT = sh[12], baseH = sh[13], baseK = sh[18];
 		TYR_STAMP(2)
 		// one array at a time (the compiler barrier keeps it from loading all records first): this copy is where the
 		// kernel's register count peaks
-		if (tid < prevS && baseS != 0xffffffffu) {
-			const uint32_t d = seg_phys(prevSeg, baseS + tid);
-			P.next.o_dx[d] = stage.sv_o_dx[tid];
-			__asm__ volatile("" ::: "memory");
-			P.next.direct_ix[d] = stage.sv_direct_ix[tid];
-			__asm__ volatile("" ::: "memory");
-			P.next.dyz[d] = stage.sv_dyz[tid];
-			P.next.flags[d] = stage.sv_flags[tid];
-			P.next.key[d] = stage.sv_key[tid];
+		{
+			const bool isTree = tid < prevT;
+			const uint32_t base = isTree ? baseT : baseK;
+			if (tid < prevS && base != 0xffffffffu) {
+				const uint32_t d = isTree ? seg_phys(prevSeg, base + tid) : P.classStride + seg_phys(prevSeg, base + (tid - prevT));
+				P.next.o_dx[d] = stage.sv_o_dx[tid];
+				__asm__ volatile("" ::: "memory");
+				P.next.direct_ix[d] = stage.sv_direct_ix[tid];
+				__asm__ volatile("" ::: "memory");
+				P.next.dyz[d] = stage.sv_dyz[tid];
+				P.next.flags[d] = stage.sv_flags[tid];
+				P.next.key[d] = stage.sv_key[tid];
+			}
 		}
 		__asm__ volatile("" ::: "memory");
 		if (tid < prevH && baseH != 0xffffffffu) {
@@ -486,8 +495,10 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		__syncthreads();
 		return vbNext;
 	};
-	for (uint32_t vb = draw_tile(); vb < nTiles; vb = draw_tile()) { // vb = tile id = 256 physical slots
-		const uint32_t slot = vb * kBlock + tid;
+	for (uint32_t vb = draw_tile(); vb < nTiles; vb = draw_tile()) { // vb = tile id = 256 physical slots of one class
+		const uint32_t cls = vb >= tiles0 ? 1u : 0u;
+		const uint32_t inClass = (vb - cls * tiles0) * kBlock + tid; // slot inside the class
+		const uint32_t slot = cls * P.classStride + inClass;
 		ShadeOut out = {};
 		uint32_t pixelBits = 0, vslot = 0;
 		// kernel.cu:622-625 for the tile BEFORE this one.  vmcnt retires loads and atomics in issue order, and an
@@ -500,7 +511,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			pendColor = mk3(0.f, 0.f, 0.f);
 			pendNew = 0;
 		};
-		const bool valid = lane < chunk_valid(P.segWork, slot & ~63u);
+		const bool valid = lane < chunk_valid(P.segWork + cls * kClassWords, inClass & ~63u);
 		float2 hitRecord = make_float2(kVeryFar, 0.f);
 		if (valid)
 			hitRecord = P.work.hit[slot];
@@ -513,28 +524,34 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 #endif
 		TYR_STAMP(0)
 
-		// ---- ranks inside the tile ----
-		const unsigned long long bs = __ballot(out.survive);
+		// ---- ranks inside the tile: survivors that may enter the tree, survivors that cannot, shadow rays ----
+		const bool sT = out.survive && out.tree, sS = out.survive && !out.tree;
+		const unsigned long long bt = __ballot(sT), bk = __ballot(sS);
 		const unsigned long long bh = __ballot(out.shadow);
-		const uint32_t rs = __popcll(bs & below), rh = __popcll(bh & below);
+		const uint32_t rt = __popcll(bt & below), rk = __popcll(bk & below), rh = __popcll(bh & below);
 		if (lane == 0) {
-			sh[4 + wave] = __popcll(bs);
+			sh[4 + wave] = __popcll(bt);
 			sh[8 + wave] = __popcll(bh);
+			sh[14 + wave] = __popcll(bk);
 		}
 		__syncthreads();
-		uint32_t ws = 0, wh = 0, totS = 0, totH = 0;
+		uint32_t wt = 0, wk = 0, wh = 0, totT = 0, totK = 0, totH = 0;
 #pragma unroll
 		for (uint32_t w = 0; w < kBlock / 64; ++w) {
-			const uint32_t cs = sh[4 + w], ch = sh[8 + w];
+			const uint32_t ct = sh[4 + w], ch = sh[8 + w], ck = sh[14 + w];
 			if (w < wave) {
-				ws += cs;
+				wt += ct;
+				wk += ck;
 				wh += ch;
 			}
-			totS += cs;
+			totT += ct;
+			totK += ck;
 			totH += ch;
 		}
-		totS = (uint32_t)__builtin_amdgcn_readfirstlane((int)totS); // block-uniform: keep them out of the vector registers
+		totT = (uint32_t)__builtin_amdgcn_readfirstlane((int)totT); // block-uniform: keep them out of the vector registers
+		totK = (uint32_t)__builtin_amdgcn_readfirstlane((int)totK);
 		totH = (uint32_t)__builtin_amdgcn_readfirstlane((int)totH);
+		const uint32_t totS = totT + totK;
 		TYR_STAMP(1)
 		if (havePrev)
 			flush_prev(); // ends with a barrier: sh[4..13] have been read by every thread
@@ -543,26 +560,32 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		const uint32_t seg = vb & (kSegs - 1u);
 		if (tid == 0) {
 			// this tile's places: consumed by flush_prev one tile later
-			uint32_t bS = 0, bH = 0;
-			if (totS) {
-				bS = atomicAdd(&P.segNext[seg * kSegStride], totS);
-				if (bS + totS > P.segCap)
-					bS = 0xffffffffu;
+			uint32_t bT = 0, bK = 0, bH = 0;
+			if (totT) {
+				bT = atomicAdd(&P.segNext[seg * kSegStride], totT);
+				if (bT + totT > P.segCap)
+					bT = 0xffffffffu;
+			}
+			if (totK) {
+				bK = atomicAdd(&P.segNext[kClassWords + seg * kSegStride], totK);
+				if (bK + totK > P.segCap)
+					bK = 0xffffffffu;
 			}
 			if (totH) {
 				bH = atomicAdd(&P.kc->seg[seg * kSegStride], totH);
 				if (bH + totH > P.segCap)
 					bH = 0xffffffffu;
 			}
-			if (bS == 0xffffffffu || bH == 0xffffffffu)
+			if (bT == 0xffffffffu || bK == 0xffffffffu || bH == 0xffffffffu)
 				atomicOr(&P.k->device_error, kErrQueueOverflow);
-			sh[12] = bS;
+			sh[12] = bT;
 			sh[13] = bH;
-			mySurvivors += bS == 0xffffffffu ? 0u : totS;
+			sh[18] = bK;
+			mySurvivors += (bT == 0xffffffffu ? 0u : totT) + (bK == 0xffffffffu ? 0u : totK);
 			myShadows += bH == 0xffffffffu ? 0u : totH;
 		}
 		if (out.survive) {
-			const uint32_t k = ws + rs;
+			const uint32_t k = out.tree ? wt + rt : totT + wk + rk; // the tile's class-0 survivors first, then its class-1 ones
 			stage.sv_o_dx[k] = make_float4(out.origin.x, out.origin.y, out.origin.z, out.direction.x);
 			stage.sv_dyz[k] = make_float2(out.direction.y, out.direction.z);
 			stage.sv_direct_ix[k] = make_float4(out.direct.x, out.direct.y, out.direct.z, __uint_as_float(pixelBits));
@@ -579,6 +602,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		havePrev = true;
 		prevSeg = seg;
 		prevS = totS;
+		prevT = totT;
 		prevH = totH;
 		// goes to the pixel under the next tile's arithmetic (or after the loop); zeros for lanes past the end
 		pendPixel = pixelBits;
@@ -610,8 +634,9 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			P.k->shadow_ray_cnt = h;
 			P.k->total_shadow_rays += h;
 			P.k->n_survive += s;
-			for (uint32_t w = 0; w < kSegs; ++w) // what the next iteration's sphere pre-pass has to do (a top-up appends behind it)
-				P.k->segSurv[w] = __hip_atomic_load(&P.segNext[w * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			for (uint32_t c = 0; c < kClasses; ++c) // what the next iteration's sphere pre-pass has to do (a top-up appends behind it)
+				for (uint32_t w = 0; w < kSegs; ++w)
+					P.k->segSurv[c][w] = __hip_atomic_load(&P.segNext[c * kClassWords + w * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 #ifdef TYR_SHADE_TIMING

@@ -398,6 +398,9 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 	if (kGuardPasses && passes > kMaxPasses)
 		atomicOr(&P.k->device_error, kErrNoProgress);
 	if (COUNT) {
+		// the rays of class 1 never come here: the reference tests the root box for each of them once and stops (bvh.h:127)
+		if (blockIdx.x == 0 && threadIdx.x == 0)
+			atomicAdd(&P.k->nodes_extend, (unsigned long long)queue_records(P.segWork + kClassWords));
 		wave_add_u64(&P.k->nodes_extend, vc.nodes);
 		wave_add_u64(&P.k->tris_extend, vc.tris);
 		wave_add_u64(&P.k->rays_in_tree_extend, inTree);
@@ -1166,12 +1169,12 @@ void launch_trace_kernel(const FrameParams& P, uint32_t items, const Tuning& t, 
 void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream) {
 	if (P.traceShadow != 2u)
 		launch_extend_spheres(P, nSurvivors, stream);
-	if (maxShadowPrev != 0) {
-		FrameParams Pc = P;
-		Pc.kc = P.kcPrev;
-		Pc.shadow = P.shadowPrev;
+	FrameParams Pc = P;
+	Pc.kc = P.kcPrev;
+	Pc.shadow = P.shadowPrev;
+	if (maxShadowPrev != 0)
 		launch_connect_spheres(Pc, maxShadowPrev, stream);
-	}
+	launch_pad_holes(Pc, P.traceShadow != 2u, maxShadowPrev != 0, stream);
 }
 
 // extend / connect as launches of their own (the stage API, tyr_launch_kernels): the same kernel with one kind of ray;

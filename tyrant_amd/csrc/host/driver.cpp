@@ -148,9 +148,10 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.k = c->dK;
 	P.kc = c->dKc + (c->iter & 1u);
 	P.kcPrev = c->dKc + ((c->iter ^ 1u) & 1u);
-	P.segWork = &c->dK->seg[c->cur][0];
-	P.segNext = &c->dK->seg[c->cur ^ 1][0];
+	P.segWork = &c->dK->seg[c->cur][0][0];
+	P.segNext = &c->dK->seg[c->cur ^ 1][0][0];
 	P.segCap = c->segCap;
+	P.classStride = c->segCap * tyr::kSegs;
 	P.survFlag = c->survFlag;
 	{
 		const int out = static_cast<int>(c->iter & 1u), prev = out ^ 1;
@@ -245,9 +246,9 @@ int stage_begin(tyr_ctx* c) {
 		c->hK->primary_ray_cnt = 0;
 		HIPCHK(hipMemcpyAsync(&c->dK->primary_ray_cnt, &c->hK->primary_ray_cnt, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 		// ... and with it the survivors in the work queue (the next top-up regenerates all N slots, quirk 16)
-		std::memset(&c->hK->seg[c->cur][0], 0, sizeof c->hK->seg[0]);
+		std::memset(&c->hK->seg[c->cur][0][0], 0, sizeof c->hK->seg[0]);
 		std::memset(c->hK->segSurv, 0, sizeof c->hK->segSurv);
-		HIPCHK(hipMemsetAsync(&c->dK->seg[c->cur][0], 0, sizeof c->dK->seg[0], c->stream));
+		HIPCHK(hipMemsetAsync(&c->dK->seg[c->cur][0][0], 0, sizeof c->dK->seg[0], c->stream));
 		HIPCHK(hipMemsetAsync(c->dK->segSurv, 0, sizeof c->dK->segSurv, c->stream));
 	}
 	return TYR_OK;
@@ -267,7 +268,7 @@ void enqueue_primary(tyr_ctx* c, const FrameParams& P, uint32_t nNew) {
 void enqueue_extend(tyr_ctx* c, const FrameParams& P, uint32_t nLive, uint32_t nSurvivors) {
 	KernelTimer t(c, TYR_K_EXTEND);
 	if (c->cfg.flags & TYR_FLAG_DEBUG_BVH) { // the reference's BVH_DEBUG build: kernel.cu:721-722
-		launch_extend_debug(P, c->segCap * tyr::kSegs, c->stream);
+		launch_extend_debug(P, c->segCap * tyr::kSegs * tyr::kClasses, c->stream);
 		return;
 	}
 	launch_extend(P, nLive, nSurvivors, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, c->stream);
@@ -434,7 +435,7 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 	// run out reports kErrQueueOverflow, it never writes past its end)
 	c->segCap = static_cast<uint32_t>(((N / 8 + N / 16 + 2048) + 63) & ~size_t(63));
 	const size_t cap = static_cast<size_t>(c->segCap) * tyr::kSegs;
-	if ((rc = alloc_rayq(c->q[0], cap)) || (rc = alloc_rayq(c->q[1], cap)))
+	if ((rc = alloc_rayq(c->q[0], cap * tyr::kClasses)) || (rc = alloc_rayq(c->q[1], cap * tyr::kClasses))) // class 0 (may enter the tree), class 1 (cannot)
 		return fail(rc);
 	for (auto& sq : c->shadow) // two: shade(i) fills one while the traversal launch of iteration i still reads shade(i - 1)'s
 		if ((rc = dev_alloc(sq.o_dx, cap)) || (rc = dev_alloc(sq.dyz_cd_ix, cap)) || (rc = dev_alloc(sq.color, cap)) || (rc = dev_alloc(sq.key, cap)))
@@ -1086,7 +1087,7 @@ int tyr_reset_accum(tyr_ctx* c) {
 		return rc;
 	HIPCHK(hipMemsetAsync(c->blit, 0, sizeof(float4) * static_cast<size_t>(c->cfg.width) * c->cfg.height, c->stream));
 	c->hK->primary_ray_cnt = 0;
-	std::memset(&c->hK->seg[c->cur][0], 0, sizeof c->hK->seg[0]);
+	std::memset(&c->hK->seg[c->cur][0][0], 0, sizeof c->hK->seg[0]);
 	std::memset(c->hK->segSurv, 0, sizeof c->hK->segSurv);
 	return push_counters(c);
 }
@@ -1119,11 +1120,16 @@ int tyr_queue_export(tyr_ctx* c, int which, tyr_ray_queue* host, uint32_t count)
 	const int qi = which == 0 ? c->cur : (c->cur ^ 1);
 	const RayQ& q = c->q[qi];
 	std::vector<uint32_t> slots;
-	if ((rc = valid_slots(&c->dK->seg[qi][0], slots)))
-		return rc;
+	for (uint32_t cls = 0; cls < tyr::kClasses; ++cls) { // both classes: where a record lies says nothing about its place in the order
+		std::vector<uint32_t> part;
+		if ((rc = valid_slots(&c->dK->seg[qi][cls][0], part)))
+			return rc;
+		for (uint32_t sl : part)
+			slots.push_back(cls * c->segCap * tyr::kSegs + sl);
+	}
 	uint32_t extent = 0;
-	for (uint32_t s : slots)
-		extent = std::max(extent, s + 1);
+	for (uint32_t sl : slots)
+		extent = std::max(extent, sl + 1);
 	std::vector<float4> a, d;
 	std::vector<float2> b, h;
 	std::vector<uint32_t> f, key;
@@ -1195,9 +1201,13 @@ int tyr_queue_import(tyr_ctx* c, const tyr_ray_queue* host, uint32_t n) {
 		HIPCHK(hipMemcpy(q.key, key.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
 	c->hK->primary_ray_cnt = n;
-	dense_counts(n, &c->hK->seg[c->cur][0]);
-	for (uint32_t w = 0; w < tyr::kSegs; ++w)
-		c->hK->segSurv[w] = c->hK->seg[c->cur][w * tyr::kSegStride];
+	// all of them in class 0 (the traversal's own root test sorts out those that miss the tree)
+	dense_counts(n, &c->hK->seg[c->cur][0][0]);
+	std::memset(&c->hK->seg[c->cur][1][0], 0, sizeof c->hK->seg[0][0]);
+	for (uint32_t w = 0; w < tyr::kSegs; ++w) {
+		c->hK->segSurv[0][w] = c->hK->seg[c->cur][0][w * tyr::kSegStride];
+		c->hK->segSurv[1][w] = 0;
+	}
 	return push_counters(c);
 }
 
