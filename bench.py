@@ -39,9 +39,11 @@ counted by the library's counting build on pair nodes, not by the timed quad-nod
 the timed launches is reported beside it as roofline.algorithmic -- the tree is largely cache resident, so that
 figure prices bytes the fabric never carried and may exceed the HBM peak; it is not `frac`.
 
-cpu_baseline (N = 1): the oracle's serial wavefront loop on this host, 1 core, on the first iterations of the same
-workload; plus, on ONE common ray set (the next iteration's queue), the oracle's traversal and the reference's own
-CachedBVH::intersect (oracle/_ref, bvh.h:118-161) side by side.
+cpu_baseline (N = 1), 1 core of this host: `value` is ONE ray set (the queue of the third iteration: bounce rays in front,
+fresh primary rays behind) through the reference's own CachedBVH::intersect (oracle/_ref, bvh.h:118-161; kind "reference")
+-- or the oracle's restatement of it where oracle/_ref is absent (kind "port"); both are listed, their distances are
+bit-identical.  Beside it: the oracle's whole wavefront loop on the first iterations of the workload, and the SAH build
+of the scene by the port and by the reference's own bvh.cpp.
 """
 from __future__ import annotations
 
@@ -64,12 +66,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 NUM_XCD, NUM_SIMD, NUM_CU = 8, 1024, 256  # MI355X: 8 XCDs x 32 CUs x 4 SIMDs
 REF_N = 2097152  # variables.h:44
-TRACE_KERNEL = "k_trace_flat<12>"  # extend(i + 1) + connect(i) in one launch (the default, TYR_TUNE_MERGE_TRACE)
-EXTEND_KERNEL = "k_extend_flat<false, 12, true, true>"  # --tune merge_trace=0
+TRACE_KERNEL = "k_trace_flat<12>"  # the traversal kernel: extend(i + 1) + connect(i) in one launch (tyr_render), or one kind of ray alone
+SHADE_KERNEL = "k_shade<"            # the second kernel of a render by time
+EXTEND_KERNEL = TRACE_KERNEL
+SHADE_BYTES_PER_RAY = 52 + 24 + 16   # state + e1, e2 + pixel RMW; + 44 per survivor + 48 per shadow ray (added from the counters)
 
 
 def dominant_kernel(tune_args) -> str:
-    return EXTEND_KERNEL if "merge_trace=0" in tune_args else TRACE_KERNEL
+    return TRACE_KERNEL
 PMC_PASSES = (
     ("FETCH_SIZE",),
     ("WRITE_SIZE",),
@@ -195,6 +199,7 @@ def run_pmc_passes(args, timeout_s: float = 150.0):
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp),
              "--queue", str(args.queue)] + [x for kv in args.tune for x in ("--tune", kv)]
     counters, launches = {}, None
+    shade_counters, shade_launches = {}, None
     kernel = dominant_kernel(args.tune)
     try:
         for i, group in enumerate(PMC_PASSES):
@@ -208,10 +213,11 @@ def run_pmc_passes(args, timeout_s: float = 150.0):
             for line in p.stdout.splitlines():
                 if line.startswith('{"pmc_child_iterations"'):
                     iters = json.loads(line)["pmc_child_iterations"]
-            rows = []
+            allrows = []
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
-                    rows += [r for r in csv.DictReader(f) if kernel in r["Kernel_Name"]]
+                    allrows += list(csv.DictReader(f))
+            rows = [r for r in allrows if kernel in r["Kernel_Name"]]
             if not rows or not iters:
                 print(f"[bench] rocprofv3 pass {group}: no rows for {kernel}", file=sys.stderr)
                 return None
@@ -222,12 +228,17 @@ def run_pmc_passes(args, timeout_s: float = 150.0):
                 last = mine[len(mine) // 2:]  # the child renders twice: the second (warm) render's launches of this kernel
                 counters[name] = sum(float(r["Counter_Value"]) for r in last) / len(last)
                 launches = len(last)
+                # the same for the shade kernel (summed over the render's launches: its per-render figure)
+                sh = sorted((r for r in allrows if SHADE_KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name), key=lambda r: int(r["Dispatch_Id"]))
+                if sh and len(sh) % 2 == 0:
+                    shade_counters[name] = sum(float(r["Counter_Value"]) for r in sh[len(sh) // 2:])
+                    shade_launches = len(sh) // 2
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
         print(f"[bench] PMC passes abandoned: {e!r}", file=sys.stderr)
         return None
     finally:
         shutil.rmtree(out_root, ignore_errors=True)
-    return {"counters": counters, "launches_averaged": launches, "kernel": kernel, "source": "live: rocprofv3 --pmc child passes of this command (" + " | ".join(" ".join(g) for g in PMC_PASSES) + ")"}
+    return {"counters": counters, "launches_averaged": launches, "kernel": kernel, "shade_counters_per_render": shade_counters, "shade_launches_per_render": shade_launches, "source": "live: rocprofv3 --pmc child passes of this command (" + " | ".join(" ".join(g) for g in PMC_PASSES) + ")"}
 
 
 def committed_pmc(workload: str, N: int):
@@ -235,10 +246,59 @@ def committed_pmc(workload: str, N: int):
         with open(os.path.join(ROOT, "profiles", f"pmc_{workload}.json")) as f:
             j = json.load(f)
         if j.get("queue_size") == N:
-            return {"counters": j["counters"], "launches_averaged": j.get("launches_averaged"), "kernel": j.get("kernel"), "source": f"committed: profiles/pmc_{workload}.json ({j.get('source', '')})"}
+            return {"counters": j["counters"], "launches_averaged": j.get("launches_averaged"), "kernel": j.get("kernel"), "shade_counters_per_render": j.get("shade_counters_per_render", {}), "shade_launches_per_render": j.get("shade_launches_per_render"), "source": f"committed: profiles/pmc_{workload}.json ({j.get('source', '')})"}
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def shade_block(pmc, shade_ms_per_render, rays_per_render, survivors_per_render, shadows_per_render):
+    """the second kernel of a render: k_shade against its byte roofline (52 + 24 + 16 B per ray, 44 per
+    survivor, 48 per shadow ray) and, from the counters, its vector-issue fraction -- it is bound by arithmetic"""
+    alg = SHADE_BYTES_PER_RAY * rays_per_render + 44.0 * survivors_per_render + 48.0 * shadows_per_render
+    t = shade_ms_per_render * 1e-3
+    out = {"kernel": "k_shade<false>", "ms_per_render": round(shade_ms_per_render, 4), "rays_per_render": int(rays_per_render),
+           "algorithmic": {"bytes_per_render": round(alg), "GBps": round(alg / t / 1e9, 2) if t > 0 else None, "frac_of_hbm_peak": round(alg / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None,
+                           "bytes_per_ray": round(alg / max(rays_per_render, 1), 1)}}
+    c = (pmc or {}).get("shade_counters_per_render") or {}
+    if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_ACTIVE_INST_VALU"):
+        cyc = c["GRBM_GUI_ACTIVE"] / NUM_XCD
+        valu = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (NUM_SIMD * cyc)
+        lanes = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        out.update({"bound": "valu-issue", "frac": round(valu, 4), "frac_kind": "vector-ALU issue cycles / SIMD cycles while k_shade runs (not an HBM fraction)",
+                    "salu_issue_frac": round(4.0 * c["SQ_ACTIVE_INST_SCA"] / (NUM_SIMD * cyc), 4), "lanes_active_per_valu_inst": round(lanes, 4)})
+        if c.get("FETCH_SIZE") is not None and c.get("WRITE_SIZE") is not None and t > 0:
+            hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            out["traffic"] = round(hbm / t / 1e9, 2)
+            out["hbm_counter_frac"] = round(hbm / t / 1e9 / HBM_PEAK_GBS, 4)
+    return out
+
+
+def drain_block(args):
+    """How much of a traversal launch is its drain: an instrumented build of the library (-DTYR_LAUNCH_ANATOMY: three
+    s_memrealtime stamps per wave) renders the workload once in a CHILD process; per launch, `feed` = first wave's start ->
+    first wave to find the queue used up, `drain` = from there to the last wave's exit."""
+    lib = os.path.join(ROOT, "tyrant_amd", "lib", "libtyrant_hip_anatomy.so")
+    if not os.path.exists(lib):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--queue", str(args.queue)]
+    try:
+        p = subprocess.run(child, capture_output=True, text=True, timeout=120, env=dict(os.environ, TYRANT_HIP_LIBRARY=lib, TYR_ANATOMY="1"))
+    except (subprocess.TimeoutExpired, OSError):
+        return None
+    rows = []
+    for line in p.stderr.splitlines():
+        if line.startswith("[anatomy]") and "feed" in line:
+            try:
+                rows.append((float(line.split("feed")[1].split("us")[0]), float(line.split("drain")[1].split("us")[0])))
+            except (IndexError, ValueError):
+                pass
+    if p.returncode != 0 or len(rows) < 2:
+        return None
+    rows = rows[len(rows) // 2:]  # the second (warm) render
+    feed, drain = sum(r[0] for r in rows), sum(r[1] for r in rows)
+    return {"drain_frac": round(drain / (feed + drain), 4), "feed_us_per_launch": [round(r[0], 1) for r in rows], "drain_us_per_launch": [round(r[1], 1) for r in rows],
+            "source": "one render of the same workload by libtyrant_hip_anatomy.so (-DTYR_LAUNCH_ANATOMY) in a child process; the render's last launch (shadow rays only) is not stamped"}
 
 
 def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_render, kernel=EXTEND_KERNEL, con_ms=0.0, shadow_rays=0.0):
@@ -282,6 +342,7 @@ def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_re
             "peak": HBM_PEAK_GBS if bound == "hbm" else 100.0,
             "unit": "GB/s" if bound == "hbm" else "% of issue cycles (SQ_ACTIVE_INST_* x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))",
             "frac": round(fr[bound], 4),
+            "frac_kind": ("HBM bytes by the memory-side counters / 8 TB/s" if bound == "hbm" else ("vector" if bound == "valu-issue" else "scalar") + "-ALU issue cycles / available cycles while the kernel runs: the tightest MEASURED resource fraction -- NOT an HBM fraction (that is hbm_counter_frac; the nominal byte count of SURVEY.md 8d is algorithmic.frac_of_hbm_peak)"),
             "traffic": round(traffic, 2),
             "hbm_counter_frac": round(fr["hbm"], 4),
             "valu_issue_frac": round(fr["valu-issue"], 4),
@@ -553,7 +614,7 @@ def main():
         # the pair the roofline needs, around the extend stage.
         tm_all = r.timings() if warmup > 0 else None
         if tm_all is not None:
-            r.set_tuning(profile_mask=(1 << 1) | (1 << 3))  # TYR_K_EXTEND (the trace launches) + TYR_K_CONNECT (merged renders: one launch per render)
+            r.set_tuning(profile_mask=(1 << 1) | (1 << 3))  # TYR_K_EXTEND (the trace launches) + TYR_K_CONNECT (merged renders: one launch per render); shade's time comes from the warm-up renders
         k0 = r.counters()
         r.timings(reset=True)
         fence()
@@ -568,6 +629,7 @@ def main():
         assert k1["device_error"] == 0, k1
         ext = k1["total_extend_rays"] - k0["total_extend_rays"]
         shd = k1["total_shadow_rays"] - k0["total_shadow_rays"]
+        survivors = k1["n_survive"] - k0["n_survive"]
         stats = torch.tensor([float(ext), float(shd), dt], dtype=torch.float64, device=cdev)
         if ranks > 1:
             tmax = stats[2:3].clone()
@@ -585,7 +647,7 @@ def main():
             comm = True if native_used else None  # (only its truth value is reported below)
         r.close()
         per_render = {k: round(v["ms"] / warmup, 3) for k, v in tm_all.items()} if tm_all is not None else {k: round(v["ms"] / steps, 3) for k, v in tm.items()}
-        return {"native_combine": bool(comm is not None and native_ok[0]), "ext": ext, "shd": shd, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, **visits}
+        return {"native_combine": bool(comm is not None and native_ok[0]), "ext": ext, "shd": shd, "survivors": survivors, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, **visits}
 
     m = measure(N, args.steps, args.warmup, spp_total, shard, world)
     mref = None
@@ -650,6 +712,13 @@ def main():
                          if dominant_kernel(args.tune) == TRACE_KERNEL else
                          roofline_block(pmc, tm["extend"]["ms"], tm["extend"]["launches"], m["ext"], m, m["kernel_ms_per_render"], kernel=EXTEND_KERNEL, con_ms=tm["connect"]["ms"], shadow_rays=m["shd"])),
         }
+        per_render = 1.0 / args.steps
+        k_sh = tm["shade"]
+        out["roofline"]["shade"] = shade_block(pmc, k_sh["ms"] * per_render if k_sh["launches"] else m["kernel_ms_per_render"].get("shade", 0.0), m["ext"] * per_render, m["survivors"] * per_render, m["shd"] * per_render)
+        if world == 1 and args.pmc != "off":
+            d = drain_block(args)
+            if d:
+                out["roofline"].update(d)
         if solo is not None:
             nsteps_solo = max(1, min(args.steps, 2))
             t1, tn = solo["dt_all"] / nsteps_solo, m["dt_all"] / args.steps
@@ -693,14 +762,12 @@ def cpu_baseline(sc, W, H, N, iterations, tri_materials, spp):
     dt = time.perf_counter() - t0
     k = o.counters()
     rays = k["total_extend_rays"] + k["total_shadow_rays"]
-    out = {
+    whole = {
         "value": round(rays / dt / 1e6, 4),
         "unit": "Mrays/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"first {iterations} wavefront iterations of the same workload ({k['total_extend_rays']} extend + {k['total_shadow_rays']} shadow rays, all stages) in {dt:.1f} s",
-        "bvh_build_s": round(t_build, 3),
-        "host_cpus": os.cpu_count(),
+        "sample": f"first {iterations} wavefront iterations of the same workload ({k['total_extend_rays']} extend + {k['total_shadow_rays']} shadow rays, all stages) in {dt:.1f} s; mostly rays that end at the root box",
     }
     # one common ray set: the first 2 Mi rays of the next iteration's queue, traversal only (no spheres, no shading)
     o.stage("begin"), o.stage("primary")
@@ -729,7 +796,29 @@ def cpu_baseline(sc, W, H, N, iterations, tri_materials, spp):
         same = bool(np.array_equal(qa["distance"].view(np.uint32), qb["distance"].view(np.uint32)))
         trace["reference"] = {"value": round(n / dtr / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference", "seconds": round(dtr, 2), "hits": int(hit.sum()),
                               "note": "CachedBVH::intersect of the reference's bvh.h (oracle/_ref/libref_traverse.so), one call for the batch", "distances_bit_identical_to_port": same}
-    out["trace_same_ray_set"] = trace
+    # the reference's own builder on the same triangles (bvh.cpp:3-225 compiled into oracle/_ref), beside the port's
+    builds = {"port": round(t_build, 3)}
+    if R is not None and hasattr(R, "ref_bvh_build"):
+        tp = np.ascontiguousarray(sc.triangles.copy())
+        bb = np.ascontiguousarray(scenes.triangle_bboxes(sc.triangles))
+        nd2 = np.zeros(max(2 * tp.shape[0] - 1, 1), dtype=scenes.NODE_DTYPE)
+        t0 = time.perf_counter()
+        nn = R.ref_bvh_build(tp.ctypes.data, tp.shape[0], bb.ctypes.data, nd2.ctypes.data, 2)
+        builds["reference"] = round(time.perf_counter() - t0, 3)
+        builds["reference_nodes_identical_to_port"] = bool(nn == nodes.shape[0] and nd2[:nn].tobytes() == nodes.tobytes())
+    # lead with the like-for-like figure: ONE ray set through the reference's own traversal (else the port's)
+    lead = trace.get("reference", trace["port"])
+    out = {
+        "value": lead["value"],
+        "unit": "Mrays/s",
+        "cores": 1,
+        "kind": lead["kind"],
+        "sample": trace["ray_set"] + f": {n} rays in {lead['seconds']} s, traversal only, one core",
+        "trace_same_ray_set": trace,
+        "whole_path_first_iterations": whole,
+        "bvh_build_s": builds,
+        "host_cpus": os.cpu_count(),
+    }
     return out
 
 

@@ -113,7 +113,8 @@ def test_bench_emits_the_contract_line():
         assert r.get("pmc_source", "").startswith("live"), r  # the counters were collected beside this very run
         assert r["traffic"] is not None and 0 < r["hbm_counter_frac"] <= 1 and 0 < r["valu_issue_frac"] <= 1
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["trace_same_ray_set"]["port"]["value"] > 0
+    assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["trace_same_ray_set"]["port"]["value"] > 0
+    assert c["whole_path_first_iterations"]["value"] > 0 and c["bvh_build_s"]["port"] > 0
 
 
 @pytest.mark.gpu

@@ -117,7 +117,8 @@ int push_counters(tyr_ctx* c) {
 	return TYR_OK;
 }
 
-constexpr uint32_t kRunAheadMaxLive = 6u << 20; // TYR_TUNE_RUN_AHEAD = 2: queues of up to this many slots run one iteration ahead of the counts
+constexpr uint32_t kRunAheadMaxLive = 6u << 20; // TYR_TUNE_RUN_AHEAD = 2: queues of up to this many slots run one iteration ahead of the counts (used in the uninstrumented builds)
+[[maybe_unused]] constexpr uint32_t kRunAheadMaxLiveUse = kRunAheadMaxLive;
 
 FrameParams make_params(const tyr_ctx* c) {
 	FrameParams P{};
