@@ -99,7 +99,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearse the multi-rank path with every rank on ONE GPU (the combine then goes through host memory and torch)")
     ap.add_argument("--combine", default="gather", choices=["gather", "reduce"], help="N > 1: rank 0 gets the rows each rank owns (1/N of the frame per rank) or the sum of the full buffers")
     ap.add_argument("--dist-preflight", action="store_true", help=argparse.SUPPRESS)  # internal: one rank of the native exchange's pre-flight check
-    ap.add_argument("--preflight-port", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--preflight-store", default="", help=argparse.SUPPRESS)  # internal: the file the pre-flight children rendezvous through
     ap.add_argument("--combine-impl", default="native", choices=["native", "torch"], help="native = tyr_dist_* (RCCL behind the C ABI, double-buffered); torch = torch.distributed collectives (always used with --backend gloo)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto: N = 1 and rocprofv3 present -> three --pmc child passes feed the roofline block")
     ap.add_argument("--save-pmc", default="", help="write the live PMC counters to this JSON file (copied to profiles/pmc_<workload>.json, the fallback when rocprofv3 cannot run beside the bench)")
@@ -393,7 +393,7 @@ def dist_preflight(args) -> int:
     rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("TYR_BENCH_PREFLIGHT_ONE_DEVICE"):
         local_rank = 0  # rehearsal on a one-GPU box: RCCL refuses two ranks on one device, which is the failure path under test
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{args.preflight_port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    dist.init_process_group("gloo", init_method=f"file://{args.preflight_store}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     ok = 1
     try:
         torch.cuda.set_device(local_rank)
@@ -432,10 +432,11 @@ def dist_preflight(args) -> int:
 
 def run_dist_preflight() -> bool:
     """spawn this rank's pre-flight child (this process has not initialised the GPU yet) and wait for it, bounded"""
-    port = int(os.environ.get("MASTER_PORT", "29500")) + 17
-    cmd = [sys.executable, os.path.abspath(__file__), "--dist-preflight", "--preflight-port", str(port)]
-    # the children make their own rendezvous (rank 0's child hosts the store): without the launcher's TORCHELASTIC_* variables,
-    # which would tell them that an agent already hosts one at that port
+    # the children make their own rendezvous through a FILE (no second port to find free and to agree on): one name per
+    # launch -- the launcher's pid is the parent of every rank, its master port tells concurrent launches apart -- and
+    # without the launcher's TORCHELASTIC_* variables, which would tell them that an agent already hosts a store
+    store = os.path.join(tempfile.gettempdir(), f"tyr_preflight_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}")
+    cmd = [sys.executable, os.path.abspath(__file__), "--dist-preflight", "--preflight-store", store]
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     try:
         p = subprocess.run(cmd, timeout=PREFLIGHT_TIMEOUT_S, env=env, stdout=subprocess.DEVNULL)
@@ -642,12 +643,17 @@ def main():
             a = (frame if frame is not None else accum).view(H * W, 4)[:, 3]
             assert float(a.min()) == float(a.max()) == float(spp), (float(a.min()), float(a.max()), spp)
         native_used = comm is not None and native_ok[0]
+        comm_info = None
         if comm is not None:
+            try:
+                comm_info = comm.info()  # ncclCommCount of the communicator the exchange ran on
+            except Exception:  # noqa: BLE001
+                comm_info = None
             comm.close()
             comm = True if native_used else None  # (only its truth value is reported below)
         r.close()
         per_render = {k: round(v["ms"] / warmup, 3) for k, v in tm_all.items()} if tm_all is not None else {k: round(v["ms"] / steps, 3) for k, v in tm.items()}
-        return {"native_combine": bool(comm is not None and native_ok[0]), "ext": ext, "shd": shd, "survivors": survivors, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, **visits}
+        return {"native_combine": bool(comm is not None and native_ok[0]), "comm_info": comm_info, "ext": ext, "shd": shd, "survivors": survivors, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, **visits}
 
     m = measure(N, args.steps, args.warmup, spp_total, shard, world)
     mref = None
@@ -686,6 +692,10 @@ def main():
                 "sharding": (f"rows y % {world} == rank; " + (("tyr_dist_combine (RCCL behind the C ABI): " + ("ncclSend/ncclRecv of each rank's packed rows, double-buffered" if args.combine == "gather" else "ncclReduce(sum) of the full buffers"))
                                                             if m["native_combine"] else ("torch.distributed gather of each rank's rows" if use_torch_gather else "torch.distributed reduce(sum) of the accumulation buffer"))) if world > 1 else "none",
                 "backend": args.backend if world > 1 else None,
+                **({"combine": {"native_combine": bool(m["native_combine"]), "form": args.combine if m["native_combine"] else ("gather" if use_torch_gather else "reduce"),
+                                "rccl_comm_ranks": (m.get("comm_info") or {}).get("comm_ranks"),
+                                "fallback_reason": None if m["native_combine"] else ("--combine-impl torch / gloo backend" if not want_native else ("pre-flight of the native exchange failed" if not preflight_ok else "the native exchange did not verify on the real job")),
+                                "measured_on_hardware_before": "no: the N > 1 RCCL exchange had never run when this was written (one GPU per test box)"}} if world > 1 else {}),
                 "wavefront_iterations_per_step": m["iters"] / args.steps,
                 "extend_Mrays/s": round(m["ext_all"] / m["dt_all"] / 1e6, 3),
                 "shadow_Mrays/s": round(m["shd_all"] / m["dt_all"] / 1e6, 3),

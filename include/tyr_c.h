@@ -318,6 +318,8 @@ int tyr_dist_destroy(tyr_dist* d);
  * tyr_dist_wait blocks the host until the last combine has finished. */
 int tyr_dist_combine(tyr_dist* d, int32_t mode, int32_t root, void* frame_out_device);
 int tyr_dist_wait(tyr_dist* d);
+/* what RCCL itself says about the communicator: ncclCommCount (-1 when this librccl has no such entry point) and this rank */
+int tyr_dist_info(tyr_dist* d, int32_t* comm_ranks_out, int32_t* rank_out);
 /* Row ownership, pure host arithmetic (no device, no communicator): rank r of nranks owns rows r, r + nranks, ...;
  * *n_rows = height / nranks; returns TYR_ERR_INVALID when height % nranks != 0 or rank >= nranks.
  * tyr_dist_row_owner: the rank that owns row y, and that row's index in the owner's packed slab. */

@@ -148,13 +148,15 @@ def test_native_exchange_preflight():
     hang, a crash or a wrong frame costs the child and not the measurement.  One rank on one GPU: verified (exit 0).  Two
     ranks on the one GPU of this box: RCCL refuses the second rank on a device -- the failure path: both children exit 1,
     within their bounds."""
+    import tempfile
+
     script = os.path.join(ROOT, "bench.py")
-    port = _free_port()
+    store = os.path.join(tempfile.mkdtemp(prefix="tyr_pf_"), "store1")  # the children rendezvous through a file (no port to agree on)
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-    p = subprocess.run([sys.executable, script, "--dist-preflight", "--preflight-port", str(port)], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    p = subprocess.run([sys.executable, script, "--dist-preflight", "--preflight-store", store], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
-    port = _free_port()
-    procs = [subprocess.Popen([sys.executable, script, "--dist-preflight", "--preflight-port", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
+    store = os.path.join(tempfile.mkdtemp(prefix="tyr_pf_"), "store2")
+    procs = [subprocess.Popen([sys.executable, script, "--dist-preflight", "--preflight-store", store], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
                               env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", TYR_BENCH_PREFLIGHT_ONE_DEVICE="1")) for r in range(2)]
     outs = [q.communicate(timeout=300) for q in procs]
     assert [q.returncode for q in procs] == [1, 1], [o[1][-1500:] for o in outs]

@@ -100,3 +100,71 @@ def test_one_rank_communicator_end_to_end(hip):
     d.close()
     g.reset_accum()
     assert g.render(1) > 0 and g.counters()["device_error"] == 0
+
+
+@pytest.mark.gpu
+def test_two_host_threads_two_contexts_render_the_two_shards_at_once(orc, hip):
+    """The host model INTEGRATION.md describes -- one host thread and one ctx per shard, rendering CONCURRENTLY -- on
+    the one device a test box has: the 1 M-triangle scene (BASELINE config C4's) at 1080p dealt to two ranks (rows
+    y % 2 == rank), each rendered by its own thread through its own ctx and streams, the rows combined with
+    tyr_dist_pack_rows / tyr_dist_scatter_rows as a host would that moves the slabs itself (two devices: hipMemcpyPeer
+    in between).  Every rank's counters equal its own oracle run's, the combined frame has exactly spp finished paths in
+    every pixel and the oracle's radiance.  (The exchange over RCCL with N > 1 needs N devices: unmeasured on hardware.)
+    Also checks what the communicator reports about itself on one rank (ncclCommCount)."""
+    import threading
+
+    import torch
+
+    W, H, R, spp = 1920, 1080, 2, 1
+    sc, nodes, prims = built_scene("mesh706")
+    N = W * (H // R) * spp
+    L = hip.lib()
+    accum = [torch.zeros(W * H * 4, dtype=torch.float32, device="cuda") for _ in range(R)]
+    torch.cuda.synchronize()
+    rs = [hip.Renderer(W, H, N, rank=r, nranks=R, flags=1, blit_buffer=accum[r].data_ptr()) for r in range(R)]
+    for g in rs:
+        g.load_scene(sc, nodes, prims)
+    iters, errors = [0] * R, []
+
+    def work(r):
+        try:
+            iters[r] = rs[r].render(spp)
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(R)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errors and all(not t.is_alive() for t in ts), errors
+    slab_bytes = (H // R) * W * 16
+    slabs = torch.zeros(R * (H // R) * W * 4, dtype=torch.float32, device="cuda")
+    frame = torch.full((H * W * 4,), -1.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for r in range(R):
+        assert L.tyr_dist_pack_rows(accum[r].data_ptr(), slabs.data_ptr() + r * slab_bytes, W, H, r, R, None) == 0
+    assert L.tyr_dist_scatter_rows(slabs.data_ptr(), frame.data_ptr(), W, H, R, None) == 0
+    torch.cuda.synchronize()
+    got = frame.cpu().numpy().reshape(H, W, 4)
+    assert np.all(got[:, :, 3] == spp)
+    for r in range(R):
+        o = orc.Oracle(W, H, N, rank=r, nranks=R, flags=1)
+        o.load_scene(sc, nodes, prims)
+        assert o.render(spp) == iters[r]
+        ko, kg = o.counters(), rs[r].counters()
+        assert kg["device_error"] == 0
+        for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible"):
+            assert ko[f] == kg[f], (r, f)
+        want = o.blit_buffer().reshape(H, W, 4)[r::R]
+        assert np.allclose(got[r::R, :, :3], want[:, :, :3], rtol=1e-5, atol=1e-6), r
+        o.close()
+    # one-rank communicator: what RCCL reports about itself
+    uid = hip.dist_unique_id()
+    g1 = hip.Renderer(64, 64, 4096)
+    d = hip.Dist(g1, uid, 0, 1)
+    info = d.info()
+    assert info["rank"] == 0 and info["comm_ranks"] in (1, -1)
+    g1.close()  # closes its communicator first
+    for g in rs:
+        g.close()

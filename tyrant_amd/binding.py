@@ -145,6 +145,7 @@ SYMBOLS = {
     "tyr_dist_destroy": (C.c_int, [P]),
     "tyr_dist_combine": (C.c_int, [P, c_i32, c_i32, P]),
     "tyr_dist_wait": (C.c_int, [P]),
+    "tyr_dist_info": (C.c_int, [P, C.POINTER(c_i32), C.POINTER(c_i32)]),
     "tyr_dist_owned_rows": (C.c_int, [c_u32, c_u32, c_u32, C.POINTER(c_u32), C.POINTER(c_u32)]),
     "tyr_dist_row_owner": (C.c_int, [c_u32, c_u32, C.POINTER(c_u32), C.POINTER(c_u32)]),
     "tyr_dist_pack_rows": (C.c_int, [P, P, c_u32, c_u32, c_u32, c_u32, P]),
@@ -260,9 +261,12 @@ class Renderer:
         h = P()
         _check(self.L.tyr_create(C.byref(h), C.byref(cfg)), "tyr_create")
         self.h = h
+        self._dists = []
         _check(self.L.tyr_set_blit_buffer(self.h, blit_buffer), "tyr_set_blit_buffer")
 
     def close(self):
+        for d in list(getattr(self, "_dists", [])):
+            d.close()
         if getattr(self, "h", None):
             self.L.tyr_destroy(self.h)
             self.h = None
@@ -448,9 +452,15 @@ class Dist:
         h = P()
         _check(self.L.tyr_dist_create(C.byref(h), renderer.h, unique_id, rank, nranks), "tyr_dist_create")
         self.h = h
+        renderer._dists.append(self)  # Renderer.close() closes its communicators first (a combine reads the ctx)
 
     def combine(self, frame_out_device_ptr, mode=TYR_DIST_GATHER, root=0):
         _check(self.L.tyr_dist_combine(self.h, mode, root, frame_out_device_ptr), "tyr_dist_combine")
+
+    def info(self) -> dict:
+        n, r = c_i32(-1), c_i32(-1)
+        _check(self.L.tyr_dist_info(self.h, C.byref(n), C.byref(r)), "tyr_dist_info")
+        return {"comm_ranks": int(n.value), "rank": int(r.value)}
 
     def wait(self):
         _check(self.L.tyr_dist_wait(self.h), "tyr_dist_wait")

@@ -15,7 +15,9 @@
 // librccl is opened with dlopen when the first communicator is made, so the render library itself loads and runs on a
 // box without RCCL.  WHICH librccl matters: a process may hold a second HIP runtime (PyTorch's wheels bundle their own
 // libamdhip64 and librccl), and streams, events and allocations of one runtime mean nothing to the other.  The copy
-// opened here is the one that sits next to the libamdhip64 THIS library is linked against (found with dladdr), and RCCL
+// opened here is the one that sits next to whichever libamdhip64 this process BOUND this library's HIP calls to (found
+// with dladdr on hipGetDeviceCount: the ROCm installation's when the library is alone, PyTorch's bundled one when torch
+// was imported first; TYR_VERBOSE=1 prints the path), and RCCL
 // is only ever handed buffers and streams this library made itself: what the caller owns (blit_buffer, frame_out --
 // possibly another runtime's allocations) is touched by this library's own copy kernels alone.
 #include <cstdio>
@@ -53,6 +55,7 @@ struct Rccl {
 	int (*GetUniqueId)(NcclId*) = nullptr;
 	int (*CommInitRank)(nccl_comm*, int, NcclId, int) = nullptr;
 	int (*CommDestroy)(nccl_comm) = nullptr;
+	int (*CommCount)(nccl_comm, int*) = nullptr;
 	int (*Send)(const void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
 	int (*Recv)(void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
 	int (*Reduce)(const void*, void*, size_t, int, int, int, nccl_comm, hipStream_t) = nullptr;
@@ -76,14 +79,18 @@ Rccl& rccl() {
 		}
 		const std::string candidates[] = { dir + "librccl.so.1", dir + "librccl.so", "/opt/rocm/lib/librccl.so.1", "librccl.so.1" };
 		for (const std::string& n : candidates)
-			if (!n.empty() && (R.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL)))
+			if (!n.empty() && (R.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL))) {
+				if (std::getenv("TYR_VERBOSE"))
+					std::fprintf(stderr, "[tyrant] RCCL: %s\n", n.c_str());
 				break;
+			}
 		if (!R.handle)
 			return false;
 		auto sym = [&](const char* s) { return dlsym(R.handle, s); };
 		R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
 		R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
 		R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+		R.CommCount = reinterpret_cast<decltype(R.CommCount)>(sym("ncclCommCount"));
 		R.Send = reinterpret_cast<decltype(R.Send)>(sym("ncclSend"));
 		R.Recv = reinterpret_cast<decltype(R.Recv)>(sym("ncclRecv"));
 		R.Reduce = reinterpret_cast<decltype(R.Reduce)>(sym("ncclReduce"));
@@ -126,12 +133,17 @@ int ensure_runtime() {
 
 struct tyr_dist {
 	tyr_ctx* ctx = nullptr;
+	int device = 0; // the ctx's device ordinal, copied: tyr_dist_destroy must not look into a ctx that may be gone already
 	nccl_comm comm = nullptr;
 	int rank = 0, nranks = 1;
 	hipStream_t commStream = nullptr;
 	float4* staging[2] = { nullptr, nullptr }; // this rank's packed rows, alternating
-	float4* recvSlabs = nullptr;               // root only, allocated on first use: nranks slabs
-	float4* fullStage = nullptr, *fullRecv = nullptr; // reduce mode, allocated on first use: whole frames RCCL may touch
+	// every exchange buffer is allocated by tyr_dist_create (collective: it fails on every rank or on none), never inside a
+	// combine, where a failure on one rank would leave its peers waiting in ncclSend / ncclRecv
+	float4* recvSlabs = nullptr;               // nranks slabs (any rank may be asked to be the root)
+	float4* fullStage = nullptr, *fullRecv = nullptr; // reduce mode: whole frames RCCL may touch
+	hipEvent_t evFullShipped = nullptr;        // comm stream: fullStage has been read by the last reduce
+	bool fullShippedValid = false;
 	hipEvent_t evPacked = nullptr;             // ctx stream: the slab is packed (or, reduce: the render is complete)
 	hipEvent_t evShipped[2] = { nullptr, nullptr }; // comm stream: staging[i] has left (it may be packed again)
 	bool shippedValid[2] = { false, false };
@@ -211,6 +223,7 @@ int tyr_dist_create(tyr_dist** out, tyr_ctx* ctx, const void* id128, int32_t ran
 	if (!d)
 		return TYR_ERR_OOM;
 	d->ctx = ctx;
+	d->device = ctx->cfg.device;
 	d->rank = rank;
 	d->nranks = nranks;
 	d->slabPixels = static_cast<size_t>(ctx->cfg.width) * ctx->localRows;
@@ -221,13 +234,21 @@ int tyr_dist_create(tyr_dist** out, tyr_ctx* ctx, const void* id128, int32_t ran
 	if (hipStreamCreateWithFlags(&d->commStream, hipStreamNonBlocking) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
 	if (hipEventCreateWithFlags(&d->evPacked, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evDone, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&d->evShipped[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evShipped[1], hipEventDisableTiming) != hipSuccess)
+	    hipEventCreateWithFlags(&d->evShipped[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evShipped[1], hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->evFullShipped, hipEventDisableTiming) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
-	for (auto& s : d->staging) {
-		void* p = nullptr;
-		if (hipMalloc(&p, d->slabPixels * sizeof(float4)) != hipSuccess)
-			return fail(TYR_ERR_OOM);
-		s = static_cast<float4*>(p);
+	{
+		const size_t framePixels = static_cast<size_t>(ctx->cfg.width) * ctx->cfg.height;
+		struct {
+			float4** p;
+			size_t pixels;
+		} bufs[] = { { &d->staging[0], d->slabPixels }, { &d->staging[1], d->slabPixels }, { &d->recvSlabs, d->slabPixels * static_cast<size_t>(nranks) }, { &d->fullStage, framePixels }, { &d->fullRecv, framePixels } };
+		for (auto& b : bufs) {
+			void* p = nullptr;
+			if (hipMalloc(&p, b.pixels * sizeof(float4)) != hipSuccess)
+				return fail(TYR_ERR_OOM);
+			*b.p = static_cast<float4*>(p);
+		}
 	}
 	NcclId id;
 	std::memcpy(&id, id128, sizeof id);
@@ -241,7 +262,7 @@ int tyr_dist_create(tyr_dist** out, tyr_ctx* ctx, const void* id128, int32_t ran
 int tyr_dist_destroy(tyr_dist* d) {
 	if (!d)
 		return TYR_OK;
-	(void)hipSetDevice(d->ctx->cfg.device);
+	(void)hipSetDevice(d->device);
 	if (d->commStream)
 		(void)hipStreamSynchronize(d->commStream);
 	if (d->comm)
@@ -252,7 +273,7 @@ int tyr_dist_destroy(tyr_dist* d) {
 	for (float4* p : { d->recvSlabs, d->fullStage, d->fullRecv })
 		if (p)
 			(void)hipFree(p);
-	for (hipEvent_t e : { d->evPacked, d->evDone, d->evShipped[0], d->evShipped[1] })
+	for (hipEvent_t e : { d->evPacked, d->evDone, d->evShipped[0], d->evShipped[1], d->evFullShipped })
 		if (e)
 			(void)hipEventDestroy(e);
 	if (d->commStream)
@@ -281,16 +302,8 @@ int tyr_dist_combine(tyr_dist* d, int32_t mode, int32_t root, void* frame_out_de
 		// RCCL works on this library's own copies (see the note on runtimes at the top): blit -> fullStage on the render
 		// stream, ncclReduce fullStage -> fullRecv and fullRecv -> frame_out on the communicator's stream.
 		const size_t pixels = static_cast<size_t>(W) * H;
-		for (float4** p : { &d->fullStage, isRoot ? &d->fullRecv : nullptr }) {
-			if (p && !*p) {
-				void* v = nullptr;
-				if (hipMalloc(&v, pixels * sizeof(float4)) != hipSuccess)
-					return TYR_ERR_OOM;
-				*p = static_cast<float4*>(v);
-			}
-		}
-		if (d->shippedValid[0]) // one staging frame: the previous reduce must have read it
-			HIPCHK(hipStreamWaitEvent(c->stream, d->evShipped[0], 0));
+		if (d->fullShippedValid) // one staging frame: the previous reduce must have read it
+			HIPCHK(hipStreamWaitEvent(c->stream, d->evFullShipped, 0));
 		launch_pack_rows(c->blit, d->fullStage, W, H, 0u, 1u, c->stream); // nranks = 1: a plain copy of the frame
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(d->evPacked, c->stream)); // from here on the blit buffer is the renderer's again
@@ -302,8 +315,8 @@ int tyr_dist_combine(tyr_dist* d, int32_t mode, int32_t root, void* frame_out_de
 			launch_pack_rows(d->fullRecv, frameOut, W, H, 0u, 1u, d->commStream);
 			HIPCHK(hipGetLastError());
 		}
-		HIPCHK(hipEventRecord(d->evShipped[0], d->commStream));
-		d->shippedValid[0] = true;
+		HIPCHK(hipEventRecord(d->evFullShipped, d->commStream));
+		d->fullShippedValid = true;
 		HIPCHK(hipEventRecord(d->evDone, d->commStream));
 		return TYR_OK;
 	}
@@ -318,12 +331,6 @@ int tyr_dist_combine(tyr_dist* d, int32_t mode, int32_t root, void* frame_out_de
 	HIPCHK(hipEventRecord(d->evPacked, c->stream)); // from here on the blit buffer is the renderer's again
 	HIPCHK(hipStreamWaitEvent(d->commStream, d->evPacked, 0));
 	const size_t slabFloats = d->slabPixels * 4;
-	if (isRoot && d->nranks > 1 && !d->recvSlabs) {
-		void* p = nullptr;
-		if (hipMalloc(&p, d->slabPixels * sizeof(float4) * d->nranks) != hipSuccess)
-			return TYR_ERR_OOM;
-		d->recvSlabs = static_cast<float4*>(p);
-	}
 	if (d->nranks > 1) {
 		int rc = nccl_status(R.GroupStart(), "ncclGroupStart");
 		if (rc)
@@ -340,7 +347,7 @@ int tyr_dist_combine(tyr_dist* d, int32_t mode, int32_t root, void* frame_out_de
 			return rc ? rc : rce;
 	}
 	if (isRoot) {
-		launch_scatter_rows(d->recvSlabs ? d->recvSlabs : d->staging[s], d->staging[s], static_cast<uint32_t>(root), frameOut, W, rows, static_cast<uint32_t>(d->nranks), d->commStream);
+		launch_scatter_rows(d->nranks > 1 ? d->recvSlabs : d->staging[s], d->staging[s], static_cast<uint32_t>(root), frameOut, W, rows, static_cast<uint32_t>(d->nranks), d->commStream);
 		HIPCHK(hipGetLastError());
 	}
 	HIPCHK(hipEventRecord(d->evShipped[s], d->commStream));
@@ -352,8 +359,22 @@ int tyr_dist_combine(tyr_dist* d, int32_t mode, int32_t root, void* frame_out_de
 int tyr_dist_wait(tyr_dist* d) {
 	if (!d)
 		return TYR_ERR_INVALID;
-	HIPCHK(hipSetDevice(d->ctx->cfg.device));
+	HIPCHK(hipSetDevice(d->device));
 	HIPCHK(hipStreamSynchronize(d->commStream));
+	return TYR_OK;
+}
+
+int tyr_dist_info(tyr_dist* d, int32_t* comm_ranks_out, int32_t* rank_out) {
+	if (!d)
+		return TYR_ERR_INVALID;
+	int n = -1;
+	if (rccl().CommCount && d->comm)
+		if (int rc = nccl_status(rccl().CommCount(d->comm, &n), "ncclCommCount"))
+			return rc;
+	if (comm_ranks_out)
+		*comm_ranks_out = n;
+	if (rank_out)
+		*rank_out = d->rank;
 	return TYR_OK;
 }
 

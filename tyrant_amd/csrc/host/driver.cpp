@@ -974,14 +974,30 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 			ahead = true;
 		}
 		const int set = static_cast<int>((iter0 + enq - 1) & 1u);
-		HIPCHK(hipEventSynchronize(c->evSnap[set]));
+		// a failure from here on leaves an iteration queued that the render will never own: drain the stream and take the
+		// host's bookkeeping of it back, so that the ctx is where its last completed iteration left it
+		auto abandon = [&](int code) {
+			if (ahead) {
+				(void)hipStreamSynchronize(c->stream);
+				c->frame = frameBefore;
+				c->cur ^= 1;
+				c->iter--;
+				c->shadowPending = false;
+			}
+			return code;
+		};
+		{
+			const hipError_t e = hipEventSynchronize(c->evSnap[set]);
+			if (e != hipSuccess)
+				return abandon(static_cast<int>(e));
+		}
 		std::memcpy(c->hK, c->hSnap[set], sizeof(DevCounters));
 		collect_timings_of(c, set);
 		it = enq;
 		s = c->hK->primary_ray_cnt; // survivors of iteration enq - 1
 		const uint32_t shadows = c->hK->shadow_ray_cnt;
 		if ((rc = check_device_error(c)))
-			return rc;
+			return abandon(rc);
 		if (budget == 0 && s == 0) { // kernel loop of the reference's caller: nothing left to trace or to start
 			if (ahead) {
 				// iteration enq was queued for nothing but the shadow rays of iteration enq - 1: take the host state back
