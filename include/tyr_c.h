@@ -363,6 +363,24 @@ int tyr_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t 
 int tyr_write_png(const char* path, const float* rgba, uint32_t width, uint32_t height);
 /* Camera::update, camera.cpp:46-52 */
 int tyr_camera_update(double horizontal_angle, double vertical_angle, float direction_out[3]);
+
+/* Camera::handle_input (camera.cpp:3-44) as a pure function: the reference reads a GLFW window (glfwGetKey,
+ * glfwGetCursorPos, glfwGetWindowSize) and re-centres the cursor (glfwSetCursorPos); a headless node has no window, so the
+ * state it would have read comes in as a record and the camera record is updated in place -- same arithmetic, same order:
+ * W/S along `direction`, A/D along normalize(cross(direction, up)), SPACE / LEFT_CONTROL along z, LEFT_SHIFT = 40 x the
+ * speed, all times float(delta); LEFT_ALT skips the mouse look; otherwise the angles move by 0.012 per pixel of cursor
+ * offset from the window centre and the vertical one is clamped to +-(pi/2 - 0.001).  Camera::update (tyr_camera_update)
+ * turns the angles into `direction` afterwards, as main.cpp:164-166 calls them. */
+typedef struct tyr_input_state {
+	uint8_t key_w, key_s, key_a, key_d, key_space, key_left_control, key_left_shift, key_left_alt; /* glfwGetKey(...) != 0 */
+	double cursor_x, cursor_y;  /* glfwGetCursorPos */
+	int32_t window_w, window_h; /* glfwGetWindowSize */
+} tyr_input_state;
+typedef struct tyr_camera_pose {
+	float position[3], direction[3], up[3]; /* camera.h:4-6 */
+	double horizontal_angle, vertical_angle; /* camera.h:17-18 */
+} tyr_camera_pose;
+int tyr_camera_handle_input(tyr_camera_pose* camera, const tyr_input_state* input, double delta);
 /* the reference's hard-wired sphere table, kernel.cu:674-680 */
 int tyr_default_spheres(tyr_sphere* out7);
 

@@ -130,6 +130,19 @@ float orc_dm_cosf(float x);
 float orc_dm_expf(float x);
 float orc_dm_powf(float x, float y);
 
+/* ---- f4, headless: Camera::handle_input / Camera::update (camera.cpp:3-52) as pure functions ---------------------- */
+typedef struct {
+	uint8_t key_w, key_s, key_a, key_d, key_space, key_left_control, key_left_shift, key_left_alt;
+	double cursor_x, cursor_y;
+	int32_t window_w, window_h;
+} orc_input_state;
+typedef struct {
+	float position[3], direction[3], up[3];
+	double horizontal_angle, vertical_angle;
+} orc_camera_pose;
+void orc_camera_handle_input(orc_camera_pose* cam, const orc_input_state* in, double delta); /* camera.cpp:3-44 */
+void orc_camera_update(orc_camera_pose* cam);                                                 /* camera.cpp:46-52 */
+
 /* ---- a13/a14: sun & sky (sunsky.cu) --------------------------------------- */
 void orc_sun_setup(const float sun_position[2], orc_sunparams* out); /* kernel.cu:683-709 */
 void orc_sun(const orc_sunparams* S, const float viewDir[3], float out[3]);

@@ -768,3 +768,41 @@ void orc_resolve(const orc_ctx* c, float* out) {
 		out[4 * i + 3] = dm_powf(1.f / (1.f + 1.f), 1.0f / 2.2f);
 	}
 }
+
+
+/* ---- Camera::handle_input / update (camera.cpp:3-52): the GLFW reads of the original arrive as a record ------------ */
+void orc_camera_handle_input(orc_camera_pose* cam, const orc_input_state* in, double delta) {
+	float speed = 1;
+	if (in->key_left_shift) /* camera.cpp:5-7 */
+		speed = 40;
+	v3 position = v3load(cam->position);
+	const v3 direction = v3load(cam->direction), up = v3load(cam->up);
+	if (in->key_w) /* camera.cpp:9-13: position += direction * speed * float(delta) */
+		position = v3add(position, v3scale(v3scale(direction, speed), (float)delta));
+	else if (in->key_s)
+		position = v3sub(position, v3scale(v3scale(direction, speed), (float)delta));
+	const v3 displacement = v3scale(v3scale(v3normalize(v3cross(direction, up)), speed), (float)delta); /* camera.cpp:15 */
+	if (in->key_a)
+		position = v3sub(position, displacement);
+	else if (in->key_d)
+		position = v3add(position, displacement);
+	if (in->key_space) /* camera.cpp:22-26 */
+		position.z += 1 * speed * (float)delta;
+	else if (in->key_left_control)
+		position.z -= 1 * speed * (float)delta;
+	v3store(cam->position, position);
+	if (in->key_left_alt) /* camera.cpp:27-29 */
+		return;
+	const double diffx = in->cursor_x - in->window_w * 0.5; /* camera.cpp:36-37 */
+	const double diffy = in->cursor_y - in->window_h * 0.5;
+	cam->horizontal_angle += diffx * 0.012;
+	cam->vertical_angle -= diffy * 0.012;
+	const double lo = -ORC_PI / 2 + 0.001, hi = ORC_PI / 2 - 0.001; /* camera.cpp:41: pi is a float, the sums are doubles */
+	double va = cam->vertical_angle < hi ? cam->vertical_angle : hi;
+	cam->vertical_angle = lo > va ? lo : va;
+}
+void orc_camera_update(orc_camera_pose* cam) {
+	v3 d = v3make((float)(cos(cam->vertical_angle) * sin(cam->horizontal_angle)), (float)(cos(cam->vertical_angle) * cos(cam->horizontal_angle)), (float)sin(cam->vertical_angle));
+	d = v3normalize(d);
+	v3store(cam->direction, d);
+}

@@ -43,6 +43,15 @@ class CameraC(C.Structure):
     _fields_ = [("position", c_f * 3), ("direction", c_f * 3), ("up", c_f * 3), ("focalDistance", c_f), ("lensRadius", c_f)]
 
 
+class InputState(C.Structure):
+    _fields_ = [("key_w", C.c_uint8), ("key_s", C.c_uint8), ("key_a", C.c_uint8), ("key_d", C.c_uint8), ("key_space", C.c_uint8), ("key_left_control", C.c_uint8), ("key_left_shift", C.c_uint8),
+                ("key_left_alt", C.c_uint8), ("cursor_x", C.c_double), ("cursor_y", C.c_double), ("window_w", C.c_int32), ("window_h", C.c_int32)]
+
+
+class CameraPose(C.Structure):
+    _fields_ = [("position", c_f * 3), ("direction", c_f * 3), ("up", c_f * 3), ("horizontal_angle", C.c_double), ("vertical_angle", C.c_double)]
+
+
 class Counters(C.Structure):
     _fields_ = [
         ("primary_ray_cnt", c_u32),
@@ -156,6 +165,8 @@ def lib() -> C.CDLL:
         L.orc_bbox_host_ops.argtypes = [P, c_i, P, P]
         L.orc_glm.restype = c_i
         L.orc_glm.argtypes = [c_i, P, P, P, c_i, P]
+        L.orc_camera_handle_input.argtypes = [C.POINTER(CameraPose), C.POINTER(InputState), C.c_double]
+        L.orc_camera_update.argtypes = [C.POINTER(CameraPose)]
         _lib = L
     return _lib
 

@@ -128,6 +128,7 @@ SYMBOLS = {
     "tyr_vecmath_probe": (C.c_int, [c_i32, c_i32, P, P, P, c_u32, P]),
     "tyr_sunsky_probe": (C.c_int, [c_i32, C.c_float, C.c_float, c_i32, P, c_u32, P]),
     "tyr_sun_setup": (C.c_int, [C.c_float, C.c_float, P]),
+    "tyr_camera_handle_input": (C.c_int, [P, P, C.c_double]),
     "tyr_get_timings": (C.c_int, [P, C.POINTER(Timings), C.c_int]),
     "tyr_set_tuning": (C.c_int, [P, C.c_int, C.c_int]),
     "tyr_bvh_build": (C.c_int, [P, c_i32, P, P, c_i32]),
@@ -391,6 +392,21 @@ def vecmath_probe(op: int, a: np.ndarray, b: np.ndarray, c: np.ndarray, device: 
 
 
 # ---- multi-GPU combine (RCCL behind the C ABI) --------------------------------------------------
+
+
+class InputState(C.Structure):
+    """tyr_input_state: what Camera::handle_input reads from the GLFW window (camera.cpp:3-44)"""
+
+    _fields_ = [("key_w", C.c_uint8), ("key_s", C.c_uint8), ("key_a", C.c_uint8), ("key_d", C.c_uint8), ("key_space", C.c_uint8), ("key_left_control", C.c_uint8), ("key_left_shift", C.c_uint8),
+                ("key_left_alt", C.c_uint8), ("cursor_x", C.c_double), ("cursor_y", C.c_double), ("window_w", c_i32), ("window_h", c_i32)]
+
+
+class CameraPose(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("direction", C.c_float * 3), ("up", C.c_float * 3), ("horizontal_angle", C.c_double), ("vertical_angle", C.c_double)]
+
+
+def camera_handle_input(pose: "CameraPose", state: "InputState", delta: float):
+    _check(lib().tyr_camera_handle_input(C.byref(pose), C.byref(state), float(delta)), "tyr_camera_handle_input")
 
 
 SUN_PARAM_FIELDS = (("sunDirection", 3), ("sunAngularDiameterCos", 1), ("sunE", 1), ("rayleighAtX", 3), ("mieAtX", 3), ("totalLightAtX", 3), ("mixFactor", 1), ("coneDir", 3), ("coneO1", 3), ("coneO2", 3), ("coneExtent", 1))

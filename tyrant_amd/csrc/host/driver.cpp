@@ -1463,6 +1463,44 @@ int tyr_camera_update(double horizontal_angle, double vertical_angle, float dire
 	return TYR_OK;
 }
 
+int tyr_camera_handle_input(tyr_camera_pose* cam, const tyr_input_state* in, double delta) {
+	if (!cam || !in || !std::isfinite(delta))
+		return TYR_ERR_INVALID;
+	// camera.cpp:3-44, statement by statement (glm's vec3 * float * float associates to the left)
+	const float dt = static_cast<float>(delta);
+	float speed = 1;
+	if (in->key_left_shift)
+		speed = 40;
+	f3 position = ld3(cam->position);
+	const f3 direction = ld3(cam->direction), up = ld3(cam->up);
+	if (in->key_w)
+		position = position + (direction * speed) * dt;
+	else if (in->key_s)
+		position = position - (direction * speed) * dt;
+	const f3 displacement = (normalize(cross(direction, up)) * speed) * dt;
+	if (in->key_a)
+		position = position - displacement;
+	else if (in->key_d)
+		position = position + displacement;
+	if (in->key_space)
+		position.z += (1 * speed) * dt;
+	else if (in->key_left_control)
+		position.z -= (1 * speed) * dt;
+	cam->position[0] = position.x;
+	cam->position[1] = position.y;
+	cam->position[2] = position.z;
+	if (in->key_left_alt)
+		return TYR_OK;
+	const double diffx = in->cursor_x - in->window_w * 0.5;
+	const double diffy = in->cursor_y - in->window_h * 0.5;
+	cam->horizontal_angle += diffx * 0.012;
+	cam->vertical_angle -= diffy * 0.012;
+	// std::max(-pi / 2 + 0.001, std::min(vertical_angle, pi / 2 - 0.001)): pi is a float (variables.h:3), the sums are doubles
+	const double lo = static_cast<double>(-kPi / 2) + 0.001, hi = static_cast<double>(kPi / 2) - 0.001;
+	cam->vertical_angle = std::max(lo, std::min(cam->vertical_angle, hi));
+	return TYR_OK;
+}
+
 int tyr_default_spheres(tyr_sphere* out7) {
 	if (!out7)
 		return TYR_ERR_INVALID;
