@@ -6,19 +6,62 @@
 namespace tyr {
 
 // ======================================================================================
+// set_wavefront_globals, kernel.cu:227-244 (+ reset of the compaction descriptors)
+// ======================================================================================
+// Runs in the LAST block of k_primary to finish (every other block has read the counts it changes): one launch and
+// one gap between dependent kernels fewer per iteration (20 iterations per frame at the reference's queue size).
+__device__ __forceinline__ void wavefront_globals(const FrameParams& P) {
+	const uint32_t i = threadIdx.x;
+	if (i < kTicketWords) {
+		P.k->extend_chunks[i * 32] = 0;
+		P.kc->chunks[i * 32] = 0;
+		P.k->shade_tiles[i * 32] = 0;
+		// what this iteration's shade appends to: the next ray queue and this iteration's shadow queue
+		P.segNext[i * kSegStride] = 0;
+		P.segNext[kClassWords + i * kSegStride] = 0;
+		P.kc->seg[i * kSegStride] = 0;
+	}
+	if (i == 0) {
+		DevCounters* k = P.k;
+		const uint32_t cnt = k->primary_ray_cnt;
+		const unsigned long long room = (unsigned long long)(P.N - cnt);
+		const unsigned long long budget = k->budget_remaining;
+		const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
+		k->start_position = (uint32_t)(((unsigned long long)k->start_position + nNew) % P.localPixels);
+		k->n_live = cnt + nNew;
+		k->first_fresh = cnt;
+		k->shade_blocks_done = 0;
+		k->scan_blocks_done = 0;
+		k->primary_blocks_done = 0;
+		for (uint32_t w = 0; w < kTicketWords; ++w)
+			k->primary_done[w * 32] = 0;
+		k->shadow_ray_cnt = 0;
+		k->primary_ray_cnt = 0;
+		k->extend_ticket = 0;
+		P.kc->ticket = 0;
+		P.kc->shadow_cnt = 0;
+		if (budget != ~0ull)
+			k->budget_remaining = budget - nNew;
+		k->total_primary_rays += nNew;
+		k->total_extend_rays += cnt + nNew;
+#if defined(TYR_QUAD_STATS) || defined(TYR_LAUNCH_ANATOMY)
+		k->debug[13] = k->debug[14] = k->debug[15] = 0ull; // launch anatomy of this iteration's extend (tools/launch_tail.py)
+		k->debug[9] = k->debug[10] = k->debug[11] = k->debug[12] = 0ull; // ... and its longest rays (k_trace_flat, TYR_QUAD_STATS)
+#endif
+	}
+}
+
+// ======================================================================================
 // primary_rays, kernel.cu:247-297.  One thread per new queue slot.
 // ======================================================================================
 __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
-	__shared__ uint32_t baseSh[kClasses], cntSh[8];
+	__shared__ uint32_t baseSh[kClasses], cntSh[8], lastSh;
 	const uint32_t index = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t cnt = P.k->primary_ray_cnt; // survivors already in the buffer (kernel.cu:253)
 	const unsigned long long room = (unsigned long long)(P.N - cnt);
 	const unsigned long long budget = P.k->budget_remaining;
 	const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
-	const uint32_t firstOfBlock = blockIdx.x * kBlock;
-	if (firstOfBlock >= nNew)
-		return; // (the whole block)
-	const bool mine = index < nNew;
+	const bool mine = index < nNew; // (a launch with nothing to generate is one block that only runs the globals below)
 	const uint32_t vslot = index + cnt; // the slot the serial order gives this ray (kernel.cu:254): what seeds its shading
 	// kernel.cu:258 seeds by the ticket `index`; with pixel sharding (nranks > 1) the ranks' tickets are interleaved so that
 	// rows y = yl * R + r, r = 0..R-1, do not share their jitter and lens samples (nranks == 1: the reference's expression)
@@ -87,60 +130,38 @@ __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 		baseSh[c] = base;
 	}
 	__syncthreads();
-	if (!mine)
-		return;
 	const uint32_t cls = tree ? 0u : 1u;
-	if (baseSh[cls] == 0xffffffffu)
-		return;
-	const uint32_t rank = before[cls] + (uint32_t)__popcll((tree ? bt : bsky) & below);
-	const uint32_t slot = cls * P.classStride + seg_phys(seg, baseSh[cls] + rank);
-	// kernel.cu:295: {origin, direction, {1,1,1}, 0, 0, 0, pixel}; lastSpecular defaults to true (variables.h:33)
-	P.work.o_dx[slot] = make_float4(lensPoint.x, lensPoint.y, lensPoint.z, direction.x);
-	P.work.dyz[slot] = make_float2(direction.y, direction.z);
-	P.work.direct_ix[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(y * (int)P.W + x));
-	P.work.flags[slot] = 0u | (1u << 8);
-	P.work.hit[slot] = hitRecord;
-	P.work.key[slot] = vslot;
-}
-
-// ======================================================================================
-// set_wavefront_globals, kernel.cu:227-244 (+ reset of the compaction descriptors)
-// ======================================================================================
-__global__ void __launch_bounds__(kBlock) k_globals(const FrameParams P) {
-	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	if (i < kTicketWords) {
-		P.k->extend_chunks[i * 32] = 0;
-		P.kc->chunks[i * 32] = 0;
-		P.k->shade_tiles[i * 32] = 0;
-		// what this iteration's shade appends to: the next ray queue and this iteration's shadow queue
-		P.segNext[i * kSegStride] = 0;
-		P.segNext[kClassWords + i * kSegStride] = 0;
-		P.kc->seg[i * kSegStride] = 0;
+	if (mine && baseSh[cls] != 0xffffffffu) {
+		const uint32_t rank = before[cls] + (uint32_t)__popcll((tree ? bt : bsky) & below);
+		const uint32_t slot = cls * P.classStride + seg_phys(seg, baseSh[cls] + rank);
+		// kernel.cu:295: {origin, direction, {1,1,1}, 0, 0, 0, pixel}; lastSpecular defaults to true (variables.h:33)
+		P.work.o_dx[slot] = make_float4(lensPoint.x, lensPoint.y, lensPoint.z, direction.x);
+		P.work.dyz[slot] = make_float2(direction.y, direction.z);
+		P.work.direct_ix[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(y * (int)P.W + x));
+		P.work.flags[slot] = 0u | (1u << 8);
+		P.work.hit[slot] = hitRecord;
+		P.work.key[slot] = vslot;
 	}
-	if (i == 0) {
-		DevCounters* k = P.k;
-		const uint32_t cnt = k->primary_ray_cnt;
-		const unsigned long long room = (unsigned long long)(P.N - cnt);
-		const unsigned long long budget = k->budget_remaining;
-		const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
-		k->start_position = (uint32_t)(((unsigned long long)k->start_position + nNew) % P.localPixels);
-		k->n_live = cnt + nNew;
-		k->first_fresh = cnt;
-		k->shade_blocks_done = 0;
-		k->shadow_ray_cnt = 0;
-		k->primary_ray_cnt = 0;
-		k->extend_ticket = 0;
-		P.kc->ticket = 0;
-		P.kc->shadow_cnt = 0;
-		if (budget != ~0ull)
-			k->budget_remaining = budget - nNew;
-		k->total_primary_rays += nNew;
-		k->total_extend_rays += cnt + nNew;
-#if defined(TYR_QUAD_STATS) || defined(TYR_LAUNCH_ANATOMY)
-		k->debug[13] = k->debug[14] = k->debug[15] = 0ull; // launch anatomy of this iteration's extend (tools/launch_tail.py)
-		k->debug[9] = k->debug[10] = k->debug[11] = k->debug[12] = 0ull; // ... and its longest rays (k_trace_flat, TYR_QUAD_STATS)
-#endif
+	// set_wavefront_globals (kernel.cu:227-244, launched behind primary_rays at kernel.cu:720): by the block that finishes last
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		// eight counters (one word serves only ~88 returning atomics per microsecond; a 16.6 M-ray top-up is 65 k blocks):
+		// the block that completes its word counts the word, the block that completes the eighth word is the last.
+		// No fence: the last block reads nothing the others wrote, it only overwrites counts they have finished reading
+		// (their own stores depended on those reads); a release here is an L2 write-back per block -- 2.4 ms of a 16.6 M-ray
+		// top-up when it was tried.
+		const uint32_t w = blockIdx.x & (kTicketWords - 1u);
+		const uint32_t mineOfWord = (gridDim.x - w + kTicketWords - 1u) / kTicketWords; // blocks b with b % 8 == w
+		uint32_t last = 0;
+		if (atomicAdd(&P.k->primary_done[w * 32], 1u) + 1u == mineOfWord) {
+			const uint32_t words = gridDim.x < kTicketWords ? gridDim.x : kTicketWords;
+			last = atomicAdd(&P.k->primary_blocks_done, 1u) + 1u == words ? 1u : 0u;
+		}
+		lastSh = last;
 	}
+	__syncthreads();
+	if (lastSh)
+		wavefront_globals(P);
 }
 
 // extend pre-pass: kernel.cu:125-136 (spheres first; their distance bounds the BVH search)
@@ -153,15 +174,21 @@ __global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) 
 	// the survivors of the last iteration, both classes: the records in front of what a top-up appended (k_primary has done
 	// its own rays).  Class 0: the distance bounds the BVH search; class 1: the record is the ray's answer.
 	for (uint32_t c = 0; c < kClasses; ++c) {
-		SegCounts sc;
+		SegCounts sc, now;
 #pragma unroll
 		for (uint32_t w = 0; w < kSegs; ++w)
 			sc.c[w] = P.k->segSurv[c][w];
-		const uint32_t n = sc.extent(), base = c * P.classStride;
+		now.load(P.segWork + c * kClassWords);
+		// class 0 is walked up to its extent: the slots at the segments' ends that hold no record become rays that enter
+		// nothing (k_trace_flat hands out slots [0, extent) without asking)
+		const uint32_t n = c == 0 ? now.extent() : sc.extent(), base = c * P.classStride;
 		for (uint32_t j = first; j < n; j += stride) {
-			if (!sc.valid(j))
-				continue;
 			const uint32_t slot = base + j;
+			if (!sc.valid(j)) {
+				if (c == 0 && !now.valid(j))
+					write_dead_ray(P.work, slot);
+				continue;
+			}
 			const float4 a = P.work.o_dx[slot];
 			const float2 b = P.work.dyz[slot];
 			P.work.hit[slot] = sphere_hit_record(P, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
@@ -169,9 +196,9 @@ __global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) 
 	}
 }
 
-// The slots at the ends of the eight segments that hold no record (a segment is a few records shorter than the longest)
-// become rays that enter nothing / shadow rays that are "occluded": k_trace_flat hands out slots [0, extent) without
-// asking which of them hold a record.  Block w does segment w; what == 0: class 0 of the work queue, 1: the shadow queue.
+// The same for an iteration whose sphere pre-pass does not run (no survivors: a render's first wavefront): the slots at
+// the ends of the eight segments that hold no record become rays that enter nothing.  Block w does segment w; what == 0:
+// class 0 of the work queue, 1: the shadow queue (unused: its pre-pass always runs).
 __global__ void __launch_bounds__(kBlock) k_pad_holes(const FrameParams P, uint32_t workQueue, uint32_t shadowQueue) {
 	const uint32_t w = blockIdx.x & (kSegs - 1u), what = blockIdx.x / kSegs;
 	if ((what == 0 && !workQueue) || (what == 1 && !shadowQueue))
@@ -200,8 +227,10 @@ __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P)
 	sc.load(P.kc->seg);
 	const uint32_t n = sc.extent();
 	for (uint32_t index = first; index < n; index += stride) {
-		if (!sc.valid(index))
-			continue; // (a hole: k_pad_holes marks it)
+		if (!sc.valid(index)) {
+			reinterpret_cast<float*>(&P.shadow.color[index])[3] = 1.0f; // a hole at a segment's end: "occluded" retires it at the traversal's refill
+			continue;
+		}
 		const float4 a = P.shadow.o_dx[index];
 		const float4 b = P.shadow.dyz_cd_ix[index];
 		const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
@@ -220,7 +249,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P)
 // The serial order, recovered as numbers (kernels.hpp "Queues"): shade wrote one byte per ray at its virtual slot --
 // survived or not; rank(v) = survivors below v is the survivor's slot in the next iteration by the reference's serial
 // ticket order (kernel.cu:607 with the atomics in slot order).  k_scan_words packs 64 bytes into one word and scans the
-// words' counts inside 16384-slot blocks; k_scan_blocks scans the blocks' totals.  v_lookup() adds the three parts.
+// words' counts inside 16384-slot blocks; the block that finishes last scans the blocks' totals.  v_lookup() adds the three parts.
 // ======================================================================================
 constexpr uint32_t kScanBlockSlots = 64u * kBlock;
 __global__ void __launch_bounds__(kBlock) k_scan_words(const FrameParams P) {
@@ -266,42 +295,45 @@ __global__ void __launch_bounds__(kBlock) k_scan_words(const FrameParams P) {
 	}
 	P.vWordOut[e] = word;
 	P.vPreOut[e] = before + incl - c;
-	if (threadIdx.x == 0)
-		P.vBlkOut[blockIdx.x] = total; // raw; k_scan_blocks turns the totals into exclusive prefixes
-}
-__global__ void __launch_bounds__(1024) k_scan_blocks(const FrameParams P) {
-	__shared__ uint32_t waveSum[16];
-	__shared__ uint32_t carrySh;
-	const uint32_t n = P.k->n_live;
-	const uint32_t nBlocks = (n + kScanBlockSlots - 1) / kScanBlockSlots;
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	if (threadIdx.x == 0)
+	// the blocks' totals become exclusive prefixes in the block that finishes last
+	__shared__ uint32_t lastSh, carrySh;
+	if (threadIdx.x == 0) {
+		__hip_atomic_store(&P.vBlkOut[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the total has arrived before this block counts as done (no L2 write-back: see k_shade)
+		const uint32_t nBlocksLive = (n + kScanBlockSlots - 1) / kScanBlockSlots;
+		lastSh = atomicAdd(&P.k->scan_blocks_done, 1u) + 1u == nBlocksLive ? 1u : 0u;
 		carrySh = 0;
+	}
 	__syncthreads();
-	for (uint32_t base = 0; base < nBlocks; base += 1024u) {
+	if (!lastSh)
+		return;
+	const uint32_t nBlocks = (n + kScanBlockSlots - 1) / kScanBlockSlots;
+	for (uint32_t base = 0; base < nBlocks; base += kBlock) {
 		const uint32_t i = base + threadIdx.x;
-		const uint32_t c = i < nBlocks ? P.vBlkOut[i] : 0u;
-		uint32_t incl = c;
+		const uint32_t v = i < nBlocks ? __hip_atomic_load(&P.vBlkOut[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		uint32_t inc2 = v;
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) {
-			const uint32_t v = __shfl_up(incl, o, 64);
+			const uint32_t u = __shfl_up(inc2, o, 64);
 			if (lane >= (uint32_t)o)
-				incl += v;
+				inc2 += u;
 		}
+		__syncthreads(); // waveSum is reused
 		if (lane == 63u)
-			waveSum[wave] = incl;
+			waveSum[wave] = inc2;
 		__syncthreads();
-		uint32_t before = carrySh, total = 0;
-		for (uint32_t w = 0; w < 16; ++w) {
+		uint32_t before2 = carrySh, total2 = 0;
+#pragma unroll
+		for (uint32_t w = 0; w < kBlock / 64; ++w) {
 			if (w < wave)
-				before += waveSum[w];
-			total += waveSum[w];
+				before2 += waveSum[w];
+			total2 += waveSum[w];
 		}
 		if (i < nBlocks)
-			P.vBlkOut[i] = before + incl - c;
+			P.vBlkOut[i] = before2 + inc2 - v;
 		__syncthreads();
 		if (threadIdx.x == 0)
-			carrySh += total;
+			carrySh += total2;
 		__syncthreads();
 	}
 }
@@ -447,16 +479,13 @@ void launch_pad_holes(const FrameParams& P, bool workQueue, bool shadowQueue, hi
 	hipLaunchKernelGGL(k_pad_holes, dim3(2 * kSegs), dim3(kBlock), 0, stream, P, workQueue ? 1u : 0u, shadowQueue ? 1u : 0u);
 }
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
-	if (maxNew == 0)
-		return;
-	hipLaunchKernelGGL(k_primary, dim3(blocks_for(maxNew)), dim3(kBlock), 0, stream, P);
+	// always launched: its last block is set_wavefront_globals
+	hipLaunchKernelGGL(k_primary, dim3(maxNew ? blocks_for(maxNew) : 1u), dim3(kBlock), 0, stream, P);
 }
-void launch_globals(const FrameParams& P, hipStream_t stream) { hipLaunchKernelGGL(k_globals, dim3(1), dim3(kBlock), 0, stream, P); }
 void launch_scan(const FrameParams& P, uint32_t maxLive, hipStream_t stream) {
 	if (maxLive == 0)
 		return;
 	hipLaunchKernelGGL(k_scan_words, dim3((maxLive + kScanBlockSlots - 1) / kScanBlockSlots), dim3(kBlock), 0, stream, P);
-	hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, P);
 }
 void launch_vecmath_probe(int op, const float* a, const float* b, const float* c, uint32_t n, float* out, hipStream_t stream) {
 	hipLaunchKernelGGL(k_vecmath_probe, dim3(blocks_for(n ? n : 1)), dim3(kBlock), 0, stream, op, a, b, c, n, out);

@@ -98,7 +98,10 @@ struct DevCounters {
 	uint32_t shade_tiles[kTicketWords * 32]; // k_shade: word w hands out tiles w, w + 8, w + 16, ...
 	uint32_t seg[2][kClasses][kSegs * kSegStride]; // records in segment w of class c of ray queue q: seg[q][c][w * kSegStride]
 	uint32_t shade_blocks_done;               // k_shade: blocks that have finished (the last one folds the segment counters into the totals)
-	uint32_t reserved3[31];
+	uint32_t scan_blocks_done;                // k_scan_words: likewise (the last one scans the blocks' totals)
+	uint32_t primary_blocks_done;             // k_primary: likewise (the last one is set_wavefront_globals)
+	uint32_t reserved3[29];
+	uint32_t primary_done[kTicketWords * 32]; // k_primary: finished blocks b with b % 8 == w, one word per 128 bytes
 	uint32_t segSurv[kClasses][kSegs];        // seg[next] as shade left it: the records in front of the primary rays a top-up appends (the sphere pre-pass's share)
 	uint32_t reserved4[16];
 };
@@ -190,7 +193,6 @@ struct LaunchCache {
 // launches (all on `stream`); grids are sized by the host from upper bounds, kernels bound-check
 // against the device counters
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream);
-void launch_globals(const FrameParams& P, hipStream_t stream);
 void launch_pad_holes(const FrameParams& P, bool workQueue, bool shadowQueue, hipStream_t stream); // the slots at the segments' ends that hold no record become rays that enter nothing
 void launch_scan(const FrameParams& P, uint32_t maxLive, hipStream_t stream); // the survive bytes of this iteration -> vWordOut / vPreOut / vBlkOut
 // nSurvivors: upper bound of the slots the sphere pre-pass still has to do (primary rays get theirs in k_primary)

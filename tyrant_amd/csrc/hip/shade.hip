@@ -626,9 +626,14 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			atomicAdd(&P.k->primary_ray_cnt, mySurvivors);
 		if (myShadows)
 			atomicAdd(&P.kc->shadow_cnt, myShadows);
+#ifdef TYR_WHATIF_SHADE_FENCE
 		__threadfence();
+#else
+		// the counts above must have arrived before this block counts as done; they are device-scope atomics, so waiting for
+		// them is enough (a release fence here is an L2 write-back per block)
+		__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 		if (atomicAdd(&P.k->shade_blocks_done, 1u) + 1u == P.shadeBlocks) {
-			__threadfence();
 			const uint32_t s = __hip_atomic_load(&P.k->primary_ray_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const uint32_t h = __hip_atomic_load(&P.kc->shadow_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			P.k->shadow_ray_cnt = h;

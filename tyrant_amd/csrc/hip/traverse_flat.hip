@@ -1174,7 +1174,8 @@ void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t 
 	Pc.shadow = P.shadowPrev;
 	if (maxShadowPrev != 0)
 		launch_connect_spheres(Pc, maxShadowPrev, stream);
-	launch_pad_holes(Pc, P.traceShadow != 2u, maxShadowPrev != 0, stream);
+	if (P.traceShadow != 2u && nSurvivors == 0)
+		launch_pad_holes(Pc, true, false, stream); // no sphere pre-pass this iteration: the holes at the ends of the work queue's segments
 }
 
 // extend / connect as launches of their own (the stage API, tyr_launch_kernels): the same kernel with one kind of ray;

@@ -262,7 +262,6 @@ void enqueue_primary(tyr_ctx* c, const FrameParams& P, uint32_t nNew) {
 		KernelTimer t(c, TYR_K_PRIMARY);
 		launch_primary(P, nNew, c->stream);
 	}
-	launch_globals(P, c->stream);
 }
 // nSurvivors: how many of the nLive rays were in the queue before this iteration's primary rays (they still need their
 // sphere pre-pass)
