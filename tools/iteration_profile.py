@@ -9,14 +9,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tyrant_amd import binding, scenes  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
-tune = {k: int(v) for k, v in (a.split("=") for a in sys.argv[2:])}  # e.g. traversal_variant=3
+tune = {k: int(v) for k, v in (a.split("=") for a in sys.argv[2:])}  # e.g. min_traversing=24
 sc = {"c1": scenes.cornell_box, "c2": lambda: scenes.cornell_soup(10000), "c3": lambda: scenes.mesh_scene(706)}[wl]()
 nodes, prims = binding.bvh_build(sc.triangles)
 base = binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0
 W, H, SPP = 1920, 1080, 8
 rows = {}
 for counting in (True, False):
-    r = binding.Renderer(W, H, W * H * SPP, flags=base | (binding.TYR_FLAG_COUNT_VISITS if counting else binding.TYR_FLAG_PROFILE), diag=("traversal_variant" in tune or "stack_lds_depth" in tune))
+    r = binding.Renderer(W, H, W * H * SPP, flags=base | (binding.TYR_FLAG_COUNT_VISITS if counting else binding.TYR_FLAG_PROFILE))
     r.load_scene(sc, nodes, prims)
     if tune:
         r.set_tuning(**tune)

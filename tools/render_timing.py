@@ -9,7 +9,7 @@ from tyrant_amd import binding, scenes
 import numpy as np
 W,H,spp=1920,1080,8
 args = [a for a in sys.argv[1:] if "=" not in a]
-tune = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a)}  # e.g. traversal_variant=5 min_traversing=24
+tune = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a)}  # e.g. min_traversing=24 staged_nodes=0
 N = int(args[0]) if args else W*H*spp  # queue size; 2097152 = the reference's
 for name, sc in (("c2", scenes.cornell_soup(10000)), ("c3", scenes.mesh_scene(706))):
     bb=scenes.triangle_bboxes(sc.triangles)
