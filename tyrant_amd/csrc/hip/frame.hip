@@ -168,24 +168,38 @@ __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 // (grid-stride over the device's count: the host may have sized the grid from an upper bound, and a capped grid makes a
 // loose bound free)
 __global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) {
+	// the counts once per block through LDS: 32 loads of eight hot cache lines per THREAD were a fixed ~25 us of this kernel
+	__shared__ uint32_t cntSh[2 * kClasses * kSegs];
+	if (threadIdx.x < kClasses * kSegs) {
+		const uint32_t c = threadIdx.x / kSegs, w = threadIdx.x % kSegs;
+		cntSh[threadIdx.x] = P.k->segSurv[c][w];
+		cntSh[kClasses * kSegs + threadIdx.x] = P.segWork[c * kClassWords + w * kSegStride];
+	}
+	__syncthreads();
 	const uint32_t first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
 	if (first == 0)
 		P.k->extend_ticket = 0;
 	// the survivors of the last iteration, both classes: the records in front of what a top-up appended (k_primary has done
 	// its own rays).  Class 0: the distance bounds the BVH search; class 1: the record is the ray's answer.
-	for (uint32_t c = 0; c < kClasses; ++c) {
-		SegCounts sc, now;
+	// (validity straight from the LDS table, one read per test: a private array of the eight counts is "promoted" to LDS
+	// by the compiler anyway -- 64 bytes per thread -- and then read eight times per test)
+	auto extent_of = [&](uint32_t at) {
+		uint32_t m = 0;
 #pragma unroll
 		for (uint32_t w = 0; w < kSegs; ++w)
-			sc.c[w] = P.k->segSurv[c][w];
-		now.load(P.segWork + c * kClassWords);
+			m = cntSh[at + w] > m ? cntSh[at + w] : m;
+		return ((m + 63u) >> 6) * (kSegs * 64u);
+	};
+	auto holds = [&](uint32_t at, uint32_t j) { return (((j >> 9) << 6) | (j & 63u)) < cntSh[at + ((j >> 6) & (kSegs - 1u))]; };
+	for (uint32_t c = 0; c < kClasses; ++c) {
+		const uint32_t surv = c * kSegs, now = (kClasses + c) * kSegs;
 		// class 0 is walked up to its extent: the slots at the segments' ends that hold no record become rays that enter
 		// nothing (k_trace_flat hands out slots [0, extent) without asking)
-		const uint32_t n = c == 0 ? now.extent() : sc.extent(), base = c * P.classStride;
+		const uint32_t n = c == 0 ? extent_of(now) : extent_of(surv), base = c * P.classStride;
 		for (uint32_t j = first; j < n; j += stride) {
 			const uint32_t slot = base + j;
-			if (!sc.valid(j)) {
-				if (c == 0 && !now.valid(j))
+			if (!holds(surv, j)) {
+				if (c == 0 && !holds(now, j))
 					write_dead_ray(P.work, slot);
 				continue;
 			}
@@ -223,11 +237,17 @@ __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P)
 		P.kc->ticket = 0;
 	if (first < kTicketWords)
 		P.k->extend_chunks[first * 32] = 0; // k_trace_flat's tickets, when this pre-pass opens the launch that ends a render (no set_wavefront_globals in front of it)
-	SegCounts sc;
-	sc.load(P.kc->seg);
-	const uint32_t n = sc.extent();
+	__shared__ uint32_t cntSh[kSegs];
+	if (threadIdx.x < kSegs)
+		cntSh[threadIdx.x] = P.kc->seg[threadIdx.x * kSegStride];
+	__syncthreads();
+	uint32_t m = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < kSegs; ++w)
+		m = cntSh[w] > m ? cntSh[w] : m;
+	const uint32_t n = ((m + 63u) >> 6) * (kSegs * 64u);
 	for (uint32_t index = first; index < n; index += stride) {
-		if (!sc.valid(index)) {
+		if ((((index >> 9) << 6) | (index & 63u)) >= cntSh[(index >> 6) & (kSegs - 1u)]) {
 			reinterpret_cast<float*>(&P.shadow.color[index])[3] = 1.0f; // a hole at a segment's end: "occluded" retires it at the traversal's refill
 			continue;
 		}

@@ -574,6 +574,11 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	if (L.rootRef == kRefDone)
 		return TYR_OK; // Scene.cpp:49-52
 	// at least one element so the pointers are never null
+	// the pair nodes are what the counting build and the BVH_DEBUG picture traverse (the reference's visit counts,
+	// bvh.h:164-209); a ctx without those flags never reads them and does not keep them in HBM (64 MB on C3, 0.4 GB on C5)
+	const bool wantPairs = (c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) != 0;
+	if (!wantPairs)
+		L.pairNodes.clear();
 	const size_t nodeFloats = std::max<size_t>(L.pairNodes.size(), 16), quadFloats = std::max<size_t>(L.quadNodes.size(), 32), triFloats = L.tris.size();
 	if ((rc = dev_alloc(c->dNodes, nodeFloats / 4)) || (rc = dev_alloc(c->dQuads, quadFloats / 4 + kWhatIfQuadPad)) || (rc = dev_alloc(c->dTris, triFloats / 4)))
 		return rc;
@@ -1388,7 +1393,8 @@ int tyr_get_scene_info(tyr_ctx* c, tyr_scene_info* out) {
 	out->n_lights = c->nLights;
 	out->max_quad_nodes = 1u << kQuadOrderShift;
 	out->max_prim_offset = kMaxPrimOffset;
-	out->device_bytes = static_cast<uint64_t>(c->scene.nQuads) * 128 + static_cast<uint64_t>(c->scene.nPairs) * 64 + static_cast<uint64_t>(c->scene.nPrims) * 48;
+	const bool havePairs = (c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) != 0;
+	out->device_bytes = static_cast<uint64_t>(c->scene.nQuads) * 128 + (havePairs ? static_cast<uint64_t>(c->scene.nPairs) * 64 : 0) + static_cast<uint64_t>(c->scene.nPrims) * 48;
 	return TYR_OK;
 }
 
