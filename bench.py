@@ -467,7 +467,7 @@ def main():
     if pmc is not None and args.save_pmc:
         with open(args.save_pmc, "w") as f:
             json.dump({"workload": args.workload, "resolution": f"{args.width}x{args.height}", "spp": spp_total, "queue_size": N, "kernel": pmc["kernel"], "counters": pmc["counters"],
-                       "launches_averaged": pmc["launches_averaged"], "source": pmc["source"], "units": "per launch of the kernel, averaged over the launches of one warm render; FETCH_SIZE / WRITE_SIZE in KB"}, f, indent=1)
+                       "launches_averaged": pmc["launches_averaged"], "shade_counters_per_render": pmc.get("shade_counters_per_render", {}), "shade_launches_per_render": pmc.get("shade_launches_per_render"), "source": pmc["source"], "units": "per launch of the kernel, averaged over the launches of one warm render; FETCH_SIZE / WRITE_SIZE in KB"}, f, indent=1)
     if pmc is None and world == 1:
         pmc = committed_pmc(args.workload, N)
 
