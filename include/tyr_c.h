@@ -288,8 +288,7 @@ enum {
 	TYR_TUNE_MERGE_TRACE = 12,       /* tyr_render: 1 (default) = connect(i) shares the launch of extend(i + 1); 0 = launch_kernels' order, iteration by iteration */
 	TYR_TUNE_STATIC_INTERLEAVE = 13, /* the fixed per-block part as interleaved 64-slot chunks (1, default) or one contiguous range per block (0) */
 	TYR_TUNE_RUN_AHEAD = 14,         /* tyr_render: queue iteration i + 1 before iteration i's counts reach the host: 0 never, 1 always, 2 (default) for queues of at most 6 Mi slots */
-	TYR_TUNE_WIDE_DRAIN = 15,        /* 1 (default) = a wave's last <= 16 rays are finished four lanes to a ray */
-	TYR_TUNE_SHADE_OVERLAP = 16      /* tyr_render: 1 (default) = the rays that cannot enter the tree are shaded on a second stream while the traversal launch drains; 0 = one shade launch behind the traversal */
+	TYR_TUNE_WIDE_DRAIN = 15         /* 1 (default) = a wave's last <= 16 rays are finished four lanes to a ray */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);
 

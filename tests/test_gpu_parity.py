@@ -404,7 +404,7 @@ def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
     g0.set_tuning(merge_trace=0)
     g1.set_tuning(merge_trace=1, run_ahead=1)
     g2.set_tuning(merge_trace=1)  # (the default) connect(i) inside the launch of extend(i + 1): k_trace_flat, iteration i + 1 queued ahead of iteration i's counts
-    g3.set_tuning(merge_trace=1, run_ahead=0, wide_drain=0, shade_overlap=0)  # ... with the host waiting for every iteration's counts, and a wave's last rays left one to a lane
+    g3.set_tuning(merge_trace=1, run_ahead=0, wide_drain=0)  # ... with the host waiting for every iteration's counts, and a wave's last rays left one to a lane
     from tyrant_amd import scenes
 
     sc, _, _ = built_scene(name)

@@ -16,7 +16,6 @@ __device__ __forceinline__ void wavefront_globals(const FrameParams& P) {
 		P.k->extend_chunks[i * 32] = 0;
 		P.kc->chunks[i * 32] = 0;
 		P.k->shade_tiles[i * 32] = 0;
-		P.k->shade_tiles_side[i * 32] = 0;
 		// what this iteration's shade appends to: the next ray queue and this iteration's shadow queue
 		P.segNext[i * kSegStride] = 0;
 		P.segNext[kClassWords + i * kSegStride] = 0;
@@ -32,7 +31,6 @@ __device__ __forceinline__ void wavefront_globals(const FrameParams& P) {
 		k->n_live = cnt + nNew;
 		k->first_fresh = cnt;
 		k->shade_blocks_done = 0;
-		k->feed_done = 0;
 		k->scan_blocks_done = 0;
 		k->primary_blocks_done = 0;
 		for (uint32_t w = 0; w < kTicketWords; ++w)

@@ -102,9 +102,6 @@ struct DevCounters {
 	uint32_t primary_blocks_done;             // k_primary: likewise (the last one is set_wavefront_globals)
 	uint32_t reserved3[29];
 	uint32_t primary_done[kTicketWords * 32]; // k_primary: finished blocks b with b % 8 == w, one word per 128 bytes
-	uint32_t shade_tiles_side[kTicketWords * 32]; // tile tickets of the shade launch that runs beside the traversal (class 1)
-	uint32_t feed_done;                           // k_trace_flat: a wave has found the queue used up (the first one tells the host: P.feedDoneHost)
-	uint32_t reserved5[31];
 	uint32_t segSurv[kClasses][kSegs];        // seg[next] as shade left it: the records in front of the primary rays a top-up appends (the sphere pre-pass's share)
 	uint32_t reserved4[16];
 };
@@ -152,9 +149,6 @@ struct FrameParams {
 	uint32_t* vPreOut;
 	uint32_t* vBlkOut;
 	uint32_t shadeBlocks;         // k_shade: blocks of all of this iteration's shade launches together (the last one to finish finalises)
-	uint32_t shadeClasses;        // k_shade: bit c set = this launch shades class c (3: the one launch of an iteration; 2 / 1: the launch beside the traversal and the one behind it)
-	volatile uint32_t* feedDoneHost; // pinned host word (device alias; may be null): k_trace_flat stores feedDoneTag there when its queue is used up
-	uint32_t feedDoneTag;
 	uint32_t refillMinIdle;       // persistent traversal: refill a wave once this many lanes are free
 	uint32_t minTraversing;       // flat traversal: leave the descent loop below this many descending lanes
 	uint32_t ticketChunk;         // variants 1 / 4: queue slots a wave takes per draw from a device-wide ticket
@@ -184,7 +178,6 @@ struct Tuning {
 	int runAhead = 2;         // tyr_render: queue iteration i + 1 before iteration i's counts are on the host: 0 never, 1 always, 2 for queues of at most 6 Mi slots
 	int mergeTrace = 1;       // tyr_render: connect(i) rides in the launch of extend(i + 1)
 	int profileMask = 31;     // TYR_FLAG_PROFILE: which stages (bit TYR_K_*) get a hipEvent pair
-	int shadeOverlap = 1;     // tyr_render: the rays that cannot enter the tree (class 1) are shaded on a second stream while the traversal launch drains
 };
 constexpr uint32_t kCountRaysPerBlock = 1024; // the counting build's kernels: queue slots owned by one 256-thread block
 
@@ -205,8 +198,6 @@ void launch_scan(const FrameParams& P, uint32_t maxLive, hipStream_t stream); //
 // nSurvivors: upper bound of the slots the sphere pre-pass still has to do (primary rays get theirs in k_primary)
 void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
 void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCache& lc, hipStream_t stream);
-uint32_t shade_grid(const FrameParams& P, uint32_t maxSlots, int numCUs, LaunchCache& lc);
-void launch_shade_classes(const FrameParams& P, uint32_t classes, uint32_t blocks, uint32_t blocksOfAllLaunches, hipStream_t stream);
 void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream);
 void launch_trace_kernel(const FrameParams& P, uint32_t items, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream); // k_trace_flat alone (launch_trace = pre-passes + this)
 void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);

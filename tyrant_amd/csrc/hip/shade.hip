@@ -421,9 +421,8 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u, wave = tid >> 6;
 	// class 0's tiles, then class 1's (from the device's counts: the host may have sized the grid from an upper bound)
-	// (P.shadeClasses: a launch may be given one class only -- class 1 needs nothing from the traversal and is shaded beside it)
-	const uint32_t tiles0 = (P.shadeClasses & 1u) ? queue_extent(P.segWork) / kBlock : 0u;
-	const uint32_t nTiles = tiles0 + ((P.shadeClasses & 2u) ? queue_extent(P.segWork + kClassWords) / kBlock : 0u);
+	const uint32_t tiles0 = queue_extent(P.segWork) / kBlock;
+	const uint32_t nTiles = tiles0 + queue_extent(P.segWork + kClassWords) / kBlock;
 	const unsigned long long below = (1ull << lane) - 1ull;
 #ifdef TYR_SHADE_TIMING
 	// diagnostic build: where a tile's time goes, in s_memtime ticks summed over this block's tiles (thread 0;
@@ -475,7 +474,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	};
 
 	uint32_t word = blockIdx.x % kTicketWords, tried = 0;
-	uint32_t* const tickets = P.shadeClasses == 2u ? P.k->shade_tiles_side : P.k->shade_tiles;
+	uint32_t* const tickets = P.k->shade_tiles;
 	auto draw_tile = [&]() -> uint32_t { // block-uniform; nTiles when nothing is left
 		uint32_t vbNext = nTiles;
 		if (tid == 0) {
@@ -672,18 +671,8 @@ uint32_t shade_grid(const FrameParams& P, uint32_t maxSlots, int numCUs, LaunchC
 	const uint32_t resident = (uint32_t)perCU[lights] * (uint32_t)numCUs;
 	return nTiles < resident ? (nTiles ? nTiles : 1u) : resident;
 }
-void launch_shade_classes(const FrameParams& P0, uint32_t classes, uint32_t blocks, uint32_t blocksOfAllLaunches, hipStream_t stream) {
-	FrameParams P = P0;
-	P.shadeClasses = classes;
-	P.shadeBlocks = blocksOfAllLaunches;
-	if (P.flags & TYR_FLAG_LIGHT_LIST)
-		hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(kBlock), 0, stream, P);
-	else
-		hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(kBlock), 0, stream, P);
-}
 void launch_shade(const FrameParams& P0, uint32_t maxSlots, int numCUs, LaunchCache& lc, hipStream_t stream) {
 	FrameParams P = P0;
-	P.shadeClasses = 3u;
 	P.shadeBlocks = shade_grid(P, maxSlots, numCUs, lc);
 	if (P.flags & TYR_FLAG_LIGHT_LIST)
 		hipLaunchKernelGGL(k_shade<true>, dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);

@@ -949,8 +949,6 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 			while (staticDone && got < nIdle) {
 				if (!feed.refill(P.k->extend_chunks, nItems - dynBase, lane)) {
 					exhausted = true;
-					if (P.feedDoneHost != nullptr && lane == 0 && atomicExch(&P.k->feed_done, 1u) == 0u) // the first wave to run dry tells the host
-						__hip_atomic_store(const_cast<uint32_t*>(P.feedDoneHost), P.feedDoneTag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 					if (kAnatomy && tExhausted == 0ull) {
 						tExhausted = __builtin_amdgcn_s_memrealtime();
 						liveAtExhaustion = (uint32_t)__popcll(__ballot(live)) + got;

@@ -34,10 +34,6 @@ struct tyr_ctx {
 
 	hipStream_t side = nullptr; // second stream of a ctx (shade launches that run beside the traversal)
 	hipEvent_t evSnapshot = nullptr;
-	hipEvent_t evTraceDone = nullptr, evSideShade = nullptr; // TYR_TUNE_SHADE_OVERLAP: the traversal launch has ended (stream); the side stream's shade launch has (side -> stream)
-	volatile uint32_t* feedDoneHost = nullptr; // pinned: the traversal launch's "queue used up" word, and its device alias
-	volatile uint32_t* feedDoneDev = nullptr;
-	uint32_t feedDoneTag = 0;
 	// tyr_render with TYR_TUNE_MERGE_TRACE: the shadow rays of the last shaded iteration have not been traced yet (they
 	// ride in the next iteration's trace launch, or in a connect of their own when the render ends)
 	bool shadowPending = false;

@@ -6,7 +6,6 @@
 // argument block (FrameParams) instead of cudaMemcpyToSymbol (kernel.cu:681-684, 707-709).
 // There is no CPU fallback: without a HIP device tyr_create fails with TYR_ERR_NO_DEVICE.
 #include <algorithm>
-#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -155,8 +154,6 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.segCap = c->segCap;
 	P.classStride = c->segCap * tyr::kSegs;
 	P.survFlag = c->survFlag;
-	P.feedDoneHost = nullptr;
-	P.shadeClasses = 3u;
 	{
 		const int out = static_cast<int>(c->iter & 1u), prev = out ^ 1;
 		P.vPrev = tyr::VTable{ c->vWord[prev], c->vPre[prev], c->vBlk[prev] };
@@ -289,56 +286,6 @@ void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	KernelTimer t(c, TYR_K_SHADE);
 	launch_shade(P, nLive, c->numCUs, c->launchCache, c->stream);
 	launch_scan(P, nLive, c->stream);
-}
-// The traversal launch and shade of one merged iteration with the two classes of rays apart (TYR_TUNE_SHADE_OVERLAP): class 1
-// -- the rays that cannot enter the tree: sky, ground sphere, the other spheres -- needs nothing from the traversal, so its
-// shade launch goes out on the side stream; class 0 is shaded behind the traversal as before.  The two launches share
-// nothing but the append counters (atomics) and the pixels (atomics), visit disjoint tiles and finalise together (the last
-// block of either).  WHEN the side launch goes out matters (profiles/r03_timeline_*): together with the traversal launch its
-// blocks take CU slots before the traversal grid is resident and stretch it; so the traversal kernel tells the host when its
-// queue is used up (a pinned word) and the launch goes out then -- into the drain, where traversal blocks retire and the
-// issue slots are idle.
-int enqueue_trace_and_shade(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t nSurvivors, uint32_t maxShadowPrev) {
-	if (!c->tuning.shadeOverlap || nLive == 0 || !c->feedDoneHost) {
-		enqueue_trace(c, P0, nLive, nSurvivors, maxShadowPrev);
-		enqueue_shade(c, P0, nLive);
-		return TYR_OK;
-	}
-	c->shadowSet = c->iter & 1u;
-	FrameParams P = P0;
-	P.traceShadow = maxShadowPrev != 0 ? 1u : 0u;
-	P.feedDoneHost = c->feedDoneDev;
-	P.feedDoneTag = ++c->feedDoneTag;
-	const uint32_t blocks = shade_grid(P, nLive, c->numCUs, c->launchCache);
-	{
-		KernelTimer timer(c, TYR_K_EXTEND);
-		launch_trace(P, nLive, nSurvivors, maxShadowPrev, c->tuning, c->numCUs, c->launchCache, c->stream);
-	}
-	HIPCHK(hipEventRecord(c->evTraceDone, c->stream));
-	HIPCHK(hipGetLastError());
-	{
-		// bounded: the launch's end ends the wait too (an empty queue never "runs dry"), and so does a second of wall time
-		const auto t0 = std::chrono::steady_clock::now();
-		unsigned spins = 0;
-		while (*c->feedDoneHost != P.feedDoneTag) {
-			if ((++spins & 255u) == 0u) {
-				if (hipEventQuery(c->evTraceDone) != hipErrorNotReady)
-					break;
-				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1))
-					break;
-			}
-		}
-	}
-	launch_shade_classes(P, 2u, blocks, 2u * blocks, c->side);
-	HIPCHK(hipEventRecord(c->evSideShade, c->side));
-	{
-		KernelTimer timer(c, TYR_K_SHADE);
-		launch_shade_classes(P, 1u, blocks, 2u * blocks, c->stream);
-		HIPCHK(hipStreamWaitEvent(c->stream, c->evSideShade, 0));
-		launch_scan(P, nLive, c->stream);
-	}
-	HIPCHK(hipGetLastError());
-	return TYR_OK;
 }
 void enqueue_connect(tyr_ctx* c, const FrameParams& P, uint32_t maxShadow) {
 	KernelTimer t(c, TYR_K_CONNECT);
@@ -503,11 +450,6 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		if (hipMemset(c->vWord[t], 0, entries * 8) != hipSuccess || hipMemset(c->vPre[t], 0, entries * 4) != hipSuccess || hipMemset(c->vBlk[t], 0, blocks * 4) != hipSuccess)
 			return fail(TYR_ERR_NO_DEVICE);
 	}
-	if (hipHostMalloc(reinterpret_cast<void**>(const_cast<uint32_t**>(&c->feedDoneHost)), 64, hipHostMallocMapped) != hipSuccess)
-		return fail(TYR_ERR_OOM);
-	*c->feedDoneHost = 0;
-	if (hipHostGetDevicePointer(reinterpret_cast<void**>(const_cast<uint32_t**>(&c->feedDoneDev)), const_cast<uint32_t*>(c->feedDoneHost), 0) != hipSuccess)
-		return fail(TYR_ERR_NO_DEVICE);
 	if ((rc = dev_alloc(c->dK, 1)) || (rc = dev_alloc(c->dKc, 2)))
 		return fail(rc);
 	if (hipMemset(c->dKc, 0, 2 * sizeof(ConnectCounters)) != hipSuccess)
@@ -532,8 +474,7 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		if (hipMemcpy(c->dPalette, pal.data(), pal.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
 			return fail(TYR_ERR_NO_DEVICE);
 	}
-	if (hipEventCreateWithFlags(&c->evSnapshot, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evTraceDone, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&c->evSideShade, hipEventDisableTiming) != hipSuccess)
+	if (hipEventCreateWithFlags(&c->evSnapshot, hipEventDisableTiming) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
 	if (hipHostMalloc(reinterpret_cast<void**>(&c->hK), sizeof(DevCounters), hipHostMallocDefault) != hipSuccess)
 		return fail(TYR_ERR_OOM);
@@ -602,12 +543,7 @@ int tyr_destroy(tyr_ctx* c) {
 	}
 	if (c->evSnapshot)
 		(void)hipEventDestroy(c->evSnapshot);
-	if (c->evTraceDone)
-		(void)hipEventDestroy(c->evTraceDone);
-	if (c->evSideShade)
-		(void)hipEventDestroy(c->evSideShade);
-	if (c->feedDoneHost)
-		(void)hipHostFree(const_cast<uint32_t*>(c->feedDoneHost));
+
 	if (c->side)
 		(void)hipStreamDestroy(c->side);
 	if (c->ownStream && c->stream)
@@ -923,8 +859,8 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 	if (merge) { // every traversal launch of a merged render is k_trace_flat; the first one has no shadow rays to carry yet
 		const uint32_t carried = c->shadowPending ? c->shadowPendingMax : 0u;
 		c->shadowPending = false;
-		if ((rc = enqueue_trace_and_shade(c, P, nLive, nLive - nNew, carried)))
-			return rc;
+		enqueue_trace(c, P, nLive, nLive - nNew, carried);
+		enqueue_shade(c, P, nLive);
 	} else {
 		if ((rc = flush_pending_shadow(c))) // (a render whose merge setting changed between iterations: never, but cheap)
 			return rc;
@@ -994,8 +930,8 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 	const int set = static_cast<int>(c->iter & 1u);
 	FrameParams P = make_params(c);
 	enqueue_primary(c, P, p.nNew);
-	if ((rc = enqueue_trace_and_shade(c, P, p.nLive, p.nSurvivors, p.carried)))
-		return rc;
+	enqueue_trace(c, P, p.nLive, p.nSurvivors, p.carried);
+	enqueue_shade(c, P, p.nLive);
 	HIPCHK(hipMemcpyAsync(c->hSnap[set], c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipEventRecord(c->evSnap[set], c->stream));
 	HIPCHK(hipGetLastError());
@@ -1480,7 +1416,6 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_STATIC_INTERLEAVE, 0, 1, &Tuning::staticInterleave },
 		{ TYR_TUNE_RUN_AHEAD, 0, 2, &Tuning::runAhead },
 		{ TYR_TUNE_WIDE_DRAIN, 0, 1, &Tuning::wideDrain },
-		{ TYR_TUNE_SHADE_OVERLAP, 0, 1, &Tuning::shadeOverlap },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)
