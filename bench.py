@@ -368,7 +368,7 @@ def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_re
         "tris_per_ray": round(visits["tris_per_ext"], 3),
         "connect_nodes_per_ray": round(visits["nodes_per_con"], 2),
         "connect_tris_per_ray": round(visits["tris_per_con"], 3),
-        "note": "SURVEY.md 8d: 24 + 8 + 32 B x nodes + 36 B x triangles the REFERENCE's binary tree visits per extend ray (44 + 32 x nodes + 36 x triangles + 12 x p_visible per shadow ray), counted by the counting build (k_extend_flat / k_connect_flat<true, 12, false, false>, pair nodes) in an untimed render -- not by the timed quad-node kernel; nominal, exceeds the HBM peak when the tree is cache resident",
+        "note": "SURVEY.md 8d: 24 + 8 + 32 B x nodes + 36 B x triangles the REFERENCE's binary tree visits per extend ray (44 + 32 x nodes + 36 x triangles + 12 x p_visible per shadow ray), counted by the counting build (k_extend_count / k_connect_count, pair nodes) in an untimed render -- not by the timed quad-node kernel; nominal, exceeds the HBM peak when the tree is cache resident",
     }
     out["kernel_ms_per_render"] = kernel_ms_per_render
     return out

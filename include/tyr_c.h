@@ -184,7 +184,7 @@ typedef struct tyr_counters {
 	uint32_t shadow_ray_cnt;  /* kernel.cu:224 */
 	uint32_t n_live;          /* rays in the work queue after top-up (== queue_size in the reference) */
 	uint32_t frame;           /* kernel.cu:667 */
-	uint32_t device_error;    /* non-zero: TYR_ERR_DEVICE detail bits: 1 traversal stack overflow, 2 compaction look-back timeout, 4 (builds with -DTYR_GUARD_PASSES only) a traversal wave gave up after 2^24 passes without finishing */
+	uint32_t device_error;    /* non-zero: TYR_ERR_DEVICE detail bits: 1 traversal stack overflow, 4 (builds with -DTYR_GUARD_PASSES only) a traversal wave gave up after 2^24 passes without finishing, 8 a queue segment ran out of room (the records beyond it were dropped) */
 	uint64_t budget_remaining;
 	uint64_t total_extend_rays; /* sum of n_live over iterations */
 	uint64_t total_shadow_rays; /* sum of shadow_ray_cnt over iterations */

@@ -19,7 +19,7 @@ for line in open(path):
         cur = m.group(1).strip()
         continue
     m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)\s+/dispatch\s+([0-9.]+)\s+\((\d+) dispatches\)", line)
-    if m and cur and cur.startswith("k_extend_flat<false"):
+    if m and cur and cur.startswith("k_trace_flat<12"):
         kernel = cur
         vals[m.group(1)] = (float(m.group(3)), int(m.group(4)))
 assert kernel and len(vals) == 2, (kernel, vals)

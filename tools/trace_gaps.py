@@ -6,7 +6,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows if "tyr::" in r["Kernel_Name"] or "rocclr" in r["Kernel_Name"])
-prod = [i for i, k in enumerate(ks) if "k_trace_flat<12" in k[2] or "k_extend_flat<false" in k[2]]  # the traversal launches of the timed renders
+prod = [i for i, k in enumerate(ks) if "k_trace_flat<12" in k[2]]  # the traversal launches of the timed renders
 n_it = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 i0 = prod[-n_it]
 while "k_primary" not in ks[i0][2] and "k_globals" not in ks[i0][2]:

@@ -29,7 +29,6 @@ __device__ __forceinline__ void wavefront_globals(const FrameParams& P) {
 		const uint32_t nNew = (uint32_t)(room < budget ? room : budget);
 		k->start_position = (uint32_t)(((unsigned long long)k->start_position + nNew) % P.localPixels);
 		k->n_live = cnt + nNew;
-		k->first_fresh = cnt;
 		k->shade_blocks_done = 0;
 		k->scan_blocks_done = 0;
 		k->primary_blocks_done = 0;
@@ -37,8 +36,6 @@ __device__ __forceinline__ void wavefront_globals(const FrameParams& P) {
 			k->primary_done[w * 32] = 0;
 		k->shadow_ray_cnt = 0;
 		k->primary_ray_cnt = 0;
-		k->extend_ticket = 0;
-		P.kc->ticket = 0;
 		P.kc->shadow_cnt = 0;
 		if (budget != ~0ull)
 			k->budget_remaining = budget - nNew;
@@ -177,8 +174,6 @@ __global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) 
 	}
 	__syncthreads();
 	const uint32_t first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
-	if (first == 0)
-		P.k->extend_ticket = 0;
 	// the survivors of the last iteration, both classes: the records in front of what a top-up appended (k_primary has done
 	// its own rays).  Class 0: the distance bounds the BVH search; class 1: the record is the ray's answer.
 	// (validity straight from the LDS table, one read per test: a private array of the eight counts is "promoted" to LDS
@@ -233,8 +228,6 @@ __global__ void __launch_bounds__(kBlock) k_pad_holes(const FrameParams P, uint3
 // color.w (unused by the reference's 44-byte record) carries the flag.
 __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P) {
 	const uint32_t first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
-	if (first == 0)
-		P.kc->ticket = 0;
 	if (first < kTicketWords)
 		P.k->extend_chunks[first * 32] = 0; // k_trace_flat's tickets, when this pre-pass opens the launch that ends a render (no set_wavefront_globals in front of it)
 	__shared__ uint32_t cntSh[kSegs];

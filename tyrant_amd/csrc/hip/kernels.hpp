@@ -75,9 +75,9 @@ struct DevCounters {
 	uint32_t start_position;
 	uint32_t shadow_ray_cnt;
 	uint32_t n_live;
-	uint32_t first_fresh;    // first slot of this iteration's primary rays = survivors in front of them
+	uint32_t reserved0;
 	uint32_t device_error;
-	uint32_t extend_ticket;  // next queue slot to hand to a free lane of the persistent extend kernel
+	uint32_t reserved_t;
 	uint32_t reserved1;      // (connect's ticket lives in ConnectCounters)
 	unsigned long long budget_remaining;
 	unsigned long long total_extend_rays;
@@ -91,7 +91,7 @@ struct DevCounters {
 	// [0]/[1] node-test loop: wave iterations / lane iterations; [2]/[3] pop loop; [4]/[5] triangle loop;
 	// [6]/[7] refills / lanes refilled; [8..15] lane-state census of the descent trips (TYR_QUAD_STATS builds)
 	unsigned long long debug[16];
-	// variant 4: chunk tickets of the persistent traversal kernels, one word per 128 bytes so that the eight words
+	// chunk tickets of the persistent traversal kernel, one word per 128 bytes so that the eight words
 	// are eight L2 lines (a single word serves only ~88 returning atomics per microsecond)
 	uint32_t extend_chunks[kTicketWords * 32];
 	uint32_t reserved2[kTicketWords * 32]; // (connect's chunk tickets live in ConnectCounters)
@@ -110,13 +110,13 @@ struct DevCounters {
 // set_wavefront_globals resets ITS set and leaves the one connect(i) is working on alone.
 struct ConnectCounters {
 	uint32_t shadow_cnt;                // = shadow_ray_cnt of the iteration (kernel.cu:416-417), written by shade's last tile
-	uint32_t ticket;                    // variant 1: next shadow-queue slot
+	uint32_t reserved_t;
 	uint32_t pad[30];
-	uint32_t chunks[kTicketWords * 32]; // variant 4: chunk tickets, one word per 128 bytes like extend_chunks
+	uint32_t chunks[kTicketWords * 32]; // (unused since the traversal launches are one kernel: extend_chunks serves them)
 	uint32_t seg[kSegs * kSegStride];   // records in segment w of this iteration's shadow queue
 };
 constexpr uint32_t kErrStackOverflow = 1u;
-constexpr uint32_t kErrScanTimeout = 2u;
+constexpr uint32_t kErrScanTimeout = 2u; // (rounds 1-2: the look-back of the stable compaction timed out; no longer raised)
 constexpr uint32_t kErrNoProgress = 4u; // -DTYR_GUARD_PASSES builds: a wave of a flat traversal kernel ran out of passes (kMaxPasses)
 constexpr uint32_t kErrQueueOverflow = 8u; // a queue segment ran out of room (the records beyond it were dropped)
 
@@ -151,9 +151,9 @@ struct FrameParams {
 	uint32_t shadeBlocks;         // k_shade: blocks of all of this iteration's shade launches together (the last one to finish finalises)
 	uint32_t refillMinIdle;       // persistent traversal: refill a wave once this many lanes are free
 	uint32_t minTraversing;       // flat traversal: leave the descent loop below this many descending lanes
-	uint32_t ticketChunk;         // variants 1 / 4: queue slots a wave takes per draw from a device-wide ticket
-	uint32_t raysPerBlock;        // variants 2 / 3: queue slots owned by one 256-thread block
-	uint32_t staticShare;         // variant 4: sixteenths of the queue handed out as fixed per-block ranges
+	uint32_t ticketChunk;         // queue slots a wave takes per draw from a device-wide ticket
+	uint32_t raysPerBlock;        // the counting build's kernels: queue slots owned by one 256-thread block
+	uint32_t staticShare;         // sixteenths of the queue handed out as fixed per-block ranges
 	uint32_t traceShadow;         // k_trace_flat: the previous iteration's shadow rays ride in this launch (0: a render's first launch; 2: they are ALL of it -- the launch that ends a render)
 	uint32_t staticInterleave;    // ... as 64-slot chunks b, b + G, ... (1) or as one contiguous range per block (0)
 	uint32_t wideDrain;           // k_trace_flat: finish a wave's last <= 16 rays four lanes to a ray

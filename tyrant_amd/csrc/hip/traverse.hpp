@@ -48,7 +48,7 @@ constexpr int kStackSize = 64;             // bvh.h:124 nodesToVisit[64]
 constexpr uint32_t kMaxLeafPrims = 31; // count-1 <= 30 keeps 0xFFFFFFFE / 0xFFFFFFFF out of the leaf encoding
 constexpr uint32_t kMaxPrimOffset = 1u << 26;
 // interior reference of the quad layout: node index in bits 0..24, the node's visit-order bits in 25..30
-// Top of the tree staged in LDS by the persistent traversal kernels (variant 4): the first kStagedNodes records
+// Top of the tree staged in LDS by the persistent traversal kernel: the first kStagedNodes records
 // of the quad array are the tree's top levels in breadth-first order (host/bvh_layout.cpp).  In LDS they are kept
 // vector-major -- vector v of node n at [v][n] -- so that lanes reading different nodes spread over 16 bank
 // groups (node-major, every node would start on bank 0 or 32); lanes reading the same node are a broadcast.

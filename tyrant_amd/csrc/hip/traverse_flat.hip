@@ -1,7 +1,8 @@
 // traverse_flat.hip -- extend (kernel.cu:331-343 via intersect_scene, kernel.cu:125-142) and connect
 // (kernel.cu:630-646 via intersect_scene_simple, kernel.cu:162-174) as flat per-lane state machines on persistent
-// waves.  Production = quad nodes on a persistent grid (variant 4); the counting build (TYR_FLAG_COUNT_VISITS) = the
-// same state machine on pair nodes, which reproduces the reference's visit counts (bvh.h:164-209).  
+// waves.  Production = k_trace_flat: quad nodes on a persistent grid; the counting build (TYR_FLAG_COUNT_VISITS) = the
+// same state machine on pair nodes (k_extend_count / k_connect_count), which reproduces the reference's visit counts
+// (bvh.h:164-209).  
 #include "device_common.hpp"
 
 namespace tyr {
@@ -17,9 +18,9 @@ namespace tyr {
 #endif
 
 // ======================================================================================
-// Flat traversal (variant 2): persistent waves, lane refill, and NO nested divergent loops.
+// Flat traversal: persistent waves, lane refill, and NO nested divergent loops.
 //
-// Measured on variant 1 with the counting build (tools/loop_occupancy.py, C2 at 1080p): the
+// Measured on the first persistent kernel (nested while loops) with the counting build (tools/loop_occupancy.py, C2 at 1080p): the
 // node-test loop ran at 19.7 % lane occupancy and the nested pop loop at 6 %, because (a) a lane
 // that reaches a leaf or finishes its ray waits until the LAST lane of the wave stops descending,
 // and (b) `while (pop) {...}` inside the divergent "both children missed" branch runs four lanes
@@ -150,145 +151,77 @@ __device__ __forceinline__ uint32_t static_slot(uint32_t s, uint32_t blockBegin,
 	return (((local >> 6) * gridDim.x + blockIdx.x) << 6) + (local & 63u);
 }
 
-template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
-__global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(const FrameParams P) {
-	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
+// ======================================================================================
+// The counting build (TYR_FLAG_COUNT_VISITS): extend and connect as launches of their own on PAIR nodes -- the only
+// layout that reproduces the reference's visit counts (intersect_debug's rule, bvh.h:164-209: every fetched node counts,
+// a leaf's triangles count one each) -- with the same flat per-lane state machine as the production kernel.  Block b owns
+// the physical slots [b * raysPerBlock, +raysPerBlock) of the queue and hands them to the free lanes of its four waves
+// through a counter in LDS; slots that hold no record are skipped (slot_valid).  Not a hot path: n-bar of the roofline
+// comes from ONE untimed render of this build.
+// ======================================================================================
+template <int STACK_LDS>
+__global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_count(const FrameParams P) {
+	constexpr bool COUNT = true; // (TYR_DBG)
 	TYR_DECLARE_FLAT_STACK(st, true)
-	// variant 4: the top of the tree lives in LDS for the lifetime of the (persistent) block
-	__shared__ float4 stagedNodes[PERSIST ? 7 * kStagedNodes : 1];
-	const uint32_t nStaged = (PERSIST && QUAD) ? P.scene.nStaged : 0u;
-	if constexpr (PERSIST && QUAD) {
-		for (uint32_t i = threadIdx.x; i < 7 * nStaged; i += kBlock) {
-			const uint32_t v = i / nStaged, n = i - v * nStaged;
-			stagedNodes[v * kStagedNodes + n] = P.scene.quads[8 * n + v];
-		}
-		// visible to the block after the __syncthreads() that precedes the main loop
-	}
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t nLive = queue_extent(P.segWork); // physical slots; the few that hold no record are skipped (slot_valid)
+	const uint32_t nSlots = queue_extent(P.segWork); // class 0; the few slots that hold no record are skipped
 	const DevScene& sc = P.scene;
-	// the ray of this lane as plain scalars: kept as one RayConst object across the refill branch, its first 16
-	// bytes (origin + direction.x) stayed in a private-memory slot that every descent and leaf phase re-read
 	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f;
-	bool regular = true;      // this lane's ray has a finite 1/d in all three components
-	bool allRegular = true;   // ... and so has every live ray of the wave (wave-uniform; refreshed at refills)
+	bool regular = true, allRegular = true;
 	float dist = 0.0f;
 	uint32_t ref = kRefDone, slot = 0;
 	int prim = 0;
 	bool hitTri = false, live = false, overflow = false;
 	VisitCount vc{ 0, 0 };
-	uint32_t inTree = 0; // COUNT: rays of this lane that passed the root box
+	uint32_t inTree = 0; // rays of this lane that passed the root box
 	uint32_t dbg[16] = {};
-	// TYR_QUAD_STATS: launch anatomy in s_memrealtime ticks (100 MHz): when this wave started, first found the queue used
-	// up, and left; the host sees min start / min exhausted / max exit per launch (tools/launch_tail.py)
-	unsigned long long tExhausted = 0ull;
-	const unsigned long long tStart = kAnatomy ? __builtin_amdgcn_s_memrealtime() : 0ull;
-	// Work distribution: this block owns queue slots [blockIdx.x * raysPerBlock, +raysPerBlock) and hands
-	// them to the free lanes of its four waves through a counter in LDS.  Balancing ACROSS blocks is the
-	// hardware dispatcher's (grid = slots / raysPerBlock blocks, more than fit at once).  The first
-	// versions pulled from one device-wide ticket: a single word serves only ~88 returning atomics per
-	// microsecond (MI355X_MICROARCH.md "dequeue"), and with >= 2 pulls per wave that alone was a
-	// 0.26 ms floor per launch, whatever the traversal cost.
 	__shared__ uint32_t blockNext;
-	// variant 4 (PERSIST): the first staticShare/16 of the queue is dealt to the blocks as fixed ranges, handed out
-	// through LDS exactly like variant 3 (no device-wide atomic: a launch of short rays -- the primary rays --
-	// would spend a third of its time on ticket round trips); the rest goes out in ticketed chunks to whoever is
-	// free, which evens out the blocks and leaves no block waiting for its longest ray.
-	const uint32_t perBlock = PERSIST ? static_range(nLive, P.staticShare) : P.raysPerBlock;
-	const uint32_t dynBase = PERSIST ? perBlock * gridDim.x : 0u;
-	const uint32_t blockBegin = blockIdx.x * perBlock;
-	const uint32_t blockEnd = PERSIST ? blockBegin + perBlock : ((blockBegin + perBlock) < nLive ? (blockBegin + perBlock) : nLive);
-	ChunkFeed feed;
-	feed.init(nLive - dynBase, P.ticketChunk);
-	bool staticDone = (perBlock == 0); // wave-uniform
+	const uint32_t blockBegin = blockIdx.x * P.raysPerBlock;
+	const uint32_t blockEnd = (blockBegin + P.raysPerBlock) < nSlots ? (blockBegin + P.raysPerBlock) : nSlots;
 	if (threadIdx.x == 0)
 		blockNext = blockBegin;
 	__syncthreads();
-	bool exhausted = (sc.rootRef == kRefDone) || (PERSIST ? nLive == 0 : blockBegin >= nLive);
+	bool exhausted = (sc.rootRef == kRefDone) || blockBegin >= nSlots;
 	uint32_t passes = 0; // see kMaxPasses
 
 	for (;;) {
 		if (kGuardPasses && ++passes > kMaxPasses)
 			break;
-		// ---- refill free lanes from the queue ----
+		// ---- refill free lanes from the block's range ----
 		const unsigned long long idleMask = __ballot(!live);
 		const uint32_t nIdle = __popcll(idleMask);
 		if (!exhausted && nIdle >= P.refillMinIdle) {
 			const uint32_t rank = __popcll(idleMask & below);
-			uint32_t s = 0;
-			bool fed = false;
-			if (PERSIST) {
-				uint32_t got = 0; // idle lanes served so far; one refill may take from the fixed range and from two chunks
-				if (!staticDone) {
-					uint32_t base = 0;
-					if (lane == 0)
-						base = atomicAdd(&blockNext, nIdle); // LDS
-					base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, 0, 64));
-					const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
-					got = avail < nIdle ? avail : nIdle;
-					if (!live && rank < got) {
-						s = static_slot(base + rank, blockBegin, P.staticInterleave != 0u);
-						fed = true;
-					}
-					staticDone = (base + nIdle >= blockEnd);
-				}
-				while (staticDone && got < nIdle) {
-					if (!feed.refill(P.k->extend_chunks, nLive - dynBase, lane)) {
-						exhausted = true;
-						if (kAnatomy && tExhausted == 0ull)
-							tExhausted = __builtin_amdgcn_s_memrealtime();
-						break;
-					}
-					const uint32_t avail = feed.end - feed.next, room = nIdle - got;
-					const uint32_t take = avail < room ? avail : room;
-					if (!live && rank >= got && rank < got + take) {
-						s = dynBase + feed.next + (rank - got);
-						fed = true;
-					}
-					feed.next += take;
-					got += take;
-				}
-			} else {
-				uint32_t base = 0;
-				if (lane == 0)
-					base = atomicAdd(&blockNext, nIdle); // LDS
-				base = __shfl(base, 0, 64);
-				const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
-				const uint32_t take = avail < nIdle ? avail : nIdle;
-				exhausted = (base + nIdle >= blockEnd);
-				s = base + rank;
-				fed = !live && rank < take;
+			uint32_t base = 0;
+			if (lane == 0)
+				base = atomicAdd(&blockNext, nIdle); // LDS
+			base = __shfl(base, 0, 64);
+			const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+			const uint32_t take = avail < nIdle ? avail : nIdle;
+			exhausted = (base + nIdle >= blockEnd);
+			const uint32_t s = base + rank;
+			bool fed = !live && rank < take;
+			if (fed)
+				fed = slot_valid(P.segWork, s);
+			if (fed) {
+				TYR_DBG(6)
+				const float4 a = P.work.o_dx[s];
+				const float2 b = P.work.dyz[s];
+				const float2 h = P.work.hit[s];
+				const RayConst nr = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+				rox = nr.o.x, roy = nr.o.y, roz = nr.o.z, rdx = nr.d.x, rdy = nr.d.y, rdz = nr.d.z, rix = nr.inv.x, riy = nr.inv.y, riz = nr.inv.z;
+				regular = ray_is_regular(nr);
+				dist = h.x; // the sphere pre-pass's distance bounds the search
+				slot = s;
+				hitTri = false;
+				st.reset();
+				ref = root_ref(sc, nr, dist);
+				// a ray that misses the root box (or is already stopped short of it by a sphere) is finished here
+				live = (ref != kRefDone);
+				vc.nodes += 1;
+				inTree += live ? 1u : 0u;
 			}
-			{
-				if (fed)
-					fed = slot_valid(P.segWork, s);
-				if (fed) {
-					TYR_DBG(6)
-					const float4 a = P.work.o_dx[s];
-					const float2 b = P.work.dyz[s];
-					const float2 h = P.work.hit[s];
-					const RayConst nr = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
-					rox = nr.o.x, roy = nr.o.y, roz = nr.o.z, rdx = nr.d.x, rdy = nr.d.y, rdz = nr.d.z, rix = nr.inv.x, riy = nr.inv.y, riz = nr.inv.z;
-					regular = ray_is_regular(nr);
-					dist = h.x;
-					slot = s;
-					hitTri = false;
-					st.reset();
-					ref = root_ref(sc, nr, dist);
-					if (QUAD && ref != kRefDone)
-						ref = sc.quadRootRef;
-					// a ray that misses the root box (or is already stopped short of it by a sphere) is finished here:
-					// the pre-pass's answer stands, nothing to write, the lane stays free
-					live = (ref != kRefDone);
-					if (COUNT) {
-						vc.nodes += 1;
-						inTree += live ? 1u : 0u;
-					}
-				}
-			}
-			// Primary rays mostly end right there (three in four on C3): top the wave up again rather than run
-			// the descent loop a quarter full.  Every pass consumes queue slots, so this terminates.
 			if (!exhausted && (uint32_t)__popcll(__ballot(live)) < P.minTraversing)
 				continue;
 		}
@@ -304,25 +237,11 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 			const uint32_t nTrav = __popcll(lanes_traversing(ref));
 			if (nTrav == 0)
 				break;
-			// leave the descent when few lanes are still descending and there is anything else to do (leaves, or a
-			// refill).  (Also leaving once many lanes hold a leaf, so that triangle tests run wide, was measured at
-			// every threshold and never paid; the test cost eight instructions per trip.)
 			if (nTrav < P.minTraversing) {
 				const bool anyLeaf = lanes_at_leaf(ref) != 0ull;
 				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
 				if (anyLeaf || canRefill)
 					break;
-			}
-			if (kLoopStats) {
-				// lane-state census at the top of a descent trip (tools/loop_occupancy.py census=1): [8] trips, lanes [9] holding
-				// a leaf (waiting for the descent to end), [10] without a ray, [11] finished but not yet retired; [12] stale pops
-				const unsigned long long mLeaf = lanes_at_leaf(ref), mIdle = __ballot(!live), mDone = __ballot(live && ref == kRefDone);
-				if (lane == 0) {
-					dbg[8] += 1;
-					dbg[9] += __popcll(mLeaf);
-					dbg[10] += __popcll(mIdle);
-					dbg[11] += __popcll(mDone);
-				}
 			}
 			if (ref == kRefPop) {
 				TYR_DBG(2)
@@ -331,34 +250,23 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 				if (st.pop(pr, pt)) {
 					if (pt < dist) // the pop-time half of Bbox.h:61
 						ref = pr;
-					else if (kLoopStats)
-						dbg[12] += 1; // (per lane: summed over the wave at the end)
 				} else {
 					ref = kRefDone;
 				}
 			}
 			if ((int)ref >= 0) {
 				TYR_DBG(0)
-				if (QUAD) {
-					const QuadHits q = allRegular ? test_quad<true, true, PERSIST>(sc.quads, ref, r, dist, stagedNodes, nStaged) : test_quad<false, true, PERSIST>(sc.quads, ref, r, dist, stagedNodes, nStaged);
-					// the earliest hit in visit order is entered now, the later ones are pushed latest first:
-					// entry k is pushed iff it hit and an earlier entry hit too
-					const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
-					st.push3(q.hit[3] & any012, q.ref[3], q.t[3], q.hit[2] & any01, q.ref[2], q.t[2], q.hit[1] & q.hit[0], q.ref[1], q.t[1]);
-					ref = lane_in(q.hit[0]) ? q.ref[0] : lane_in(q.hit[1]) ? q.ref[1] : lane_in(q.hit[2]) ? q.ref[2] : lane_in(q.hit[3]) ? q.ref[3] : kRefPop;
+				const PairTest p = allRegular ? test_pair_fast(sc.nodes, ref, r, dist) : test_pair(sc.nodes, ref, r, dist);
+				if (!p.synthetic)
+					vc.nodes += 2;
+				if (p.nearHit) {
+					if (p.farHit)
+						st.push(p.farRef, p.farT);
+					ref = p.nearRef;
+				} else if (p.farHit) {
+					ref = p.farRef;
 				} else {
-					const PairTest p = allRegular ? test_pair_fast(sc.nodes, ref, r, dist) : test_pair(sc.nodes, ref, r, dist);
-					if (COUNT && !p.synthetic)
-						vc.nodes += 2;
-					if (p.nearHit) {
-						if (p.farHit)
-							st.push(p.farRef, p.farT);
-						ref = p.nearRef;
-					} else if (p.farHit) {
-						ref = p.farRef;
-					} else {
-						ref = kRefPop;
-					}
+					ref = kRefPop;
 				}
 			}
 		}
@@ -369,13 +277,11 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 			TriData tri = triangle_load(sc.tris, off);
 			for (uint32_t i = 0; i < cnt; ++i) {
 				TYR_DBG(4)
-				// the next primitive of the leaf is on its way while this one is tested (a leaf is 1..4 consecutive records)
 				const TriData cur = tri;
 				if (i + 1 < cnt)
 					tri = triangle_load(sc.tris, off + i + 1);
 				const float t = triangle_test(cur, r);
-				if (COUNT)
-					vc.tris += 1;
+				vc.tris += 1;
 				if (t > kEpsilon && t < dist && ((dist - t) > kEpsilon)) {
 					prim = (int)(off + i);
 					dist = t;
@@ -384,9 +290,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 			}
 			ref = kRefPop;
 		}
-		// ---- finished rays: a triangle hit replaces the sphere answer of the pre-pass (kernel.cu:138-140).
-		// (Holding the record back until the wave's next refill, one store for all lanes that finished in between,
-		// was measured: +1 %.) ----
+		// ---- finished rays ----
 		if (live && ref == kRefDone) {
 			finish_extend_ray(P.work.hit, slot, hitTri, dist, prim);
 			overflow = overflow || st.overflow;
@@ -397,61 +301,34 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_extend_flat(c
 		atomicOr(&P.k->device_error, kErrStackOverflow);
 	if (kGuardPasses && passes > kMaxPasses)
 		atomicOr(&P.k->device_error, kErrNoProgress);
-	if (COUNT) {
-		// the rays of class 1 never come here: the reference tests the root box for each of them once and stops (bvh.h:127)
-		if (blockIdx.x == 0 && threadIdx.x == 0)
-			atomicAdd(&P.k->nodes_extend, (unsigned long long)queue_records(P.segWork + kClassWords));
-		wave_add_u64(&P.k->nodes_extend, vc.nodes);
-		wave_add_u64(&P.k->tris_extend, vc.tris);
-		wave_add_u64(&P.k->rays_in_tree_extend, inTree);
-	}
-	if (COUNT || kLoopStats) {
-		for (int i = 0; i < 13; ++i)
-			wave_add_u64(&P.k->debug[i], dbg[i]);
-	}
-	if (kAnatomy && lane == 0) {
-		// debug[13] = earliest wave start, [14] = earliest "queue used up" (both stored as ~t so that atomicMax finds the
-		// minimum with a zero-initialised word), [15] = latest exit
-		const unsigned long long tEnd = __builtin_amdgcn_s_memrealtime();
-		atomicMax(&P.k->debug[13], ~tStart);
-		atomicMax(&P.k->debug[14], ~(tExhausted ? tExhausted : tEnd));
-		atomicMax(&P.k->debug[15], tEnd);
-	}
+	// the rays of class 1 never come here: the reference tests the root box for each of them once and stops (bvh.h:127)
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		atomicAdd(&P.k->nodes_extend, (unsigned long long)queue_records(P.segWork + kClassWords));
+	wave_add_u64(&P.k->nodes_extend, vc.nodes);
+	wave_add_u64(&P.k->tris_extend, vc.tris);
+	wave_add_u64(&P.k->rays_in_tree_extend, inTree);
+	for (int i = 0; i < 13; ++i)
+		wave_add_u64(&P.k->debug[i], dbg[i]);
 }
 
-template <bool COUNT, int STACK_LDS, bool QUAD, bool PERSIST>
-__global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(const FrameParams P) {
-	static_assert(!(COUNT && QUAD), "only pair nodes reproduce the reference's visit counts");
-	constexpr bool kKeepT = !(QUAD && !COUNT); // the pair / counting path marks failed boxes through the entry distance
-	TYR_DECLARE_FLAT_STACK(st, kKeepT)
-	// variant 4: the top of the tree lives in LDS for the lifetime of the (persistent) block
-	__shared__ float4 stagedNodes[PERSIST ? 7 * kStagedNodes : 1];
-	const uint32_t nStaged = (PERSIST && QUAD) ? P.scene.nStaged : 0u;
-	if constexpr (PERSIST && QUAD) {
-		for (uint32_t i = threadIdx.x; i < 7 * nStaged; i += kBlock) {
-			const uint32_t v = i / nStaged, n = i - v * nStaged;
-			stagedNodes[v * kStagedNodes + n] = P.scene.quads[8 * n + v];
-		}
-		// visible to the block after the __syncthreads() that precedes the main loop
-	}
+template <int STACK_LDS>
+__global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_count(const FrameParams P) {
+	TYR_DECLARE_FLAT_STACK(st, true) // (the counting path marks failed boxes through the entry distance)
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
-	const uint32_t nRays = queue_extent(P.kc->seg); // physical slots of the shadow queue
+	const uint32_t nSlots = queue_extent(P.kc->seg); // physical slots of the shadow queue
 	const DevScene& sc = P.scene;
 	const bool haveBvh = (sc.rootRef != kRefDone);
-	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f; // see k_extend_flat
-	bool regular = true;      // this lane's ray has a finite 1/d in all three components
-	bool allRegular = true;   // ... and so has every live ray of the wave (wave-uniform; refreshed at refills)
+	float rox = 0.f, roy = 0.f, roz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, rix = 0.f, riy = 0.f, riz = 0.f;
+	bool regular = true, allRegular = true;
 	float closest = 0.0f;
 	uint32_t ref = kRefDone, index = 0;
 	bool live = false, occluded = false, overflow = false;
 	VisitCount vc{ 0, 0 };
-	uint32_t inTree = 0; // COUNT: rays of this lane that passed the root box
+	uint32_t inTree = 0;
 	uint32_t visible = 0;
-	// kernel.cu:640-644, deferred: a lane whose ray came through unoccluded notes the slot and goes idle; the wave
-	// adds all such colours to their pixels at its next refill (and once after the loop), loads batched with the new
-	// rays' loads and the atomics transposed (accumulate_pixels_wave) -- instead of two dependent loads and three
-	// scattered atomics in the middle of the descent every time some lane finishes.
+	// kernel.cu:640-644, deferred: a lane whose ray came through unoccluded notes the slot; the wave adds all such colours
+	// to their pixels at its next refill (and once after the loop), transposed (accumulate_pixels_wave)
 	constexpr uint32_t kNoPending = 0xffffffffu;
 	uint32_t pendIdx = kNoPending;
 	auto flush_visible = [&]() {
@@ -465,17 +342,12 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 		pendIdx = kNoPending;
 	};
 	__shared__ uint32_t blockNext;
-	const uint32_t perBlock = PERSIST ? static_range(nRays, P.staticShare) : P.raysPerBlock; // see k_extend_flat
-	const uint32_t dynBase = PERSIST ? perBlock * gridDim.x : 0u;
-	const uint32_t blockBegin = blockIdx.x * perBlock;
-	const uint32_t blockEnd = PERSIST ? blockBegin + perBlock : ((blockBegin + perBlock) < nRays ? (blockBegin + perBlock) : nRays);
-	ChunkFeed feed;
-	feed.init(nRays - dynBase, P.ticketChunk);
-	bool staticDone = (perBlock == 0); // wave-uniform
+	const uint32_t blockBegin = blockIdx.x * P.raysPerBlock;
+	const uint32_t blockEnd = (blockBegin + P.raysPerBlock) < nSlots ? (blockBegin + P.raysPerBlock) : nSlots;
 	if (threadIdx.x == 0)
 		blockNext = blockBegin;
 	__syncthreads();
-	bool exhausted = PERSIST ? nRays == 0 : (blockBegin >= nRays);
+	bool exhausted = blockBegin >= nSlots;
 	const float kFailed = __builtin_inff();
 	uint32_t passes = 0; // see kMaxPasses
 
@@ -486,75 +358,36 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 		const uint32_t nIdle = __popcll(idleMask);
 		if (!exhausted && nIdle >= P.refillMinIdle) {
 			const uint32_t rank = __popcll(idleMask & below);
-			uint32_t s = 0;
-			bool fed = false;
-			if (PERSIST) {
-				uint32_t got = 0;
-				if (!staticDone) {
-					uint32_t base = 0;
-					if (lane == 0)
-						base = atomicAdd(&blockNext, nIdle); // LDS
-					base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, 0, 64));
-					const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
-					got = avail < nIdle ? avail : nIdle;
-					if (!live && rank < got) {
-						s = static_slot(base + rank, blockBegin, P.staticInterleave != 0u);
-						fed = true;
-					}
-					staticDone = (base + nIdle >= blockEnd);
-				}
-				while (staticDone && got < nIdle) {
-					if (!feed.refill(P.kc->chunks, nRays - dynBase, lane)) {
-						exhausted = true;
-						break;
-					}
-					const uint32_t avail = feed.end - feed.next, room = nIdle - got;
-					const uint32_t take = avail < room ? avail : room;
-					if (!live && rank >= got && rank < got + take) {
-						s = dynBase + feed.next + (rank - got);
-						fed = true;
-					}
-					feed.next += take;
-					got += take;
-				}
-			} else {
-				uint32_t base = 0;
-				if (lane == 0)
-					base = atomicAdd(&blockNext, nIdle); // LDS
-				base = __shfl(base, 0, 64);
-				const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
-				const uint32_t take = avail < nIdle ? avail : nIdle;
-				exhausted = (base + nIdle >= blockEnd);
-				s = base + rank;
-				fed = !live && rank < take;
-			}
+			uint32_t base = 0;
+			if (lane == 0)
+				base = atomicAdd(&blockNext, nIdle); // LDS
+			base = __shfl(base, 0, 64);
+			const uint32_t avail = base < blockEnd ? blockEnd - base : 0u;
+			const uint32_t take = avail < nIdle ? avail : nIdle;
+			exhausted = (base + nIdle >= blockEnd);
+			const uint32_t s = base + rank;
+			bool fed = !live && rank < take;
 			if (__ballot(pendIdx != kNoPending) != 0ull)
 				flush_visible();
-			{
-				if (fed)
-					fed = slot_valid(P.kc->seg, s);
-				if (fed) {
-					const float4 a = P.shadow.o_dx[s];
-					const float4 b = P.shadow.dyz_cd_ix[s];
-					const float sphereOccluded = reinterpret_cast<const float*>(&P.shadow.color[s])[3];
-					index = s;
-					closest = b.z;
-					occluded = (sphereOccluded != 0.0f);
-					live = true;
-					st.reset();
-					ref = kRefDone;
-					if (haveBvh && (COUNT || !occluded)) {
-						const RayConst nr = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
-						rox = nr.o.x, roy = nr.o.y, roz = nr.o.z, rdx = nr.d.x, rdy = nr.d.y, rdz = nr.d.z, rix = nr.inv.x, riy = nr.inv.y, riz = nr.inv.z;
-						regular = ray_is_regular(nr);
-						ref = root_ref(sc, nr, closest);
-						if (QUAD && ref != kRefDone)
-							ref = sc.quadRootRef;
-						if (COUNT) {
-							vc.nodes += 1;
-							inTree += (ref != kRefDone) ? 1u : 0u;
-						}
-					}
+			if (fed)
+				fed = slot_valid(P.kc->seg, s);
+			if (fed) {
+				const float4 a = P.shadow.o_dx[s];
+				const float4 b = P.shadow.dyz_cd_ix[s];
+				const float sphereOccluded = reinterpret_cast<const float*>(&P.shadow.color[s])[3];
+				index = s;
+				closest = b.z;
+				occluded = (sphereOccluded != 0.0f);
+				live = true;
+				st.reset();
+				ref = kRefDone;
+				if (haveBvh) { // (the counting rule traverses the BVH whatever the spheres said: kernel.cu:164-172 tests it first)
+					const RayConst nr = make_ray(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+					rox = nr.o.x, roy = nr.o.y, roz = nr.o.z, rdx = nr.d.x, rdy = nr.d.y, rdz = nr.d.z, rix = nr.inv.x, riy = nr.inv.y, riz = nr.inv.z;
+					regular = ray_is_regular(nr);
+					ref = root_ref(sc, nr, closest);
+					vc.nodes += 1;
+					inTree += (ref != kRefDone) ? 1u : 0u;
 				}
 			}
 		}
@@ -569,9 +402,6 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 			const uint32_t nTrav = __popcll(lanes_traversing(ref));
 			if (nTrav == 0)
 				break;
-			// leave the descent when few lanes are still descending and there is anything else to do (leaves, or a
-			// refill).  (Also leaving once many lanes hold a leaf, so that triangle tests run wide, was measured at
-			// every threshold and never paid; the test cost eight instructions per trip.)
 			if (nTrav < P.minTraversing) {
 				const bool anyLeaf = lanes_at_leaf(ref) != 0ull;
 				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
@@ -582,8 +412,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 				uint32_t pr;
 				float pt;
 				if (st.pop(pr, pt)) {
-					if (COUNT)
-						vc.nodes += 1; // the reference fetches the popped node before testing its box (bvh.h:222-224)
+					vc.nodes += 1; // the reference fetches the popped node before testing its box (bvh.h:222-224)
 					if (pt < closest)
 						ref = pr;
 				} else {
@@ -591,15 +420,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 				}
 			}
 			if ((int)ref >= 0) {
-				if (QUAD) {
-					const QuadHits q = allRegular ? test_quad<true, TYR_CONNECT_ORDERED, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged) : test_quad<false, TYR_CONNECT_ORDERED, PERSIST>(sc.quads, ref, r, closest, stagedNodes, nStaged);
-					const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
-					st.push3(q.hit[3] & any012, q.ref[3], q.t[3], q.hit[2] & any01, q.ref[2], q.t[2], q.hit[1] & q.hit[0], q.ref[1], q.t[1]);
-					ref = lane_in(q.hit[0]) ? q.ref[0] : lane_in(q.hit[1]) ? q.ref[1] : lane_in(q.hit[2]) ? q.ref[2] : lane_in(q.hit[3]) ? q.ref[3] : kRefPop;
-					continue;
-				}
 				const PairTest p = allRegular ? test_pair_fast(sc.nodes, ref, r, closest) : test_pair(sc.nodes, ref, r, closest);
-				if (COUNT && !p.synthetic) {
+				if (!p.synthetic) {
 					vc.nodes += 1;
 					st.push(p.farRef, p.farHit ? p.farT : kFailed);
 					ref = p.nearHit ? p.nearRef : kRefPop;
@@ -624,8 +446,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 				if (i + 1 < cnt)
 					tri = triangle_load(sc.tris, off + i + 1);
 				const float t = triangle_test(cur, r);
-				if (COUNT)
-					vc.tris += 1;
+				vc.tris += 1;
 				found = (t > kEpsilon && ((closest - t) > kEpsilon)); // bvh.h:232-236
 			}
 			if (found) {
@@ -650,11 +471,9 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_connect_flat(
 	if (kGuardPasses && passes > kMaxPasses)
 		atomicOr(&P.k->device_error, kErrNoProgress);
 	wave_add_u64(&P.k->n_shadow_visible, visible);
-	if (COUNT) {
-		wave_add_u64(&P.k->nodes_connect, vc.nodes);
-		wave_add_u64(&P.k->tris_connect, vc.tris);
-		wave_add_u64(&P.k->rays_in_tree_connect, inTree);
-	}
+	wave_add_u64(&P.k->nodes_connect, vc.nodes);
+	wave_add_u64(&P.k->tris_connect, vc.tris);
+	wave_add_u64(&P.k->rays_in_tree_connect, inTree);
 }
 
 // LDS executes a wave's instructions in order; this only keeps the COMPILER from moving a lane's LDS read above another
@@ -895,7 +714,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	unsigned long long tExhausted = 0ull;
 	uint32_t liveAtExhaustion = 0;
 	const unsigned long long tStart = kAnatomy ? __builtin_amdgcn_s_memrealtime() : 0ull;
-	// kernel.cu:640-644, deferred to the wave's next refill (see k_connect_flat)
+	// kernel.cu:640-644, deferred to the wave's next refill (see k_connect_count)
 	constexpr uint32_t kNoPending = 0xffffffffu;
 	uint32_t pendIdx = kNoPending;
 	auto flush_visible = [&]() {
@@ -1189,7 +1008,7 @@ void launch_extend(const FrameParams& P0, uint32_t maxLive, uint32_t nSurvivors,
 		launch_extend_spheres(P, nSurvivors, stream);
 		P.raysPerBlock = kCountRaysPerBlock;
 		const uint32_t blocks = (P.segCap * kSegs + kCountRaysPerBlock - 1) / kCountRaysPerBlock; // every physical slot a record could lie in
-		hipLaunchKernelGGL((k_extend_flat<true, 12, false, false>), dim3(blocks), dim3(kBlock), 0, stream, P);
+		hipLaunchKernelGGL((k_extend_count<12>), dim3(blocks), dim3(kBlock), 0, stream, P);
 		return;
 	}
 	P.traceShadow = 0u;
@@ -1203,7 +1022,7 @@ void launch_connect(const FrameParams& P0, uint32_t maxShadow, bool countVisits,
 		launch_connect_spheres(P, maxShadow, stream);
 		P.raysPerBlock = kCountRaysPerBlock;
 		const uint32_t blocks = (P.segCap * kSegs + kCountRaysPerBlock - 1) / kCountRaysPerBlock;
-		hipLaunchKernelGGL((k_connect_flat<true, 12, false, false>), dim3(blocks), dim3(kBlock), 0, stream, P);
+		hipLaunchKernelGGL((k_connect_count<12>), dim3(blocks), dim3(kBlock), 0, stream, P);
 		return;
 	}
 	P.kcPrev = P.kc; // the rays of THIS iteration's shadow queue

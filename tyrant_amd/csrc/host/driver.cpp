@@ -911,7 +911,7 @@ int tyr_launch_kernels(tyr_ctx* c) {
 // ---- tyr_render, one iteration ahead of the counts (TYR_TUNE_RUN_AHEAD) -------------------------
 // Between shade(i) and the first kernel of iteration i + 1 the stream used to run dry for ~20 us: the counters travel
 // to the host, the host wakes up, sizes the grids and launches.  Nothing in iteration i + 1 needs the host for that:
-// k_primary and k_globals compute the top-up from the device's counters (kernel.cu:253, 227-244 do the same), the
+// k_primary (and set_wavefront_globals in its last block) compute the top-up from the device's counters (kernel.cu:253, 227-244 do the same), the
 // persistent kernels read their item counts there, k_shade its tile count.  So the host queues iteration i + 1 right
 // behind iteration i, sizing every grid from upper bounds it can already compute -- survivors(i) <= live(i), shadow rays
 // (i) <= live(i), and live(i), the budget and the top-up of i + 1's predecessors follow exactly from the last counts that
