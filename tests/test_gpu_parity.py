@@ -43,10 +43,12 @@ def assert_accum_close(bo, bg, what):
     assert np.allclose(bg[:, :3], bo[:, :3], rtol=1e-5, atol=1e-6), f"{what}: max rel err {np.max(np.abs(bg[:, :3] - bo[:, :3]) / np.maximum(np.abs(bo[:, :3]), 1e-3))}"
 
 
-@pytest.mark.parametrize("name,W,H,N", [("cornell36", 64, 64, 6000), ("tyrant_default", 96, 64, 5000), ("cornell_soup2k", 80, 48, 4096), ("mesh32", 64, 64, 4096), ("glass_dof48", 96, 54, 4096), ("cornell_area_light", 96, 64, 5000), ("cornell_colored", 96, 64, 5000)])
-def test_stage_by_stage_bit_parity(orc, hip, name, W, H, N):
-    """every kernel of every iteration, fed by its predecessors on each side, matches the oracle bit for bit"""
-    o, g = pair(orc, hip, name, W, H, N)
+@pytest.mark.parametrize("name,W,H,N,flags", [("cornell36", 64, 64, 6000, 0), ("tyrant_default", 96, 64, 5000, 0), ("cornell_soup2k", 80, 48, 4096, 0), ("mesh32", 64, 64, 4096, 0), ("glass_dof48", 96, 54, 4096, 0),
+                                              ("cornell_area_light", 96, 64, 5000, 0), ("cornell_colored", 96, 64, 5000, 0), ("cornell_soup2k", 80, 48, 4096, 4), ("glass_dof48", 96, 54, 4096, 4)])
+def test_stage_by_stage_bit_parity(orc, hip, name, W, H, N, flags):
+    """every kernel of every iteration, fed by its predecessors on each side, matches the oracle bit for bit
+    (flags = 4: the counting build of the traversal on pair nodes, TYR_FLAG_COUNT_VISITS)"""
+    o, g = pair(orc, hip, name, W, H, N, flags=flags)
     for it in range(5):
         tag = f"{name} iteration {it}"
         o.stage("begin"), g.stage("begin")
