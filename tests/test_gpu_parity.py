@@ -31,6 +31,12 @@ def pair(orc, hip, name, W, H, N, flags=0, rank=0, nranks=1):
     return o, g
 
 
+def hash_spread(i: np.ndarray, seed: int) -> np.ndarray:
+    from tyrant_amd import scenes
+
+    return scenes.hash_unit(np.asarray(i), seed)
+
+
 def assert_state_equal(qo, qg, what):
     for f in LIVE_FIELDS:
         assert np.array_equal(bits(qo[f]), bits(qg[f])), f"{what}: {f} differs in {np.count_nonzero(np.any(bits(qo[f]) != bits(qg[f]), axis=-1))} records"
@@ -98,6 +104,62 @@ def test_render_matches_oracle(orc, hip, name, W, H, N, spp):
     bo, bg = o.blit_buffer(), g.blit_buffer()
     assert np.all(bg[:, 3] == spp)
     assert_accum_close(bo, bg, name)
+
+
+def test_every_survivor_lands_in_one_queue_segment(orc, hip):
+    """The worst case the queue segments are sized for (hip/kernels.hpp "Queues").  A shade tile appends to
+    segment (tile / 2) % 8, so records whose index j has (j / 512) % 8 == 0 all send their survivors and shadow rays to
+    segment 0: exactly those rays hit a wall here, the other seven eighths leave for the sky.  The top-up primaries that
+    follow spread evenly over the segments on top of that: segment 0 then holds N/8 + 7N/64 records, more than
+    1.5 x its share.  No overflow, and the oracle's counts, queues and radiance, iteration after iteration."""
+    from tyrant_amd import scenes
+
+    W, H = 512, 256
+    N = W * H
+    j = np.arange(N)
+    stay = (j // 512) % 8 == 0
+    rays = np.zeros(N, dtype=scenes.RAY_DTYPE)
+    rays["origin"] = np.stack([hash_spread(j, 1) * 400.0 - 200.0, np.full(N, -100.0), hash_spread(j, 2) * 400.0 - 200.0], axis=1).astype(np.float32)
+    rays["direction"] = np.where(stay[:, None], np.float32([0, 1, 0]), np.float32([0, -1, 0]))
+    rays["direct"] = 1.0
+    rays["distance"] = 1e20
+    rays["index"] = j
+    wall = scenes._quad((-5000.0, 0.0, -5000.0), (5000.0, 0.0, -5000.0), (5000.0, 0.0, 5000.0), (-5000.0, 0.0, 5000.0), (0, -1, 0))
+    spheres = scenes.cornell_spheres()
+    spheres[4] = spheres[0]  # no ground, no light
+    spheres[6] = spheres[1]
+    cam = scenes.Camera(position=(0.0, -190.0, 50.0), direction=(0.0, -1.0, 0.0), up=(0.0, 0.0, 1.0))  # looks away from the wall
+    sc = scenes.SceneData("one_segment", wall, spheres, cam)
+    nodes, prims = orc.bvh_build(sc.triangles, scenes.triangle_bboxes(sc.triangles))
+    o, g = orc.Oracle(W, H, N), hip.Renderer(W, H, N)
+    for r in (o, g):
+        r.load_scene(sc, nodes, prims)
+        r.set_camera(cam)
+        r.stage("begin")
+        r.import_work_queue(rays, N)
+        r.set_budget(0)
+        r.stage("primary")
+    for it in range(4):
+        if it:
+            for r in (o, g):
+                r.set_budget(N * 8)
+                r.stage("begin"), r.stage("primary")
+        for r in (o, g):
+            r.stage("extend"), r.stage("shade")
+        ko, kg = o.counters(), g.counters()
+        assert kg["device_error"] == 0, f"iteration {it}"
+        for f in ("n_live", "primary_ray_cnt", "shadow_ray_cnt", "total_primary_rays", "total_extend_rays"):
+            assert ko[f] == kg[f], (it, f)
+        if it == 0:
+            assert ko["primary_ray_cnt"] > N // 8 - N // 256, "every ray aimed at the wall is meant to survive its first bounce"
+        ns, nh = ko["primary_ray_cnt"], ko["shadow_ray_cnt"]
+        assert_state_equal(o.ray_queue(1, ns), g.ray_queue(1, ns), f"iteration {it} survivors")
+        assert o.shadow_queue(nh).tobytes() == g.shadow_queue(nh).tobytes(), f"iteration {it} shadow rays"
+        for r in (o, g):
+            r.stage("connect"), r.stage("end")
+    assert o.counters()["n_shadow_visible"] == g.counters()["n_shadow_visible"]
+    assert_accum_close(o.blit_buffer(), g.blit_buffer(), "one segment")
+    g.close()
 
 
 def test_reference_traversal_fixture_through_the_abi(orc, hip):

@@ -36,8 +36,11 @@ constexpr uint32_t kHitSphere = 0x80000000u;
 // the serial order gives it), the RNG is seeded from it, and where the record physically lies is free:
 //   * a queue is eight segments; segment w owns the 64-slot chunks w, w + 8, w + 16, ... of the arrays, filled in
 //     order (record j of segment w lies at slot ((j / 64) * 8 + w) * 64 + j % 64).  A producer block appends its tile's
-//     records to segment (tile % 8) with ONE atomic on that segment's counter (eight counters, 128 bytes apart: a single
-//     word serves only ~88 returning atomics per microsecond);
+//     records to ONE segment with ONE atomic on that segment's counter (eight counters, 128 bytes apart: a single
+//     word serves only ~88 returning atomics per microsecond): k_primary block b to segment b % 8, shade tile t to
+//     segment (t / 2) % 8 -- tiles 2k and 2k + 1 hold records [64k, 64k + 64) of all eight segments, so the tiles that
+//     feed one segment hold an eighth of every segment and no choice of surviving rays can hand a segment more than
+//     N/8 + 1024 records; with the top-up's eighth of the new primaries on top: segCap = 15 N/64 + 4096 (host/driver.cpp);
 //   * consumers walk physical slots [0, extent) and skip the few holes at the segments' ends (slot_valid);
 //   * shade(i) writes one byte per ray at its virtual slot v: survived or not.  A scan of those bytes (k_scan_*) gives
 //     rank(v) = survivors with a lower virtual slot = the survivor's slot in iteration i + 1 by the serial order.  The

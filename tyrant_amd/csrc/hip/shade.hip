@@ -557,7 +557,9 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			flush_prev(); // ends with a barrier: sh[4..13] have been read by every thread
 		else
 			__syncthreads();
-		const uint32_t seg = vb & (kSegs - 1u);
+		// tiles 2k and 2k + 1 hold records [64k, 64k + 64) of all eight segments between them and both append to segment
+		// k % 8: whichever rays survive, a segment receives at most an eighth of the queue's records (+ 64 per segment)
+		const uint32_t seg = (vb >> 1) & (kSegs - 1u);
 		if (tid == 0) {
 			// this tile's places: consumed by flush_prev one tile later
 			uint32_t bT = 0, bK = 0, bH = 0;

@@ -430,10 +430,12 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		c->ownStream = true;
 	}
 	const size_t N = cfg->queue_size;
-	// a queue is eight segments (hip/kernels.hpp "Queues"): tiles are dealt to them round-robin, so each holds an eighth of
-	// the records give or take the tiles' luck; half as much again is room no render has come near (a segment that does
-	// run out reports kErrQueueOverflow, it never writes past its end)
-	c->segCap = static_cast<uint32_t>(((N / 8 + N / 16 + 2048) + 63) & ~size_t(63));
+	// A queue is eight segments (hip/kernels.hpp "Queues"), sized so that none can run out whatever the rays do.  What one
+	// segment of one class can receive in an iteration: from shade, the survivors of the tile pairs dealt to it, which
+	// between them hold an eighth of every segment of both classes, N/8 + 1024 records at most; from the top-up an eighth
+	// of the new primaries, (N - survivors)/8 + 256.  The sum is largest when a segment's survivors are all there are:
+	// N/8 + 1024 + 7/8 (N/8 + 1024)... < 15 N/64 + 4096.  (kErrQueueOverflow stays as a check: a segment never writes past its end.)
+	c->segCap = static_cast<uint32_t>(((N / 8 + 7 * (N / 64) + 4096) + 63) & ~size_t(63));
 	const size_t cap = static_cast<size_t>(c->segCap) * tyr::kSegs;
 	if ((rc = alloc_rayq(c->q[0], cap * tyr::kClasses)) || (rc = alloc_rayq(c->q[1], cap * tyr::kClasses))) // class 0 (may enter the tree), class 1 (cannot)
 		return fail(rc);
