@@ -506,6 +506,13 @@ constexpr int kWideStackEntries = 4 * 12; // the four lanes' LDS columns of a gr
 	// same accept rule, same answers -- at a quarter of the instructions per step.
 // (A function of its own, not inlined: inside k_trace_flat its scalar registers competed with the feed loop's -- 35 instead
 // of 16 spilled there, 2.5 % of a render whether or not a wave ever got here.)
+#ifdef TYR_LAUNCH_ANATOMY
+#define TYR_WIDE_STEPS_PARAM , uint32_t& wideSteps
+#define TYR_WIDE_STEPS_ARG , wideSteps
+#else
+#define TYR_WIDE_STEPS_PARAM
+#define TYR_WIDE_STEPS_ARG
+#endif
 struct WideState {
 	float rox, roy, roz, rdx, rdy, rdz, rix, riy, riz, dist;
 	uint32_t ref, slot, flags; // flags: 1 regular, 2 hitTri, 4 isShadow, 8 occluded, 16 live
@@ -513,7 +520,7 @@ struct WideState {
 };
 template <int STACK_LDS>
 __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __restrict__ quads, const float4* __restrict__ tris, const float4* __restrict__ shadowColor, const float4* __restrict__ shadowDyzCdIx,
-                                                         float2* __restrict__ workHit, float4* __restrict__ blit, typename LdsStack<STACK_LDS, true>::entry_t* smem_, WideState w, uint32_t passes) {
+                                                         float2* __restrict__ workHit, float4* __restrict__ blit, typename LdsStack<STACK_LDS, true>::entry_t* smem_, WideState w, uint32_t passes TYR_WIDE_STEPS_PARAM) {
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 	float rox = w.rox, roy = w.roy, roz = w.roz, rdx = w.rdx, rdy = w.rdy, rdz = w.rdz, rix = w.rix, riy = w.riy, riz = w.riz, dist = w.dist;
@@ -569,6 +576,9 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 	while (__ballot(gActive) != 0ull) {
 		if (kGuardPasses && ++passes > kMaxPasses)
 			break;
+#ifdef TYR_LAUNCH_ANATOMY
+		wideSteps += 1;
+#endif
 		if (gActive && ref == kRefPop) {
 			if (n == 0) {
 				ref = kRefDone;
@@ -711,8 +721,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	uint32_t visible = 0;
 	uint32_t dbg[16] = {};
 	uint32_t steps = 0; // TYR_QUAD_STATS: quad steps of this lane's current ray
-	unsigned long long tExhausted = 0ull;
-	uint32_t liveAtExhaustion = 0;
+	unsigned long long tExhausted = 0ull, tWide = 0ull;
+	uint32_t liveAtExhaustion = 0, liveAtWide = 0, tripsAfter = 0, passesAfter = 0, wideSteps = 0; // (anatomy build)
 	const unsigned long long tStart = kAnatomy ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	// kernel.cu:640-644, deferred to the wave's next refill (see k_connect_count)
 	constexpr uint32_t kNoPending = 0xffffffffu;
@@ -834,8 +844,14 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 			const uint32_t nLiveNow = (uint32_t)__popcll(__ballot(live));
 			if (exhausted && nLiveNow <= wideLimit && __ballot(live && st.n > STACK_LDS) == 0ull) {
 				wide = nLiveNow != 0u;
+				if (kAnatomy) {
+					tWide = __builtin_amdgcn_s_memrealtime();
+					liveAtWide = nLiveNow;
+				}
 				break;
 			}
+			if (kAnatomy && exhausted)
+				passesAfter += 1;
 			if (nLiveNow == 0u)
 				continue;
 		}
@@ -852,6 +868,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 				if (anyLeaf || canRefill)
 					break;
 			}
+			if (kAnatomy && exhausted)
+				tripsAfter += 1;
 			if (ref == kRefPop) {
 				TYR_DBG(2)
 				uint32_t pr;
@@ -936,7 +954,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		w.rox = rox, w.roy = roy, w.roz = roz, w.rdx = rdx, w.rdy = rdy, w.rdz = rdz, w.rix = rix, w.riy = riy, w.riz = riz, w.dist = dist;
 		w.ref = ref, w.slot = slot, w.prim = prim, w.n = st.n;
 		w.flags = (regular ? 1u : 0u) | (hitTri ? 2u : 0u) | (isShadow ? 4u : 0u) | (occluded ? 8u : 0u) | (live ? 16u : 0u);
-		const uint32_t res = wide_drain<STACK_LDS>(sc.quads, sc.tris, P.shadowPrev.color, P.shadowPrev.dyz_cd_ix, P.work.hit, P.blit, smem_, w, passes);
+		const uint32_t res = wide_drain<STACK_LDS>(sc.quads, sc.tris, P.shadowPrev.color, P.shadowPrev.dyz_cd_ix, P.work.hit, P.blit, smem_, w, passes TYR_WIDE_STEPS_ARG);
 		visible += res & 0x3fffffffu;
 		overflow = overflow || (res & 0x80000000u) != 0u;
 		if (res & 0x40000000u)
@@ -963,8 +981,11 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		const uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 		if (w < P.N)
 			P.next.hit[w] = make_float2((float)((tExhausted ? tExhausted : tEnd) - tStart) * 0.01f, (float)(tEnd - tStart) * 0.01f + (float)liveAtExhaustion * 0.0f);
-		if (w < P.N)
-			P.next.flags[w] = liveAtExhaustion;
+		if (w < 8192u && 32768u < P.N) { // three more records per wave, further up the same column (host/driver.cpp prints them with TYR_ANATOMY=2)
+			P.next.hit[8192u + w] = make_float2(tWide ? (float)(tWide - tStart) * 0.01f : 0.0f, (float)(liveAtExhaustion + 256u * liveAtWide));
+			P.next.hit[16384u + w] = make_float2((float)tripsAfter, (float)wideSteps); // trips after the queue ran out one ray to a lane, steps four lanes to a ray
+			P.next.hit[24576u + w] = make_float2((float)passesAfter, 0.0f);
+		}
 #endif
 	}
 }

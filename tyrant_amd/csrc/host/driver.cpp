@@ -838,6 +838,54 @@ int tyr_sync(tyr_ctx* c) {
 // One wavefront iteration.  pipelined = false is launch_kernels as the reference has it: primary, extend, shade, connect on
 // one stream, done when it returns (kernel.cu:719-733).  Inside tyr_render (pipelined, merged launches) connect(i) rides in
 // the traversal launch of iteration i + 1 and the call returns as soon as shade's counts are on the host.
+#ifdef TYR_LAUNCH_ANATOMY
+// TYR_ANATOMY=2: the per-wave records k_trace_flat's anatomy build leaves in the next queue's hit column (tools/drain_profile.py)
+static void print_wave_anatomy(const float2* dHit, unsigned long long feedTicks) {
+	std::vector<float2> rec(4 * 8192);
+	if (hipMemcpy(rec.data(), dHit, rec.size() * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess)
+		return;
+	std::vector<float> drain, normal, wide, perTrip, perStep, liveExh, liveWide, trips, steps, passes;
+	for (uint32_t w = 0; w < 8192; ++w) {
+		const float tExh = rec[w].x, tEnd = rec[w].y, tWide = rec[8192 + w].x;
+		if (!(tExh > 0.0f) || !(tEnd >= tExh) || !(tEnd < 1e5f))
+			continue;
+		const uint32_t lv = (uint32_t)rec[8192 + w].y;
+		const float nTrips = rec[16384 + w].x, nSteps = rec[16384 + w].y;
+		drain.push_back(tEnd - tExh);
+		normal.push_back((tWide > 0.0f ? tWide : tEnd) - tExh);
+		wide.push_back(tWide > 0.0f ? tEnd - tWide : 0.0f);
+		if (nTrips > 0.0f)
+			perTrip.push_back(((tWide > 0.0f ? tWide : tEnd) - tExh) / nTrips);
+		if (nSteps > 0.0f && tWide > 0.0f)
+			perStep.push_back((tEnd - tWide) / nSteps);
+		liveExh.push_back((float)(lv & 255u));
+		liveWide.push_back((float)(lv >> 8));
+		trips.push_back(nTrips);
+		steps.push_back(nSteps);
+		passes.push_back(rec[24576 + w].x);
+	}
+	auto pct = [](std::vector<float>& v, double p) {
+		if (v.empty())
+			return 0.0f;
+		const size_t k = (size_t)(p * (v.size() - 1));
+		std::nth_element(v.begin(), v.begin() + k, v.end());
+		return v[k];
+	};
+	auto line = [&](const char* name, std::vector<float>& v) { std::fprintf(stderr, "[anatomy]    %-44s n %5zu  median %8.2f  90 %% %8.2f  99 %% %8.2f  max %8.2f\n", name, v.size(), pct(v, 0.5), pct(v, 0.9), pct(v, 0.99), pct(v, 1.0)); };
+	std::fprintf(stderr, "[anatomy]  per wave, after the queue ran out (feed %.1f us):\n", feedTicks / 100.0);
+	line("drain: exit - 'used up' [us]", drain);
+	line("  one ray to a lane [us]", normal);
+	line("  four lanes to a ray [us]", wide);
+	line("rays held when the queue ran out", liveExh);
+	line("rays held on going wide", liveWide);
+	line("descent trips one ray to a lane", trips);
+	line("outer passes (leaf rounds) one ray to a lane", passes);
+	line("steps four lanes to a ray", steps);
+	line("us per trip, one ray to a lane", perTrip);
+	line("us per step, four lanes to a ray", perStep);
+}
+#endif
+
 static int launch_iteration(tyr_ctx* c, bool pipelined) {
 	// hK is current: every entry point that enqueues work ends with sync_counters
 	int rc = stage_begin(c);
@@ -887,6 +935,10 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 			std::fprintf(stderr, "; longest ray %llu quad steps, rays with > 64 / 128 / 256 steps: %llu / %llu / %llu (running totals)", c->hK->debug[12], c->hK->debug[9], c->hK->debug[10], c->hK->debug[11]);
 #endif
 			std::fprintf(stderr, "\n");
+#ifdef TYR_LAUNCH_ANATOMY
+			if (std::getenv("TYR_ANATOMY")[0] == '2' && P.N > 32768u)
+				print_wave_anatomy(P.next.hit, tx - t0);
+#endif
 		}
 #endif
 	} else {
