@@ -101,7 +101,7 @@ enum {
 	TYR_ERR_NO_SCENE = -3,
 	TYR_ERR_NO_BUFFER = -4,  /* no blit_buffer bound */
 	TYR_ERR_OOM = -5,
-	TYR_ERR_DEVICE = -6,     /* a kernel reported an internal error (stack overflow, scan timeout) */
+	TYR_ERR_DEVICE = -6,     /* a kernel reported an internal error: tyr_counters.device_error says which */
 	TYR_ERR_UNSUPPORTED = -7,
 	TYR_ERR_IO = -8          /* a file could not be opened, or a write came up short */
 };
@@ -184,7 +184,7 @@ typedef struct tyr_counters {
 	uint32_t shadow_ray_cnt;  /* kernel.cu:224 */
 	uint32_t n_live;          /* rays in the work queue after top-up (== queue_size in the reference) */
 	uint32_t frame;           /* kernel.cu:667 */
-	uint32_t device_error;    /* non-zero: TYR_ERR_DEVICE detail bits: 1 traversal stack overflow, 4 (builds with -DTYR_GUARD_PASSES only) a traversal wave gave up after 2^24 passes without finishing, 8 a queue segment ran out of room (the records beyond it were dropped) */
+	uint32_t device_error;    /* non-zero: TYR_ERR_DEVICE detail bits: 1 traversal stack overflow, 4 (builds with -DTYR_GUARD_PASSES only) a traversal wave gave up after 2^24 passes without finishing, 8 a queue segment ran out of room (the records beyond it were dropped; the segments are sized so that no set of rays can do it -- a check, not an expected outcome) */
 	uint64_t budget_remaining;
 	uint64_t total_extend_rays; /* sum of n_live over iterations */
 	uint64_t total_shadow_rays; /* sum of shadow_ray_cnt over iterations */

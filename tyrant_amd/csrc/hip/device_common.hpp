@@ -120,30 +120,6 @@ __device__ __forceinline__ uint32_t chunk_valid(const uint32_t* cnt, uint32_t s0
 	const uint32_t c = cnt[((s0 >> 6) & (kSegs - 1u)) * kSegStride], first = (s0 >> 9) << 6;
 	return c > first ? (c - first < 64u ? c - first : 64u) : 0u;
 }
-// the eight counts in registers, for kernels that test many slots (one load each at kernel start, then selects)
-struct SegCounts {
-	uint32_t c[kSegs];
-	__device__ __forceinline__ void load(const uint32_t* cnt) {
-#pragma unroll
-		for (uint32_t w = 0; w < kSegs; ++w)
-			c[w] = cnt[w * kSegStride];
-	}
-	__device__ __forceinline__ uint32_t extent() const {
-		uint32_t m = 0;
-#pragma unroll
-		for (uint32_t w = 0; w < kSegs; ++w)
-			m = c[w] > m ? c[w] : m;
-		return ((m + 63u) >> 6) * (kSegs * 64u);
-	}
-	__device__ __forceinline__ bool valid(uint32_t s) const {
-		const uint32_t seg = (s >> 6) & (kSegs - 1u);
-		uint32_t lim = c[0];
-#pragma unroll
-		for (uint32_t w = 1; w < kSegs; ++w)
-			lim = seg == w ? c[w] : lim;
-		return (((s >> 9) << 6) | (s & 63u)) < lim;
-	}
-};
 // what a slot that holds no record looks like to the traversal kernel: a ray that cannot enter any box (k_pad_holes
 // writes it into the holes at the segments' ends, so that k_trace_flat hands out slots without asking)
 __device__ __forceinline__ void write_dead_ray(const RayQ& q, uint32_t slot) {

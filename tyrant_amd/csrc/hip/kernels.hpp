@@ -119,9 +119,9 @@ struct ConnectCounters {
 	uint32_t seg[kSegs * kSegStride];   // records in segment w of this iteration's shadow queue
 };
 constexpr uint32_t kErrStackOverflow = 1u;
-constexpr uint32_t kErrScanTimeout = 2u; // (rounds 1-2: the look-back of the stable compaction timed out; no longer raised)
+// (bit 2 was the look-back time-out of rounds 1-2's stable compaction: no longer raised, not reused)
 constexpr uint32_t kErrNoProgress = 4u; // -DTYR_GUARD_PASSES builds: a wave of a flat traversal kernel ran out of passes (kMaxPasses)
-constexpr uint32_t kErrQueueOverflow = 8u; // a queue segment ran out of room (the records beyond it were dropped)
+constexpr uint32_t kErrQueueOverflow = 8u; // a queue segment ran out of room (the records beyond it were dropped); cannot happen with segCap as host/driver.cpp sizes it, kept as a check
 
 struct FrameParams {
 	uint32_t W, H, N;
