@@ -411,7 +411,7 @@ struct ShadeStage { // one tile's output, waiting for the tile's place in the qu
 // tiles of a full queue).  Nothing waits for anything here: any grid size is safe.
 //
 // A tile's survivors (kernel.cu:607-608) and shadow rays (kernel.cu:416-417 ...) get their place with ONE atomic per
-// queue on the counter of segment (tile % 8), issued as soon as the tile's counts are known; the records wait in LDS at
+// queue on the counter of segment (tile / 2) % 8, issued as soon as the tile's counts are known; the records wait in LDS at
 // their rank inside the tile and leave as coalesced stores (thread t writes record t) AFTER the next tile has been
 // shaded -- by then the atomics have long returned.
 template <bool LIGHTS>
