@@ -883,6 +883,19 @@ static void print_wave_anatomy(const float2* dHit, unsigned long long feedTicks)
 	line("steps four lanes to a ray", steps);
 	line("us per trip, one ray to a lane", perTrip);
 	line("us per step, four lanes to a ray", perStep);
+	// the launch ends with these: the five waves that left last
+	std::vector<uint32_t> order;
+	for (uint32_t w = 0; w < 8192; ++w)
+		if (rec[w].x > 0.0f && rec[w].y >= rec[w].x && rec[w].y < 1e5f)
+			order.push_back(w);
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rec[a].y > rec[b].y; });
+	for (size_t i = 0; i < order.size() && i < 5; ++i) {
+		const uint32_t w = order[i];
+		const float tExh = rec[w].x, tEnd = rec[w].y, tWide = rec[8192 + w].x;
+		const uint32_t lv = (uint32_t)rec[8192 + w].y;
+		std::fprintf(stderr, "[anatomy]    last wave %zu: exit at %.1f us; queue used up at %.1f (%u rays held), %.1f us / %.0f trips one ray to a lane, %.1f us / %.0f steps four lanes to a ray (from %u rays)\n", i + 1, tEnd, tExh,
+		             lv & 255u, (tWide > 0.0f ? tWide : tEnd) - tExh, rec[16384 + w].x, tWide > 0.0f ? tEnd - tWide : 0.0f, rec[16384 + w].y, lv >> 8);
+	}
 }
 #endif
 
