@@ -106,12 +106,16 @@ def test_render_matches_oracle(orc, hip, name, W, H, N, spp):
     assert_accum_close(bo, bg, name)
 
 
-def test_every_survivor_lands_in_one_queue_segment(orc, hip):
+@pytest.mark.parametrize("second_wall", [False, True])
+def test_every_survivor_lands_in_one_queue_segment(orc, hip, second_wall):
     """The worst case the queue segments are sized for (hip/kernels.hpp "Queues").  A shade tile appends to
     segment (tile / 2) % 8, so records whose index j has (j / 512) % 8 == 0 all send their survivors and shadow rays to
     segment 0: exactly those rays hit a wall here, the other seven eighths leave for the sky.  The top-up primaries that
     follow spread evenly over the segments on top of that: segment 0 then holds N/8 + 7N/64 records, more than
-    1.5 x its share.  No overflow, and the oracle's counts, queues and radiance, iteration after iteration."""
+    1.5 x its share.  No overflow, and the oracle's counts, queues and radiance, iteration after iteration.
+    One wall: the survivors leave the tree's box for good (class 1, the traversal kernel never sees them).  A second wall
+    behind the rays, facing the first: they bounce between the two (class 0: the lopsided segments, holes included, go
+    through the traversal kernel), and so do the top-up primaries, whose camera looks at the second wall."""
     from tyrant_amd import scenes
 
     W, H = 512, 256
@@ -120,11 +124,13 @@ def test_every_survivor_lands_in_one_queue_segment(orc, hip):
     stay = (j // 512) % 8 == 0
     rays = np.zeros(N, dtype=scenes.RAY_DTYPE)
     rays["origin"] = np.stack([hash_spread(j, 1) * 400.0 - 200.0, np.full(N, -100.0), hash_spread(j, 2) * 400.0 - 200.0], axis=1).astype(np.float32)
-    rays["direction"] = np.where(stay[:, None], np.float32([0, 1, 0]), np.float32([0, -1, 0]))
+    rays["direction"] = np.where(stay[:, None], np.float32([0, 1, 0]), np.float32([0, 0, 1]) if second_wall else np.float32([0, -1, 0]))
     rays["direct"] = 1.0
     rays["distance"] = 1e20
     rays["index"] = j
     wall = scenes._quad((-5000.0, 0.0, -5000.0), (5000.0, 0.0, -5000.0), (5000.0, 0.0, 5000.0), (-5000.0, 0.0, 5000.0), (0, -1, 0))
+    if second_wall:
+        wall = np.concatenate([wall, scenes._quad((-5000.0, -200.0, -5000.0), (-5000.0, -200.0, 5000.0), (5000.0, -200.0, 5000.0), (5000.0, -200.0, -5000.0), (0, 1, 0))])
     spheres = scenes.cornell_spheres()
     spheres[4] = spheres[0]  # no ground, no light
     spheres[6] = spheres[1]
