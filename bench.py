@@ -24,6 +24,9 @@ Queue size: the reference's ray_queue_buffer_size (2,097,152, variables.h:44) wa
 thin wavefront iterations per 8-spp frame.  It is a runtime parameter here and the headline run sizes it for the GPU --
 spp x local pixels slots (16.6 M, 2.5 GB of 288 GB; capped at 32 Mi), i.e. every primary ray of the render in flight at
 once.  The same workload at the reference's queue size is measured too (config.reference_queue_size).
+config.steady_state: the same kernels with the queue kept full by top-ups for as long as the measurement lasts (the
+reference's viewer never stops: main.cpp:164-170) -- no thin iterations at the end of a render.  Reported beside the
+metric, never as it.
 
 Mrays/s = (extend rays + shadow rays traced by all ranks) / wall time.  config.in_tree_Mrays/s
 is the same with only the rays that pass the root box (three primary rays in four miss the tree on c3 and cost one box
@@ -94,6 +97,7 @@ def parse_args(argv=None):
     ap.add_argument("--queue", type=int, default=0, help="ray_queue_buffer_size (variables.h:44); 0 = sized for the GPU: spp x local pixels, at most 32 Mi slots")
     ap.add_argument("--no-reference-queue", action="store_true", help="skip the second measurement at the reference's queue size (2,097,152)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-steady-state", action="store_true", help="skip config.steady_state (the queue kept full by top-ups, as the reference's viewer runs: no thin iterations)")
     ap.add_argument("--no-one-gpu-job", action="store_true", help="N > 1, strong: skip rank 0's solo render of the same job (strong_scaling block)")
     ap.add_argument("--cpu-iterations", type=int, default=2)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearse the multi-rank path with every rank on ONE GPU (the combine then goes through host memory and torch)")
@@ -272,6 +276,35 @@ def shade_block(pmc, shade_ms_per_render, rays_per_render, survivors_per_render,
             out["traffic"] = round(hbm / t / 1e9, 2)
             out["hbm_counter_frac"] = round(hbm / t / 1e9 / HBM_PEAK_GBS, 4)
     return out
+
+
+def steady_state(binding, sc, nodes, prims, W, H, N, flags, device):
+    """The path as the reference's viewer drives it (main.cpp:164-170): launch_kernels without end, every iteration's
+    queue topped up with fresh camera rays (kernel.cu:247-297), so that no iteration is thin.  An 8-spp render -- the
+    metric -- ends in four or five iterations of survivors only, each paying a traversal launch's drain for a tenth of the
+    rays; this is the same kernels' throughput without that tail.  NOT the metric: reported beside it."""
+    import time
+
+    import torch
+
+    r = binding.Renderer(W, H, N, device=device, flags=flags)
+    r.load_scene(sc, nodes, prims)
+    spp_never = 1 << 12  # a budget the measurement never uses up (tyr_render sets it again at every call)
+    r.render(spp_never, 8)  # the mix of fresh rays and survivors of every depth has settled after max-bounces iterations
+    torch.cuda.synchronize()
+    k0 = r.counters()
+    t0 = time.perf_counter()
+    iters = r.render(spp_never, 12)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k1 = r.counters()
+    ok = k1["device_error"] == 0
+    r.close()
+    rays = (k1["total_extend_rays"] - k0["total_extend_rays"]) + (k1["total_shadow_rays"] - k0["total_shadow_rays"])
+    if not ok or dt <= 0 or iters == 0:
+        return None
+    return {"Mrays/s": round(rays / dt / 1e6, 1), "ms_per_iteration": round(dt / iters * 1e3, 3), "iterations": iters, "queue_size": N,
+            "note": "tyr_render with a budget that never runs out: every iteration's queue is full (survivors + top-up), the reference viewer's mode; an 8-spp render ends in thin iterations instead"}
 
 
 def drain_block(args):
@@ -666,6 +699,10 @@ def main():
             solo = measure(min(spp_total * W * H, 1 << 25), max(1, min(args.steps, 2)), 1, spp_total, tdist.shard_spec(0, 1, H), 1)
         dist.barrier()
 
+    steady = None
+    if world == 1 and not args.no_steady_state:
+        steady = steady_state(binding, sc, nodes, prims, W, H, N, flags, local_rank)
+
     if rank == 0:
         mrays = (m["ext_all"] + m["shd_all"]) / m["dt_all"] / 1e6
         tm = m["tm"]
@@ -703,6 +740,7 @@ def main():
                 "in_tree_fraction": {"all_rays": round(m["in_tree_frac"], 4), "extend_rays": round(m["in_tree_ext_frac"], 4), "note": "rays whose test of the root box passes (counting build, rank 0's shard); the others cost one box test"},
                 "host_bvh_build_s": round(t_build, 3),
                 **({"tuning": tune} if tune else {}),
+                **({"steady_state": steady} if steady else {}),
                 **(
                     {
                         "reference_queue_size": {

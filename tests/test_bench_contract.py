@@ -107,6 +107,8 @@ def test_bench_emits_the_contract_line():
     assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["in_tree_Mrays/s"] <= d["value"]
+    ss = d["config"]["steady_state"]  # the same kernels with the queue kept full, beside the metric (never instead of it)
+    assert ss["Mrays/s"] > 0 and ss["iterations"] == 12 and ss["queue_size"] == d["config"]["queue_size"]
     r = d["roofline"]
     assert 0 < r["frac"] <= 1 and r["bound"] in ("hbm", "valu-issue", "salu-issue") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     if bench.find_rocprof():
