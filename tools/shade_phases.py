@@ -13,7 +13,7 @@ nodes, prims = binding.bvh_build(sc.triangles)
 W, H, SPP = 1920, 1080, 8
 r = binding.Renderer(W, H, W * H * SPP, flags=(binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0) | binding.TYR_FLAG_PROFILE)
 r.load_scene(sc, nodes, prims)
-names = ["load+shade", "ranks+barrier", "look-back", "barrier after it", "copy out+barrier", "stage+pixel atomics"]
+names = ["load+shade", "ranks+barrier", "places (the append atomics of the tile before) arrive", "(unused)", "copy out+barrier", "stage+pixel atomics"]
 for rep in range(2):
     r.reset_accum()
     r.set_budget(W * H * SPP)

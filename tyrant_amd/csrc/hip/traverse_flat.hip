@@ -721,8 +721,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	uint32_t visible = 0;
 	uint32_t dbg[16] = {};
 	uint32_t steps = 0; // TYR_QUAD_STATS: quad steps of this lane's current ray
-	unsigned long long tExhausted = 0ull, tWide = 0ull;
-	uint32_t liveAtExhaustion = 0, liveAtWide = 0, tripsAfter = 0, passesAfter = 0, wideSteps = 0; // (anatomy build)
+	[[maybe_unused]] unsigned long long tExhausted = 0ull, tWide = 0ull;
+	[[maybe_unused]] uint32_t liveAtExhaustion = 0, liveAtWide = 0, tripsAfter = 0, passesAfter = 0, wideSteps = 0; // (anatomy build)
 	const unsigned long long tStart = kAnatomy ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	// kernel.cu:640-644, deferred to the wave's next refill (see k_connect_count)
 	constexpr uint32_t kNoPending = 0xffffffffu;
@@ -829,10 +829,6 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 				// an extend ray that misses the root box is finished here (the pre-pass's answer stands, nothing to write); a
 				// shadow ray a sphere blocks likewise; a shadow ray that misses the tree is visible: it retires below
 				live = (ref != kRefDone) || (isShadow && !blocked);
-#ifdef TYR_RAY_STEPS
-				if (!live && s < P.N)
-					P.next.hit[s] = make_float2(0.0f, isShadow ? 1.0f : 0.0f); // never entered the tree
-#endif
 			}
 			if (!exhausted && (uint32_t)__popcll(__ballot(live && ref != kRefDone)) < P.minTraversing)
 				if (__ballot(live && ref == kRefDone) == 0ull)
@@ -935,15 +931,6 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 					atomicAdd(&P.k->debug[10], 1ull);
 				if (steps > 256)
 					atomicAdd(&P.k->debug[11], 1ull);
-#ifdef TYR_RAY_STEPS
-				// per-ray record for tools/ray_length_probe.py (with -DTYR_QUAD_STATS), parked in the NEXT queue's hit column
-				// like the per-wave records of the anatomy build: quad steps of item s (shadow rays behind the extend rays)
-				{
-					const uint32_t item = isShadow ? nExt + slot : slot;
-					if (item < P.N)
-						P.next.hit[item] = make_float2((float)steps, isShadow ? 1.0f : 0.0f);
-				}
-#endif
 				steps = 0;
 			}
 		}
@@ -974,10 +961,9 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		atomicMax(&P.k->debug[13], ~tStart);
 		atomicMax(&P.k->debug[14], ~(tExhausted ? tExhausted : tEnd));
 		atomicMax(&P.k->debug[15], tEnd);
-		// per-wave record for tools/drain_profile.py, parked in an array nobody uses during this launch (the NEXT queue's
+		// per-wave records for host/driver.cpp's TYR_ANATOMY=2 printout, parked in an array nobody uses during this launch (the NEXT queue's
 		// hit column): microseconds from this wave's start to "queue used up" and to its exit, and how many of its lanes
 		// still held a ray when the queue ran out
-#ifndef TYR_RAY_STEPS // (that build keeps per-RAY records in the same column)
 		const uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 		if (w < P.N)
 			P.next.hit[w] = make_float2((float)((tExhausted ? tExhausted : tEnd) - tStart) * 0.01f, (float)(tEnd - tStart) * 0.01f + (float)liveAtExhaustion * 0.0f);
@@ -986,7 +972,6 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 			P.next.hit[16384u + w] = make_float2((float)tripsAfter, (float)wideSteps); // trips after the queue ran out one ray to a lane, steps four lanes to a ray
 			P.next.hit[24576u + w] = make_float2((float)passesAfter, 0.0f);
 		}
-#endif
 	}
 }
 

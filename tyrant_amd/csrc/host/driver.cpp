@@ -839,7 +839,7 @@ int tyr_sync(tyr_ctx* c) {
 // one stream, done when it returns (kernel.cu:719-733).  Inside tyr_render (pipelined, merged launches) connect(i) rides in
 // the traversal launch of iteration i + 1 and the call returns as soon as shade's counts are on the host.
 #ifdef TYR_LAUNCH_ANATOMY
-// TYR_ANATOMY=2: the per-wave records k_trace_flat's anatomy build leaves in the next queue's hit column (tools/drain_profile.py)
+// TYR_ANATOMY=2: the per-wave records k_trace_flat's anatomy build leaves in the next queue's hit column
 static void print_wave_anatomy(const float2* dHit, unsigned long long feedTicks) {
 	std::vector<float2> rec(4 * 8192);
 	if (hipMemcpy(rec.data(), dHit, rec.size() * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess)
