@@ -738,7 +738,7 @@ def main():
                 "shadow_Mrays/s": round(m["shd_all"] / m["dt_all"] / 1e6, 3),
                 "in_tree_Mrays/s": round(mrays * m["in_tree_frac"], 3),
                 "in_tree_fraction": {"all_rays": round(m["in_tree_frac"], 4), "extend_rays": round(m["in_tree_ext_frac"], 4), "note": "rays whose test of the root box passes (counting build, rank 0's shard); the others cost one box test"},
-                "host_bvh_build_s": round(t_build, 3),
+                "host_bvh_build_s": round(t_build, 6),
                 **({"tuning": tune} if tune else {}),
                 **({"steady_state": steady} if steady else {}),
                 **(
@@ -832,7 +832,7 @@ def cpu_baseline(sc, W, H, N, iterations, tri_materials, spp):
     hits_port = int(hit_p.sum())
     trace = {
         "ray_set": f"the first {n} rays of iteration {iterations + 1}'s queue (survivors of {iterations} bounces in front, fresh primary rays behind), BVH only",
-        "port": {"value": round(n / dtp / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port", "seconds": round(dtp, 2), "hits": int(hits_port), "note": "orc_bvh_intersect_batch (the oracle's restatement of bvh.h:118-161), one call for the batch"},
+        "port": {"value": round(n / dtp / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port", "seconds": round(dtp, 6), "hits": int(hits_port), "note": "orc_bvh_intersect_batch (the oracle's restatement of bvh.h:118-161), one call for the batch"},
     }
     R = pyorc.ref()
     if R is not None:
@@ -842,17 +842,17 @@ def cpu_baseline(sc, W, H, N, iterations, tri_materials, spp):
         R.ref_bvh_intersect(nd.ctypes.data_as(ctypes.c_void_p), pr.ctypes.data_as(ctypes.c_void_p), qb.ctypes.data_as(ctypes.c_void_p), n, hit.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), None)
         dtr = time.perf_counter() - t0
         same = bool(np.array_equal(qa["distance"].view(np.uint32), qb["distance"].view(np.uint32)))
-        trace["reference"] = {"value": round(n / dtr / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference", "seconds": round(dtr, 2), "hits": int(hit.sum()),
+        trace["reference"] = {"value": round(n / dtr / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference", "seconds": round(dtr, 6), "hits": int(hit.sum()),
                               "note": "CachedBVH::intersect of the reference's bvh.h (oracle/_ref/libref_traverse.so), one call for the batch", "distances_bit_identical_to_port": same}
     # the reference's own builder on the same triangles (bvh.cpp:3-225 compiled into oracle/_ref), beside the port's
-    builds = {"port": round(t_build, 3)}
+    builds = {"port": round(t_build, 6), "port_us": round(t_build * 1e6, 1)}  # full precision: a 36-triangle tree builds in 0.2 ms (round 3 rounded this to 0.0)
     if R is not None and hasattr(R, "ref_bvh_build"):
         tp = np.ascontiguousarray(sc.triangles.copy())
         bb = np.ascontiguousarray(scenes.triangle_bboxes(sc.triangles))
         nd2 = np.zeros(max(2 * tp.shape[0] - 1, 1), dtype=scenes.NODE_DTYPE)
         t0 = time.perf_counter()
         nn = R.ref_bvh_build(tp.ctypes.data, tp.shape[0], bb.ctypes.data, nd2.ctypes.data, 2)
-        builds["reference"] = round(time.perf_counter() - t0, 3)
+        builds["reference"] = round(time.perf_counter() - t0, 6)
         builds["reference_nodes_identical_to_port"] = bool(nn == nodes.shape[0] and nd2[:nn].tobytes() == nodes.tobytes())
     # lead with the like-for-like figure: ONE ray set through the reference's own traversal (else the port's)
     lead = trace.get("reference", trace["port"])

@@ -116,7 +116,9 @@ def test_bench_emits_the_contract_line():
         assert r["traffic"] is not None and 0 < r["hbm_counter_frac"] <= 1 and 0 < r["valu_issue_frac"] <= 1
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["trace_same_ray_set"]["port"]["value"] > 0
-    assert c["whole_path_first_iterations"]["value"] > 0 and c["bvh_build_s"]["port"] > 0
+    # timings of this micro-job sit at the resolution of the clock and of the line's rounding: presence and sign only
+    # (round 3: `bvh_build_s.port > 0` on a 0.2 ms build rounded to 3 places was a coin flip that hid every parity test)
+    assert c["whole_path_first_iterations"]["value"] >= 0 and c["bvh_build_s"]["port"] >= 0 and "port_us" in c["bvh_build_s"]
 
 
 @pytest.mark.gpu
