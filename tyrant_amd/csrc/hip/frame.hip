@@ -208,8 +208,10 @@ __global__ void __launch_bounds__(kBlock) k_extend_spheres(const FrameParams P) 
 // The same for an iteration whose sphere pre-pass does not run (no survivors: a render's first wavefront): the slots at
 // the ends of the eight segments that hold no record become rays that enter nothing.  Block w does segment w; what == 0:
 // class 0 of the work queue, 1: the shadow queue (unused: its pre-pass always runs).
-__global__ void __launch_bounds__(kBlock) k_pad_holes(const FrameParams P, uint32_t workQueue, uint32_t shadowQueue) {
+__global__ void __launch_bounds__(kBlock) k_pad_holes(const FrameParams P, uint32_t workQueue, uint32_t shadowQueue, uint32_t resetTickets) {
 	const uint32_t w = blockIdx.x & (kSegs - 1u), what = blockIdx.x / kSegs;
+	if (resetTickets && blockIdx.x == 0 && threadIdx.x < kTicketWords)
+		P.k->extend_chunks[threadIdx.x * 32] = 0; // k_trace_flat's tickets, when no connect pre-pass opens the launch that ends a render (P.foldSpheres)
 	if ((what == 0 && !workQueue) || (what == 1 && !shadowQueue))
 		return;
 	const uint32_t* cnt = what == 0 ? P.segWork : P.kc->seg;
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P)
 constexpr uint32_t kScanBlockSlots = 64u * kBlock;
 __global__ void __launch_bounds__(kBlock) k_scan_words(const FrameParams P) {
 	__shared__ uint32_t waveSum[kBlock / 64];
-	const uint32_t n = P.k->n_live;
+	const uint32_t n = *P.scanLive; // &k->n_live, or the streamed tail's StreamIter::nLive
 	const uint32_t e = blockIdx.x * kBlock + threadIdx.x, first = e * 64u;
 	if (blockIdx.x * kScanBlockSlots >= n)
 		return; // (the whole block: the host sized the grid from an upper bound)
@@ -349,6 +351,49 @@ __global__ void __launch_bounds__(kBlock) k_scan_words(const FrameParams P) {
 			carrySh += total2;
 		__syncthreads();
 	}
+}
+
+// ======================================================================================
+// The streamed tail's first iteration (kernels.hpp "the STREAMED TAIL"): what set_wavefront_globals (kernel.cu:227-244) does
+// for an iteration without a top-up, and the iteration's StreamIter -- closed from the start: its rays were made by a
+// shade LAUNCH that has ended.  One wave.  (The StreamState has been zeroed by the host.)
+// ======================================================================================
+__global__ void __launch_bounds__(64) k_stream_begin(const FrameParams P, uint32_t traceShadowPrev) {
+	const uint32_t i = threadIdx.x;
+	StreamIter* const I = &P.stream->it[0];
+	uint32_t n = 0, h = 0;
+	if (i < kClasses * kSegs) {
+		const uint32_t c = i / kSegs, w = i % kSegs;
+		n = P.segWork[c * kClassWords + w * kSegStride];
+		I->segWork[c][w] = n;
+		P.segNext[c * kClassWords + w * kSegStride] = 0; // what this iteration's shade appends to
+	}
+	if (i < kSegs) {
+		h = traceShadowPrev ? P.kcPrev->seg[i * kSegStride] : 0u;
+		I->segShadowPrev[i] = h;
+		P.kc->seg[i * kSegStride] = 0;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		n += __shfl_xor(n, o, 64);
+		h += __shfl_xor(h, o, 64);
+	}
+	if (i == 0) {
+		I->nLive = n;
+		I->nShadowPrev = h;
+		DevCounters* k = P.k;
+		k->n_live = n;
+		k->total_extend_rays += n;
+		k->primary_ray_cnt = 0;
+		k->shadow_ray_cnt = 0;
+		k->scan_blocks_done = 0;
+		P.kc->shadow_cnt = 0;
+		__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		I->closed = 1u;
+	}
+}
+void launch_stream_begin(const FrameParams& P, bool traceShadowPrev, hipStream_t stream) {
+	hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(64), 0, stream, P, traceShadowPrev ? 1u : 0u);
 }
 
 // ======================================================================================
@@ -488,8 +533,8 @@ __global__ void __launch_bounds__(kBlock) k_extend_debug(const FrameParams P) {
 // ---- launch wrappers ---------------------------------------------------------------------
 
 constexpr uint32_t kPrepassMaxBlocks = 8192; // 8 waves of 256 threads per SIMD of a 256-CU part: enough to stream at full rate
-void launch_pad_holes(const FrameParams& P, bool workQueue, bool shadowQueue, hipStream_t stream) {
-	hipLaunchKernelGGL(k_pad_holes, dim3(2 * kSegs), dim3(kBlock), 0, stream, P, workQueue ? 1u : 0u, shadowQueue ? 1u : 0u);
+void launch_pad_holes(const FrameParams& P, bool workQueue, bool shadowQueue, hipStream_t stream, bool resetTickets) {
+	hipLaunchKernelGGL(k_pad_holes, dim3(2 * kSegs), dim3(kBlock), 0, stream, P, workQueue ? 1u : 0u, shadowQueue ? 1u : 0u, resetTickets ? 1u : 0u);
 }
 void launch_primary(const FrameParams& P, uint32_t maxNew, hipStream_t stream) {
 	// always launched: its last block is set_wavefront_globals

@@ -19,6 +19,10 @@ struct ShadeOut {
 	float sClosest;
 	f3 color;                      // kernel.cu:622-625: contribution to the pixel, added at the end of the kernel
 	int newFrame;
+	// P.foldSpheres: the sphere half of the NEXT stage for the rays this one emits, while they are in registers (what
+	// k_extend_spheres / k_connect_spheres would re-read them for: kernel.cu:127-136, 168-172)
+	float2 hitRec;                 // survivor: closest sphere (distance, id | kHitSphere) or VERY_FAR
+	float sBlocked;                // shadow ray: 1 = a sphere occludes it
 };
 
 // NEE toward spheres[6], kernel.cu:419-447 / 559-590 (common part)
@@ -370,9 +374,16 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 			bounces++;
 			direct = direct * (1.0f / p);
 			out.survive = true;
-			// the traversal's own first test on the new ray, without the sphere bound it does not have yet (a bound only
-			// takes rays away): a ray that fails it can never enter the tree and goes to class 1
-			out.tree = P.scene.rootRef != kRefDone && root_ref(P.scene, make_ray(origin, direction), kVeryFar) != kRefDone;
+			// the traversal's own first test on the new ray: a ray that fails it can never enter the tree and goes to class 1.
+			// Without the sphere pre-pass's distance as bound when a pre-pass follows (a bound only takes rays away); with it
+			// when this kernel does the pre-pass's work itself (k_primary's form: same function, same bound, same answer
+			// as root_ref at the traversal's refill)
+			float bound = kVeryFar;
+			if (P.foldSpheres) {
+				out.hitRec = sphere_hit_record(P, origin, direction);
+				bound = out.hitRec.x;
+			}
+			out.tree = P.scene.rootRef != kRefDone && root_ref(P.scene, make_ray(origin, direction), bound) != kRefDone;
 			out.origin = origin;
 			out.direction = direction;
 			out.direct = direct;
@@ -384,6 +395,16 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 		new_frame++;
 	}
 
+	out.sBlocked = 0.0f;
+	if (P.foldSpheres && out.shadow) { // kernel.cu:168-172 (k_connect_spheres' test, on the ray in registers)
+		bool occluded = false;
+#pragma unroll
+		for (int i = TYR_NUM_SPHERES; i--;) {
+			const float t = sphere_intersect(P.spheres[i], out.sOrigin, out.sDir);
+			occluded = occluded || (t && (t + kEpsilon) < out.sClosest);
+		}
+		out.sBlocked = occluded ? 1.0f : 0.0f;
+	}
 	out.color = color;
 	out.newFrame = new_frame;
 }
@@ -394,6 +415,7 @@ struct ShadeStage { // one tile's output, waiting for the tile's place in the qu
 	float4 sv_direct_ix[kBlock];
 	uint32_t sv_flags[kBlock];
 	uint32_t sv_key[kBlock];
+	float2 sv_hit[kBlock];   // (P.foldSpheres) the survivor's sphere record
 	float4 sh_o_dx[kBlock];
 	float4 sh_dyz_cd_ix[kBlock];
 	float4 sh_color[kBlock];
@@ -414,12 +436,21 @@ struct ShadeStage { // one tile's output, waiting for the tile's place in the qu
 // queue on the counter of segment (tile / 2) % 8, issued as soon as the tile's counts are known; the records wait in LDS at
 // their rank inside the tile and leave as coalesced stores (thread t writes record t) AFTER the next tile has been
 // shaded -- by then the atomics have long returned.
-template <bool LIGHTS>
+//
+// STREAM = the streamed tail's form (kernels.hpp "the STREAMED TAIL"): this launch shades ONE iteration while k_trace_stream
+// -- resident beside it -- is still tracing it: a class-0 tile is shaded once the traversal has finished its rays
+// (done[tile]), class 1 (nothing to wait for) goes first; the records it emits for the traversal are stored sc1 and
+// published chunk by chunk (fill[chunk]); the block that finishes last closes the next iteration (StreamIter).
+template <bool LIGHTS, bool STREAM>
 __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const FrameParams P) {
 	__shared__ uint32_t sh[32];
 	__shared__ ShadeStage stage;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u, wave = tid >> 6;
+	StreamIter* const SI = STREAM ? &P.stream->it[P.streamIter] : nullptr;
+	if (STREAM && P.stream->ended)
+		return; // the render ended in an earlier iteration (the host queues a launch per iteration the tail can have)
+	bool gaveUp = false; // STREAM: a wait ran into its bound (kErrNoProgress is raised): leave without shading further tiles
 	// class 0's tiles, then class 1's (from the device's counts: the host may have sized the grid from an upper bound)
 	const uint32_t tiles0 = queue_extent(P.segWork) / kBlock;
 	const uint32_t nTiles = tiles0 + queue_extent(P.segWork + kClassWords) / kBlock;
@@ -450,11 +481,22 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			const uint32_t base = isTree ? baseT : baseK;
 			if (tid < prevS && base != 0xffffffffu) {
 				const uint32_t d = isTree ? seg_phys(prevSeg, base + tid) : P.classStride + seg_phys(prevSeg, base + (tid - prevT));
-				P.next.o_dx[d] = stage.sv_o_dx[tid];
+				const bool through = STREAM && isTree; // what the traversal kernel reads while this launch is still running: write-through
+				if (through) {
+					st_sc1_f4(&P.next.o_dx[d], stage.sv_o_dx[tid]);
+					st_sc1_f2(&P.next.dyz[d], stage.sv_dyz[tid]);
+					st_sc1_f2(&P.next.hit[d], stage.sv_hit[tid]);
+				} else {
+					P.next.o_dx[d] = stage.sv_o_dx[tid];
+				}
 				__asm__ volatile("" ::: "memory");
 				P.next.direct_ix[d] = stage.sv_direct_ix[tid];
 				__asm__ volatile("" ::: "memory");
-				P.next.dyz[d] = stage.sv_dyz[tid];
+				if (!through) {
+					P.next.dyz[d] = stage.sv_dyz[tid];
+					if (P.foldSpheres)
+						P.next.hit[d] = stage.sv_hit[tid];
+				}
 				P.next.flags[d] = stage.sv_flags[tid];
 				P.next.key[d] = stage.sv_key[tid];
 			}
@@ -462,31 +504,80 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		__asm__ volatile("" ::: "memory");
 		if (tid < prevH && baseH != 0xffffffffu) {
 			const uint32_t d = seg_phys(prevSeg, baseH + tid);
-			P.shadow.o_dx[d] = stage.sh_o_dx[tid];
-			__asm__ volatile("" ::: "memory");
-			P.shadow.dyz_cd_ix[d] = stage.sh_dyz_cd_ix[tid];
-			__asm__ volatile("" ::: "memory");
-			P.shadow.color[d] = stage.sh_color[tid];
+			if (STREAM) {
+				st_sc1_f4(&P.shadow.o_dx[d], stage.sh_o_dx[tid]);
+				st_sc1_f4(&P.shadow.dyz_cd_ix[d], stage.sh_dyz_cd_ix[tid]);
+				st_sc1_f4(&P.shadow.color[d], stage.sh_color[tid]);
+			} else {
+				P.shadow.o_dx[d] = stage.sh_o_dx[tid];
+				__asm__ volatile("" ::: "memory");
+				P.shadow.dyz_cd_ix[d] = stage.sh_dyz_cd_ix[tid];
+				__asm__ volatile("" ::: "memory");
+				P.shadow.color[d] = stage.sh_color[tid];
+			}
 			P.shadow.key[d] = stage.sh_key[tid];
 		}
+		if (STREAM)
+			__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave, before anybody signals for it
 		__syncthreads(); // `stage` and sh[] are free again
+		if (STREAM) {
+			// publish: the records [base, base + n) of segment prevSeg lie in the chunks of rows base / 64 .. (base + n - 1) / 64
+			// (at most five); one thread per chunk adds what this tile wrote there
+			auto publish = [&](uint32_t* fill, uint32_t base, uint32_t n, uint32_t k) {
+				if (n == 0u || base == 0xffffffffu)
+					return;
+				const uint32_t row = (base >> 6) + k, lastRow = (base + n - 1u) >> 6;
+				if (row > lastRow)
+					return;
+				const uint32_t lo = base > row * 64u ? base : row * 64u, hi = base + n < (row + 1u) * 64u ? base + n : (row + 1u) * 64u;
+				__hip_atomic_fetch_add(&fill[row * kSegs + prevSeg], hi - lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			};
+			if (tid < 8u)
+				publish(P.fillNext, baseT, prevT, tid);
+			else if (tid >= 64u && tid < 72u)
+				publish(P.fillShadow, baseH, prevH, tid - 64u);
+		}
 		TYR_STAMP(4)
 	};
 
 	uint32_t word = blockIdx.x % kTicketWords, tried = 0;
-	uint32_t* const tickets = P.k->shade_tiles;
+	uint32_t* const tickets = STREAM ? SI->shadeTiles : P.k->shade_tiles;
 	auto draw_tile = [&]() -> uint32_t { // block-uniform; nTiles when nothing is left
 		uint32_t vbNext = nTiles;
 		if (tid == 0) {
-			while (tried < kTicketWords) {
+			while (tried < kTicketWords && !gaveUp) {
 				const uint32_t t = atomicAdd(&tickets[word * 32], 1u);
 				const unsigned long long cand = (unsigned long long)t * kTicketWords + word;
 				if (cand < nTiles) {
 					vbNext = (uint32_t)cand;
+					if (STREAM) // class 1 first (its rays wait for nobody), then class 0 in the order the traversal hands it out
+						vbNext = vbNext < nTiles - tiles0 ? vbNext + tiles0 : vbNext - (nTiles - tiles0);
 					break;
 				}
 				word = (word + 1) % kTicketWords;
 				++tried;
+			}
+			if (STREAM && vbNext < tiles0) {
+				// the traversal's answers for this tile: done[tile] counts the rays it has finished (agent-scope adds behind the
+				// storing wave's vmcnt(0)); the barrier below stands between this poll and every load of the answers
+				const uint32_t s0 = vbNext * kBlock;
+				uint32_t want = 0;
+#pragma unroll
+				for (uint32_t q = 0; q < 4u; ++q)
+					want += chunk_valid(P.segWork, s0 + 64u * q);
+				const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+				uint32_t polls = 0;
+				while (ld_sc1_u32(&P.doneWork[vbNext]) != want) {
+					__builtin_amdgcn_s_sleep(8);
+					if ((++polls & 63u) == 0u && (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks || ld_sc1_u32(&P.k->device_error) != 0u)) {
+						atomicOr(&P.k->device_error, kErrNoProgress);
+						vbNext = nTiles;
+						gaveUp = true;
+						break;
+					}
+				}
+				if (!gaveUp)
+					st_sc1_u32(&P.doneWork[vbNext], 0u); // the counter is its reader's to reset (the slot's next use is two iterations away)
 			}
 			sh[3] = vbNext;
 		}
@@ -514,7 +605,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		const bool valid = lane < chunk_valid(P.segWork + cls * kClassWords, inClass & ~63u);
 		float2 hitRecord = make_float2(kVeryFar, 0.f);
 		if (valid)
-			hitRecord = P.work.hit[slot];
+			hitRecord = (STREAM && cls == 0u) ? ld_sc1_f2(&P.work.hit[slot]) : P.work.hit[slot];
 		if (valid)
 			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
 		shade_ray<LIGHTS>(P, slot, valid, hitRecord, out, vslot, flush_pixels);
@@ -593,12 +684,14 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			stage.sv_direct_ix[k] = make_float4(out.direct.x, out.direct.y, out.direct.z, __uint_as_float(pixelBits));
 			stage.sv_flags[k] = out.flags;
 			stage.sv_key[k] = vslot | kKeyIndirect; // next iteration's slot = rank of vslot among this iteration's survivors
+			if (P.foldSpheres)
+				stage.sv_hit[k] = out.hitRec;
 		}
 		if (out.shadow) {
 			const uint32_t k = wh + rh;
 			stage.sh_o_dx[k] = make_float4(out.sOrigin.x, out.sOrigin.y, out.sOrigin.z, out.sDir.x);
 			stage.sh_dyz_cd_ix[k] = make_float4(out.sDir.y, out.sDir.z, out.sClosest, __uint_as_float(pixelBits));
-			stage.sh_color[k] = make_float4(out.sColor.x, out.sColor.y, out.sColor.z, 0.0f);
+			stage.sh_color[k] = make_float4(out.sColor.x, out.sColor.y, out.sColor.z, out.sBlocked); // .w: the connect pre-pass's verdict (0 when a pre-pass follows and writes it)
 			stage.sh_key[k] = vslot;
 		}
 		havePrev = true;
@@ -623,6 +716,70 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	}
 	// kernel.cu:607 / 416: the totals the next top-up and connect read.  Every block adds what it appended; the block
 	// that finishes last publishes the per-iteration figures.
+	if (STREAM) {
+		// The block that finishes last closes the NEXT iteration for the traversal kernel: final counts, then the flag.  Its
+		// own records and fill adds are out (flush_prev waits and publishes); the other blocks' likewise before they counted
+		// as done.
+		if (tid == 0) {
+			__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (atomicAdd(&SI->shadeBlocksDone, 1u) + 1u == P.shadeBlocks && !gaveUp && ld_sc1_u32(&P.k->device_error) == 0u) {
+				StreamIter* const NI = SI + 1; // (P.streamIter + 1 < kStreamMaxIters: the host queues at most kMaxBounces + 1 of these launches)
+				uint32_t s = 0, h = 0;
+				for (uint32_t c = 0; c < kClasses; ++c)
+					for (uint32_t w = 0; w < kSegs; ++w) {
+						const uint32_t n = ld_sc1_u32(&P.segNext[c * kClassWords + w * kSegStride]);
+						st_sc1_u32(&NI->segWork[c][w], n);
+						s += n;
+					}
+				for (uint32_t w = 0; w < kSegs; ++w) {
+					const uint32_t n = ld_sc1_u32(&P.kc->seg[w * kSegStride]);
+					st_sc1_u32(&NI->segShadowPrev[w], n);
+					h += n;
+				}
+				st_sc1_u32(&NI->nLive, s);
+				st_sc1_u32(&NI->nShadowPrev, h);
+				// the iteration's totals (what set_wavefront_globals and the last shade block keep in the launch-per-iteration path)
+				P.k->n_live = SI->nLive;
+				P.k->shadow_ray_cnt = h;
+				P.k->total_shadow_rays += h;
+				P.k->n_survive += s;
+				P.k->total_extend_rays += s;
+				// what the next iteration's shade appends to: this iteration's work queue (two iterations on it is `next` again)
+				// and the other set of shadow counters; nobody reads either any more (every shade block is done, the traversal
+				// kernel works from the StreamIter copies)
+				for (uint32_t c = 0; c < kClasses; ++c)
+					for (uint32_t w = 0; w < kSegs; ++w)
+						st_sc1_u32(&P.segWork[c * kClassWords + w * kSegStride], 0u);
+				for (uint32_t w = 0; w < kSegs; ++w)
+					st_sc1_u32(&P.kcPrev->seg[w * kSegStride], 0u);
+				P.k->scan_blocks_done = 0;
+				// the shadow rays that were traced beside this iteration's rays lie in the buffers the next iteration's shade
+				// writes: it may not start (= this launch may not end) before the traversal has finished them
+				{
+					const uint32_t want = SI->nShadowPrev;
+					const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+					uint32_t polls = 0;
+					while (ld_sc1_u32(&SI->shadowDone) != want) {
+						__builtin_amdgcn_s_sleep(8);
+						if ((++polls & 63u) == 0u && (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks || ld_sc1_u32(&P.k->device_error) != 0u)) {
+							atomicOr(&P.k->device_error, kErrNoProgress);
+							break;
+						}
+					}
+				}
+				__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				st_sc1_u32(&NI->closed, 1u);
+				if (s == 0u) {
+					// no survivors: the next iteration is the last shadow rays alone (or nothing); the one after it is empty and
+					// closed (its counts are the zeros the tail started with) -- the traversal kernel ends there
+					if (h != 0u && P.streamIter + 2u < kStreamMaxIters)
+						st_sc1_u32(&(NI + 1)->closed, 1u);
+					st_sc1_u32(&P.stream->ended, 1u);
+				}
+			}
+		}
+		return;
+	}
 	if (tid == 0) {
 		if (mySurvivors)
 			atomicAdd(&P.k->primary_ray_cnt, mySurvivors);
@@ -665,7 +822,7 @@ uint32_t shade_grid(const FrameParams& P, uint32_t maxSlots, int numCUs, LaunchC
 	int* perCU = lc.perCU[kLcShade]; // [0] default kernel, [1] the light-list instantiation
 	if (perCU[lights] == 0) {
 		int q = 0;
-		const hipError_t e = lights ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<true>, kBlock, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<false>, kBlock, 0);
+		const hipError_t e = lights ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<true, false>, kBlock, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<false, false>, kBlock, 0);
 		if (e != hipSuccess || q < 1)
 			q = 2;
 		perCU[lights] = q > 6 ? 6 : q;
@@ -677,9 +834,21 @@ void launch_shade(const FrameParams& P0, uint32_t maxSlots, int numCUs, LaunchCa
 	FrameParams P = P0;
 	P.shadeBlocks = shade_grid(P, maxSlots, numCUs, lc);
 	if (P.flags & TYR_FLAG_LIGHT_LIST)
-		hipLaunchKernelGGL(k_shade<true>, dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
+		hipLaunchKernelGGL((k_shade<true, false>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
 	else
-		hipLaunchKernelGGL(k_shade<false>, dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
+		hipLaunchKernelGGL((k_shade<false, false>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
+}
+// one iteration of the streamed tail: resident beside the traversal kernel (blocksPerCU blocks per CU; the grid must
+// not exceed what fits there, or its late blocks would only start when the early ones -- which wait for the traversal -- end:
+// slower, never wrong, every wait is bounded)
+void launch_shade_stream(const FrameParams& P0, int blocksPerCU, int numCUs, hipStream_t stream) {
+	FrameParams P = P0;
+	P.shadeBlocks = (uint32_t)(blocksPerCU < 1 ? 1 : blocksPerCU) * (uint32_t)numCUs;
+	P.foldSpheres = 1u;
+	if (P.flags & TYR_FLAG_LIGHT_LIST)
+		hipLaunchKernelGGL((k_shade<true, true>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
+	else
+		hipLaunchKernelGGL((k_shade<false, true>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
 }
 
 } // namespace tyr

@@ -992,11 +992,17 @@ void launch_trace_kernel(const FrameParams& P, uint32_t items, const Tuning& t, 
 	hipLaunchKernelGGL((k_trace_flat<TYR_TRACE_STACK>), dim3(persistent_blocks(k_trace_flat<TYR_TRACE_STACK>, items, t, numCUs, lc.perCU[kLcTrace][0])), dim3(kBlock), 0, stream, P);
 }
 void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream) {
-	if (P.traceShadow != 2u)
-		launch_extend_spheres(P, nSurvivors, stream);
 	FrameParams Pc = P;
 	Pc.kc = P.kcPrev;
 	Pc.shadow = P.shadowPrev;
+	if (P.prevFolded) {
+		// the sphere halves were done by the shade launch that made these rays (P.foldSpheres there): only the holes at the
+		// segments' ends are left, of the work queue's class 0 and of the shadow queue in one launch
+		launch_pad_holes(Pc, P.traceShadow != 2u, maxShadowPrev != 0, stream, P.traceShadow == 2u);
+		return;
+	}
+	if (P.traceShadow != 2u)
+		launch_extend_spheres(P, nSurvivors, stream);
 	if (maxShadowPrev != 0)
 		launch_connect_spheres(Pc, maxShadowPrev, stream);
 	if (P.traceShadow != 2u && nSurvivors == 0)

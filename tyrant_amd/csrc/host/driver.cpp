@@ -154,6 +154,16 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.segCap = c->segCap;
 	P.classStride = c->segCap * tyr::kSegs;
 	P.survFlag = c->survFlag;
+	P.scanLive = &c->dK->n_live;
+	P.foldSpheres = 0u;
+	P.stream = c->dStream;
+	P.streamIter = 0u;
+	P.fillWork = c->fillRay[c->cur];
+	P.fillNext = c->fillRay[c->cur ^ 1];
+	P.fillShadow = c->fillSh[c->iter & 1u];
+	P.fillShadowPrev = c->fillSh[(c->iter ^ 1u) & 1u];
+	P.doneWork = c->doneRay[c->cur];
+	P.doneNext = c->doneRay[c->cur ^ 1];
 	{
 		const int out = static_cast<int>(c->iter & 1u), prev = out ^ 1;
 		P.vPrev = tyr::VTable{ c->vWord[prev], c->vPre[prev], c->vBlk[prev] };
@@ -265,7 +275,9 @@ void enqueue_primary(tyr_ctx* c, const FrameParams& P, uint32_t nNew) {
 }
 // nSurvivors: how many of the nLive rays were in the queue before this iteration's primary rays (they still need their
 // sphere pre-pass)
-void enqueue_extend(tyr_ctx* c, const FrameParams& P, uint32_t nLive, uint32_t nSurvivors) {
+void enqueue_extend(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t nSurvivors) {
+	FrameParams P = P0;
+	P.prevFolded = c->lastShadeFolded ? 1u : 0u;
 	KernelTimer t(c, TYR_K_EXTEND);
 	if (c->cfg.flags & TYR_FLAG_DEBUG_BVH) { // the reference's BVH_DEBUG build: kernel.cu:721-722
 		launch_extend_debug(P, c->segCap * tyr::kSegs * tyr::kClasses, c->stream);
@@ -277,17 +289,21 @@ void enqueue_extend(tyr_ctx* c, const FrameParams& P, uint32_t nLive, uint32_t n
 void enqueue_trace(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t nSurvivors, uint32_t maxShadowPrev) {
 	FrameParams P = P0;
 	P.traceShadow = maxShadowPrev != 0 ? 1u : 0u;
+	P.prevFolded = c->lastShadeFolded ? 1u : 0u;
 	KernelTimer t(c, TYR_K_EXTEND);
 	launch_trace(P, nLive, nSurvivors, maxShadowPrev, c->tuning, c->numCUs, c->launchCache, c->stream);
 }
 // shade, then the scan that turns its survive bytes into the next iteration's slots
 void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	c->shadowSet = c->iter & 1u;
+	c->lastShadeFolded = P.foldSpheres != 0u;
 	KernelTimer t(c, TYR_K_SHADE);
 	launch_shade(P, nLive, c->numCUs, c->launchCache, c->stream);
 	launch_scan(P, nLive, c->stream);
 }
-void enqueue_connect(tyr_ctx* c, const FrameParams& P, uint32_t maxShadow) {
+void enqueue_connect(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow) {
+	FrameParams P = P0;
+	P.prevFolded = c->lastShadeFolded ? 1u : 0u;
 	KernelTimer t(c, TYR_K_CONNECT);
 	launch_connect(P, maxShadow, (c->cfg.flags & TYR_FLAG_COUNT_VISITS) != 0, c->tuning, c->numCUs, c->launchCache, c->stream);
 }
@@ -454,14 +470,30 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 	}
 	if ((rc = dev_alloc(c->dK, 1)) || (rc = dev_alloc(c->dKc, 2)))
 		return fail(rc);
+	{
+		// the streamed tail's hand-off counters (self-resetting: whoever consumes a chunk / tile zeroes its counter)
+		const size_t chunks = cap / 64 + 8, tiles = cap / 256 + 8;
+		if ((rc = dev_alloc(c->dStream, 1)))
+			return fail(rc);
+		for (int t = 0; t < 2; ++t) {
+			if ((rc = dev_alloc(c->fillRay[t], chunks)) || (rc = dev_alloc(c->fillSh[t], chunks)) || (rc = dev_alloc(c->doneRay[t], tiles)))
+				return fail(rc);
+			if (hipMemset(c->fillRay[t], 0, chunks * 4) != hipSuccess || hipMemset(c->fillSh[t], 0, chunks * 4) != hipSuccess || hipMemset(c->doneRay[t], 0, tiles * 4) != hipSuccess)
+				return fail(TYR_ERR_NO_DEVICE);
+		}
+		if (hipHostMalloc(reinterpret_cast<void**>(&c->hStream), sizeof(StreamState), hipHostMallocDefault) != hipSuccess)
+			return fail(TYR_ERR_OOM);
+		if (hipEventCreateWithFlags(&c->evTail, hipEventDisableTiming) != hipSuccess)
+			return fail(TYR_ERR_NO_DEVICE);
+	}
 	if (hipMemset(c->dKc, 0, 2 * sizeof(ConnectCounters)) != hipSuccess)
 		return fail(TYR_ERR_NO_DEVICE);
 	{
-		// the side stream carries the shade launch that runs BESIDE a traversal launch: lowest priority, so that its blocks
-		// only take what the traversal grid leaves free (nothing until traversal blocks retire) instead of displacing it
+		// the side stream carries the streamed tail's shade and scan launches, which run BESIDE the traversal kernel (the
+		// traversal grid leaves room for them: four of its blocks per CU instead of five)
 		int least = 0, greatest = 0;
 		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-		if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess)
+		if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, greatest) != hipSuccess)
 			return fail(TYR_ERR_NO_DEVICE);
 	}
 	if (cfg->flags & TYR_FLAG_TRIANGLE_COLORS) {
@@ -524,6 +556,16 @@ int tyr_destroy(tyr_ctx* c) {
 	}
 	dev_free(c->dK);
 	dev_free(c->dKc);
+	dev_free(c->dStream);
+	for (int t = 0; t < 2; ++t) {
+		dev_free(c->fillRay[t]);
+		dev_free(c->fillSh[t]);
+		dev_free(c->doneRay[t]);
+	}
+	if (c->hStream)
+		(void)hipHostFree(c->hStream);
+	if (c->evTail)
+		(void)hipEventDestroy(c->evTail);
 	dev_free(c->dNodes);
 	dev_free(c->dQuads);
 	dev_free(c->dTris);
@@ -918,6 +960,8 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 		return rc ? rc : check_device_error(c);
 	}
 	const bool merge = pipelined && merged_render(c);
+	if (merge && c->tuning.foldSpheres)
+		P.foldSpheres = 1u; // this iteration's shade does the sphere halves for the rays it emits
 	enqueue_primary(c, P, nNew);
 	if (merge) { // every traversal launch of a merged render is k_trace_flat; the first one has no shadow rays to carry yet
 		const uint32_t carried = c->shadowPending ? c->shadowPendingMax : 0u;
@@ -1097,6 +1141,97 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 	}
 }
 
+// ---- tyr_render, the streamed tail (TYR_TUNE_STREAM_TAIL; hip/kernels.hpp "the STREAMED TAIL of a render") -----------------
+// Once the budget is spent no iteration tops the queue up any more and each is thinner than the last: as launches they
+// cost a traversal drain (~300 us), a shade launch, a scan and a host round trip apiece.  Here the remaining iterations
+// are queued in one go: k_trace_stream on the ctx stream -- one launch that lives until the render ends -- and, on the side
+// stream, one k_shade_stream + k_scan_words per iteration the tail can still have (a ray that has survived b times ends by
+// iteration kMaxBounces + 1 - b of the tail; launches beyond the render's end return at once).  The host only waits for
+// the two streams and reads how far the tail went.
+constexpr uint32_t kTailLaunches = static_cast<uint32_t>(kMaxBounces) + 1u;
+static bool stream_tail_eligible(const tyr_ctx* c, uint32_t iterationsLeft) {
+#if defined(TYR_QUAD_STATS) || defined(TYR_LAUNCH_ANATOMY)
+	return false; // the instrumented builds stamp k_trace_flat's launches
+#else
+	if (const char* e = std::getenv("TYR_STREAM_TAIL"))
+		if (e[0] == '0')
+			return false;
+	return c->tuning.streamTail != 0 && merged_render(c) && c->blit != nullptr && iterationsLeft >= kTailLaunches && c->hK->budget_remaining == 0 && c->hK->primary_ray_cnt != 0;
+#endif
+}
+static int render_stream_tail(tyr_ctx* c, uint32_t& it) {
+	int rc = stage_begin(c); // (the camera has not moved inside a render: no reset)
+	if (rc)
+		return rc;
+	const size_t chunks = static_cast<size_t>(c->segCap) * tyr::kSegs / 64 + 8, tiles = static_cast<size_t>(c->segCap) * tyr::kSegs / 256 + 8;
+	if (c->streamDirty) {
+		for (int t = 0; t < 2; ++t) {
+			HIPCHK(hipMemsetAsync(c->fillRay[t], 0, chunks * 4, c->stream));
+			HIPCHK(hipMemsetAsync(c->fillSh[t], 0, chunks * 4, c->stream));
+			HIPCHK(hipMemsetAsync(c->doneRay[t], 0, tiles * 4, c->stream));
+		}
+		c->streamDirty = false;
+	}
+	HIPCHK(hipMemsetAsync(c->dStream, 0, sizeof(StreamState), c->stream));
+	const bool carried = c->shadowPending;
+	c->shadowPending = false;
+	const uint32_t frame0 = c->frame, iter0 = c->iter;
+	const int cur0 = c->cur;
+	{
+		FrameParams P = make_params(c);
+		{
+			// the sphere halves of the tail's first iteration, unless the shade launch that made its rays has done them (every
+			// later iteration's are done by k_shade_stream)
+			FrameParams Pp = P;
+			Pp.traceShadow = carried ? 1u : 0u;
+			Pp.prevFolded = c->lastShadeFolded ? 1u : 0u;
+			if (!c->lastShadeFolded)
+				launch_trace_prepasses(Pp, c->hK->primary_ray_cnt, carried ? c->shadowPendingMax : 0u, c->stream);
+		}
+		launch_stream_begin(P, carried, c->stream);
+		HIPCHK(hipEventRecord(c->evTail, c->stream));
+		HIPCHK(hipStreamWaitEvent(c->side, c->evTail, 0));
+		KernelTimer t(c, TYR_K_EXTEND);
+		launch_trace_stream(P, c->tuning.streamTracePerCU, c->numCUs, c->stream);
+	}
+	for (uint32_t jj = 0; jj < kTailLaunches; ++jj) {
+		FrameParams P = make_params(c);
+		P.streamIter = jj;
+		P.scanLive = &c->dStream->it[jj].nLive;
+		launch_shade_stream(P, c->tuning.streamShadePerCU, c->numCUs, c->side);
+		launch_scan(P, c->hK->primary_ray_cnt, c->side); // (an upper bound of every later iteration's rays: nothing is topped up)
+		stage_end(c);
+	}
+	HIPCHK(hipMemcpyAsync(c->hStream, c->dStream, sizeof(StreamState), hipMemcpyDeviceToHost, c->side));
+	HIPCHK(hipGetLastError());
+	const hipError_t e1 = hipStreamSynchronize(c->side), e2 = hipStreamSynchronize(c->stream);
+	// the iterations that had rays of their own are the render's (the one behind them at most traced the last shadow rays)
+	uint32_t real = 0;
+	while (real < kTailLaunches && c->hStream->it[real].nLive != 0)
+		++real;
+	c->frame = frame0;
+	c->iter = iter0;
+	c->cur = cur0;
+	for (uint32_t jj = 0; jj < real; ++jj)
+		stage_end(c);
+	c->shadowSet = (c->iter - 1u) & 1u;
+	c->lastShadeFolded = true;
+	it += real;
+	if (e1 != hipSuccess || e2 != hipSuccess) {
+		c->streamDirty = true;
+		return static_cast<int>(e1 != hipSuccess ? e1 : e2);
+	}
+	rc = sync_counters(c);
+	collect_timings(c);
+	if (!rc)
+		rc = check_device_error(c);
+	if (rc || !c->hStream->ended)
+		c->streamDirty = true;
+	if (!rc && !c->hStream->ended)
+		rc = TYR_ERR_DEVICE; // (cannot happen: the tail has as many shade launches as a ray can have bounces left)
+	return rc;
+}
+
 int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iterations_out) {
 	if (!c)
 		return TYR_ERR_INVALID;
@@ -1112,6 +1247,10 @@ int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iter
 		rc = render_run_ahead(c, max_iterations, it);
 	} else {
 		while (it < max_iterations) {
+			if (stream_tail_eligible(c, max_iterations - it)) {
+				rc = render_stream_tail(c, it); // every remaining iteration
+				break;
+			}
 			if ((rc = launch_iteration(c, true)))
 				break;
 			++it;
@@ -1483,6 +1622,10 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_STATIC_INTERLEAVE, 0, 1, &Tuning::staticInterleave },
 		{ TYR_TUNE_RUN_AHEAD, 0, 2, &Tuning::runAhead },
 		{ TYR_TUNE_WIDE_DRAIN, 0, 1, &Tuning::wideDrain },
+		{ TYR_TUNE_STREAM_TAIL, 0, 1, &Tuning::streamTail },
+		{ TYR_TUNE_STREAM_SHADE_PER_CU, 1, 2, &Tuning::streamShadePerCU },
+		{ TYR_TUNE_STREAM_TRACE_PER_CU, 1, 5, &Tuning::streamTracePerCU },
+		{ TYR_TUNE_FOLD_SPHERES, 0, 1, &Tuning::foldSpheres },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)
