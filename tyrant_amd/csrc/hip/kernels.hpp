@@ -142,7 +142,7 @@ struct StreamIter {
 	uint32_t closed;                     // 1: the work queue of this iteration and the shadow queue of the one before are complete (their producers have all finished)
 	uint32_t nLive;                      // rays of this iteration, both classes (= the virtual slots its scan covers)
 	uint32_t nShadowPrev;                // shadow rays of the iteration before (traced beside this iteration's rays)
-	uint32_t shadowDone;                 // ... of which the traversal has finished so many (wave-aggregated adds)
+	uint32_t unused0;
 	uint32_t shadeBlocksDone;            // k_shade_stream of this iteration: blocks that have finished
 	uint32_t pad0[3];
 	uint32_t segWork[kClasses][kSegs];   // final record counts of this iteration's work queue
@@ -150,6 +150,10 @@ struct StreamIter {
 	uint32_t pad1[64 - 8 - kClasses * kSegs - kSegs];
 	uint32_t tick[2][kSegs * kSegStride]; // the traversal's chunk tickets, one word per 128 bytes: [0] work rays of class 0, [1] shadow rays; word w hands out the chunks of segment w
 	uint32_t shadeTiles[kSegs * kSegStride]; // k_shade_stream's tile tickets
+	// shadow rays of the iteration before that the traversal has finished: eight partial counts, 128 bytes apart (a wave adds to
+	// word blockIdx % 8 whenever it has 64 to report, runs dry or moves on -- one word would be a serial queue of atomics,
+	// ~12 ns each: the first build reported per refill and spent 5 ms per iteration there)
+	uint32_t shadowDone[kSegs * kSegStride];
 };
 struct StreamState {
 	uint32_t ended;                      // set when an iteration closes with no ray of either kind: the render is over

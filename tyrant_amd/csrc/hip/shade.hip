@@ -450,6 +450,8 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	StreamIter* const SI = STREAM ? &P.stream->it[P.streamIter] : nullptr;
 	if (STREAM && P.stream->ended)
 		return; // the render ended in an earlier iteration (the host queues a launch per iteration the tail can have)
+	if (STREAM)
+		__builtin_amdgcn_s_setprio(3); // one wave per SIMD beside four of the traversal kernel's, which wait for what this one makes
 	bool gaveUp = false; // STREAM: a wait ran into its bound (kErrNoProgress is raised): leave without shading further tiles
 	// class 0's tiles, then class 1's (from the device's counts: the host may have sized the grid from an upper bound)
 	const uint32_t tiles0 = queue_extent(P.segWork) / kBlock;
@@ -587,6 +589,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		return vbNext;
 	};
 	for (uint32_t vb = draw_tile(); vb < nTiles; vb = draw_tile()) { // vb = tile id = 256 physical slots of one class
+		TYR_STAMP(3) // (the draw: ticket, and in the streamed tail the wait for the traversal's answers)
 		const uint32_t cls = vb >= tiles0 ? 1u : 0u;
 		const uint32_t inClass = (vb - cls * tiles0) * kBlock + tid; // slot inside the class
 		const uint32_t slot = cls * P.classStride + inClass;
@@ -716,6 +719,13 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	}
 	// kernel.cu:607 / 416: the totals the next top-up and connect read.  Every block adds what it appended; the block
 	// that finishes last publishes the per-iteration figures.
+#ifdef TYR_SHADE_TIMING
+	if (tid == 0) {
+		for (int i = 0; i < 6; ++i)
+			atomicAdd(&P.k->debug[i], tacc_[i]);
+		atomicAdd(&P.k->debug[7], ntiles_);
+	}
+#endif
 	if (STREAM) {
 		// The block that finishes last closes the NEXT iteration for the traversal kernel: final counts, then the flag.  Its
 		// own records and fill adds are out (flush_prev waits and publishes); the other blocks' likewise before they counted
@@ -759,7 +769,13 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 					const uint32_t want = SI->nShadowPrev;
 					const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 					uint32_t polls = 0;
-					while (ld_sc1_u32(&SI->shadowDone) != want) {
+					auto shadows_done = [&]() {
+						uint32_t n = 0;
+						for (uint32_t w = 0; w < kSegs; ++w)
+							n += ld_sc1_u32(&SI->shadowDone[w * kSegStride]);
+						return n;
+					};
+					while (shadows_done() != want) {
 						__builtin_amdgcn_s_sleep(8);
 						if ((++polls & 63u) == 0u && (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks || ld_sc1_u32(&P.k->device_error) != 0u)) {
 							atomicOr(&P.k->device_error, kErrNoProgress);
@@ -803,13 +819,6 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 					P.k->segSurv[c][w] = __hip_atomic_load(&P.segNext[c * kClassWords + w * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
-#ifdef TYR_SHADE_TIMING
-	if (tid == 0) {
-		for (int i = 0; i < 6; ++i)
-			atomicAdd(&P.k->debug[i], tacc_[i]);
-		atomicAdd(&P.k->debug[7], ntiles_);
-	}
-#endif
 #undef TYR_STAMP
 }
 

@@ -54,7 +54,8 @@ __global__ void __launch_bounds__(kBlock, 5) k_trace_stream(const FrameParams P)
 	constexpr uint32_t kNone = 0xffffffffu;
 	uint32_t pendVisible = kNone; // a shadow ray that came through: its colour goes to its pixel at the wave's next refill (slot | parity)
 	uint32_t pendDone = kNone;    // a finished work ray not yet reported to done[tile] (slot | parity): reported at the next refill, behind a vmcnt(0)
-	uint32_t shadowFinished[2] = { 0u, 0u }; // finished shadow rays of either parity, not yet added to their iteration's shadowDone
+	uint32_t shadowFinished[2] = { 0u, 0u }; // (wave-uniform) finished shadow rays of either parity, not yet added to their iteration's shadowDone
+	bool reportShadows = false;             // (wave-uniform) ... and they are due: the wave has moved on to another iteration
 
 	// ---- per-wave feed state (uniform) ----
 	uint32_t j = 0, kind = 0, word = blockIdx.x % kSegs, tried = 0;
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(kBlock, 5) k_trace_stream(const FrameParams P)
 							}
 							kind = 0u;
 							++j;
+							reportShadows = true; // (iter_of() needs the counts of iteration j - 2's parity out before rays of j's come in)
 						}
 					}
 					continue;
@@ -156,26 +158,34 @@ __global__ void __launch_bounds__(kBlock, 5) k_trace_stream(const FrameParams P)
 			accumulate_pixels_wave(P.blit, px, mk3(c.x, c.y, c.z), 0);
 			pendVisible = kNone;
 		}
-		if (__ballot(pendDone != kNone) != 0ull) {
+		unsigned long long owing = __ballot(pendDone != kNone);
+		if (owing != 0ull) {
 			__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's answers (stored a pass ago at least) have arrived
-			if (pendDone != kNone) {
-				uint32_t* const done = (pendDone >> 31) ? P.doneNext : P.doneWork;
-				__hip_atomic_fetch_add(&done[(pendDone & 0x7fffffffu) >> 8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			// one add per 64-slot chunk, not per ray: a chunk's rays are all this wave's, and 256 adds to one word are a serial
+			// queue (~12 ns each)
+			while (owing != 0ull) {
+				const uint32_t first = (uint32_t)__ffsll((long long)owing) - 1u;
+				const uint32_t chunk = (uint32_t)__builtin_amdgcn_readlane((int)(pendDone >> 6), (int)first); // (the parity rides in bit 25)
+				const unsigned long long same = __ballot(pendDone != kNone && (pendDone >> 6) == chunk);
+				if (lane == first) {
+					uint32_t* const done = (pendDone >> 31) ? P.doneNext : P.doneWork;
+					__hip_atomic_fetch_add(&done[(pendDone & 0x7fffffffu) >> 8], (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				owing &= ~same;
 			}
 			pendDone = kNone;
 		}
+		// finished shadow rays: when the wave has 64 to report, holds no ray, or has moved on to another iteration
+		const bool dry = __ballot(live) == 0ull;
 #pragma unroll
 		for (uint32_t p = 0; p < 2u; ++p) {
-			if (__ballot(shadowFinished[p] != 0u) != 0ull) {
-				uint32_t sum = shadowFinished[p];
-#pragma unroll
-				for (int o = 32; o > 0; o >>= 1)
-					sum += __shfl_xor(sum, o, 64);
+			if (shadowFinished[p] != 0u && (shadowFinished[p] >= 64u || dry || reportShadows)) {
 				if (lane == 0)
-					__hip_atomic_fetch_add(&S->it[iter_of(p)].shadowDone, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_fetch_add(&S->it[iter_of(p)].shadowDone[(blockIdx.x % kSegs) * kSegStride], shadowFinished[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				shadowFinished[p] = 0u;
 			}
 		}
+		reportShadows = false;
 	};
 
 	for (;;) {
@@ -213,8 +223,10 @@ __global__ void __launch_bounds__(kBlock, 5) k_trace_stream(const FrameParams P)
 					// nothing to do and nothing ready: wait a little (bounded by the wall clock)
 					if (tIdle == 0ull)
 						tIdle = __builtin_amdgcn_s_memrealtime();
-					__builtin_amdgcn_s_sleep(16);
-					if ((++idlePolls & 31u) == 0u) {
+					// (a long sleep: four idle waves per SIMD polling at a microsecond's pace took most of the issue slots the
+					// shade wave beside them -- the producer they are waiting for -- needed: 3-5x slower tiles, measured)
+					__builtin_amdgcn_s_sleep(127);
+					if ((++idlePolls & 7u) == 0u) {
 						uint32_t err = 0;
 						if (lane == 0)
 							err = ld_sc1_u32(&P.k->device_error);
@@ -328,6 +340,14 @@ __global__ void __launch_bounds__(kBlock, 5) k_trace_stream(const FrameParams P)
 			ref = found ? kRefDone : kRefPop;
 		}
 		// ---- finished rays ----
+		{
+			const unsigned long long fin = __ballot(live && ref == kRefDone && isShadow);
+			if (fin != 0ull) { // (scalar bookkeeping: the wave's count per parity)
+				const unsigned long long odd = __ballot((slot >> 31) != 0u);
+				shadowFinished[0] += (uint32_t)__popcll(fin & ~odd);
+				shadowFinished[1] += (uint32_t)__popcll(fin & odd);
+			}
+		}
 		if (live && ref == kRefDone) {
 			const uint32_t par = slot >> 31, idx = slot & 0x7fffffffu;
 			if (isShadow) {
@@ -335,7 +355,6 @@ __global__ void __launch_bounds__(kBlock, 5) k_trace_stream(const FrameParams P)
 					pendVisible = slot;
 					visible += 1;
 				}
-				shadowFinished[par] += 1u;
 			} else {
 				if (hitTri) // a triangle hit replaces the sphere answer (kernel.cu:138-140); write-through: k_shade_stream reads it beside us
 					st_sc1_f2(&(par ? P.next : P.work).hit[idx], make_float2(dist, __uint_as_float((uint32_t)prim)));

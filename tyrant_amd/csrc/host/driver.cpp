@@ -117,8 +117,7 @@ int push_counters(tyr_ctx* c) {
 	return TYR_OK;
 }
 
-constexpr uint32_t kRunAheadMaxLive = 6u << 20; // TYR_TUNE_RUN_AHEAD = 2: queues of up to this many slots run one iteration ahead of the counts (used in the uninstrumented builds)
-[[maybe_unused]] constexpr uint32_t kRunAheadMaxLiveUse = kRunAheadMaxLive;
+[[maybe_unused]] constexpr uint32_t kRunAheadMaxLive = 6u << 20; // TYR_TUNE_RUN_AHEAD = 2: queues of up to this many slots run one iteration ahead of the counts (used in the uninstrumented builds)
 
 FrameParams make_params(const tyr_ctx* c) {
 	FrameParams P{};
@@ -1080,11 +1079,17 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 		// iterations 0 .. enq - 1 are queued; the counts of 0 .. enq - 2 have arrived
 		bool ahead = false;
 		uint32_t frameBefore = c->frame;
+		const uint32_t shadowSetBefore = c->shadowSet; // (enqueue_shade of an iteration queued ahead moves it: an iteration that turns out empty must give it back, or tyr_shadow_export would read the empty iteration's counters)
+		const bool foldedBefore = c->lastShadeFolded;
 		if (enq < max_iterations) {
 			const uint32_t liveMax = static_cast<uint32_t>(std::min<uint64_t>(N, static_cast<uint64_t>(live) + budget));
 			const uint32_t newMax = static_cast<uint32_t>(std::min<uint64_t>(N, budget));
-			if ((rc = enqueue_merged_iteration(c, IterationPlan{ newMax, liveMax, live, live }, false)))
+			if ((rc = enqueue_merged_iteration(c, IterationPlan{ newMax, liveMax, live, live }, false))) {
+				(void)hipStreamSynchronize(c->stream); // (the failed iteration may be partly queued; nothing of it is the render's)
+				c->shadowSet = shadowSetBefore;
+				c->lastShadeFolded = foldedBefore;
 				return rc;
+			}
 			ahead = true;
 		}
 		const int set = static_cast<int>((iter0 + enq - 1) & 1u);
@@ -1097,6 +1102,8 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 				c->cur ^= 1;
 				c->iter--;
 				c->shadowPending = false;
+				c->shadowSet = shadowSetBefore;
+				c->lastShadeFolded = foldedBefore;
 			}
 			return code;
 		};
@@ -1107,11 +1114,11 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 		}
 		std::memcpy(c->hK, c->hSnap[set], sizeof(DevCounters));
 		collect_timings_of(c, set);
-		it = enq;
 		s = c->hK->primary_ray_cnt; // survivors of iteration enq - 1
 		const uint32_t shadows = c->hK->shadow_ray_cnt;
 		if ((rc = check_device_error(c)))
 			return abandon(rc);
+		it = enq; // (counted once it is known to have completed without a device error)
 		if (budget == 0 && s == 0) { // kernel loop of the reference's caller: nothing left to trace or to start
 			if (ahead) {
 				// iteration enq was queued for nothing but the shadow rays of iteration enq - 1: take the host state back
@@ -1119,6 +1126,8 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 				c->cur ^= 1;
 				c->iter--;
 				c->shadowPending = false;
+				c->shadowSet = shadowSetBefore;
+				c->lastShadeFolded = foldedBefore;
 				c->runAheadUndo = true;
 				c->undoLive = live;
 				c->undoShadows = shadows;
