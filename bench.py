@@ -181,9 +181,12 @@ def pmc_child(args) -> int:
     for _ in range(2):
         r.reset_accum()
         iters = r.render(spp_total)
-    assert r.counters()["device_error"] == 0
+    k = r.counters()
+    assert k["device_error"] == 0
     r.close()
     print(json.dumps({"pmc_child_iterations": iters}), flush=True)
+    if os.environ.get("TYR_BENCH_PRINT_DEBUG"):  # the -DTYR_QUAD_STATS build's loop counters (quad_block)
+        print(json.dumps({"child_debug": [int(v) for v in k["debug"]], "renders": 2}), flush=True)
     return 0
 
 
@@ -334,7 +337,30 @@ def drain_block(args):
             "source": "one render of the same workload by libtyrant_hip_anatomy.so (-DTYR_LAUNCH_ANATOMY) in a child process; the render's last launch (shadow rays only) is not stamped"}
 
 
-def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_render, kernel=EXTEND_KERNEL, con_ms=0.0, shadow_rays=0.0):
+def quad_block(args):
+    """What the timed kernel's OWN layout needs, counted by an instrumented build of it (-DTYR_QUAD_STATS) in a child process:
+    quad steps (one 128-byte quad node each, 112 bytes of it read) and triangle tests (48-byte records) per render."""
+    lib = os.path.join(ROOT, "tyrant_amd", "lib", "libtyrant_hip_stats.so")
+    if not os.path.exists(lib):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--queue", str(args.queue)]
+    try:
+        p = subprocess.run(child, capture_output=True, text=True, timeout=120, env=dict(os.environ, TYRANT_HIP_LIBRARY=lib, TYR_BENCH_PRINT_DEBUG="1"))
+    except (subprocess.TimeoutExpired, OSError):
+        return None
+    if p.returncode != 0:
+        return None
+    for line in p.stdout.splitlines():
+        if line.startswith('{"child_debug"'):
+            j = json.loads(line)
+            d, renders = j["child_debug"], max(j.get("renders", 1), 1)
+            # tyr_counters.debug of the TYR_QUAD_STATS build: [1] lanes x trips of the quad-test loop, [5] lanes x trips of the triangle loop (traverse_flat.hip TYR_DBG)
+            return {"quad_steps_per_render": d[1] / renders, "triangle_tests_per_render": d[5] / renders,
+                    "source": "one cold + one warm render of the same workload by libtyrant_hip_stats.so (-DTYR_QUAD_STATS) in a child process, averaged"}
+    return None
+
+
+def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_render, kernel=EXTEND_KERNEL, con_ms=0.0, shadow_rays=0.0, quad=None, renders=1):
     """`bound` = the tightest of the measured resource fractions of the dominant kernel; the algorithmic-bytes figure of
     SURVEY.md 8d is a separate entry.  Merged launches (kernel = TRACE_KERNEL): the kernel traces this iteration's extend
     rays and the previous iteration's shadow rays, and the launch that ends a render with the last iteration's shadow rays is
@@ -403,11 +429,34 @@ def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_re
         "connect_tris_per_ray": round(visits["tris_per_con"], 3),
         "note": "SURVEY.md 8d: 24 + 8 + 32 B x nodes + 36 B x triangles the REFERENCE's binary tree visits per extend ray (44 + 32 x nodes + 36 x triangles + 12 x p_visible per shadow ray), counted by the counting build (k_extend_count / k_connect_count, pair nodes) in an untimed render -- not by the timed quad-node kernel; nominal, exceeds the HBM peak when the tree is cache resident",
     }
+    # (a) the same nominal count charged to the traversal kernel only for the rays it is handed: extend rays of class 1
+    # (they fail the root box in the kernel that MAKES them, hip/kernels.hpp "Queues") cost it nothing -- their one
+    # box test (32 B of the nominal count) and their 32-byte record belong to k_primary / k_shade
+    t_all = (ext_ms + con_ms) * 1e-3
+    in_ext = visits.get("in_tree_ext_frac")
+    if in_ext is not None and merged and t_all > 0:
+        rays_in = in_ext * ext_rays
+        nodes_in = max(visits["nodes_per_ext"] * ext_rays - (ext_rays - rays_in), 0.0)  # the counting build counts ONE node for a ray that misses the root box
+        alg_in = (24 + 8) * rays_in + 32 * nodes_in + 36 * visits["tris_per_ext"] * ext_rays + bytes_per_con * shadow_rays
+        out["algorithmic"]["class0_only"] = {"GBps": round(alg_in / t_all / 1e9, 2), "frac_of_hbm_peak": round(alg_in / t_all / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": round(alg_in / max(ext_launches, 1)),
+                                             "extend_rays_charged": round(rays_in), "note": "SURVEY.md 8d's count for the rays that reach k_trace_flat: extend rays that pass the root box + every shadow ray"}
+    # (b) what the kernel's own layout needs: 128 B per quad step, 48 B per triangle test, 32 B per ray handed to it
+    if quad and t_all > 0:
+        handed = (in_ext if in_ext is not None else 1.0) * ext_rays + shadow_rays
+        qb = (128.0 * quad["quad_steps_per_render"] + 48.0 * quad["triangle_tests_per_render"]) * renders + 32.0 * handed
+        out["algorithmic"]["quad"] = {"GBps": round(qb / t_all / 1e9, 2), "frac_of_hbm_peak": round(qb / t_all / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": round(qb / max(ext_launches, 1)),
+                                      "quad_steps_per_render": round(quad["quad_steps_per_render"]), "triangle_tests_per_render": round(quad["triangle_tests_per_render"]),
+                                      "note": "bytes the 128-byte quad nodes and 48-byte triangle records of the timed kernel amount to (every step and test counted, cache hits included): " + quad["source"]}
+    # (c) north_star's ">= 50 % of the HBM roofline", answered both ways
+    out["hbm_target_met"] = {"target": 0.5, "nominal": bool(out["algorithmic"]["frac_of_hbm_peak"] >= 0.5), "nominal_class0_only": (bool(out["algorithmic"]["class0_only"]["frac_of_hbm_peak"] >= 0.5) if "class0_only" in out["algorithmic"] else None),
+                             "counters": (bool(out["hbm_counter_frac"] >= 0.5) if out.get("hbm_counter_frac") is not None else None),
+                             "note": "nominal = SURVEY.md 8d's per-ray bytes of the REFERENCE's binary tree over the traversal time (can exceed 1: not traffic); counters = bytes that crossed the fabric (FETCH_SIZE x 2 + WRITE_SIZE) / 8 TB/s -- the tree lives in the 256 MB Infinity Cache and the kernel is bound by instruction issue and by its launches' drains, not by HBM"}
     out["kernel_ms_per_render"] = kernel_ms_per_render
     return out
 
 
 PREFLIGHT_TIMEOUT_S = 150.0
+PREFLIGHT_TORCH_NCCL_ONLY = 2  # exit code of the pre-flight child: the native exchange failed, torch's nccl backend works
 
 
 def dist_preflight(args) -> int:
@@ -426,6 +475,7 @@ def dist_preflight(args) -> int:
     rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("TYR_BENCH_PREFLIGHT_ONE_DEVICE"):
         local_rank = 0  # rehearsal on a one-GPU box: RCCL refuses two ranks on one device, which is the failure path under test
+    local_rank %= max(torch.cuda.device_count(), 1)  # (fewer GPUs than ranks: the same failure path, not an invalid-device crash)
     dist.init_process_group("gloo", init_method=f"file://{args.preflight_store}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     ok = 1
     try:
@@ -457,14 +507,29 @@ def dist_preflight(args) -> int:
     except Exception as e:  # noqa: BLE001
         print(f"[bench preflight] rank {rank}: {e!r}", file=sys.stderr)
         ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32)
+    # ... and torch's own RCCL backend (what the combine falls back to when the native exchange does not verify): one
+    # all-reduce on this rank's device.  If that fails too, the bench ranks combine over gloo, host-staged.
+    nccl_ok = 1
+    if not ok or os.environ.get("TYR_BENCH_PREFLIGHT_PROBE_TORCH_NCCL"):
+        try:
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=45))
+            t = torch.ones(4, dtype=torch.float32, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, group=g)
+            torch.cuda.synchronize()
+            nccl_ok = int(float(t[0].item()) == float(world))
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench preflight] rank {rank}: torch's nccl backend: {e!r}", file=sys.stderr)
+            nccl_ok = 0
+    flag = torch.tensor([ok, nccl_ok], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
-    return 0 if int(flag.item()) == 1 else 1
+    return 0 if int(flag[0].item()) == 1 else (PREFLIGHT_TORCH_NCCL_ONLY if int(flag[1].item()) == 1 else 1)
 
 
-def run_dist_preflight() -> bool:
-    """spawn this rank's pre-flight child (this process has not initialised the GPU yet) and wait for it, bounded"""
+def run_dist_preflight() -> int:
+    """spawn this rank's pre-flight child (this process has not initialised the GPU yet) and wait for it, bounded:
+    0 = the native exchange verified on every rank; PREFLIGHT_TORCH_NCCL_ONLY = it did not, torch's nccl backend does;
+    1 = neither (or the child crashed / ran out of time)"""
     # the children make their own rendezvous through a FILE (no second port to find free and to agree on): one name per
     # launch -- the launcher's pid is the parent of every rank, its master port tells concurrent launches apart -- and
     # without the launcher's TORCHELASTIC_* variables, which would tell them that an agent already hosts a store
@@ -473,10 +538,10 @@ def run_dist_preflight() -> bool:
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     try:
         p = subprocess.run(cmd, timeout=PREFLIGHT_TIMEOUT_S, env=env, stdout=subprocess.DEVNULL)
-        return p.returncode == 0
+        return p.returncode if p.returncode in (0, PREFLIGHT_TORCH_NCCL_ONLY) else 1
     except subprocess.TimeoutExpired:
         print(f"[bench] rank {os.environ.get('RANK', '?')}: the native exchange's pre-flight did not finish in {PREFLIGHT_TIMEOUT_S:.0f} s", file=sys.stderr)
-        return False
+        return 1
 
 
 def main():
@@ -506,9 +571,19 @@ def main():
 
     # the native exchange is checked by a child of every rank BEFORE this process initialises its GPU (see dist_preflight)
     preflight_ok = True
+    backend = args.backend  # what torch.distributed runs on: the asked-for backend, or gloo when RCCL does not work on this box at all
+    backend_fallback = None
     want_native = world > 1 and args.combine_impl == "native" and (args.backend == "nccl" or bool(os.environ.get("TYR_BENCH_PREFLIGHT_ONE_DEVICE")))
     if want_native:
-        preflight_ok = run_dist_preflight()
+        pre = run_dist_preflight()
+        preflight_ok = pre == 0
+        if pre == 1 and args.backend == "nccl":
+            # neither the library's RCCL exchange nor torch's nccl backend came through the children's check (an RCCL that cannot
+            # initialise, two ranks on one device, a hang): the ranks combine over gloo, host-staged -- slower, and a line
+            # instead of a crash.  Every rank's child reports the children's common verdict, so all ranks branch alike.
+            backend = "gloo"
+            backend_fallback = "pre-flight: neither the native exchange (tyr_dist_*) nor torch's nccl backend works on this box; the combine runs over gloo, host-staged"
+            print("[bench] " + backend_fallback, file=sys.stderr)
 
     import numpy as np  # noqa: F401
     import torch
@@ -520,17 +595,18 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     if args.backend == "gloo":
         local_rank = 0  # rehearsal: all ranks share device 0
+    local_rank %= max(torch.cuda.device_count(), 1)  # (a box with fewer GPUs than ranks: the gloo fallback of an nccl run shares devices)
     torch.cuda.set_device(local_rank)
-    dist = tdist.init_process_group(args.backend) if world > 1 else None
+    dist = tdist.init_process_group(backend) if world > 1 else None
     dev = f"cuda:{local_rank}"
-    cdev = "cpu" if args.backend == "gloo" else dev  # where torch's collectives live
+    cdev = "cpu" if backend == "gloo" else dev  # where torch's collectives live
 
     W, H = args.width, args.height
     sc, nodes, prims, label, t_build = build_workload(args.workload, binding, scenes)
     flags = binding.TYR_FLAG_PROFILE | (binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0)
     shard = tdist.shard_spec(rank, world, H)
     tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune)}
-    native = world > 1 and args.combine_impl == "native" and args.backend == "nccl"
+    native = world > 1 and args.combine_impl == "native" and backend == "nccl"
     if native:
         # every rank's child must have verified, or nobody uses the native path (the ranks have to branch alike)
         flag = torch.tensor([1 if preflight_ok else 0], dtype=torch.int32, device=cdev)
@@ -582,7 +658,7 @@ def main():
                 else:
                     # (after a failed native check: the sum-reduce, which needs no probing)
                     combine = (lambda t: tdist.gather_rows(t, H, W, rank, world, dst=0)) if use_torch_gather else (lambda t: tdist.reduce_accum(t, dst=0))
-                    if args.backend == "gloo":
+                    if backend == "gloo":
                         host = accum.cpu()
                         combine(host)
                         if rank == 0:
@@ -728,10 +804,10 @@ def main():
                 "bvh_nodes": int(nodes.shape[0]),
                 "sharding": (f"rows y % {world} == rank; " + (("tyr_dist_combine (RCCL behind the C ABI): " + ("ncclSend/ncclRecv of each rank's packed rows, double-buffered" if args.combine == "gather" else "ncclReduce(sum) of the full buffers"))
                                                             if m["native_combine"] else ("torch.distributed gather of each rank's rows" if use_torch_gather else "torch.distributed reduce(sum) of the accumulation buffer"))) if world > 1 else "none",
-                "backend": args.backend if world > 1 else None,
+                "backend": (backend if backend_fallback is None else f"{backend} (asked for {args.backend})") if world > 1 else None,
                 **({"combine": {"native_combine": bool(m["native_combine"]), "form": args.combine if m["native_combine"] else ("gather" if use_torch_gather else "reduce"),
                                 "rccl_comm_ranks": (m.get("comm_info") or {}).get("comm_ranks"),
-                                "fallback_reason": None if m["native_combine"] else ("--combine-impl torch / gloo backend" if not want_native else ("pre-flight of the native exchange failed" if not preflight_ok else "the native exchange did not verify on the real job")),
+                                "fallback_reason": None if m["native_combine"] else (backend_fallback if backend_fallback else ("--combine-impl torch / gloo backend" if not want_native else ("pre-flight of the native exchange failed" if not preflight_ok else "the native exchange did not verify on the real job"))),
                                 "measured_on_hardware_before": "no: the N > 1 RCCL exchange had never run when this was written (one GPU per test box)"}} if world > 1 else {}),
                 "wavefront_iterations_per_step": m["iters"] / args.steps,
                 "extend_Mrays/s": round(m["ext_all"] / m["dt_all"] / 1e6, 3),
@@ -756,7 +832,8 @@ def main():
             },
             # merged renders: EVERY traversal launch is k_trace_flat -- the ones timed as the extend stage and the one that ends a
             # render with the last iteration's shadow rays (timed as the connect stage): one kernel, one average
-            "roofline": (roofline_block(pmc, tm["extend"]["ms"] + tm["connect"]["ms"], tm["extend"]["launches"] + tm["connect"]["launches"], m["ext"], m, m["kernel_ms_per_render"], kernel=TRACE_KERNEL, con_ms=0.0, shadow_rays=m["shd"])
+            "roofline": (roofline_block(pmc, tm["extend"]["ms"] + tm["connect"]["ms"], tm["extend"]["launches"] + tm["connect"]["launches"], m["ext"], m, m["kernel_ms_per_render"], kernel=TRACE_KERNEL, con_ms=0.0, shadow_rays=m["shd"],
+                                        quad=(quad_block(args) if world == 1 and args.pmc != "off" else None), renders=args.steps)
                          if dominant_kernel(args.tune) == TRACE_KERNEL else
                          roofline_block(pmc, tm["extend"]["ms"], tm["extend"]["launches"], m["ext"], m, m["kernel_ms_per_render"], kernel=EXTEND_KERNEL, con_ms=tm["connect"]["ms"], shadow_rays=m["shd"])),
         }

@@ -228,6 +228,12 @@ int tyr_sync(tyr_ctx* ctx);
 /* AoS import/export of the SoA device queues in the reference's record formats.
  * which: 0 = work queue (input of the next extend), 1 = next queue (survivors of the last shade). */
 int tyr_queue_export(tyr_ctx* ctx, int which, tyr_ray_queue* host, uint32_t count);
+/* Test hook: every record of the queue (`which` as tyr_queue_export) is looked up in the DEVICE's rank tables -- the scan of the
+ * survive bytes that k_shade resolves virtual slots with -- and the slot found is compared with the record's place in the
+ * order tyr_queue_export presents (its host-side sort by key).  *checked_out = records, *mismatches_out = records whose
+ * table rank differs from that place.  Call it between tyr_stage_shade and tyr_stage_end (which = 1) or after
+ * tyr_stage_primary (which = 0). */
+int tyr_queue_rank_check(tyr_ctx* ctx, int which, uint32_t* checked_out, uint32_t* mismatches_out);
 int tyr_queue_import(tyr_ctx* ctx, const tyr_ray_queue* host, uint32_t n_survivors);
 int tyr_shadow_export(tyr_ctx* ctx, tyr_shadow_queue* host, uint32_t count);
 /* overwrite the shadow queue with `n` records (the input of the next tyr_stage_connect; kernel-level parity tests) */
@@ -289,10 +295,10 @@ enum {
 	TYR_TUNE_STATIC_INTERLEAVE = 13, /* the fixed per-block part as interleaved 64-slot chunks (1, default) or one contiguous range per block (0) */
 	TYR_TUNE_RUN_AHEAD = 14,         /* tyr_render: queue iteration i + 1 before iteration i's counts reach the host: 0 never, 1 always, 2 (default) for queues of at most 6 Mi slots */
 	TYR_TUNE_WIDE_DRAIN = 15,        /* 1 (default) = a wave's last <= 16 rays are finished four lanes to a ray */
-	TYR_TUNE_STREAM_TAIL = 16,       /* tyr_render: 1 (default) = once the primary budget is spent, the remaining iterations run as ONE traversal kernel with shade resident beside it (DESIGN.md "One drain per render"); 0 = a traversal launch per iteration */
+	TYR_TUNE_STREAM_TAIL = 16,       /* tyr_render: 1 = once the primary budget is spent, the remaining iterations run as ONE traversal kernel with shade resident beside it (DESIGN.md "One drain per render": bit-exact, measured slower, hence not the default); 0 (default) = a traversal launch per iteration */
 	TYR_TUNE_STREAM_SHADE_PER_CU = 17, /* streamed tail: shade blocks per CU (1..2, default 1) ... */
 	TYR_TUNE_STREAM_TRACE_PER_CU = 18, /* ... beside this many traversal blocks per CU (1..5, default 4) */
-	TYR_TUNE_FOLD_SPHERES = 19       /* launch-per-iteration path of tyr_render: 1 = shade does the sphere pre-passes' work for the rays it emits (default 0; the streamed tail always does) */
+	TYR_TUNE_FOLD_SPHERES = 19       /* merged path of tyr_render: 1 (default) = shade does the sphere pre-passes' work (kernel.cu:127-136, 168-172) for the rays it emits, while they are in registers; 0 = the pre-pass kernels re-read them */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);
 

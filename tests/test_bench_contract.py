@@ -72,6 +72,18 @@ def test_roofline_block_of_the_merged_trace_kernel():
     assert abs(r["algorithmic"]["GBps"] - want) < 0.02 * want
     assert r["algorithmic"]["bytes_per_launch"] == round((per_ext * ext_rays + per_con * shadow_rays) / 6)
     assert "shadow" in r["algorithmic"]["covers"]
+    # round 4: the nominal count charged for the rays the kernel is handed only, the quad layout's own bytes, and north_star's target answered both ways
+    v2 = dict(visits, in_tree_ext_frac=0.4)
+    quad = {"quad_steps_per_render": 2.0e8, "triangle_tests_per_render": 3.0e7, "source": "unit test"}
+    r3 = bench.roofline_block(pmc, ext_ms=4.4, ext_launches=6, ext_rays=ext_rays, visits=v2, kernel_ms_per_render={}, kernel=bench.TRACE_KERNEL, con_ms=0.26, shadow_rays=shadow_rays, quad=quad, renders=1)
+    c0 = r3["algorithmic"]["class0_only"]
+    rays_in = 0.4 * ext_rays
+    want0 = 32 * rays_in + 32 * (12.3 * ext_rays - (ext_rays - rays_in)) + 36 * 0.9 * ext_rays + per_con * shadow_rays
+    assert abs(c0["bytes_per_launch"] - want0 / 6) < 1e-6 * want0 and c0["frac_of_hbm_peak"] < r3["algorithmic"]["frac_of_hbm_peak"]
+    q = r3["algorithmic"]["quad"]
+    assert abs(q["bytes_per_launch"] - (128 * 2.0e8 + 48 * 3.0e7 + 32 * (rays_in + shadow_rays)) / 6) < 1e3
+    t = r3["hbm_target_met"]
+    assert t["nominal"] == (r3["algorithmic"]["frac_of_hbm_peak"] >= 0.5) and t["counters"] == (r3["hbm_counter_frac"] >= 0.5) and t["nominal_class0_only"] == (c0["frac_of_hbm_peak"] >= 0.5)
     # the separate-launch form of the same numbers prices the extend launches only
     r2 = bench.roofline_block(pmc, ext_ms=4.4, ext_launches=6, ext_rays=ext_rays, visits=visits, kernel_ms_per_render={})
     assert bench.EXTEND_KERNEL in r2["kernel"] and r2["algorithmic"]["GBps"] < r["algorithmic"]["GBps"] * 1.2
@@ -179,6 +191,27 @@ def test_bench_ranks_run_the_preflight_and_fall_back():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     d = _bench_line(p.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 0 and "torch.distributed" in d["config"]["sharding"]
+
+
+@pytest.mark.gpu
+def test_bench_nccl_on_a_box_where_rccl_cannot_work_falls_back_and_says_why():
+    """`bench.py --gpus 2 --backend nccl` on the one GPU of a test box: RCCL refuses two ranks on one device -- the
+    library's exchange and torch's nccl backend alike -- which is what an RCCL that cannot initialise looks like to the
+    driver's 8-GPU run.  The children's pre-flight finds out, the ranks combine over gloo (host-staged), and the line is
+    well-formed and says why (config.combine.fallback_reason, config.backend)."""
+    import torch
+
+    if torch.cuda.device_count() > 1:
+        pytest.skip("more than one GPU: RCCL would work")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "nccl", "--workload", "c1", "--width", "320", "--height", "180", "--queue", "32768", "--spp", "4", "--no-reference-queue"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = _bench_line(p.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["spp_total"] == 4
+    c = d["config"]["combine"]
+    assert c["native_combine"] is False and "gloo" in d["config"]["backend"] and "nccl" in d["config"]["backend"]
+    assert c["fallback_reason"] and "pre-flight" in c["fallback_reason"] and "gloo" in c["fallback_reason"]
 
 
 def test_bench_refuses_to_run_without_a_gpu():

@@ -245,8 +245,8 @@ def test_stack_bound_of_the_tree_gates_the_wide_drain(orc, hip):
     assert kg["total_extend_rays"] > W * H * spp  # (rays did reach the chains and bounce)
 
 
-@pytest.mark.parametrize("N,spp", [(W1080 * H1080, 1), (N2M, 2)])
-def test_benchmarked_render_path_matches_oracle_at_full_size(orc, hip, N, spp):
+@pytest.mark.parametrize("N,spp,knobs", [(W1080 * H1080, 1, {}), (N2M, 2, {}), (W1080 * H1080, 1, dict(stream_tail=1, run_ahead=0)), (N2M, 2, dict(stream_tail=1, run_ahead=0))])
+def test_benchmarked_render_path_matches_oracle_at_full_size(orc, hip, N, spp, knobs):
     """The code path bench.py times -- `tyr_render` with DEFAULT tuning: merged extend(i+1) + connect(i) launches
     (`k_trace_flat`), run-ahead where the default enables it, the four-lanes-per-ray drain -- on C3 (996,882 triangles)
     at 1920x1080 against `orc_render` (main.cpp:164-170 looping kernel.cu:664-748): same iteration count, every counter
@@ -258,6 +258,7 @@ def test_benchmarked_render_path_matches_oracle_at_full_size(orc, hip, N, spp):
     o = orc.Oracle(W1080, H1080, N, flags=1)
     g = hip.Renderer(W1080, H1080, N, flags=1)
     o.load_scene(sc, nodes, prims), g.load_scene(sc, nodes, prims)
+    g.set_tuning(**knobs)  # {}: the defaults bench.py times; stream_tail: the remaining iterations as ONE traversal kernel once the budget is spent (opt-in)
     it_o, it_g = o.render(spp), g.render(spp)
     ko, kg = o.counters(), g.counters()
     assert kg["device_error"] == 0

@@ -65,6 +65,8 @@ def test_stage_by_stage_bit_parity(orc, hip, name, W, H, N, flags):
             assert ko[f] == kg[f], (tag, f)
         n = ko["n_live"]
         assert_state_equal(o.ray_queue(0, n), g.ray_queue(0, n), tag + " after primary")
+        if it > 0 and not (flags & 4):
+            assert g.queue_rank_check(0) == (n, 0), tag + " rank tables: survivors in front, fresh primary rays behind"
 
         o.stage("extend"), g.stage("extend")
         qo, qg = o.ray_queue(0, n), g.ray_queue(0, n)
@@ -79,6 +81,9 @@ def test_stage_by_stage_bit_parity(orc, hip, name, W, H, N, flags):
         assert ko["primary_ray_cnt"] == kg["primary_ray_cnt"] and ko["shadow_ray_cnt"] == kg["shadow_ray_cnt"], tag
         ns, nh = ko["primary_ray_cnt"], ko["shadow_ray_cnt"]
         assert_state_equal(o.ray_queue(1, ns), g.ray_queue(1, ns), tag + " survivors")
+        # the order above comes from the export's host-side sort by virtual slot; the kernels resolve the same keys through the
+        # scan's rank tables: every survivor's table rank must be its place in that order
+        assert g.queue_rank_check(1) == (ns, 0), tag + " rank tables of the scan"
         so, sg = o.shadow_queue(nh), g.shadow_queue(nh)
         for f in ("origin", "direction", "color", "closestDistance"):
             assert np.array_equal(bits(so[f]), bits(sg[f])), f"{tag} shadow {f}"
@@ -475,29 +480,43 @@ def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
     g1.set_tuning(merge_trace=1, run_ahead=1)
     g2.set_tuning(merge_trace=1)  # (the default) connect(i) inside the launch of extend(i + 1): k_trace_flat, iteration i + 1 queued ahead of iteration i's counts
     g3.set_tuning(merge_trace=1, run_ahead=0, wide_drain=0)  # ... with the host waiting for every iteration's counts, and a wave's last rays left one to a lane
+    _, g4 = pair(orc, hip, name, W, H, N)
+    _, g5 = pair(orc, hip, name, W, H, N)
+    g4.set_tuning(merge_trace=1, run_ahead=0, stream_tail=1)  # once the budget is spent: ONE traversal kernel across the remaining iterations, shade resident beside it (k_trace_stream / k_shade<.., true>)
+    g5.set_tuning(merge_trace=1, fold_spheres=0)  # the sphere pre-pass kernels instead of shade doing their work for the rays it emits
     from tyrant_amd import scenes
 
     sc, _, _ = built_scene(name)
     moved = scenes.Camera(position=tuple(np.array(sc.camera.position) + np.array([3.0, 2.0, -1.0])), direction=sc.camera.direction, up=sc.camera.up)
     for cam in (sc.camera, moved):
-        for r in (o, g0, g1, g2, g3):
+        for r in (o, g0, g1, g2, g3, g4, g5):
             r.set_camera(cam)
-        io, i0, i1, i2, i3 = o.render(spp), g0.render(spp), g1.render(spp), g2.render(spp), g3.render(spp)
-        assert io == i0 == i1 == i2 == i3
-        ko, k0, k1, k2, k3 = o.counters(), g0.counters(), g1.counters(), g2.counters(), g3.counters()
-        assert k0["device_error"] == 0 and k1["device_error"] == 0 and k2["device_error"] == 0 and k3["device_error"] == 0
+        io, i0, i1, i2, i3, i4, i5 = o.render(spp), g0.render(spp), g1.render(spp), g2.render(spp), g3.render(spp), g4.render(spp), g5.render(spp)
+        assert io == i0 == i1 == i2 == i3 == i4 == i5
+        ko, k0, k1, k2, k3, k4, k5 = o.counters(), g0.counters(), g1.counters(), g2.counters(), g3.counters(), g4.counters(), g5.counters()
+        assert k0["device_error"] == 0 and k1["device_error"] == 0 and k2["device_error"] == 0 and k3["device_error"] == 0 and k4["device_error"] == 0 and k5["device_error"] == 0
         # (n_live, shadow_ray_cnt: the iteration a run-ahead render queues for nothing must not show in the counters)
         for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible", "start_position", "frame", "n_live", "shadow_ray_cnt", "primary_ray_cnt"):
-            assert ko[f] == k0[f] == k1[f] == k2[f] == k3[f], (name, f)
+            assert ko[f] == k0[f] == k1[f] == k2[f] == k3[f] == k4[f] == k5[f], (name, f)
+        assert_accum_close(o.blit_buffer(), g4.blit_buffer(), name + " streamed tail")
+        assert_accum_close(o.blit_buffer(), g5.blit_buffer(), name + " sphere pre-pass kernels")
+        # the last iteration's shadow queue, whatever path made it (the run-ahead path once exported the EMPTY look-ahead iteration's)
+        nh = ko["shadow_ray_cnt"]
+        so = o.shadow_queue(nh)
+        for g in (g0, g1, g2, g3, g4, g5):
+            sg = g.shadow_queue(nh)
+            for f in ("origin", "direction", "color", "closestDistance"):
+                assert np.array_equal(bits(so[f]), bits(sg[f])), f"{name}: shadow queue after the render, {f}"
         assert_accum_close(o.blit_buffer(), g3.blit_buffer(), name + " merged trace launches, no run-ahead")
         assert_accum_close(o.blit_buffer(), g0.blit_buffer(), name + " one stream")
         assert_accum_close(o.blit_buffer(), g1.blit_buffer(), name + " merged, always one iteration ahead")
         assert_accum_close(o.blit_buffer(), g2.blit_buffer(), name + " merged trace launches")
     # stage by stage right after a render with deferred / merged connects: nothing is left in flight or owed
     for st in ("begin", "primary", "extend", "shade", "connect", "end"):
-        o.stage(st), g1.stage(st), g2.stage(st)
+        o.stage(st), g1.stage(st), g2.stage(st), g4.stage(st)
     assert_accum_close(o.blit_buffer(), g1.blit_buffer(), name + " staged iteration after the render")
     assert_accum_close(o.blit_buffer(), g2.blit_buffer(), name + " staged iteration after the merged render")
+    assert_accum_close(o.blit_buffer(), g4.blit_buffer(), name + " staged iteration after a streamed tail")
     # a render cut short by max_iterations still settles its last shadow rays before it returns
     o.reset_accum(), g2.reset_accum()
     assert o.render(spp, 2) == g2.render(spp, 2) == 2

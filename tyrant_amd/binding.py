@@ -122,6 +122,7 @@ SYMBOLS = {
     "tyr_sync": (C.c_int, [P]),
     "tyr_queue_export": (C.c_int, [P, C.c_int, P, c_u32]),
     "tyr_queue_import": (C.c_int, [P, P, c_u32]),
+    "tyr_queue_rank_check": (C.c_int, [P, C.c_int, P, P]),
     "tyr_shadow_export": (C.c_int, [P, P, c_u32]),
     "tyr_shadow_import": (C.c_int, [P, P, c_u32]),
     "tyr_get_scene_info": (C.c_int, [P, C.POINTER(SceneInfo)]),
@@ -356,6 +357,12 @@ class Renderer:
 
     def resolve_into(self, device_ptr):
         _check(self.L.tyr_resolve(self.h, device_ptr), "tyr_resolve")
+
+    def queue_rank_check(self, which=1):
+        """(records, mismatches): the device's rank tables against the order ray_queue() presents (tyr_queue_rank_check)"""
+        n, bad = c_u32(0), c_u32(0)
+        _check(self.L.tyr_queue_rank_check(self.h, which, C.byref(n), C.byref(bad)), "tyr_queue_rank_check")
+        return n.value, bad.value
 
     def ray_queue(self, which=0, count=None) -> np.ndarray:
         n = self.N if count is None else count

@@ -237,10 +237,10 @@ struct Tuning {
 	int runAhead = 2;         // tyr_render: queue iteration i + 1 before iteration i's counts are on the host: 0 never, 1 always, 2 for queues of at most 6 Mi slots
 	int mergeTrace = 1;       // tyr_render: connect(i) rides in the launch of extend(i + 1)
 	int profileMask = 31;     // TYR_FLAG_PROFILE: which stages (bit TYR_K_*) get a hipEvent pair
-	int streamTail = 1;       // tyr_render: once the budget is spent, ONE traversal kernel across the remaining iterations with shade resident beside it (0: a launch per iteration)
+	int streamTail = 0;       // tyr_render: once the budget is spent, ONE traversal kernel across the remaining iterations with shade resident beside it (0, the default: a launch per iteration -- the streamed form is bit-exact and slower, DESIGN.md "One drain per render")
 	int streamShadePerCU = 1; // streamed tail: k_shade_stream blocks per CU ...
 	int streamTracePerCU = 4; // ... beside this many blocks of k_trace_stream
-	int foldSpheres = 0;      // launch-per-iteration path of tyr_render: shade does the sphere pre-passes' work for the rays it emits (the streamed tail always does)
+	int foldSpheres = 1;      // merged path of tyr_render: shade does the sphere pre-passes' work for the rays it emits (the streamed tail always does); 0: k_extend_spheres / k_connect_spheres re-read them
 };
 constexpr uint32_t kCountRaysPerBlock = 1024; // the counting build's kernels: queue slots owned by one 256-thread block
 

@@ -48,6 +48,16 @@ constexpr bool kAnatomy = true; // three s_memrealtime stamps per wave (start, q
 #else
 constexpr bool kAnatomy = false;
 #endif
+// -DTYR_AGE_PRIO=<quad steps>: a wave that holds a ray older than this many quad steps raises its issue priority
+// (s_setprio 3) until that ray is done: the launch ends on its longest rays, and during the feed phase their steps take
+// 3.5 us apiece because five waves per SIMD take turns (DESIGN.md section 4.4 "the drain, wave by wave")
+#ifdef TYR_AGE_PRIO
+constexpr bool kAgePrio = true;
+constexpr uint32_t kAgePrioSteps = TYR_AGE_PRIO;
+#else
+constexpr bool kAgePrio = false;
+constexpr uint32_t kAgePrioSteps = 0;
+#endif
 #define TYR_DBG(i)                                                     \
 	if (COUNT || kLoopStats) {                                         \
 		const unsigned long long m_ = __ballot(1);                     \
@@ -720,7 +730,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	bool isShadow = false, occluded = false;
 	uint32_t visible = 0;
 	uint32_t dbg[16] = {};
-	uint32_t steps = 0; // TYR_QUAD_STATS: quad steps of this lane's current ray
+	uint32_t steps = 0; // TYR_QUAD_STATS / TYR_AGE_PRIO: quad steps of this lane's current ray
+	[[maybe_unused]] bool agedWave = false;
 	[[maybe_unused]] unsigned long long tExhausted = 0ull, tWide = 0ull;
 	[[maybe_unused]] uint32_t liveAtExhaustion = 0, liveAtWide = 0, tripsAfter = 0, passesAfter = 0, wideSteps = 0; // (anatomy build)
 	const unsigned long long tStart = kAnatomy ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -822,6 +833,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 				dist = bound;
 				hitTri = false;
 				occluded = blocked;
+				if (kAgePrio)
+					steps = 0;
 				st.reset();
 				ref = blocked ? kRefDone : root_ref(sc, nr, dist);
 				if (ref != kRefDone)
@@ -852,6 +865,16 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 				continue;
 		}
 		allRegular = (__ballot(live && !regular) == 0ull);
+		if (kAgePrio) {
+			const bool old = __ballot(live && steps > kAgePrioSteps) != 0ull;
+			if (old != agedWave) {
+				agedWave = old;
+				if (old)
+					__builtin_amdgcn_s_setprio(3);
+				else
+					__builtin_amdgcn_s_setprio(0);
+			}
+		}
 		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
 		// ---- descent: one pop attempt + one quad test per lane per trip (the same for both kinds of ray) ----
 		for (;;) {
@@ -879,7 +902,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 			}
 			if ((int)ref >= 0) {
 				TYR_DBG(0)
-				if (kLoopStats)
+				if (kLoopStats || kAgePrio)
 					steps += 1;
 				const QuadHits q = allRegular ? test_quad<true, true, true>(sc.quads, ref, r, dist, stagedNodes, nStaged) : test_quad<false, true, true>(sc.quads, ref, r, dist, stagedNodes, nStaged);
 				const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];

@@ -1039,6 +1039,8 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 		return rc;
 	const int set = static_cast<int>(c->iter & 1u);
 	FrameParams P = make_params(c);
+	if (c->tuning.foldSpheres)
+		P.foldSpheres = 1u;
 	enqueue_primary(c, P, p.nNew);
 	enqueue_trace(c, P, p.nLive, p.nSurvivors, p.carried);
 	enqueue_shade(c, P, p.nLive);
@@ -1401,6 +1403,65 @@ int tyr_queue_export(tyr_ctx* c, int which, tyr_ray_queue* host, uint32_t count)
 	return TYR_OK;
 }
 
+// Test hook: the device's OWN rank tables against the order tyr_queue_export presents.  The export sorts the records by
+// their key on the host; the kernels never sort -- k_shade turns a key into the ray's slot with v_lookup() over the scan
+// tables of the iteration before (hip/device_common.hpp).  Here the same three-part sum is taken from copies of those
+// tables for every record of the queue, and compared with the record's place in the sorted order: a wrong table shows
+// here, not one iteration later as wrong random numbers.
+int tyr_queue_rank_check(tyr_ctx* c, int which, uint32_t* checked_out, uint32_t* mismatches_out) {
+	if (!c || (which != 0 && which != 1) || !checked_out || !mismatches_out)
+		return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	const int qi = which == 0 ? c->cur : (c->cur ^ 1);
+	// the tables the keys of this queue point into: written by the scan of the iteration that made its survivors
+	const int t = which == 1 ? static_cast<int>(c->iter & 1u) : static_cast<int>((c->iter & 1u) ^ 1u);
+	const size_t N = c->cfg.queue_size, entries = (N + 63) / 64 + kBlock, blocks = (N + 16383) / 16384 + 1;
+	std::vector<unsigned long long> word(entries);
+	std::vector<uint32_t> pre(entries), blk(blocks);
+	HIPCHK(hipMemcpy(word.data(), c->vWord[t], entries * 8, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(pre.data(), c->vPre[t], entries * 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(blk.data(), c->vBlk[t], blocks * 4, hipMemcpyDeviceToHost));
+	std::vector<uint32_t> keys;
+	for (uint32_t cls = 0; cls < tyr::kClasses; ++cls) {
+		std::vector<uint32_t> part, k;
+		if ((rc = valid_slots(&c->dK->seg[qi][cls][0], part)))
+			return rc;
+		for (uint32_t& sl : part)
+			sl += cls * c->segCap * tyr::kSegs;
+		uint32_t extent = 0;
+		for (uint32_t sl : part)
+			extent = std::max(extent, sl + 1);
+		if ((rc = gather(c->q[qi].key, part, extent, k)))
+			return rc;
+		keys.insert(keys.end(), k.begin(), k.end());
+	}
+	auto sortKey = [&](uint32_t key) { return (static_cast<uint64_t>((key & tyr::kKeyIndirect) ? 0u : 1u) << 32) | (key & tyr::kKeyMask); };
+	std::sort(keys.begin(), keys.end(), [&](uint32_t x, uint32_t y) { return sortKey(x) < sortKey(y); });
+	uint32_t bad = 0;
+	for (uint32_t i = 0; i < keys.size(); ++i) {
+		const uint32_t v = keys[i] & tyr::kKeyMask;
+		uint32_t slot = v; // a fresh primary ray carries its slot itself
+		if (keys[i] & tyr::kKeyIndirect) {
+			const uint32_t e = v >> 6;
+			if (e >= entries || (e >> 8) >= blocks) {
+				++bad;
+				continue;
+			}
+			slot = blk[e >> 8] + pre[e] + static_cast<uint32_t>(__builtin_popcountll(word[e] & ((1ull << (v & 63u)) - 1ull)));
+			if (!((word[e] >> (v & 63u)) & 1ull))
+				++bad; // the record's own survive bit must be set
+		}
+		if (slot != i)
+			++bad;
+	}
+	*checked_out = static_cast<uint32_t>(keys.size());
+	*mismatches_out = bad;
+	return TYR_OK;
+}
+
 int tyr_queue_import(tyr_ctx* c, const tyr_ray_queue* host, uint32_t n) {
 	if (!c || (!host && n) || n > c->cfg.queue_size)
 		return TYR_ERR_INVALID;
@@ -1409,6 +1470,7 @@ int tyr_queue_import(tyr_ctx* c, const tyr_ray_queue* host, uint32_t n) {
 		return rc;
 	if ((rc = sync_counters(c)))
 		return rc;
+	c->lastShadeFolded = false; // imported rays carry no sphere record: the pre-pass kernels do them
 	const RayQ& q = c->q[c->cur];
 	std::vector<float4> a(n), d(n);
 	std::vector<float2> b(n), h(n);
@@ -1516,6 +1578,7 @@ int tyr_shadow_import(tyr_ctx* c, const tyr_shadow_queue* host, uint32_t n) {
 	// what shade leaves behind (kernel.cu:416-417): the counts connect reads, in this iteration's set
 	c->hK->shadow_ray_cnt = n;
 	c->shadowSet = c->iter & 1u;
+	c->lastShadeFolded = false; // (imported shadow rays carry no sphere verdict)
 	ConnectCounters* kc = c->dKc + (c->iter & 1u);
 	uint32_t cnt[tyr::kSegs * tyr::kSegStride];
 	dense_counts(n, cnt);
