@@ -6,7 +6,14 @@
 // frames, which -- like any camera change -- resets the accumulation (kernel.cu:702-718): the path count of a probe
 // pixel is printed so the accumulate / reset behaviour is visible.
 //
-//   flythrough [device] [seconds_per_view = 10] [Performance.txt]
+//   flythrough [device] [seconds_per_view = 10] [Performance.txt] [K = 0] [prefix = frame]
+//
+// K > 0 is the progressive display of the interactive build (main.cpp:164-203) in the form a headless node can have: every
+// K-th frame what interop.blit() would put on the screen -- blit_onto_framebuffer's tone-mapped picture of the
+// accumulation so far (kernel.cu:648-662) -- goes to <prefix>_<frame>.ppm, and at the end <prefix>_hud.txt holds what the
+// "Performance" window of main.cpp:177-198 shows: the average over the last 120 frames as ImGui's IO.Framerate keeps it,
+// the last 200 frame times that PlotHistogram draws (one per line, seconds, as main.cpp:179-183 collects them), camera
+// position and angles, the sun position.
 //
 // Layout of the file, as performance_measure.cpp:27-31 writes it (quirk kept: the "Min ms" / "Max ms" lines hold
 // SECONDS -- `delta` is printed unscaled there; the true milliseconds go to stdout):
@@ -24,6 +31,7 @@
 #include <fstream>
 #include <limits>
 #include <numeric>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -63,6 +71,8 @@ int main(int argc, char** argv) {
 	const int device = argc > 1 ? std::atoi(argv[1]) : 0;
 	const double seconds_per_view = argc > 2 ? std::atof(argv[2]) : 10.0; // performance_measure.cpp:24
 	const char* out_path = argc > 3 ? argv[3] : "Performance.txt";         // performance_measure.cpp:4
+	const unsigned progressive = argc > 4 ? static_cast<unsigned>(std::atoi(argv[4])) : 0u;
+	const std::string prefix = argc > 5 ? argv[5] : "frame";
 	const unsigned W = 1920, H = 1080, N = ray_queue_buffer_size;          // variables.h:9-10, 44
 
 	// performance_measure.h:4-5
@@ -93,6 +103,30 @@ int main(int argc, char** argv) {
 		return px.w;
 	};
 
+	// the progressive display (K > 0): the picture interop.blit() would show, every K-th frame
+	vec4* screen = nullptr;
+	std::vector<float> screen_host;
+	std::vector<float> frame_times; // main.cpp:177-183: the last 200 deltas
+	unsigned long long frame_no = 0;
+	unsigned pictures = 0;
+	if (progressive) {
+		TYR_CHECK(hipMalloc(reinterpret_cast<void**>(&screen), sizeof(vec4) * W * H));
+		screen_host.resize(static_cast<size_t>(W) * H * 4);
+	}
+	auto hud_frame = [&](double delta) {
+		frame_times.push_back(static_cast<float>(delta)); // main.cpp:179
+		if (frame_times.size() > 200)
+			frame_times.erase(frame_times.begin());        // main.cpp:181-183
+		++frame_no;
+		if (progressive && frame_no % progressive == 0) {
+			TYR_CHECK(tyr_resolve(ctx, screen)); // kernel.cu:729-731 (the surface write) + interop.blit()
+			TYR_CHECK(hipMemcpy(screen_host.data(), screen, sizeof(vec4) * W * H, hipMemcpyDeviceToHost));
+			const std::string name = prefix + "_" + std::to_string(frame_no) + ".ppm";
+			TYR_CHECK(tyr_write_ppm(name.c_str(), screen_host.data(), W, H));
+			++pictures;
+		}
+	};
+
 	double previous_time = now_s();
 	for (size_t current_test = 0; current_test < test_positions.size(); ++current_test) {
 		if (current_test > 0) {
@@ -110,6 +144,7 @@ int main(int argc, char** argv) {
 				camera.update();                // main.cpp:166
 				TYR_CHECK(launch_kernels(nullptr, blit_buffer, scene.gpuScene, ray_buffer_work, ray_buffer_next, shadow_queue_buffer));
 				std::swap(ray_buffer_work, ray_buffer_next);
+				hud_frame(delta);
 			}
 			std::printf("walked 8 frames under scripted input: every frame moved the camera, probe pixel holds %.0f finished paths (reset each frame)\n", probe_paths());
 		}
@@ -131,6 +166,7 @@ int main(int argc, char** argv) {
 			camera.update(); // main.cpp:166
 			TYR_CHECK(launch_kernels(nullptr, blit_buffer, scene.gpuScene, ray_buffer_work, ray_buffer_next, shadow_queue_buffer));
 			std::swap(ray_buffer_work, ray_buffer_next); // main.cpp:169
+			hud_frame(delta);
 			++frames;
 		}
 		const double average_delta = std::accumulate(times.begin(), times.end(), 0.f) / times.size();
@@ -146,6 +182,24 @@ int main(int argc, char** argv) {
 			frames, seconds_per_view, average_delta * 1e3, 1.0 / average_delta, delta_min * 1e3, delta_max * 1e3, probe_paths(), k.frame);
 	}
 	file.close();
+	if (progressive) {
+		// the "Performance" window, main.cpp:185-196
+		const size_t m = std::min<size_t>(frame_times.size(), 120); // ImGui's IO.Framerate: the average over its last 120 frames
+		double sum = 0.0;
+		for (size_t i = frame_times.size() - m; i < frame_times.size(); ++i)
+			sum += frame_times[i];
+		const double framerate = m && sum > 0.0 ? m / sum : 0.0;
+		std::ofstream hud(prefix + "_hud.txt");
+		char line[256];
+		std::snprintf(line, sizeof line, "Application average %.3f ms/frame (%.1f FPS)\n", framerate > 0.0 ? 1000.0 / framerate : 0.0, framerate);
+		hud << line << "Frametimes (" << frame_times.size() << ")\n";
+		for (float t : frame_times)
+			hud << t << "\n";
+		std::snprintf(line, sizeof line, "X: %f, Y: %f, Z: %f\nHor: %f, Vert: %f\nSun X: %f Y: %f\n", camera.position.x, camera.position.y, camera.position.z, camera.horizontal_angle, camera.vertical_angle, sun_position.x, sun_position.y);
+		hud << line;
+		std::printf("progressive display: %u pictures (every %u-th of %llu frames) as %s_<frame>.ppm, HUD text in %s_hud.txt\n", pictures, progressive, frame_no, prefix.c_str(), prefix.c_str());
+		(void)hipFree(screen);
+	}
 	tyr_counters k;
 	TYR_CHECK(tyr_get_counters(ctx, &k));
 	std::printf("wrote %s; %.1f M rays traced, device_error %u\n", out_path, (k.total_extend_rays + k.total_shadow_rays) / 1e6, k.device_error);

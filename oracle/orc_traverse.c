@@ -6,7 +6,7 @@
  *   CachedBVH::intersectSimple bvh.h:213-256  (any hit)
  *   Sphere::intersect          kernel.cu:83-93
  * TEST INFRASTRUCTURE (see orc.h).  Checked bit-for-bit against the reference's
- * own headers compiled in oracle/_ref (tests/test_oracle_vs_ref.py).
+ * own headers compiled in oracle/_ref (tests/test_oracle_golden.py).
  */
 #include "orc_internal.h"
 

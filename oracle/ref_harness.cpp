@@ -15,9 +15,11 @@
  *   Triangle::intersect                                         loader.h:21-46
  *   struct layouts and constants                                variables.h, bvh.h, sunsky.cuh
  *
- * Not buildable here (DESIGN.md "Oracle"): bvh.cpp, Bbox.cpp, sunsky.cu,
- * kernel.cu, Scene.cpp -- all include stdafx.h, which needs "BVH.h" (a
- * case-insensitive file system), Windows-only .lib dependencies and nvcc.
+ * The reference's own bvh.cpp, Bbox.cpp and sunsky.cu are compiled, unmodified, by the
+ * second harness beside this one (ref_host_harness.cpp, `make ref`: their stdafx.h finds
+ * "BVH.h" through a symlink to bvh.h the Makefile creates).  Not buildable here
+ * (DESIGN.md "Oracle"): kernel.cu (nvcc: <<< >>>, surface<>, atomicAdd) and Scene.cpp /
+ * static_mesh.cpp (assimp ships as a Windows-only .lib).
  */
 #include <cmath>
 #include <cstddef>

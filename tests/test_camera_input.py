@@ -97,3 +97,32 @@ def test_flythrough_writes_the_references_performance_file(hip, tmp_path):
     for l in walks:  # a moving camera resets every frame: at most what ONE launch_kernels finishes for that pixel
         assert float(l.split("holds ")[1].split(" ")[0]) <= 2
     assert "device_error 0" in p.stdout
+
+
+@pytest.mark.gpu
+def test_flythrough_progressive_display_writes_pictures_and_the_hud(hip, tmp_path):
+    """the interactive build's progressive display (main.cpp:164-203), headless: every K-th frame the tone-mapped picture of the
+    accumulation so far (kernel.cu:648-662) as a PPM, and the "Performance" window's text (main.cpp:177-198): the frame-rate
+    line, the last <= 200 frame times, camera and sun"""
+    exe = os.path.join(ROOT, "tyrant_amd", "bin", "flythrough")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tyrant_amd", "csrc"), "example"], check=True)
+    prefix = str(tmp_path / "shot")
+    p = subprocess.run([exe, "0", "0.3", str(tmp_path / "Performance.txt"), "150", prefix], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    shots = sorted(f for f in os.listdir(tmp_path) if f.startswith("shot_") and f.endswith(".ppm"))
+    assert len(shots) >= 2 and all(int(f[5:-4]) % 150 == 0 for f in shots)
+    data = open(tmp_path / shots[-1], "rb").read()
+    assert data.startswith(b"P6") and len(data) > 1920 * 1080 * 3
+    import numpy as np
+
+    px = np.frombuffer(data[-1920 * 1080 * 3:], dtype=np.uint8)
+    assert px.max() > 32 and px.std() > 4  # a picture, not a constant frame
+    hud = open(prefix + "_hud.txt").read().split("\n")
+    assert hud[0].startswith("Application average ") and "ms/frame" in hud[0] and "FPS" in hud[0]
+    n = int(hud[1].split("(")[1].rstrip(")"))
+    assert hud[1].startswith("Frametimes") and 1 <= n <= 200
+    times = [float(x) for x in hud[2 : 2 + n]]
+    assert all(0 < t < 1.0 for t in times)
+    assert hud[2 + n].startswith("X: ") and hud[3 + n].startswith("Hor: ") and hud[4 + n].startswith("Sun X: ")
+    assert "progressive display:" in p.stdout and "device_error 0" in p.stdout

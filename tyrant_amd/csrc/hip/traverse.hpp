@@ -147,6 +147,29 @@ __device__ __forceinline__ float triangle_test(const TriData& d, const RayConst&
 	return dot(e2, qvec) * invDet;
 }
 
+// The same test without a branch: every operation of loader.h:21-46 in its order, the three early-outs folded into one
+// select at the end (identical results: a lane that would have left early computes values nobody reads -- 1 / det may be
+// inf or NaN there, which no comparison of the select lets through).  For code whose cost is its SCALAR instructions
+// (the four-lanes-to-a-ray drain): three early-outs are three exec-mask save / branch / restore sequences per test.
+__device__ __forceinline__ float triangle_test_select(const TriData& d, const RayConst& r) {
+	const float4 a = d.a, b = d.b, c = d.c;
+	const f3 vert = mk3(a.x, a.y, a.z);
+	const f3 e1 = mk3(a.w, b.x, b.y);
+	const f3 e2 = mk3(b.z, b.w, c.x);
+	const f3 pvec = cross(r.d, e2);
+	const float det = dot(e1, pvec);
+	const bool out0 = det < 0.0000001f;
+	const float invDet = 1 / det;
+	const f3 tvec = r.o - vert;
+	const float u = dot(tvec, pvec) * invDet;
+	const bool out1 = u < 0 || u > 1;
+	const f3 qvec = cross(tvec, e1);
+	const float v = dot(r.d, qvec) * invDet;
+	const bool out2 = v < 0 || u + v > 1;
+	const float t = dot(e2, qvec) * invDet;
+	return (out0 || out1 || out2) ? 0.0f : t;
+}
+
 // Per-lane traversal stack: the first LDS_DEPTH entries in LDS, the rest in a private (scratch)
 // array, the top entry cached in registers (a push followed by a pop never touches memory).
 //

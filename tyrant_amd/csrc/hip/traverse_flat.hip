@@ -583,6 +583,110 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 	const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 };
 	const uint32_t signBits = (r.nx ? 1u : 0u) | (r.ny ? 2u : 0u) | (r.nz ? 4u : 0u);
 	bool wideOverflow = false;
+#ifndef TYR_WIDE_BRANCHY
+	// The loop below is written with SELECTS, not branches.  A SIMD issues one scalar instruction per four cycles whichever of
+	// its waves it comes from; the first form of this loop (lane-varying `if`s: pop / node / leaf / four accepts per leaf /
+	// fast or generic box test) compiled to ~300 scalar instructions per step -- exec-mask save, branch, restore around
+	// every block -- so that five waves per SIMD took 5 x 300 x 4 = 6000 cycles = 2.9 us per step, which is what the
+	// per-wave anatomy measured (DESIGN.md section 4.4 "the drain, wave by wave"): the drain of every traversal launch was
+	// bound by the scalar pipe, not by memory latency and not by the vector pipe.  Here every lane runs every block a wave
+	// needs at all (wave-uniform branches on ballots), state changes are selects, loads of lanes that have nothing to load
+	// go to record 0.  A lane that turns a node into a leaf tests the leaf in the same trip.
+	const bool allRegular = __ballot(gActive && !regular) == 0ull; // (the generic box test is exact for regular rays too: one path for the wave)
+	while (__ballot(gActive) != 0ull) {
+		if (kGuardPasses && ++passes > kMaxPasses)
+			break;
+#ifdef TYR_LAUNCH_ANATOMY
+		wideSteps += 1;
+#endif
+		// ---- pop: the group's top entry (entry 0 when it has none) ----
+		{
+			const bool popping = gActive && ref == kRefPop;
+			const bool has = n > 0;
+			const int top = has ? n - 1 : 0;
+			const entry_t e = gstack[(top >> 2) * kBlock + (top & 3)];
+			const uint32_t popped = !has ? kRefDone : (__uint_as_float(e.y) < dist ? e.x : kRefPop); // the pop-time half of Bbox.h:61
+			ref = popping ? popped : ref;
+			n = (popping && has) ? n - 1 : n;
+		}
+		// ---- one quad node: this lane's child box ----
+		const bool atNode = gActive && (int)ref >= 0;
+		if (__ballot(atNode) != 0ull) {
+			const uint32_t idx = atNode ? (ref & kQuadIndexMask) : 0u, meta = ref >> kQuadOrderShift;
+			const float* qf = reinterpret_cast<const float*>(quads + 8 * idx);
+			const uint32_t at = (sub >> 1) * 4u + (sub & 1u) * 2u;
+			const float2 bx = *reinterpret_cast<const float2*>(qf + at);
+			const float2 by = *reinterpret_cast<const float2*>(qf + 8 + at);
+			const float2 bz = *reinterpret_cast<const float2*>(qf + 16 + at);
+			const uint32_t cref = __float_as_uint(qf[24 + sub]);
+			float t;
+			bool h;
+			if (allRegular)
+				h = slab_fast(r, bx.x, bx.y, by.x, by.y, bz.x, bz.y, dist, t);
+			else
+				h = slab_test(r, r.nx ? bx.y : bx.x, r.nx ? bx.x : bx.y, r.ny ? by.y : by.x, r.ny ? by.x : by.y, r.nz ? bz.y : bz.x, r.nz ? bz.x : bz.y, dist, t);
+			h = h && atNode;
+			// this slot's place in the reference's visit order (test_quad: near slot first inside each group, near group first)
+			const uint32_t aT = meta & 3u, aL = (meta >> 2) & 3u, aR = (meta >> 4) & 3u;
+			const uint32_t bT = (signBits >> aT) & 1u, bG = (signBits >> ((sub >> 1) ? aR : aL)) & 1u;
+			const uint32_t rank = 2u * ((sub >> 1) ^ bT) + ((sub & 1u) ^ bG);
+			const uint32_t hr = quad_or(h ? (1u << rank) : 0u); // the group's hits, in visit order
+			const uint32_t first = (uint32_t)__ffs((int)(hr | 16u)) - 1u; // (4 when nothing was hit: no lane's rank)
+			// the others go onto the stack farthest first, so that the nearest pops first (push3's order)
+			const int e = n + (int)__popc(hr >> (rank + 1u));
+			if (h && rank != first && e < kWideStackEntries)
+				gstack[(e >> 2) * kBlock + (e & 3)] = make_uint2(cref, __float_as_uint(t));
+			int n2 = n + (int)__popc(hr) - (hr != 0u ? 1 : 0);
+			wideOverflow = wideOverflow || (atNode && n2 > kWideStackEntries);
+			n2 = n2 > kWideStackEntries ? kWideStackEntries : n2;
+			const uint32_t nearest = quad_or((h && rank == first) ? cref : 0u);
+			ref = atNode ? (hr == 0u ? kRefPop : nearest) : ref;
+			n = atNode ? n2 : n;
+		}
+		// ---- a leaf: four primitives per round, accepted in array order (bvh.h:129-140 / 229-238) ----
+		const bool atLeaf = gActive && ref_is_leaf(ref);
+		if (__ballot(atLeaf) != 0ull) {
+			const uint32_t off = ref & (kMaxPrimOffset - 1);
+			const uint32_t cnt = atLeaf ? ((ref >> 26) & 31u) + 1u : 0u;
+			bool found = false;
+			for (uint32_t base = 0; __ballot(base < cnt) != 0ull; base += 4u) {
+				const uint32_t i = base + sub;
+				const bool mine = i < cnt;
+				const TriData td = triangle_load(tris, mine ? off + i : 0u);
+				float tm = triangle_test_select(td, r);
+				tm = mine ? tm : 0.0f;
+				const float t0 = quad_bcast_f<0>(tm), t1 = quad_bcast_f<1>(tm), t2 = quad_bcast_f<2>(tm), t3 = quad_bcast_f<3>(tm);
+				const float tk[4] = { t0, t1, t2, t3 };
+#pragma unroll
+				for (uint32_t k = 0; k < 4u; ++k) {
+					const float t = tk[k];
+					const bool in = (base + k < cnt) && t > kEpsilon && ((dist - t) > kEpsilon);
+					found = found || (in && isShadow);                 // bvh.h:232-236
+					const bool closer = in && !isShadow && t < dist;    // bvh.h:133-137
+					prim = closer ? (int)(off + base + k) : prim;
+					hitTri = hitTri || closer;
+					dist = closer ? t : dist;
+				}
+			}
+			occluded = occluded || found;
+			ref = atLeaf ? (found ? kRefDone : kRefPop) : ref;
+		}
+		if (gActive && ref == kRefDone) {
+			if (sub == 0u) {
+				if (isShadow) {
+					if (!occluded) { // kernel.cu:640-644
+						const float4 c = shadowColor[slot];
+						accumulate_pixel(blit, __float_as_int(shadowDyzCdIx[slot].w), mk3(c.x, c.y, c.z), 0);
+						visible += 1;
+					}
+				} else {
+					finish_extend_ray(workHit, slot, hitTri, dist, prim);
+				}
+			}
+			gActive = false;
+		}
+	}
+#else
 	while (__ballot(gActive) != 0ull) {
 		if (kGuardPasses && ++passes > kMaxPasses)
 			break;
@@ -644,8 +748,16 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 			for (uint32_t base = 0; base < cnt; base += 4u) {
 				const uint32_t i = base + sub;
 				float tm = 0.0f;
-				if (i < cnt)
-					tm = triangle_test(triangle_load(tris, off + i), r);
+				if (i < cnt) {
+					// all three vectors of the record before the test starts: left alone, the compiler sinks the loads of
+					// `vert` and e2.z behind Moeller-Trumbore's first early-out -- a second dependent round trip per leaf on
+					// the launch's critical path
+					const TriData td = triangle_load(tris, off + i);
+#ifndef TYR_WHATIF_NO_TRI_HOIST
+					__asm__ volatile("" ::"v"(td.a.x), "v"(td.b.x), "v"(td.c.x));
+#endif
+					tm = triangle_test(td, r);
+				}
 				const float t0 = quad_bcast_f<0>(tm), t1 = quad_bcast_f<1>(tm), t2 = quad_bcast_f<2>(tm), t3 = quad_bcast_f<3>(tm);
 				const float tk[4] = { t0, t1, t2, t3 };
 #pragma unroll
@@ -680,6 +792,7 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 			gActive = false;
 		}
 	}
+#endif
 	return visible | (wideOverflow ? 0x80000000u : 0u) | (kGuardPasses && passes > kMaxPasses ? 0x40000000u : 0u);
 }
 
@@ -716,6 +829,22 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	}
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
+	[[maybe_unused]] uint32_t tripsFeed = 0; // (anatomy build) descent trips before the queue ran out
+	[[maybe_unused]] bool quietCU = false;
+#ifdef TYR_WHATIF_QUIET_CUS
+	// what-if (with -DTYR_LAUNCH_ANATOMY): on one CU in TYR_WHATIF_QUIET_CUS only the first wave of every block works -- five
+	// waves on the CU instead of twenty -- and every wave reports its feed-phase trips: how fast does a trip go on a quiet CU
+	// while the rest of the chip is as busy as ever (is the 3.5 us per trip a property of the CU or of the chip)?
+	{
+		const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+		const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20); // HW_REG_XCC_ID [3:0]
+		const uint32_t cuKey = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+		quietCU = (cuKey % (uint32_t)(TYR_WHATIF_QUIET_CUS)) == 0u;
+		__syncthreads();
+		if (quietCU && (threadIdx.x >> 6) != 0u)
+			return;
+	}
+#endif
 	// items = physical slots: the work queue's [0, nExt), then the shadow queue's; the few slots at the segments' ends that
 	// hold no record are handed out like the others: the pre-passes (and k_primary) have made them rays that enter nothing
 	const uint32_t nExt = P.traceShadow == 2u ? 0u : queue_extent(P.segWork);
@@ -889,6 +1018,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 			}
 			if (kAnatomy && exhausted)
 				tripsAfter += 1;
+			if (kAnatomy && !exhausted)
+				tripsFeed += 1;
 			if (ref == kRefPop) {
 				TYR_DBG(2)
 				uint32_t pr;
@@ -993,7 +1124,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		if (w < 8192u && 32768u < P.N) { // three more records per wave, further up the same column (host/driver.cpp prints them with TYR_ANATOMY=2)
 			P.next.hit[8192u + w] = make_float2(tWide ? (float)(tWide - tStart) * 0.01f : 0.0f, (float)(liveAtExhaustion + 256u * liveAtWide));
 			P.next.hit[16384u + w] = make_float2((float)tripsAfter, (float)wideSteps); // trips after the queue ran out one ray to a lane, steps four lanes to a ray
-			P.next.hit[24576u + w] = make_float2((float)passesAfter, 0.0f);
+			P.next.hit[24576u + w] = make_float2((float)passesAfter, quietCU ? -(float)tripsFeed : (float)tripsFeed);
 		}
 	}
 }

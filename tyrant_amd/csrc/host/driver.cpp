@@ -924,6 +924,20 @@ static void print_wave_anatomy(const float2* dHit, unsigned long long feedTicks)
 	line("steps four lanes to a ray", steps);
 	line("us per trip, one ray to a lane", perTrip);
 	line("us per step, four lanes to a ray", perStep);
+	{
+		// the feed phase: microseconds per descent trip while the queue lasted; with -DTYR_WHATIF_QUIET_CUS the waves of the quiet
+		// CUs (negative trip counts) apart from the others
+		std::vector<float> feedBusy, feedQuiet;
+		for (uint32_t w = 0; w < 8192; ++w) {
+			const float tExh = rec[w].x, n = rec[24576 + w].y;
+			if (!(tExh > 0.0f) || n == 0.0f)
+				continue;
+			(n < 0.0f ? feedQuiet : feedBusy).push_back(tExh / std::fabs(n));
+		}
+		line("feed phase: us per trip", feedBusy);
+		if (!feedQuiet.empty())
+			line("feed phase: us per trip, waves of the QUIET CUs", feedQuiet);
+	}
 	// the launch ends with these: the five waves that left last
 	std::vector<uint32_t> order;
 	for (uint32_t w = 0; w < 8192; ++w)
