@@ -298,7 +298,6 @@ enum {
 	TYR_TUNE_STREAM_TAIL = 16,       /* tyr_render: 1 = once the primary budget is spent, the remaining iterations run as ONE traversal kernel with shade resident beside it (DESIGN.md "One drain per render": bit-exact, measured slower, hence not the default); 0 (default) = a traversal launch per iteration */
 	TYR_TUNE_STREAM_SHADE_PER_CU = 17, /* streamed tail: shade blocks per CU (1..2, default 1) ... */
 	TYR_TUNE_STREAM_TRACE_PER_CU = 18, /* ... beside this many traversal blocks per CU (1..5, default 4) */
-	TYR_TUNE_HEX_DRAIN = 20,         /* 1 (default) = the four-lanes-per-ray drain steps TWO quad levels per fetch (hex records: the quad records of a node's four slots side by side, 4 x the quad nodes' bytes, built at tyr_scene_upload -- set the knob before uploading); 0 = quad steps only */
 	TYR_TUNE_FOLD_SPHERES = 19       /* merged path of tyr_render: 1 (default) = shade does the sphere pre-passes' work (kernel.cu:127-136, 168-172) for the rays it emits, while they are in registers; 0 = the pre-pass kernels re-read them */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);

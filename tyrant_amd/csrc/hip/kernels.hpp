@@ -203,7 +203,7 @@ struct FrameParams {
 	uint32_t staticShare;         // sixteenths of the queue handed out as fixed per-block ranges
 	uint32_t traceShadow;         // k_trace_flat: the previous iteration's shadow rays ride in this launch (0: a render's first launch; 2: they are ALL of it -- the launch that ends a render)
 	uint32_t staticInterleave;    // ... as 64-slot chunks b, b + G, ... (1) or as one contiguous range per block (0)
-	uint32_t wideDrain;           // k_trace_flat: finish a wave's last <= 16 rays four lanes to a ray (2: and step two quad levels per fetch where the scene has hex records)
+	uint32_t wideDrain;           // k_trace_flat: finish a wave's last <= 16 rays four lanes to a ray
 	// the streamed tail (StreamState above); all zero / null in the launch-per-iteration path
 	StreamState* stream;
 	uint32_t streamIter;          // k_shade_stream: which StreamIter this launch shades; k_trace_stream: 0 (it starts at the tail's first iteration)
@@ -240,7 +240,6 @@ struct Tuning {
 	int streamTail = 0;       // tyr_render: once the budget is spent, ONE traversal kernel across the remaining iterations with shade resident beside it (0, the default: a launch per iteration -- the streamed form is bit-exact and slower, DESIGN.md "One drain per render")
 	int streamShadePerCU = 1; // streamed tail: k_shade_stream blocks per CU ...
 	int streamTracePerCU = 4; // ... beside this many blocks of k_trace_stream
-	int hexDrain = 0;         // the four-lanes-per-ray drain steps two quad levels per fetch through the hex records (uploaded at tyr_scene_upload when set: 4 x the quad nodes' bytes); 0: quad steps only
 	int foldSpheres = 1;      // merged path of tyr_render: shade does the sphere pre-passes' work for the rays it emits (the streamed tail always does); 0: k_extend_spheres / k_connect_spheres re-read them
 };
 constexpr uint32_t kCountRaysPerBlock = 1024; // the counting build's kernels: queue slots owned by one 256-thread block

@@ -58,7 +58,6 @@ constexpr uint32_t kQuadIndexMask = (1u << kQuadOrderShift) - 1u;
 
 struct DevScene {
 	const float4* quads; // QuadNode array, 8 float4 each (the production traversal)
-	const float4* hexes; // hex records, 32 float4 per quad node (four quad records side by side; null: not uploaded) -- the four-lanes-per-ray drain's two-levels-per-fetch steps
 	uint32_t quadRootRef;
 	uint32_t nQuads;
 	uint32_t nStaged;    // the first nStaged quad nodes are the top of the tree in breadth-first order (<= kStagedNodes)

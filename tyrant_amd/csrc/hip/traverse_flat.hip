@@ -529,7 +529,7 @@ struct WideState {
 	int prim, n;
 };
 template <int STACK_LDS>
-__device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __restrict__ quads, const float4* __restrict__ hexes, const float4* __restrict__ tris, const float4* __restrict__ shadowColor, const float4* __restrict__ shadowDyzCdIx,
+__device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __restrict__ quads, const float4* __restrict__ tris, const float4* __restrict__ shadowColor, const float4* __restrict__ shadowDyzCdIx,
                                                          float2* __restrict__ workHit, float4* __restrict__ blit, typename LdsStack<STACK_LDS, true>::entry_t* smem_, WideState w, uint32_t passes TYR_WIDE_STEPS_PARAM) {
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
@@ -609,65 +609,8 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 			ref = popping ? popped : ref;
 			n = (popping && has) ? n - 1 : n;
 		}
-		// ---- a node: TWO quad levels in one fetch where the hex records are there and the group's stack has room for the
-		// fifteen entries a hex step can push (the layout pass only bounds the quad steps' need: quadMaxStack); else one ----
-		const bool anyNode = gActive && (int)ref >= 0;
-		const bool atHex = anyNode && hexes != nullptr && n <= kWideStackEntries - 15;
-		if (__ballot(atHex) != 0ull) {
-			// this lane: sub-record `sub` of the node's hex record = the quad record of the node's slot `sub` (or that slot
-			// alone when it is a leaf): four boxes, in that quad's own visit order; the group: the four sub-records in the
-			// node's visit order.  Sixteen hits at most, visited depth-first: position 4 * (slot's rank) + (box's rank).
-			const uint32_t idx = atHex ? (ref & kQuadIndexMask) : 0u, metaQ = ref >> kQuadOrderShift;
-			const float4* hq = hexes + (size_t)32 * idx + 8u * sub;
-			const float4 x01 = hq[0], x23 = hq[1], y01 = hq[2], y23 = hq[3], z01 = hq[4], z23 = hq[5], rf = hq[6];
-			const uint32_t metaG = __float_as_uint(reinterpret_cast<const float*>(hq + 7)[0]);
-			float tb[4];
-			bool hb[4];
-			if (allRegular) {
-				hb[0] = slab_fast(r, x01.x, x01.y, y01.x, y01.y, z01.x, z01.y, dist, tb[0]);
-				hb[1] = slab_fast(r, x01.z, x01.w, y01.z, y01.w, z01.z, z01.w, dist, tb[1]);
-				hb[2] = slab_fast(r, x23.x, x23.y, y23.x, y23.y, z23.x, z23.y, dist, tb[2]);
-				hb[3] = slab_fast(r, x23.z, x23.w, y23.z, y23.w, z23.z, z23.w, dist, tb[3]);
-			} else {
-				hb[0] = slab_test(r, r.nx ? x01.y : x01.x, r.nx ? x01.x : x01.y, r.ny ? y01.y : y01.x, r.ny ? y01.x : y01.y, r.nz ? z01.y : z01.x, r.nz ? z01.x : z01.y, dist, tb[0]);
-				hb[1] = slab_test(r, r.nx ? x01.w : x01.z, r.nx ? x01.z : x01.w, r.ny ? y01.w : y01.z, r.ny ? y01.z : y01.w, r.nz ? z01.w : z01.z, r.nz ? z01.z : z01.w, dist, tb[1]);
-				hb[2] = slab_test(r, r.nx ? x23.y : x23.x, r.nx ? x23.x : x23.y, r.ny ? y23.y : y23.x, r.ny ? y23.x : y23.y, r.nz ? z23.y : z23.x, r.nz ? z23.x : z23.y, dist, tb[2]);
-				hb[3] = slab_test(r, r.nx ? x23.w : x23.z, r.nx ? x23.z : x23.w, r.ny ? y23.w : y23.z, r.ny ? y23.z : y23.w, r.nz ? z23.w : z23.z, r.nz ? z23.z : z23.w, dist, tb[3]);
-			}
-			const uint32_t rb[4] = { __float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w) };
-			// the slot's place among the node's four (as in a quad step), and each box's place inside the sub-record
-			const uint32_t aT = metaQ & 3u, aL = (metaQ >> 2) & 3u, aR = (metaQ >> 4) & 3u;
-			const uint32_t bT = (signBits >> aT) & 1u, bG = (signBits >> ((sub >> 1) ? aR : aL)) & 1u;
-			const uint32_t rankQ = 2u * ((sub >> 1) ^ bT) + ((sub & 1u) ^ bG);
-			const uint32_t gT = (signBits >> (metaG & 3u)) & 1u, gL = (signBits >> ((metaG >> 2) & 3u)) & 1u, gR = (signBits >> ((metaG >> 4) & 3u)) & 1u;
-			uint32_t mine = 0u; // this lane's hits at their positions 4 * rankQ + rank of the box
-			uint32_t pos[4];
-#pragma unroll
-			for (uint32_t k = 0; k < 4u; ++k) {
-				const uint32_t rk = 2u * ((k >> 1) ^ gT) + ((k & 1u) ^ ((k >> 1) ? gR : gL));
-				pos[k] = 4u * rankQ + rk;
-				mine |= (hb[k] && atHex) ? (1u << pos[k]) : 0u;
-			}
-			const uint32_t hr = quad_or(mine); // the group's hits, in visit order
-			const uint32_t first = (uint32_t)__ffs((int)(hr | 0x10000u)) - 1u;
-			uint32_t nearestMine = 0u;
-#pragma unroll
-			for (uint32_t k = 0; k < 4u; ++k) {
-				const bool hitK = ((mine >> pos[k]) & 1u) != 0u;
-				// the others go onto the stack farthest first, so that the nearest pops first
-				if (hitK && pos[k] != first) {
-					const int e = n + (int)__popc(hr >> (pos[k] + 1u));
-					gstack[(e >> 2) * kBlock + (e & 3)] = make_uint2(rb[k], __float_as_uint(tb[k]));
-				}
-				nearestMine |= (hitK && pos[k] == first) ? rb[k] : 0u;
-			}
-			const uint32_t nearest = quad_or(nearestMine);
-			const int n2 = n + (int)__popc(hr) - (hr != 0u ? 1 : 0);
-			ref = atHex ? (hr == 0u ? kRefPop : nearest) : ref;
-			n = atHex ? n2 : n;
-		}
 		// ---- one quad node: this lane's child box ----
-		const bool atNode = anyNode && !atHex;
+		const bool atNode = gActive && (int)ref >= 0;
 		if (__ballot(atNode) != 0ull) {
 			const uint32_t idx = atNode ? (ref & kQuadIndexMask) : 0u, meta = ref >> kQuadOrderShift;
 			const float* qf = reinterpret_cast<const float*>(quads + 8 * idx);
@@ -1152,7 +1095,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		w.rox = rox, w.roy = roy, w.roz = roz, w.rdx = rdx, w.rdy = rdy, w.rdz = rdz, w.rix = rix, w.riy = riy, w.riz = riz, w.dist = dist;
 		w.ref = ref, w.slot = slot, w.prim = prim, w.n = st.n;
 		w.flags = (regular ? 1u : 0u) | (hitTri ? 2u : 0u) | (isShadow ? 4u : 0u) | (occluded ? 8u : 0u) | (live ? 16u : 0u);
-		const uint32_t res = wide_drain<STACK_LDS>(sc.quads, P.wideDrain == 2u ? sc.hexes : nullptr, sc.tris, P.shadowPrev.color, P.shadowPrev.dyz_cd_ix, P.work.hit, P.blit, smem_, w, passes TYR_WIDE_STEPS_ARG);
+		const uint32_t res = wide_drain<STACK_LDS>(sc.quads, sc.tris, P.shadowPrev.color, P.shadowPrev.dyz_cd_ix, P.work.hit, P.blit, smem_, w, passes TYR_WIDE_STEPS_ARG);
 		visible += res & 0x3fffffffu;
 		overflow = overflow || (res & 0x80000000u) != 0u;
 		if (res & 0x40000000u)

@@ -49,9 +49,8 @@ struct Emit {
 
 } // namespace
 
-int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims, DeviceLayout& L, bool wantHex) {
+int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims, DeviceLayout& L) {
 	L.pairNodes.clear();
-	L.hexNodes.clear();
 	L.tris.clear();
 	L.nPairs = 0;
 	L.rootRef = kRefDone;
@@ -402,45 +401,6 @@ int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_tri
 		}
 	}
 	L.quadRootRef = with_order_bits(L.quadRootRef);
-
-	// ---- hex records (512 B, the four-lanes-per-ray drain only): record q = the quad records of q's four slots side by
-	// side, so that ONE fetch yields the boxes two quad levels down (sixteen of them) and a ray's longest chain of
-	// dependent fetches is halved where nothing else is left to hide it.  Sub-record s of record q:
-	//   slot s of q is an interior reference g  ->  a copy of quad record g, its word 28 = g's visit-order bits
-	//   slot s is a leaf (or a synthetic chain, or unused) -> that slot alone: box and reference in slot 0, the other three
-	//                                                         unused (+inf boxes), order bits "no swap"
-	// A reference found in a hex record is a reference of the quad layout (same indices, same order bits): a traversal may
-	// take quad steps and hex steps in any mix, its stack means the same either way.
-	if (wantHex && L.nQuads > 0) {
-		L.hexNodes.assign(static_cast<size_t>(L.nQuads) * 128, 0.0f);
-		const float inf = std::numeric_limits<float>::infinity();
-		for (uint32_t qi = 0; qi < L.nQuads; ++qi) {
-			const float* q = &L.quadNodes[static_cast<size_t>(qi) * 32];
-			for (int sidx = 0; sidx < 4; ++sidx) {
-				float* h = &L.hexNodes[static_cast<size_t>(qi) * 128 + static_cast<size_t>(sidx) * 32];
-				uint32_t ref;
-				std::memcpy(&ref, q + 24 + sidx, 4);
-				if (static_cast<int32_t>(ref) >= 0) {
-					const uint32_t g = ref & kQuadIndexMask;
-					std::memcpy(h, &L.quadNodes[static_cast<size_t>(g) * 32], 32 * sizeof(float));
-					const uint32_t order = (ref >> kQuadOrderShift) & 63u;
-					std::memcpy(h + 28, &order, 4);
-				} else {
-					for (int k = 0; k < 3; ++k)
-						for (int t = 0; t < 4; ++t) {
-							h[8 * k + 2 * t + 0] = t == 0 ? q[8 * k + 2 * sidx + 0] : inf;
-							h[8 * k + 2 * t + 1] = t == 0 ? q[8 * k + 2 * sidx + 1] : inf;
-						}
-					const uint32_t none = kRefDone, order = 63u;
-					std::memcpy(h + 24, &ref, 4); // (an unused slot of q: its own +inf box and kRefDone come along)
-					std::memcpy(h + 25, &none, 4);
-					std::memcpy(h + 26, &none, 4);
-					std::memcpy(h + 27, &none, 4);
-					std::memcpy(h + 28, &order, 4);
-				}
-			}
-		}
-	}
 	return TYR_OK;
 }
 

@@ -64,7 +64,6 @@ struct tyr_ctx {
 
 	float4* dNodes = nullptr;
 	float4* dQuads = nullptr;
-	float4* dHexes = nullptr; // (TYR_TUNE_HEX_DRAIN at upload time)
 	float4* dTris = nullptr;
 	uint32_t* dLights = nullptr; // TYR_FLAG_LIGHT_LIST: emissive triangles, array order
 	uint32_t nLights = 0;

@@ -176,7 +176,7 @@ FrameParams make_params(const tyr_ctx* c) {
 	P.raysPerBlock = tyr::kCountRaysPerBlock;
 	P.staticShare = static_cast<uint32_t>(std::min(std::max(c->tuning.staticShare, 0), 15));
 	P.staticInterleave = c->tuning.staticInterleave ? 1u : 0u;
-	P.wideDrain = c->tuning.wideDrain ? (c->tuning.hexDrain && c->scene.hexes ? 2u : 1u) : 0u;
+	P.wideDrain = c->tuning.wideDrain ? 1u : 0u;
 	P.lights = c->dLights;
 	P.nLights = c->nLights;
 	std::memcpy(P.triEmission, c->triEmission, 12);
@@ -567,7 +567,6 @@ int tyr_destroy(tyr_ctx* c) {
 		(void)hipEventDestroy(c->evTail);
 	dev_free(c->dNodes);
 	dev_free(c->dQuads);
-	dev_free(c->dHexes);
 	dev_free(c->dTris);
 	dev_free(c->dLights);
 	dev_free(c->dPalette);
@@ -603,12 +602,11 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	if (rc)
 		return rc;
 	DeviceLayout L;
-	if ((rc = build_device_layout(nodes, nNodes, prims, nPrims, L, c->tuning.hexDrain != 0)))
+	if ((rc = build_device_layout(nodes, nNodes, prims, nPrims, L)))
 		return rc;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	dev_free(c->dNodes);
 	dev_free(c->dQuads);
-	dev_free(c->dHexes);
 	dev_free(c->dTris);
 	dev_free(c->dLights);
 	c->nLights = 0;
@@ -635,12 +633,6 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 		HIPCHK(hipMemcpy(c->dQuads + kWhatIfQuadPad, L.quadNodes.data(), L.quadNodes.size() * sizeof(float), hipMemcpyHostToDevice));
 #endif
 	c->scene.quads = c->dQuads;
-	if (!L.hexNodes.empty()) {
-		if ((rc = dev_alloc(c->dHexes, L.hexNodes.size() / 4)))
-			return rc;
-		HIPCHK(hipMemcpy(c->dHexes, L.hexNodes.data(), L.hexNodes.size() * sizeof(float), hipMemcpyHostToDevice));
-		c->scene.hexes = c->dHexes;
-	}
 	c->scene.quadRootRef = L.quadRootRef;
 	c->scene.nQuads = L.nQuads;
 	c->scene.nStaged = L.nStaged;
@@ -1693,7 +1685,7 @@ int tyr_get_scene_info(tyr_ctx* c, tyr_scene_info* out) {
 	out->max_quad_nodes = 1u << kQuadOrderShift;
 	out->max_prim_offset = kMaxPrimOffset;
 	const bool havePairs = (c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) != 0;
-	out->device_bytes = static_cast<uint64_t>(c->scene.nQuads) * (c->scene.hexes ? 128 + 512 : 128) + (havePairs ? static_cast<uint64_t>(c->scene.nPairs) * 64 : 0) + static_cast<uint64_t>(c->scene.nPrims) * 48; // (+ the hex records, TYR_TUNE_HEX_DRAIN: four quad records per quad node)
+	out->device_bytes = static_cast<uint64_t>(c->scene.nQuads) * 128 + (havePairs ? static_cast<uint64_t>(c->scene.nPairs) * 64 : 0) + static_cast<uint64_t>(c->scene.nPrims) * 48;
 	return TYR_OK;
 }
 
@@ -1720,7 +1712,6 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_STREAM_SHADE_PER_CU, 1, 2, &Tuning::streamShadePerCU },
 		{ TYR_TUNE_STREAM_TRACE_PER_CU, 1, 5, &Tuning::streamTracePerCU },
 		{ TYR_TUNE_FOLD_SPHERES, 0, 1, &Tuning::foldSpheres },
-		{ TYR_TUNE_HEX_DRAIN, 0, 1, &Tuning::hexDrain },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)

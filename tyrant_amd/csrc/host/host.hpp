@@ -24,7 +24,6 @@ void set_build_threads(int threads); // 0 = automatic (TYR_BUILD_THREADS or min(
 struct DeviceLayout {
 	std::vector<float> pairNodes; // 16 floats per pair node
 	std::vector<float> quadNodes; // 32 floats per quad node (hip/traverse.hpp "QuadNode")
-	std::vector<float> hexNodes;  // 128 floats per quad node: the quad records of its four slots side by side (hip/traverse.hpp "Hex records"); empty when not asked for
 	uint32_t quadRootRef = 0;
 	uint32_t nQuads = 0;
 	uint32_t nStaged = 0; // leading records that are the top of the tree in breadth-first order
@@ -35,6 +34,6 @@ struct DeviceLayout {
 	uint32_t nPairs;
 };
 // returns TYR_OK or TYR_ERR_INVALID (malformed tree, non-finite geometry, too many primitives)
-int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims, DeviceLayout& out, bool wantHex = false);
+int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims, DeviceLayout& out);
 
 } // namespace tyr
