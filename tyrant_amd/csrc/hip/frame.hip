@@ -95,9 +95,30 @@ __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 	// same bound, same answer): a ray that fails it goes to class 1 and is finished with this record
 	const float2 hitRecord = sphere_hit_record(P, lensPoint, direction);
 	const bool tree = mine && P.scene.rootRef != kRefDone && root_ref(P.scene, make_ray(lensPoint, direction), hitRecord.x) != kRefDone;
-	// the block's rays of either class go to segment blockIdx % 8 of that class, behind what it holds: one atomic each
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const unsigned long long bt = __ballot(tree), bsky = __ballot(mine && !tree), below = (1ull << lane) - 1ull;
+	// A camera ray that hits no sphere and fails the root box is finished before it is queued (P.retireSky, tyr_render's
+	// merged path): what shade would do with it is fixed -- kernel.cu:613-617 with the fresh ray's lastSpecular = true and
+	// direct = (1,1,1) (kernel.cu:295, variables.h:33): color = sunsky(direction), one finished path, no survivor, no shadow
+	// ray, and NO random number drawn -- so it is done here, while the direction is in registers: the pixel gets its
+	// radiance (the same operations: 0 + 1 * x is x), the ray's survive byte is 0, and the record is never written or read
+	// (42 % of the first wavefront's rays on C3: 112 bytes of queue traffic and a shade lane each).  Every count stays: the
+	// ray was generated and traced (n_live and the totals are sums, not queue lengths).
+	const bool sky = P.retireSky != 0u && mine && !tree && !(hitRecord.x < kVeryFar);
+	if (__ballot(sky) != 0ull) {
+		f3 radiance = mk3(0.f, 0.f, 0.f);
+		if (sky) {
+			if (P.sun.sunAngularDiameterCos == 1.0f) {
+				radiance = mk3(1.0f, 0.0f, 0.0f); // sunsky.cu:118-119
+			} else {
+				const Atmosphere a = atmosphere(P.sun, direction);
+				radiance = sunsky_radiance(P.sun, a);
+			}
+			P.survFlag[vslot] = 0; // what k_shade writes for a ray that does not survive (k_scan_words reads every slot below n_live)
+		}
+		accumulate_pixels_wave(P.blit, y * (int)P.W + x, radiance, sky ? 1 : 0);
+	}
+	// the block's rays of either class go to segment blockIdx % 8 of that class, behind what it holds: one atomic each
+	const unsigned long long bt = __ballot(tree), bsky = __ballot(mine && !tree && !sky), below = (1ull << lane) - 1ull;
 	if (lane == 0) {
 		cntSh[wave] = (uint32_t)__popcll(bt);
 		cntSh[4 + wave] = (uint32_t)__popcll(bsky);
@@ -128,7 +149,7 @@ __global__ void __launch_bounds__(kBlock) k_primary(const FrameParams P) {
 	}
 	__syncthreads();
 	const uint32_t cls = tree ? 0u : 1u;
-	if (mine && baseSh[cls] != 0xffffffffu) {
+	if (mine && !sky && baseSh[cls] != 0xffffffffu) {
 		const uint32_t rank = before[cls] + (uint32_t)__popcll((tree ? bt : bsky) & below);
 		const uint32_t slot = cls * P.classStride + seg_phys(seg, baseSh[cls] + rank);
 		// kernel.cu:295: {origin, direction, {1,1,1}, 0, 0, 0, pixel}; lastSpecular defaults to true (variables.h:33)

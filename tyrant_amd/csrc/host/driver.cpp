@@ -975,6 +975,8 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 	const bool merge = pipelined && merged_render(c);
 	if (merge && c->tuning.foldSpheres)
 		P.foldSpheres = 1u; // this iteration's shade does the sphere halves for the rays it emits
+	if (merge && c->tuning.retireSky)
+		P.retireSky = 1u;   // ... and k_primary finishes the camera rays that hit nothing
 	enqueue_primary(c, P, nNew);
 	if (merge) { // every traversal launch of a merged render is k_trace_flat; the first one has no shadow rays to carry yet
 		const uint32_t carried = c->shadowPending ? c->shadowPendingMax : 0u;
@@ -1055,6 +1057,8 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 	FrameParams P = make_params(c);
 	if (c->tuning.foldSpheres)
 		P.foldSpheres = 1u;
+	if (c->tuning.retireSky)
+		P.retireSky = 1u;
 	enqueue_primary(c, P, p.nNew);
 	enqueue_trace(c, P, p.nLive, p.nSurvivors, p.carried);
 	enqueue_shade(c, P, p.nLive);
@@ -1712,6 +1716,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_STREAM_SHADE_PER_CU, 1, 2, &Tuning::streamShadePerCU },
 		{ TYR_TUNE_STREAM_TRACE_PER_CU, 1, 5, &Tuning::streamTracePerCU },
 		{ TYR_TUNE_FOLD_SPHERES, 0, 1, &Tuning::foldSpheres },
+		{ TYR_TUNE_RETIRE_SKY, 0, 1, &Tuning::retireSky },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)
