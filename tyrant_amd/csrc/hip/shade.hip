@@ -588,7 +588,8 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		__syncthreads();
 		return vbNext;
 	};
-	for (uint32_t vb = draw_tile(); vb < nTiles; vb = draw_tile()) { // vb = tile id = 256 physical slots of one class
+	// (no tile at all -- a launch for an iteration without rays: no ticket is drawn, eight round trips saved per block)
+	for (uint32_t vb = nTiles != 0u ? draw_tile() : nTiles; vb < nTiles; vb = draw_tile()) { // vb = tile id = 256 physical slots of one class
 		TYR_STAMP(3) // (the draw: ticket, and in the streamed tail the wait for the traversal's answers)
 		const uint32_t cls = vb >= tiles0 ? 1u : 0u;
 		const uint32_t inClass = (vb - cls * tiles0) * kBlock + tid; // slot inside the class
