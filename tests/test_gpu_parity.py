@@ -483,7 +483,7 @@ def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
     _, g4 = pair(orc, hip, name, W, H, N)
     _, g5 = pair(orc, hip, name, W, H, N)
     g4.set_tuning(merge_trace=1, run_ahead=0, stream_tail=1)  # once the budget is spent: ONE traversal kernel across the remaining iterations, shade resident beside it (k_trace_stream / k_shade<.., true>)
-    g5.set_tuning(merge_trace=1, fold_spheres=0)  # the sphere pre-pass kernels instead of shade doing their work for the rays it emits
+    g5.set_tuning(merge_trace=1, fold_spheres=0, retire_sky=0)  # the sphere pre-pass kernels instead of shade doing their work for the rays it emits; camera rays that hit nothing queued for shade instead of finished by k_primary
     from tyrant_amd import scenes
 
     sc, _, _ = built_scene(name)

@@ -208,6 +208,7 @@ struct FrameParams {
 	StreamState* stream;
 	uint32_t streamIter;          // k_shade_stream: which StreamIter this launch shades; k_trace_stream: 0 (it starts at the tail's first iteration)
 	uint32_t foldSpheres;         // k_shade: also do the sphere half of extend / connect for the rays it emits (kernel.cu:125-136, 168-172), as k_primary does for its own: no sphere pre-pass follows
+	uint32_t resolveShadows;      // k_shade (with foldSpheres): a shadow ray that a sphere occludes, or that cannot enter the tree, is answered in place and never queued
 	uint32_t retireSky;           // k_primary: finish the camera rays that hit nothing (no sphere, not the root box) on the spot instead of queueing them for shade (tyr_render's merged path; the stage API keeps the reference's full queue)
 	uint32_t prevFolded;          // the traversal launchers: the shade launch that made this iteration's survivors and shadow rays did so (only the holes at the segments' ends are left to mark)
 	uint32_t* fillWork;           // fill counters of the work queue's class 0 (what k_trace_stream waits on for iteration j), one per 64-slot chunk
@@ -241,6 +242,7 @@ struct Tuning {
 	int streamTail = 0;       // tyr_render: once the budget is spent, ONE traversal kernel across the remaining iterations with shade resident beside it (0, the default: a launch per iteration -- the streamed form is bit-exact and slower, DESIGN.md "One drain per render")
 	int streamShadePerCU = 1; // streamed tail: k_shade_stream blocks per CU ...
 	int streamTracePerCU = 4; // ... beside this many blocks of k_trace_stream
+	int resolveShadows = 1;   // merged path of tyr_render (needs foldSpheres): shade answers the shadow rays that cannot reach a triangle itself
 	int retireSky = 1;        // merged path of tyr_render: k_primary finishes the camera rays that hit nothing itself (they never reach a queue)
 	int foldSpheres = 1;      // merged path of tyr_render: shade does the sphere pre-passes' work for the rays it emits (the streamed tail always does); 0: k_extend_spheres / k_connect_spheres re-read them
 };

@@ -23,6 +23,9 @@ struct ShadeOut {
 	// k_extend_spheres / k_connect_spheres would re-read them for: kernel.cu:127-136, 168-172)
 	float2 hitRec;                 // survivor: closest sphere (distance, id | kHitSphere) or VERY_FAR
 	float sBlocked;                // shadow ray: 1 = a sphere occludes it
+	// P.resolveShadows: a shadow ray whose answer is known here -- a sphere occludes it, or it cannot enter the tree (it fails
+	// the root box for its bound: the traversal kernel's own first test) -- is answered here and never queued
+	bool sResolved, sVisible;
 };
 
 // NEE toward spheres[6], kernel.cu:419-447 / 559-590 (common part)
@@ -149,6 +152,8 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 	int material = TYR_DIFF;
 	out.survive = false;
 	out.shadow = false;
+	out.sResolved = false;
+	out.sVisible = false;
 
 	enum { kAtmoNone = 0, kAtmoSun, kAtmoSky, kAtmoSunSky };
 	int atmo = kAtmoNone;   // what this ray wants from the atmosphere model, evaluated once for the whole wave below
@@ -404,6 +409,19 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 			occluded = occluded || (t && (t + kEpsilon) < out.sClosest);
 		}
 		out.sBlocked = occluded ? 1.0f : 0.0f;
+		if (P.resolveShadows) {
+			// connect for this ray (kernel.cu:630-646) comes down to what is known now: blocked by a sphere -> nothing; not
+			// blocked and unable to enter the tree -> visible, its colour goes to the pixel (kernel.cu:640-644) with this
+			// ray's own contribution; only a ray that may meet a triangle is left to the traversal kernel
+			const bool mayEnter = P.scene.rootRef != kRefDone && root_ref(P.scene, make_ray(out.sOrigin, out.sDir), out.sClosest) != kRefDone;
+			if (occluded || !mayEnter) {
+				out.shadow = false;
+				out.sResolved = true;
+				out.sVisible = !occluded;
+				if (!occluded)
+					color = color + out.sColor;
+			}
+		}
 	}
 	out.color = color;
 	out.newFrame = new_frame;
@@ -471,6 +489,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	f3 pendColor = mk3(0.f, 0.f, 0.f);
 	uint32_t prevSeg = 0, prevS = 0, prevT = 0, prevH = 0;
 	uint32_t mySurvivors = 0, myShadows = 0; // thread 0: what this block appended
+	uint32_t waveResolved = 0, waveVisible = 0; // (wave-uniform) shadow rays answered in place (P.resolveShadows): they count as emitted, the visible ones as visible
 
 	// finish the waiting tile: its places have arrived (sh[12], sh[13]); move its records from LDS to the queues
 	auto flush_prev = [&]() {
@@ -623,6 +642,10 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		const bool sT = out.survive && out.tree, sS = out.survive && !out.tree;
 		const unsigned long long bt = __ballot(sT), bk = __ballot(sS);
 		const unsigned long long bh = __ballot(out.shadow);
+		if (P.resolveShadows) {
+			waveResolved += (uint32_t)__popcll(__ballot(out.sResolved));
+			waveVisible += (uint32_t)__popcll(__ballot(out.sVisible));
+		}
 		const uint32_t rt = __popcll(bt & below), rk = __popcll(bk & below), rh = __popcll(bh & below);
 		if (lane == 0) {
 			sh[4 + wave] = __popcll(bt);
@@ -718,6 +741,20 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		__syncthreads();
 		flush_prev();
 	}
+	uint32_t myResolved = 0;
+	if (P.resolveShadows) { // (block-uniform)
+		if (lane == 0) {
+			sh[20 + wave] = waveResolved;
+			sh[24 + wave] = waveVisible;
+		}
+		__syncthreads();
+		if (tid == 0) {
+			myResolved = sh[20] + sh[21] + sh[22] + sh[23];
+			const uint32_t vis = sh[24] + sh[25] + sh[26] + sh[27];
+			if (vis)
+				atomicAdd(&P.k->n_shadow_visible, (unsigned long long)vis);
+		}
+	}
 	// kernel.cu:607 / 416: the totals the next top-up and connect read.  Every block adds what it appended; the block
 	// that finishes last publishes the per-iteration figures.
 #ifdef TYR_SHADE_TIMING
@@ -732,6 +769,8 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		// own records and fill adds are out (flush_prev waits and publishes); the other blocks' likewise before they counted
 		// as done.
 		if (tid == 0) {
+			if (myResolved)
+				atomicAdd(&P.kc->shadow_cnt, myResolved); // (here: only the shadow rays answered in place; the queued ones are counted by the segments)
 			__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			if (atomicAdd(&SI->shadeBlocksDone, 1u) + 1u == P.shadeBlocks && !gaveUp && ld_sc1_u32(&P.k->device_error) == 0u) {
 				StreamIter* const NI = SI + 1; // (P.streamIter + 1 < kStreamMaxIters: the host queues at most kMaxBounces + 1 of these launches)
@@ -750,9 +789,11 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 				st_sc1_u32(&NI->nLive, s);
 				st_sc1_u32(&NI->nShadowPrev, h);
 				// the iteration's totals (what set_wavefront_globals and the last shade block keep in the launch-per-iteration path)
+				const uint32_t hAll = h + __hip_atomic_load(&P.kc->shadow_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // + the shadow rays answered in place
+				P.kc->shadow_cnt = 0;
 				P.k->n_live = SI->nLive;
-				P.k->shadow_ray_cnt = h;
-				P.k->total_shadow_rays += h;
+				P.k->shadow_ray_cnt = hAll;
+				P.k->total_shadow_rays += hAll;
 				P.k->n_survive += s;
 				P.k->total_extend_rays += s;
 				// what the next iteration's shade appends to: this iteration's work queue (two iterations on it is `next` again)
@@ -763,6 +804,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 						st_sc1_u32(&P.segWork[c * kClassWords + w * kSegStride], 0u);
 				for (uint32_t w = 0; w < kSegs; ++w)
 					st_sc1_u32(&P.kcPrev->seg[w * kSegStride], 0u);
+				P.kcPrev->shadow_cnt = 0;
 				P.k->scan_blocks_done = 0;
 				// the shadow rays that were traced beside this iteration's rays lie in the buffers the next iteration's shade
 				// writes: it may not start (= this launch may not end) before the traversal has finished them
@@ -800,8 +842,8 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	if (tid == 0) {
 		if (mySurvivors)
 			atomicAdd(&P.k->primary_ray_cnt, mySurvivors);
-		if (myShadows)
-			atomicAdd(&P.kc->shadow_cnt, myShadows);
+		if (myShadows + myResolved)
+			atomicAdd(&P.kc->shadow_cnt, myShadows + myResolved);
 #ifdef TYR_WHATIF_SHADE_FENCE
 		__threadfence();
 #else

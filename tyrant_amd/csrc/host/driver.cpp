@@ -973,8 +973,10 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 		return rc ? rc : check_device_error(c);
 	}
 	const bool merge = pipelined && merged_render(c);
-	if (merge && c->tuning.foldSpheres)
+	if (merge && c->tuning.foldSpheres) {
 		P.foldSpheres = 1u; // this iteration's shade does the sphere halves for the rays it emits
+		P.resolveShadows = c->tuning.resolveShadows ? 1u : 0u; // ... and answers the shadow rays that cannot reach a triangle
+	}
 	if (merge && c->tuning.retireSky)
 		P.retireSky = 1u;   // ... and k_primary finishes the camera rays that hit nothing
 	enqueue_primary(c, P, nNew);
@@ -1055,8 +1057,10 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 		return rc;
 	const int set = static_cast<int>(c->iter & 1u);
 	FrameParams P = make_params(c);
-	if (c->tuning.foldSpheres)
+	if (c->tuning.foldSpheres) {
 		P.foldSpheres = 1u;
+		P.resolveShadows = c->tuning.resolveShadows ? 1u : 0u;
+	}
 	if (c->tuning.retireSky)
 		P.retireSky = 1u;
 	enqueue_primary(c, P, p.nNew);
@@ -1227,6 +1231,7 @@ static int render_stream_tail(tyr_ctx* c, uint32_t& it) {
 		FrameParams P = make_params(c);
 		P.streamIter = jj;
 		P.scanLive = &c->dStream->it[jj].nLive;
+		P.resolveShadows = c->tuning.resolveShadows ? 1u : 0u; // (k_shade<.., true> always does the sphere halves)
 		launch_shade_stream(P, c->tuning.streamShadePerCU, c->numCUs, c->side);
 		launch_scan(P, c->hK->primary_ray_cnt, c->side); // (an upper bound of every later iteration's rays: nothing is topped up)
 		stage_end(c);
@@ -1717,6 +1722,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_STREAM_TRACE_PER_CU, 1, 5, &Tuning::streamTracePerCU },
 		{ TYR_TUNE_FOLD_SPHERES, 0, 1, &Tuning::foldSpheres },
 		{ TYR_TUNE_RETIRE_SKY, 0, 1, &Tuning::retireSky },
+		{ TYR_TUNE_RESOLVE_SHADOWS, 0, 1, &Tuning::resolveShadows },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)
