@@ -483,6 +483,7 @@ def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
     _, g4 = pair(orc, hip, name, W, H, N)
     _, g5 = pair(orc, hip, name, W, H, N)
     g4.set_tuning(merge_trace=1, run_ahead=0, stream_tail=1)  # once the budget is spent: ONE traversal kernel across the remaining iterations, shade resident beside it (k_trace_stream / k_shade<.., true>)
+    g3.set_tuning(resolve_shadows=0)  # (and one merged path that queues every shadow ray although shade has done their sphere halves)
     g5.set_tuning(merge_trace=1, fold_spheres=0, retire_sky=0)  # the sphere pre-pass kernels instead of shade doing their work for the rays it emits; camera rays that hit nothing queued for shade instead of finished by k_primary
     from tyrant_amd import scenes
 
@@ -503,7 +504,7 @@ def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
         # the last iteration's shadow queue, whatever path made it (the run-ahead path once exported the EMPTY look-ahead iteration's)
         nh = ko["shadow_ray_cnt"]
         so = o.shadow_queue(nh)
-        for g in (g0, g1, g2, g3, g4, g5):
+        for g in (g0, g3, g5):  # (the paths that queue every shadow ray: the others answer in place those that cannot reach a triangle, TYR_TUNE_RESOLVE_SHADOWS)
             sg = g.shadow_queue(nh)
             for f in ("origin", "direction", "color", "closestDistance"):
                 assert np.array_equal(bits(so[f]), bits(sg[f])), f"{name}: shadow queue after the render, {f}"
