@@ -296,10 +296,13 @@ __global__ void __launch_bounds__(kBlock) k_scan_words(const FrameParams P) {
 		return; // (the whole block: the host sized the grid from an upper bound)
 	unsigned long long word = 0ull;
 	if (first < n) {
-		const uint4* p = reinterpret_cast<const uint4*>(P.survFlag + first);
+		uint4* p = reinterpret_cast<uint4*>(P.survFlag + first);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint4 q = p[k];
+			// read and cleared: a survivor that shade finished in place (P.retireGhosts) occupies a slot of the NEXT iteration's
+			// order that nobody will write -- it must read "did not survive" there
+			p[k] = make_uint4(0u, 0u, 0u, 0u);
 			const uint32_t x[4] = { q.x, q.y, q.z, q.w };
 #pragma unroll
 			for (int j = 0; j < 4; ++j) { // four bytes, each 0 or 1 -> four bits
@@ -400,9 +403,10 @@ __global__ void __launch_bounds__(64) k_stream_begin(const FrameParams P, uint32
 		h += __shfl_xor(h, o, 64);
 	}
 	if (i == 0) {
+		DevCounters* k = P.k;
+		n = k->primary_ray_cnt; // the survivors, those the last shade launch finished in place included (P.retireGhosts: they hold slots of this iteration's order without lying in a queue)
 		I->nLive = n;
 		I->nShadowPrev = h;
-		DevCounters* k = P.k;
 		k->n_live = n;
 		k->total_extend_rays += n;
 		k->primary_ray_cnt = 0;

@@ -190,7 +190,7 @@ struct FrameParams {
 	uint32_t* segNext;
 	uint32_t segCap;              // records one segment has room for
 	uint32_t classStride;         // first slot of class 1 in the ray queues' arrays (= kSegs * segCap)
-	uint8_t* survFlag;            // [N] shade writes 1 / 0 at the ray's virtual slot
+	uint8_t* survFlag;            // [N + 64] shade writes 1 / 0 at the ray's virtual slot; k_scan_words clears what it reads
 	VTable vPrev;                 // the scan of the previous iteration's survive bytes (what kKeyIndirect keys are looked up in)
 	unsigned long long* vWordOut; // ... and where the scan of this iteration's goes
 	uint32_t* vPreOut;
@@ -208,6 +208,7 @@ struct FrameParams {
 	StreamState* stream;
 	uint32_t streamIter;          // k_shade_stream: which StreamIter this launch shades; k_trace_stream: 0 (it starts at the tail's first iteration)
 	uint32_t foldSpheres;         // k_shade: also do the sphere half of extend / connect for the rays it emits (kernel.cu:125-136, 168-172), as k_primary does for its own: no sphere pre-pass follows
+	uint32_t retireGhosts;        // k_shade (with foldSpheres, renders that run to their end): a survivor that will hit nothing is finished in place (it still counts as a survivor and keeps its slot in the next iteration's order)
 	uint32_t resolveShadows;      // k_shade (with foldSpheres): a shadow ray that a sphere occludes, or that cannot enter the tree, is answered in place and never queued
 	uint32_t retireSky;           // k_primary: finish the camera rays that hit nothing (no sphere, not the root box) on the spot instead of queueing them for shade (tyr_render's merged path; the stage API keeps the reference's full queue)
 	uint32_t prevFolded;          // the traversal launchers: the shade launch that made this iteration's survivors and shadow rays did so (only the holes at the segments' ends are left to mark)

@@ -26,6 +26,11 @@ struct ShadeOut {
 	// P.resolveShadows: a shadow ray whose answer is known here -- a sphere occludes it, or it cannot enter the tree (it fails
 	// the root box for its bound: the traversal kernel's own first test) -- is answered here and never queued
 	bool sResolved, sVisible;
+	// P.retireGhosts: a survivor that will hit nothing -- no sphere, not the root box -- is finished here: what the next
+	// iteration's shade would do with it is fixed (kernel.cu:613-617: sky or sunsky of its direction times its throughput,
+	// the path ends; no random number).  It still SURVIVES this iteration (its survive byte, the counts, its slot in the
+	// next iteration's order -- every other ray's random numbers depend on that), it just never enters a queue.
+	bool ghost;
 };
 
 // NEE toward spheres[6], kernel.cu:419-447 / 559-590 (common part)
@@ -154,6 +159,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 	out.shadow = false;
 	out.sResolved = false;
 	out.sVisible = false;
+	out.ghost = false;
 
 	enum { kAtmoNone = 0, kAtmoSun, kAtmoSky, kAtmoSunSky };
 	int atmo = kAtmoNone;   // what this ray wants from the atmosphere model, evaluated once for the whole wave below
@@ -393,10 +399,25 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 			out.direction = direction;
 			out.direct = direct;
 			out.flags = (uint32_t)bounces | ((lastSpecular ? 1u : 0u) << 8);
+			out.ghost = P.retireGhosts != 0u && !out.tree && !(out.hitRec.x < kVeryFar); // (retireGhosts implies foldSpheres: hitRec is the sphere answer)
 		} else {
 			new_frame++;
 		}
 	} else if (valid) {
+		new_frame++;
+	}
+	if (out.ghost) {
+		// the next iteration's shade of this ray, now (kernel.cu:613-617 with its lastSpecular, its throughput): one more
+		// evaluation of the atmosphere for the lanes that need it; the pixel receives this iteration's and the next one's
+		// contribution as one sum, and the path is finished
+		f3 seen;
+		if (lastSpecular && P.sun.sunAngularDiameterCos == 1.0f) {
+			seen = mk3(1.0f, 0.0f, 0.0f); // sunsky.cu:118-119
+		} else {
+			const Atmosphere a = atmosphere(P.sun, direction);
+			seen = lastSpecular ? sunsky_radiance(P.sun, a) : sky_radiance(a);
+		}
+		color = color + direct * seen;
 		new_frame++;
 	}
 
@@ -489,6 +510,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	f3 pendColor = mk3(0.f, 0.f, 0.f);
 	uint32_t prevSeg = 0, prevS = 0, prevT = 0, prevH = 0;
 	uint32_t mySurvivors = 0, myShadows = 0; // thread 0: what this block appended
+	uint32_t waveGhosts = 0; // (wave-uniform) survivors finished in place (P.retireGhosts): they count as survivors
 	uint32_t waveResolved = 0, waveVisible = 0; // (wave-uniform) shadow rays answered in place (P.resolveShadows): they count as emitted, the visible ones as visible
 
 	// finish the waiting tile: its places have arrived (sh[12], sh[13]); move its records from LDS to the queues
@@ -639,7 +661,9 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		TYR_STAMP(0)
 
 		// ---- ranks inside the tile: survivors that may enter the tree, survivors that cannot, shadow rays ----
-		const bool sT = out.survive && out.tree, sS = out.survive && !out.tree;
+		const bool sT = out.survive && out.tree, sS = out.survive && !out.tree && !out.ghost;
+		if (P.retireGhosts)
+			waveGhosts += (uint32_t)__popcll(__ballot(out.ghost));
 		const unsigned long long bt = __ballot(sT), bk = __ballot(sS);
 		const unsigned long long bh = __ballot(out.shadow);
 		if (P.resolveShadows) {
@@ -704,7 +728,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			mySurvivors += (bT == 0xffffffffu ? 0u : totT) + (bK == 0xffffffffu ? 0u : totK);
 			myShadows += bH == 0xffffffffu ? 0u : totH;
 		}
-		if (out.survive) {
+		if (out.survive && !out.ghost) {
 			const uint32_t k = out.tree ? wt + rt : totT + wk + rk; // the tile's class-0 survivors first, then its class-1 ones
 			stage.sv_o_dx[k] = make_float4(out.origin.x, out.origin.y, out.origin.z, out.direction.x);
 			stage.sv_dyz[k] = make_float2(out.direction.y, out.direction.z);
@@ -742,10 +766,11 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		flush_prev();
 	}
 	uint32_t myResolved = 0;
-	if (P.resolveShadows) { // (block-uniform)
+	if (P.resolveShadows || P.retireGhosts) { // (block-uniform)
 		if (lane == 0) {
 			sh[20 + wave] = waveResolved;
 			sh[24 + wave] = waveVisible;
+			sh[28 + wave] = waveGhosts;
 		}
 		__syncthreads();
 		if (tid == 0) {
@@ -753,6 +778,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			const uint32_t vis = sh[24] + sh[25] + sh[26] + sh[27];
 			if (vis)
 				atomicAdd(&P.k->n_shadow_visible, (unsigned long long)vis);
+			mySurvivors += sh[28] + sh[29] + sh[30] + sh[31]; // survivors all the same: the next iteration's ray count, the totals
 		}
 	}
 	// kernel.cu:607 / 416: the totals the next top-up and connect read.  Every block adds what it appended; the block

@@ -56,6 +56,7 @@ struct tyr_ctx {
 	uint32_t* fillRay[2] = { nullptr, nullptr };
 	uint32_t* fillSh[2] = { nullptr, nullptr };
 	uint32_t* doneRay[2] = { nullptr, nullptr };
+	bool unboundedRender = false; // tyr_render was called without an iteration limit: contributions may arrive an iteration early (TYR_TUNE_RETIRE_SKY's survivors)
 	bool lastShadeFolded = false; // the shade launch that filled the current work / shadow queues did the sphere pre-passes' work too (TYR_TUNE_FOLD_SPHERES)
 	bool streamDirty = false; // a tail ended in an error: the counters above are re-zeroed before the next one
 	hipEvent_t evTail = nullptr;

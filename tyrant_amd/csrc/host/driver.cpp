@@ -976,6 +976,10 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 	if (merge && c->tuning.foldSpheres) {
 		P.foldSpheres = 1u; // this iteration's shade does the sphere halves for the rays it emits
 		P.resolveShadows = c->tuning.resolveShadows ? 1u : 0u; // ... and answers the shadow rays that cannot reach a triangle
+		P.retireGhosts = (c->tuning.retireSky && c->unboundedRender) ? 1u : 0u; // ... and finishes the survivors that will hit nothing (a render cut short would see their pixels an iteration early)
+#ifdef TYR_WHATIF_NO_GHOSTS
+		P.retireGhosts = 0u;
+#endif
 	}
 	if (merge && c->tuning.retireSky)
 		P.retireSky = 1u;   // ... and k_primary finishes the camera rays that hit nothing
@@ -1060,6 +1064,7 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 	if (c->tuning.foldSpheres) {
 		P.foldSpheres = 1u;
 		P.resolveShadows = c->tuning.resolveShadows ? 1u : 0u;
+		P.retireGhosts = (c->tuning.retireSky && c->unboundedRender) ? 1u : 0u;
 	}
 	if (c->tuning.retireSky)
 		P.retireSky = 1u;
@@ -1275,6 +1280,7 @@ int tyr_render(tyr_ctx* c, uint32_t spp, uint32_t max_iterations, uint32_t* iter
 	if (!c->haveScene)
 		return TYR_ERR_NO_SCENE;
 	uint32_t it = 0;
+	c->unboundedRender = max_iterations == 0xFFFFFFFFu;
 	if (run_ahead_eligible(c)) {
 		if ((rc = use_device(c)))
 			return rc;
