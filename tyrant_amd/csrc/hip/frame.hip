@@ -580,9 +580,12 @@ void launch_extend_debug(const FrameParams& P, uint32_t maxLive, hipStream_t str
 	if (maxLive != 0)
 		hipLaunchKernelGGL(k_extend_debug, dim3(blocks_for(maxLive)), dim3(kBlock), 0, stream, P);
 }
-void launch_extend_spheres(const FrameParams& P, uint32_t nSurvivors, hipStream_t stream) {
+void launch_extend_spheres(const FrameParams& P, uint32_t nSurvivors, hipStream_t stream, uint32_t maxLive) {
+	// the grid also covers the hole padding at the ends of class 0's segments, which walks up to the extent of ALL this
+	// iteration's rays: a handful of survivors in front of a full top-up must not leave that walk to a single block
+	const uint32_t walk = std::max(nSurvivors, maxLive);
 	if (nSurvivors != 0)
-		hipLaunchKernelGGL(k_extend_spheres, dim3(std::min(blocks_for(nSurvivors), kPrepassMaxBlocks)), dim3(kBlock), 0, stream, P);
+		hipLaunchKernelGGL(k_extend_spheres, dim3(std::min(blocks_for(walk), kPrepassMaxBlocks)), dim3(kBlock), 0, stream, P);
 }
 void launch_connect_spheres(const FrameParams& P, uint32_t maxShadow, hipStream_t stream) {
 	hipLaunchKernelGGL(k_connect_spheres, dim3(std::min(blocks_for(maxShadow), kPrepassMaxBlocks)), dim3(kBlock), 0, stream, P);

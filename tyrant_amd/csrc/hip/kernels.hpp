@@ -73,6 +73,12 @@ struct ShadowQ {
 
 // kernel.cu:211-224 device counters + the extensions (budget, totals, visit counters)
 constexpr uint32_t kTicketWords = 8; // = XCDs: block b draws from word b % 8 first (round-robin block placement)
+// INVARIANT of the "block that finishes last does X" patterns (k_primary -> set_wavefront_globals, k_shade's totals, k_scan_words'
+// block totals): they count finished blocks with relaxed agent-scope atomics behind an `s_waitcnt vmcnt(0)`, NOT behind a
+// release fence (a fence per block is an L2 write-back per block: 2.4 ms per 16.6 M-ray top-up when it was tried).  That is
+// only sound while everything the finishing block READS of the others' output was written with agent-scope atomics (the
+// counters, vBlkOut) or is only OVERWRITTEN by it (counts the others have finished reading).  A plain store added to
+// something a finaliser reads would race silently across the XCDs' L2s: use __hip_atomic_store / atomicAdd there.
 struct DevCounters {
 	uint32_t primary_ray_cnt;
 	uint32_t start_position;
@@ -270,12 +276,12 @@ void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCach
 void launch_stream_begin(const FrameParams& P, bool traceShadowPrev, hipStream_t stream); // the tail's first StreamIter from the device's counts (+ what set_wavefront_globals does for an iteration without a top-up)
 void launch_trace_stream(const FrameParams& P, int blocksPerCU, int numCUs, hipStream_t stream);
 void launch_shade_stream(const FrameParams& P, int blocksPerCU, int numCUs, hipStream_t stream);
-void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream);
+void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream, uint32_t maxLive = 0);
 void launch_trace_kernel(const FrameParams& P, uint32_t items, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream); // k_trace_flat alone (launch_trace = pre-passes + this)
 void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
 void launch_trace(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, uint32_t maxShadowPrev, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
 // the sphere pre-passes of extend / connect (frame.hip), launched by the traversal launchers
-void launch_extend_spheres(const FrameParams& P, uint32_t nSurvivors, hipStream_t stream);
+void launch_extend_spheres(const FrameParams& P, uint32_t nSurvivors, hipStream_t stream, uint32_t maxLive = 0);
 void launch_connect_spheres(const FrameParams& P, uint32_t maxShadow, hipStream_t stream);
 void launch_resolve(const float4* blit, float4* out, uint32_t nPixels, hipStream_t stream);
 void launch_extend_debug(const FrameParams& P, uint32_t maxLive, hipStream_t stream); // TYR_FLAG_DEBUG_BVH

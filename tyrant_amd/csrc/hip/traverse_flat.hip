@@ -1137,15 +1137,14 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 #ifndef TYR_TRACE_STACK
 #define TYR_TRACE_STACK 12 // LDS stack entries per lane of k_trace_flat (a what-if build may pair 8 with TYR_FLAT_WAVES_PER_EU=6)
 #endif
-void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream);
 void launch_trace(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, uint32_t maxShadowPrev, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
-	launch_trace_prepasses(P, nSurvivors, maxShadowPrev, stream); // (the shadow rays' pre-pass reads its counts in kcPrev)
+	launch_trace_prepasses(P, nSurvivors, maxShadowPrev, stream, maxLive); // (the shadow rays' pre-pass reads its counts in kcPrev)
 	launch_trace_kernel(P, maxLive + maxShadowPrev, t, numCUs, lc, stream);
 }
 void launch_trace_kernel(const FrameParams& P, uint32_t items, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
 	hipLaunchKernelGGL((k_trace_flat<TYR_TRACE_STACK>), dim3(persistent_blocks(k_trace_flat<TYR_TRACE_STACK>, items, t, numCUs, lc.perCU[kLcTrace][0])), dim3(kBlock), 0, stream, P);
 }
-void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream) {
+void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream, uint32_t maxLive) {
 	FrameParams Pc = P;
 	Pc.kc = P.kcPrev;
 	Pc.shadow = P.shadowPrev;
@@ -1156,7 +1155,7 @@ void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t 
 		return;
 	}
 	if (P.traceShadow != 2u)
-		launch_extend_spheres(P, nSurvivors, stream);
+		launch_extend_spheres(P, nSurvivors, stream, maxLive);
 	if (maxShadowPrev != 0)
 		launch_connect_spheres(Pc, maxShadowPrev, stream);
 	if (P.traceShadow != 2u && nSurvivors == 0)
@@ -1171,7 +1170,7 @@ void launch_extend(const FrameParams& P0, uint32_t maxLive, uint32_t nSurvivors,
 		return;
 	FrameParams P = P0;
 	if (countVisits) {
-		launch_extend_spheres(P, nSurvivors, stream);
+		launch_extend_spheres(P, nSurvivors, stream, maxLive);
 		P.raysPerBlock = kCountRaysPerBlock;
 		const uint32_t blocks = (P.segCap * kSegs + kCountRaysPerBlock - 1) / kCountRaysPerBlock; // every physical slot a record could lie in
 		hipLaunchKernelGGL((k_extend_count<12>), dim3(blocks), dim3(kBlock), 0, stream, P);
