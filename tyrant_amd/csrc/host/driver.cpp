@@ -452,6 +452,10 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 	// N/8 + 1024 + 7/8 (N/8 + 1024)... < 15 N/64 + 4096.  (kErrQueueOverflow stays as a check: a segment never writes past its end.)
 	c->segCap = static_cast<uint32_t>(((N / 8 + 7 * (N / 64) + 4096) + 63) & ~size_t(63));
 	const size_t cap = static_cast<size_t>(c->segCap) * tyr::kSegs;
+	// slots are uint32 everywhere on the device: class 1's last slot is 2 * cap - 1.  At the admitted maximum
+	// (queue_size < 2^30) 2 * cap = 16 * segCap < 3.75 * 2^30 + 2^20 < 2^32; checked rather than assumed.
+	if (static_cast<uint64_t>(cap) * tyr::kClasses >= (1ull << 32))
+		return fail(TYR_ERR_INVALID);
 	if ((rc = alloc_rayq(c->q[0], cap * tyr::kClasses)) || (rc = alloc_rayq(c->q[1], cap * tyr::kClasses))) // class 0 (may enter the tree), class 1 (cannot)
 		return fail(rc);
 	for (auto& sq : c->shadow) // two: shade(i) fills one while the traversal launch of iteration i still reads shade(i - 1)'s
