@@ -14,16 +14,21 @@ from tyrant_amd import binding, scenes  # noqa: E402
 knobs = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:])}
 renders = knobs.pop("renders", 3)
 queue = knobs.pop("queue", 1920 * 1080 * 8)
+profile = knobs.pop("profile", 0)  # 1: hipEvent pairs around every stage (TYR_FLAG_PROFILE), the stages' times of the last render printed
 sc = scenes.mesh_scene(706)
 nodes, prims = binding.bvh_build(sc.triangles)
-g = binding.Renderer(1920, 1080, queue, flags=1)
+g = binding.Renderer(1920, 1080, queue, flags=1 | (2 if profile else 0))
 g.load_scene(sc, nodes, prims)
 g.set_tuning(**knobs)
 for r in range(renders):
     g.reset_accum()
+    if profile:
+        g.timings(reset=True)
     t0 = time.perf_counter()
     it = g.render(8)
     print(f"render {r}: {(time.perf_counter() - t0) * 1e3:.3f} ms, {it} iterations, err {g.counters()['device_error']}", flush=True)
+if profile:
+    print("stages of the last render (ms):", {k: (round(v["ms"], 4), v["launches"]) for k, v in g.timings().items() if v["launches"]})
 if os.environ.get("TYR_PROBE_DEBUG"):
     d = g.counters()["debug"]
     tiles = max(d[7], 1)

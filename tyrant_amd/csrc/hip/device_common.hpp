@@ -13,6 +13,19 @@
 
 namespace tyr {
 
+// The kernel's by-value argument, read where it lies: a view of the kernarg segment (the argument is the kernel's only
+// one: offset 0) behind a pointer the compiler cannot see through.  Fields read through `P` are loaded in the kernel's
+// first block and stay in scalar registers for its whole life (and are spilled to vector lanes when those run out); read
+// through this view they are s_load-ed where they are used, from the scalar cache, and die there.  Call it INSIDE the loop
+// whose body should reload.
+template <class Params>
+__device__ __forceinline__ const Params& kernarg_view() {
+	auto p = (const __attribute__((address_space(4))) Params*)__builtin_amdgcn_kernarg_segment_ptr();
+	__asm__ volatile("" : "+s"(p));
+	return *(const Params*)p;
+}
+
+
 // ---- RNG, kernel.cu:23-41 ----------------------------------------------------------------
 __device__ __forceinline__ uint32_t rng_int(uint32_t& s) {
 	s ^= s << 13;

@@ -462,7 +462,7 @@ struct ShadeStage { // one tile's output, waiting for the tile's place in the qu
 };
 
 #ifndef TYR_SHADE_BLOCKS_PER_CU
-#define TYR_SHADE_BLOCKS_PER_CU 4 // tiles in flight per CU: 128 vector registers each
+#define TYR_SHADE_BLOCKS_PER_CU 5 // tiles in flight per CU: 102 vector registers each (96 used; 5 x 27.8 KB of the CU's 160 KB LDS)
 #endif
 // One tile = 256 consecutive physical slots of the work queue = four 64-slot chunks (one per wave), each the tail or
 // the middle of one segment: a wave's valid lanes are the first chunk_valid() of its chunk.
@@ -481,7 +481,8 @@ struct ShadeStage { // one tile's output, waiting for the tile's place in the qu
 // (done[tile]), class 1 (nothing to wait for) goes first; the records it emits for the traversal are stored sc1 and
 // published chunk by chunk (fill[chunk]); the block that finishes last closes the next iteration (StreamIter).
 template <bool LIGHTS, bool STREAM>
-__global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const FrameParams P) {
+__global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const FrameParams P_) {
+	const FrameParams& P = P_;
 	__shared__ uint32_t sh[32];
 	__shared__ ShadeStage stage;
 	const uint32_t tid = threadIdx.x;
@@ -515,6 +516,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 
 	// finish the waiting tile: its places have arrived (sh[12], sh[13]); move its records from LDS to the queues
 	auto flush_prev = [&]() {
+		const FrameParams& P = kernarg_view<FrameParams>();
 		const uint32_t baseT = sh[12], baseH = sh[13], baseK = sh[18];
 		TYR_STAMP(2)
 		// one array at a time (the compiler barrier keeps it from loading all records first): this copy is where the
@@ -632,6 +634,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	// (no tile at all -- a launch for an iteration without rays: no ticket is drawn, eight round trips saved per block)
 	for (uint32_t vb = nTiles != 0u ? draw_tile() : nTiles; vb < nTiles; vb = draw_tile()) { // vb = tile id = 256 physical slots of one class
 		TYR_STAMP(3) // (the draw: ticket, and in the streamed tail the wait for the traversal's answers)
+		const FrameParams& P = kernarg_view<FrameParams>(); // this tile's reads of the arguments: loaded where they are used (device_common.hpp; 113 scalar spills -> 2, 128 vector registers -> 96)
 		const uint32_t cls = vb >= tiles0 ? 1u : 0u;
 		const uint32_t inClass = (vb - cls * tiles0) * kBlock + tid; // slot inside the class
 		const uint32_t slot = cls * P.classStride + inClass;

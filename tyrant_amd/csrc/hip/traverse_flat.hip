@@ -813,6 +813,9 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 // (shadow rays traverse in the reference's near-first order here; any-hit answers do not depend on the order).
 // ======================================================================================
 template <int STACK_LDS>
+// the arguments read where they lie (device_common.hpp kernarg_view): what the refill, the pixel flush and the kernel's end
+// read of them is loaded there and not held in scalar registers through the descent (24 scalar spills -> 2)
+#define TYR_TRACE_VIEW(name) const FrameParams& name = kernarg_view<FrameParams>();
 __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(const FrameParams P) {
 	constexpr bool COUNT = false; // (TYR_DBG)
 	TYR_DECLARE_FLAT_STACK(st, true)
@@ -868,6 +871,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	constexpr uint32_t kNoPending = 0xffffffffu;
 	uint32_t pendIdx = kNoPending;
 	auto flush_visible = [&]() {
+		TYR_TRACE_VIEW(P)
 		float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
 		int px = 0;
 		if (pendIdx != kNoPending) {
@@ -898,6 +902,8 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		const unsigned long long idleMask = __ballot(!live);
 		const uint32_t nIdle = __popcll(idleMask);
 		if (!exhausted && nIdle >= P.refillMinIdle) {
+			TYR_TRACE_VIEW(P) // the refill's reads of the arguments (queue pointers, tickets, the root box): loaded here, not held through the descent
+			const DevScene& sc = P.scene;
 			const uint32_t rank = __popcll(idleMask & below);
 			uint32_t s = 0;
 			bool fed = false;
@@ -1090,25 +1096,26 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		}
 	}
 	flush_visible();
+	TYR_TRACE_VIEW(PE) // what the kernel's end reads (not held through the loop)
 	if (wide) {
 		WideState w;
 		w.rox = rox, w.roy = roy, w.roz = roz, w.rdx = rdx, w.rdy = rdy, w.rdz = rdz, w.rix = rix, w.riy = riy, w.riz = riz, w.dist = dist;
 		w.ref = ref, w.slot = slot, w.prim = prim, w.n = st.n;
 		w.flags = (regular ? 1u : 0u) | (hitTri ? 2u : 0u) | (isShadow ? 4u : 0u) | (occluded ? 8u : 0u) | (live ? 16u : 0u);
-		const uint32_t res = wide_drain<STACK_LDS>(sc.quads, sc.tris, P.shadowPrev.color, P.shadowPrev.dyz_cd_ix, P.work.hit, P.blit, smem_, w, passes TYR_WIDE_STEPS_ARG);
+		const uint32_t res = wide_drain<STACK_LDS>(PE.scene.quads, PE.scene.tris, PE.shadowPrev.color, PE.shadowPrev.dyz_cd_ix, PE.work.hit, PE.blit, smem_, w, passes TYR_WIDE_STEPS_ARG);
 		visible += res & 0x3fffffffu;
 		overflow = overflow || (res & 0x80000000u) != 0u;
 		if (res & 0x40000000u)
 			passes = kMaxPasses + 1;
 	}
 	if (overflow)
-		atomicOr(&P.k->device_error, kErrStackOverflow);
+		atomicOr(&PE.k->device_error, kErrStackOverflow);
 	if (kGuardPasses && passes > kMaxPasses)
-		atomicOr(&P.k->device_error, kErrNoProgress);
-	wave_add_u64(&P.k->n_shadow_visible, visible);
+		atomicOr(&PE.k->device_error, kErrNoProgress);
+	wave_add_u64(&PE.k->n_shadow_visible, visible);
 	if (kLoopStats) {
 		for (int i = 0; i < 9; ++i)
-			wave_add_u64(&P.k->debug[i], dbg[i]);
+			wave_add_u64(&PE.k->debug[i], dbg[i]);
 	}
 	if (kAnatomy && lane == 0) {
 		const unsigned long long tEnd = __builtin_amdgcn_s_memrealtime();
@@ -1130,6 +1137,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 }
 
 #undef TYR_DBG
+#undef TYR_TRACE_VIEW
 
 
 // extend of this iteration + connect of the previous one in one launch.  P.kc must be this iteration's set, P.kcPrev the
