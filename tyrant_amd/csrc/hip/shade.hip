@@ -31,6 +31,9 @@ struct ShadeOut {
 	// the path ends; no random number).  It still SURVIVES this iteration (its survive byte, the counts, its slot in the
 	// next iteration's order -- every other ray's random numbers depend on that), it just never enters a queue.
 	bool ghost;
+#ifdef TYR_SHADE_CENSUS
+	int atmoKind; // (diagnostic build) what the ray asked of the atmosphere model: 0 nothing, 1 sun, 2 sky, 3 sunsky
+#endif
 };
 
 // NEE toward spheres[6], kernel.cu:419-447 / 559-590 (common part)
@@ -364,6 +367,9 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 	// miss (sky / sunsky(direction), kernel.cu:613-617).  A ray asks at most once, nothing random is drawn in
 	// between, so all of them evaluate it HERE, in one pass of the wave, instead of one pass per place of call; every
 	// lane still performs exactly the operations the reference's order of evaluation prescribes.
+#ifdef TYR_SHADE_CENSUS
+	out.atmoKind = atmo;
+#endif
 	if (atmo != kAtmoNone) {
 		const bool miss = !hit;
 		const f3 viewDir = miss ? direction : out.sDir;
@@ -662,6 +668,23 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			P.survFlag[vslot] = out.survive ? 1 : 0; // what k_scan_words turns into next iteration's slots
 #endif
 		TYR_STAMP(0)
+#ifdef TYR_SHADE_CENSUS
+		{
+			// diagnostic build: how full the atmosphere model's two passes run (debug[8] wave-tiles, [9] rays, [10] rays asking in the
+			// first pass -- for themselves --, [11] waves in which any does, [12] rays finished in place (the second pass: for the
+			// survivor), [13] waves with any, [14] sun samples among [10])
+			const unsigned long long bm = __ballot(out.atmoKind != 0), bg = __ballot(out.ghost), bv = __ballot(valid), bs = __ballot(out.atmoKind == 1);
+			if (lane == 0) {
+				atomicAdd(&P.k->debug[8], 1ull);
+				atomicAdd(&P.k->debug[9], (unsigned long long)__popcll(bv));
+				atomicAdd(&P.k->debug[10], (unsigned long long)__popcll(bm));
+				atomicAdd(&P.k->debug[11], bm ? 1ull : 0ull);
+				atomicAdd(&P.k->debug[12], (unsigned long long)__popcll(bg));
+				atomicAdd(&P.k->debug[13], bg ? 1ull : 0ull);
+				atomicAdd(&P.k->debug[14], (unsigned long long)__popcll(bs));
+			}
+		}
+#endif
 
 		// ---- ranks inside the tile: survivors that may enter the tree, survivors that cannot, shadow rays ----
 		const bool sT = out.survive && out.tree, sS = out.survive && !out.tree && !out.ghost;
