@@ -179,6 +179,8 @@ __device__ __forceinline__ void st_sc1_f4(float4* p, float4 x) {
 	st_sc1_f2(reinterpret_cast<float2*>(p) + 1, make_float2(x.z, x.w));
 }
 
+// bits of a wave mask below this lane (v_mbcnt: no per-lane copy of the 64-bit "lanes below me" mask to keep in two vector registers)
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // wave-aggregated 64-bit counter add (one atomic per wave)

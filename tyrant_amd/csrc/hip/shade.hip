@@ -502,7 +502,6 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	// class 0's tiles, then class 1's (from the device's counts: the host may have sized the grid from an upper bound)
 	const uint32_t tiles0 = queue_extent(P.segWork) / kBlock;
 	const uint32_t nTiles = tiles0 + queue_extent(P.segWork + kClassWords) / kBlock;
-	const unsigned long long below = (1ull << lane) - 1ull;
 #ifdef TYR_SHADE_TIMING
 	// diagnostic build: where a tile's time goes, in s_memtime ticks summed over this block's tiles (thread 0;
 	// debug[0] shade, [1] ranks + barrier, [2] place, [4] copy out + barrier, [5] stage + pixel atomics, [7] tiles)
@@ -594,6 +593,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	uint32_t word = blockIdx.x % kTicketWords, tried = 0;
 	uint32_t* const tickets = STREAM ? SI->shadeTiles : P.k->shade_tiles;
 	auto draw_tile = [&]() -> uint32_t { // block-uniform; nTiles when nothing is left
+		const FrameParams& P = kernarg_view<FrameParams>();
 		uint32_t vbNext = nTiles;
 		if (tid == 0) {
 			while (tried < kTicketWords && !gaveUp) {
@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			waveResolved += (uint32_t)__popcll(__ballot(out.sResolved));
 			waveVisible += (uint32_t)__popcll(__ballot(out.sVisible));
 		}
-		const uint32_t rt = __popcll(bt & below), rk = __popcll(bk & below), rh = __popcll(bh & below);
+		const uint32_t rt = lanes_below(bt), rk = lanes_below(bk), rh = lanes_below(bh);
 		if (lane == 0) {
 			sh[4 + wave] = __popcll(bt);
 			sh[8 + wave] = __popcll(bh);
@@ -786,13 +786,14 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		++ntiles_;
 #endif
 	}
-	accumulate_pixels_wave(P.blit, (int)pendPixel, pendColor, pendNew);
+	const FrameParams& PE = kernarg_view<FrameParams>(); // the kernel's end: its reads of the arguments, not held through the loop
+	accumulate_pixels_wave(PE.blit, (int)pendPixel, pendColor, pendNew);
 	if (havePrev) {
 		__syncthreads();
 		flush_prev();
 	}
 	uint32_t myResolved = 0;
-	if (P.resolveShadows || P.retireGhosts) { // (block-uniform)
+	if (PE.resolveShadows || PE.retireGhosts) { // (block-uniform)
 		if (lane == 0) {
 			sh[20 + wave] = waveResolved;
 			sh[24 + wave] = waveVisible;
@@ -803,7 +804,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			myResolved = sh[20] + sh[21] + sh[22] + sh[23];
 			const uint32_t vis = sh[24] + sh[25] + sh[26] + sh[27];
 			if (vis)
-				atomicAdd(&P.k->n_shadow_visible, (unsigned long long)vis);
+				atomicAdd(&PE.k->n_shadow_visible, (unsigned long long)vis);
 			mySurvivors += sh[28] + sh[29] + sh[30] + sh[31]; // survivors all the same: the next iteration's ray count, the totals
 		}
 	}
@@ -812,8 +813,8 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 #ifdef TYR_SHADE_TIMING
 	if (tid == 0) {
 		for (int i = 0; i < 6; ++i)
-			atomicAdd(&P.k->debug[i], tacc_[i]);
-		atomicAdd(&P.k->debug[7], ntiles_);
+			atomicAdd(&PE.k->debug[i], tacc_[i]);
+		atomicAdd(&PE.k->debug[7], ntiles_);
 	}
 #endif
 	if (STREAM) {
@@ -822,42 +823,42 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		// as done.
 		if (tid == 0) {
 			if (myResolved)
-				atomicAdd(&P.kc->shadow_cnt, myResolved); // (here: only the shadow rays answered in place; the queued ones are counted by the segments)
+				atomicAdd(&PE.kc->shadow_cnt, myResolved); // (here: only the shadow rays answered in place; the queued ones are counted by the segments)
 			__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (atomicAdd(&SI->shadeBlocksDone, 1u) + 1u == P.shadeBlocks && !gaveUp && ld_sc1_u32(&P.k->device_error) == 0u) {
-				StreamIter* const NI = SI + 1; // (P.streamIter + 1 < kStreamMaxIters: the host queues at most kMaxBounces + 1 of these launches)
+			if (atomicAdd(&SI->shadeBlocksDone, 1u) + 1u == PE.shadeBlocks && !gaveUp && ld_sc1_u32(&PE.k->device_error) == 0u) {
+				StreamIter* const NI = SI + 1; // (PE.streamIter + 1 < kStreamMaxIters: the host queues at most kMaxBounces + 1 of these launches)
 				uint32_t s = 0, h = 0;
 				for (uint32_t c = 0; c < kClasses; ++c)
 					for (uint32_t w = 0; w < kSegs; ++w) {
-						const uint32_t n = ld_sc1_u32(&P.segNext[c * kClassWords + w * kSegStride]);
+						const uint32_t n = ld_sc1_u32(&PE.segNext[c * kClassWords + w * kSegStride]);
 						st_sc1_u32(&NI->segWork[c][w], n);
 						s += n;
 					}
 				for (uint32_t w = 0; w < kSegs; ++w) {
-					const uint32_t n = ld_sc1_u32(&P.kc->seg[w * kSegStride]);
+					const uint32_t n = ld_sc1_u32(&PE.kc->seg[w * kSegStride]);
 					st_sc1_u32(&NI->segShadowPrev[w], n);
 					h += n;
 				}
 				st_sc1_u32(&NI->nLive, s);
 				st_sc1_u32(&NI->nShadowPrev, h);
 				// the iteration's totals (what set_wavefront_globals and the last shade block keep in the launch-per-iteration path)
-				const uint32_t hAll = h + __hip_atomic_load(&P.kc->shadow_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // + the shadow rays answered in place
-				P.kc->shadow_cnt = 0;
-				P.k->n_live = SI->nLive;
-				P.k->shadow_ray_cnt = hAll;
-				P.k->total_shadow_rays += hAll;
-				P.k->n_survive += s;
-				P.k->total_extend_rays += s;
+				const uint32_t hAll = h + __hip_atomic_load(&PE.kc->shadow_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // + the shadow rays answered in place
+				PE.kc->shadow_cnt = 0;
+				PE.k->n_live = SI->nLive;
+				PE.k->shadow_ray_cnt = hAll;
+				PE.k->total_shadow_rays += hAll;
+				PE.k->n_survive += s;
+				PE.k->total_extend_rays += s;
 				// what the next iteration's shade appends to: this iteration's work queue (two iterations on it is `next` again)
 				// and the other set of shadow counters; nobody reads either any more (every shade block is done, the traversal
 				// kernel works from the StreamIter copies)
 				for (uint32_t c = 0; c < kClasses; ++c)
 					for (uint32_t w = 0; w < kSegs; ++w)
-						st_sc1_u32(&P.segWork[c * kClassWords + w * kSegStride], 0u);
+						st_sc1_u32(&PE.segWork[c * kClassWords + w * kSegStride], 0u);
 				for (uint32_t w = 0; w < kSegs; ++w)
-					st_sc1_u32(&P.kcPrev->seg[w * kSegStride], 0u);
-				P.kcPrev->shadow_cnt = 0;
-				P.k->scan_blocks_done = 0;
+					st_sc1_u32(&PE.kcPrev->seg[w * kSegStride], 0u);
+				PE.kcPrev->shadow_cnt = 0;
+				PE.k->scan_blocks_done = 0;
 				// the shadow rays that were traced beside this iteration's rays lie in the buffers the next iteration's shade
 				// writes: it may not start (= this launch may not end) before the traversal has finished them
 				{
@@ -872,8 +873,8 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 					};
 					while (shadows_done() != want) {
 						__builtin_amdgcn_s_sleep(8);
-						if ((++polls & 63u) == 0u && (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks || ld_sc1_u32(&P.k->device_error) != 0u)) {
-							atomicOr(&P.k->device_error, kErrNoProgress);
+						if ((++polls & 63u) == 0u && (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks || ld_sc1_u32(&PE.k->device_error) != 0u)) {
+							atomicOr(&PE.k->device_error, kErrNoProgress);
 							break;
 						}
 					}
@@ -883,9 +884,9 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 				if (s == 0u) {
 					// no survivors: the next iteration is the last shadow rays alone (or nothing); the one after it is empty and
 					// closed (its counts are the zeros the tail started with) -- the traversal kernel ends there
-					if (h != 0u && P.streamIter + 2u < kStreamMaxIters)
+					if (h != 0u && PE.streamIter + 2u < kStreamMaxIters)
 						st_sc1_u32(&(NI + 1)->closed, 1u);
-					st_sc1_u32(&P.stream->ended, 1u);
+					st_sc1_u32(&PE.stream->ended, 1u);
 				}
 			}
 		}
@@ -893,9 +894,9 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	}
 	if (tid == 0) {
 		if (mySurvivors)
-			atomicAdd(&P.k->primary_ray_cnt, mySurvivors);
+			atomicAdd(&PE.k->primary_ray_cnt, mySurvivors);
 		if (myShadows + myResolved)
-			atomicAdd(&P.kc->shadow_cnt, myShadows + myResolved);
+			atomicAdd(&PE.kc->shadow_cnt, myShadows + myResolved);
 #ifdef TYR_WHATIF_SHADE_FENCE
 		__threadfence();
 #else
@@ -903,15 +904,15 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		// them is enough (a release fence here is an L2 write-back per block)
 		__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-		if (atomicAdd(&P.k->shade_blocks_done, 1u) + 1u == P.shadeBlocks) {
-			const uint32_t s = __hip_atomic_load(&P.k->primary_ray_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const uint32_t h = __hip_atomic_load(&P.kc->shadow_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			P.k->shadow_ray_cnt = h;
-			P.k->total_shadow_rays += h;
-			P.k->n_survive += s;
+		if (atomicAdd(&PE.k->shade_blocks_done, 1u) + 1u == PE.shadeBlocks) {
+			const uint32_t s = __hip_atomic_load(&PE.k->primary_ray_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t h = __hip_atomic_load(&PE.kc->shadow_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			PE.k->shadow_ray_cnt = h;
+			PE.k->total_shadow_rays += h;
+			PE.k->n_survive += s;
 			for (uint32_t c = 0; c < kClasses; ++c) // what the next iteration's sphere pre-pass has to do (a top-up appends behind it)
 				for (uint32_t w = 0; w < kSegs; ++w)
-					P.k->segSurv[c][w] = __hip_atomic_load(&P.segNext[c * kClassWords + w * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					PE.k->segSurv[c][w] = __hip_atomic_load(&PE.segNext[c * kClassWords + w * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 #undef TYR_STAMP
