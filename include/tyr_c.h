@@ -293,7 +293,7 @@ enum {
 	TYR_TUNE_PROFILE_MASK = 11,      /* with TYR_FLAG_PROFILE: bit TYR_K_* set = that stage gets a hipEvent pair (default 31 = all five; a pair costs ~10 us of idle GPU) */
 	TYR_TUNE_MERGE_TRACE = 12,       /* tyr_render: 1 (default) = connect(i) shares the launch of extend(i + 1); 0 = launch_kernels' order, iteration by iteration */
 	TYR_TUNE_STATIC_INTERLEAVE = 13, /* the fixed per-block part as interleaved 64-slot chunks (1, default) or one contiguous range per block (0) */
-	TYR_TUNE_RUN_AHEAD = 14,         /* tyr_render: queue iteration i + 1 before iteration i's counts reach the host: 0 never, 1 always, 2 (default) for queues of at most 6 Mi slots */
+	TYR_TUNE_RUN_AHEAD = 14,         /* tyr_render: queue iteration i + 1 before iteration i's counts reach the host: 0 never, 1 or 2 (default) always -- nothing is queued behind the iteration that is known to end the render (budget spent, kMaxBounces iterations since the last top-up) */
 	TYR_TUNE_WIDE_DRAIN = 15,        /* 1 (default) = a wave's last <= 16 rays are finished four lanes to a ray */
 	TYR_TUNE_STREAM_TAIL = 16,       /* tyr_render: 1 = once the primary budget is spent, the remaining iterations run as ONE traversal kernel with shade resident beside it (DESIGN.md "One drain per render": bit-exact, measured slower, hence not the default); 0 (default) = a traversal launch per iteration */
 	TYR_TUNE_STREAM_SHADE_PER_CU = 17, /* streamed tail: shade blocks per CU (1..2, default 1) ... */

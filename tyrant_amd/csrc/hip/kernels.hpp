@@ -243,7 +243,7 @@ struct Tuning {
 	int stagedNodes = 64;
 	int refillMinIdle = 16;
 	int wavesPerSimd = 0;     // persistent grid size; 0 = what the occupancy query admits
-	int runAhead = 2;         // tyr_render: queue iteration i + 1 before iteration i's counts are on the host: 0 never, 1 always, 2 for queues of at most 6 Mi slots
+	int runAhead = 2;         // tyr_render: queue iteration i + 1 before iteration i's counts are on the host: 0 never, 1 / 2 always
 	int mergeTrace = 1;       // tyr_render: connect(i) rides in the launch of extend(i + 1)
 	int profileMask = 31;     // TYR_FLAG_PROFILE: which stages (bit TYR_K_*) get a hipEvent pair
 	int streamTail = 0;       // tyr_render: once the budget is spent, ONE traversal kernel across the remaining iterations with shade resident beside it (0, the default: a launch per iteration -- the streamed form is bit-exact and slower, DESIGN.md "One drain per render")

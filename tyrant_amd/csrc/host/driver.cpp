@@ -117,7 +117,6 @@ int push_counters(tyr_ctx* c) {
 	return TYR_OK;
 }
 
-[[maybe_unused]] constexpr uint32_t kRunAheadMaxLive = 6u << 20; // TYR_TUNE_RUN_AHEAD = 2: queues of up to this many slots run one iteration ahead of the counts (used in the uninstrumented builds)
 
 FrameParams make_params(const tyr_ctx* c) {
 	FrameParams P{};
@@ -1085,7 +1084,7 @@ static bool run_ahead_eligible(const tyr_ctx* c) {
 #if defined(TYR_QUAD_STATS) || defined(TYR_LAUNCH_ANATOMY)
 	return false; // the instrumented builds print per-iteration records from the host mirror (launch_iteration)
 #else
-	const bool wanted = c->tuning.runAhead == 1 || (c->tuning.runAhead == 2 && c->cfg.queue_size <= kRunAheadMaxLive);
+	const bool wanted = c->tuning.runAhead != 0; // (2 meant "queues of at most 6 Mi slots" while a render's last iteration was followed by an empty one: render_run_ahead's lastBirth)
 	return wanted && merged_render(c) && c->blit != nullptr;
 #endif
 }
@@ -1108,13 +1107,19 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 	if ((rc = enqueue_merged_iteration(c, IterationPlan{ nNew, live, static_cast<uint32_t>(s), 0u }, true)))
 		return rc;
 	uint32_t enq = 1;
+	// The last iteration (of this render) that gave birth to rays: a primary ray survives at most kMaxBounces times
+	// (kernel.cu:600-607), so shade of iteration lastBirth + kMaxBounces leaves no survivor -- once the budget is spent the
+	// render's end is known in advance and no iteration has to be queued ahead for nothing.  (Survivors the ctx held when the
+	// render began count as born in iteration 0: their bounce counts are not known here.)
+	uint32_t lastBirth = 0;
 	for (;;) {
 		// iterations 0 .. enq - 1 are queued; the counts of 0 .. enq - 2 have arrived
 		bool ahead = false;
 		uint32_t frameBefore = c->frame;
 		const uint32_t shadowSetBefore = c->shadowSet; // (enqueue_shade of an iteration queued ahead moves it: an iteration that turns out empty must give it back, or tyr_shadow_export would read the empty iteration's counters)
 		const bool foldedBefore = c->lastShadeFolded;
-		if (enq < max_iterations) {
+		const bool canHaveSurvivors = budget != 0 || enq - 1 < lastBirth + static_cast<uint32_t>(kMaxBounces); // of iteration enq - 1
+		if (enq < max_iterations && canHaveSurvivors) {
 			const uint32_t liveMax = static_cast<uint32_t>(std::min<uint64_t>(N, static_cast<uint64_t>(live) + budget));
 			const uint32_t newMax = static_cast<uint32_t>(std::min<uint64_t>(N, budget));
 			if ((rc = enqueue_merged_iteration(c, IterationPlan{ newMax, liveMax, live, live }, false))) {
@@ -1170,15 +1175,23 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 			}
 			return TYR_OK;
 		}
-		if (!ahead) { // max_iterations reached
+		if (!ahead && enq >= max_iterations) { // max_iterations reached
 			c->shadowPending = shadows != 0;
 			c->shadowPendingMax = shadows;
 			return TYR_OK;
 		}
 		// iteration enq is real; what it does, exactly, now that its predecessor's survivors are known
 		nNew = static_cast<uint32_t>(std::min<uint64_t>(N - s, budget));
+		if (nNew != 0)
+			lastBirth = enq;
 		live = static_cast<uint32_t>(s) + nNew;
 		budget -= nNew;
+		if (!ahead) {
+			// (it was not queued ahead because no survivor was expected, and there are some: cannot happen while a ray survives
+			// at most kMaxBounces times -- queued now, from the exact counts, rather than trusted)
+			if ((rc = enqueue_merged_iteration(c, IterationPlan{ nNew, live, static_cast<uint32_t>(s), shadows }, false)))
+				return rc;
+		}
 		++enq;
 	}
 }
