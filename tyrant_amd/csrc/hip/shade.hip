@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		const uint32_t cls = vb >= tiles0 ? 1u : 0u;
 		const uint32_t inClass = (vb - cls * tiles0) * kBlock + tid; // slot inside the class
 		const uint32_t slot = cls * P.classStride + inClass;
-		ShadeOut out = {};
+		ShadeOut out; // (not zeroed: every field is written before the flag that admits its reading is set)
 		uint32_t pixelBits = 0, vslot = 0;
 		// kernel.cu:622-625 for the tile BEFORE this one.  vmcnt retires loads and atomics in issue order, and an
 		// atomic that has to reach the memory side takes thousands of cycles under load: issued at the end of a
