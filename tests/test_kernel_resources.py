@@ -66,10 +66,18 @@ def test_k_shade_keeps_nothing_in_spills_and_runs_five_blocks_per_cu(resources, 
 
 
 def test_k_trace_flat_fits_five_blocks_per_cu_without_vector_spills(resources):
-    k = _kernel(resources, "k_trace_flatILi12E")
+    k = _kernel(resources, "k_trace_flatILi12ELj256E")
     assert k["VGPRs Spill"] == 0 and k["SGPRs Spill"] <= 4, k  # (24 scalar spills before the refill / flush / end read the argument through the view)
     assert k["Occupancy [waves/SIMD]"] >= 5 and k["VGPRs"] + k["AGPRs"] <= 96, k
     assert _blocks_that_fit(k["LDS Size [bytes/block]"]) >= 5, k  # one granule more and the persistent grid's fifth blocks run after the others (+30 % per render, round 2)
+
+
+def test_k_trace_flat_in_768_thread_blocks_is_six_waves_per_simd(resources):
+    # two 12-wave blocks per CU share two copies of the staged nodes instead of five: 2 x (73,728 + 7,168 + 4) B is ALL of the CU's LDS
+    k = _kernel(resources, "k_trace_flatILi12ELj768E")
+    assert k["VGPRs Spill"] == 0 and k["SGPRs Spill"] <= 4, k
+    assert k["Occupancy [waves/SIMD]"] >= 6 and k["VGPRs"] + k["AGPRs"] <= 80, k
+    assert _blocks_that_fit(k["LDS Size [bytes/block]"]) >= 2, k
 
 
 def test_k_primary_has_no_spills(resources):

@@ -274,21 +274,21 @@ static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock
 // host-side call of ~0.1-0.2 ms: asked once per kernel and context (`cachedPerCU` lives in the ctx's LaunchCache),
 // not once per launch -- there it sat between the pre-pass and the persistent kernel with the GPU idle.
 template <class K>
-static inline uint32_t persistent_blocks(K kernel, uint32_t nItems, const Tuning& t, int numCUs, int& cachedPerCU) {
+static inline uint32_t persistent_blocks(K kernel, uint32_t nItems, const Tuning& t, int numCUs, int& cachedPerCU, uint32_t blockThreads = kBlock) {
 	int perCU = 0;
 	if (t.wavesPerSimd > 0) {
-		perCU = t.wavesPerSimd; // 4 SIMDs x w waves = w blocks of 4 waves
+		perCU = (int)((4u * (uint32_t)t.wavesPerSimd * 64u + blockThreads - 1u) / blockThreads); // 4 SIMDs x w waves, in blocks of blockThreads / 64 waves (rounded up)
 	} else {
 		if (cachedPerCU == 0) {
 			int q = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kernel, kBlock, 0) != hipSuccess || q <= 0)
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kernel, (int)blockThreads, 0) != hipSuccess || q <= 0)
 				q = 4;
 			cachedPerCU = q;
 		}
 		perCU = cachedPerCU;
 	}
 	const uint32_t resident = (uint32_t)perCU * (uint32_t)numCUs;
-	const uint32_t needed = (nItems + kBlock - 1) / kBlock;
+	const uint32_t needed = (nItems + blockThreads - 1) / blockThreads;
 	return needed < resident ? (needed ? needed : 1) : resident;
 }
 

@@ -251,6 +251,7 @@ struct Tuning {
 	int streamTracePerCU = 4; // ... beside this many blocks of k_trace_stream
 	int resolveShadows = 1;   // merged path of tyr_render (needs foldSpheres): shade answers the shadow rays that cannot reach a triangle itself
 	int retireSky = 1;        // merged path of tyr_render: k_primary finishes the camera rays that hit nothing itself (they never reach a queue)
+	int wideBlockMinItems = 3 << 20; // k_trace_flat: launches of at least this many rays run as 768-thread blocks, six waves per SIMD (< 0: never)
 	int foldSpheres = 1;      // merged path of tyr_render: shade does the sphere pre-passes' work for the rays it emits (the streamed tail always does); 0: k_extend_spheres / k_connect_spheres re-read them
 };
 constexpr uint32_t kCountRaysPerBlock = 1024; // the counting build's kernels: queue slots owned by one 256-thread block

@@ -13,6 +13,12 @@ namespace tyr {
 #ifndef TYR_CONNECT_ORDERED
 #define TYR_CONNECT_ORDERED false
 #endif
+// Threads per block of k_trace_flat (template parameter): 256 -- five blocks per CU, five waves per SIMD -- or 768 = three
+// 256-thread parts that share ONE copy of the staged nodes: two such blocks per CU are SIX waves per SIMD with all 64 staged
+// nodes (2 x (73,728 B of stacks + 7,168 + 4) = the CU's 160 KB in 1,280-byte granules; 75 vector registers under that
+// bound, no spill).  The sixth wave feeds a fat launch faster (-2.3 % per C3 render at 16.6 M slots) and lengthens the drain
+// of a thin one (+0.7 % at 2 Mi slots): launch_trace_kernel picks by the launch's item count (Tuning::wideBlockMinItems).
+constexpr uint32_t kTraceBlockWide = 768;
 #ifndef TYR_FLAT_WAVES_PER_EU
 #define TYR_FLAT_WAVES_PER_EU (STACK_LDS <= 8 ? 6 : STACK_LDS <= 12 ? 5 : STACK_LDS <= 16 ? 3 : 2)
 #endif
@@ -99,7 +105,7 @@ struct ChunkFeed {
 		// at the word before every atomic, launches of short rays (the primary rays) were 30-60 % slower than
 		// block-owned ranges; with that gone, 64- and 128-slot chunks beat larger ones by 2-4 %.  Guided
 		// (shrinking) draws over 64-slot granules lost to fixed chunks.
-		const uint32_t waves = gridDim.x * (kBlock / 64);
+		const uint32_t waves = gridDim.x * (blockDim.x / 64u);
 		chunk = chunkWanted;
 		while (chunk > 64 && (unsigned long long)waves * chunk > nItems)
 			chunk >>= 1;
@@ -566,7 +572,7 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 	// the ray's stack (at most STACK_LDS entries, all in its old lane's LDS column) moves into the group's four columns:
 	// entry e at row e / 4 of lane e % 4
 	typedef typename LdsStack<STACK_LDS, true>::entry_t entry_t;
-	entry_t* const column0 = smem_ + (threadIdx.x & ~63u); // row 0 of this wave's lane 0
+	entry_t* const column0 = smem_ + (threadIdx.x >> 8) * (STACK_LDS * kBlock) + (threadIdx.x & 255u & ~63u); // row 0 of this wave's lane 0 (a block is one or more 256-thread parts, each with its own [STACK_LDS][256] stack array)
 	entry_t moved[STACK_LDS / 4];
 #pragma unroll
 	for (int row = 0; row < STACK_LDS / 4; ++row) {
@@ -812,13 +818,19 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 // the end of the launch.  Every ray is still answered on its own, into its own slot / pixel: bit-exact as before
 // (shadow rays traverse in the reference's near-first order here; any-hit answers do not depend on the order).
 // ======================================================================================
-template <int STACK_LDS>
+template <int STACK_LDS, uint32_t kTraceBlock>
 // the arguments read where they lie (device_common.hpp kernarg_view): what the refill, the pixel flush and the kernel's end
 // read of them is loaded there and not held in scalar registers through the descent (24 scalar spills -> 2)
 #define TYR_TRACE_VIEW(name) const FrameParams& name = kernarg_view<FrameParams>();
-__global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(const FrameParams P) {
+__global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ? 6 : TYR_FLAT_WAVES_PER_EU)) k_trace_flat(const FrameParams P) {
 	constexpr bool COUNT = false; // (TYR_DBG)
-	TYR_DECLARE_FLAT_STACK(st, true)
+	// the flat kernels' stack (TYR_DECLARE_FLAT_STACK), one [STACK_LDS][256] array per 256-thread part of the block
+	__shared__ typename LdsStack<STACK_LDS, true>::entry_t smem_[STACK_LDS * kTraceBlock];
+	uint32_t spillRef_[kStackSize - STACK_LDS];
+	float spillT_[kStackSize - STACK_LDS];
+	LdsStack<STACK_LDS, true> st;
+	st.bind(smem_ + (threadIdx.x >> 8) * (STACK_LDS * kBlock) + (threadIdx.x & 255u), spillRef_, spillT_);
+	st.reset();
 	// LDS: 24,576 B of stack + 7,168 B of staged nodes + 4 = 31,748 B per block, and five blocks per CU are 158,740 of its
 	// 163,840 B: ONE more allocation granule (a 256-byte array was enough) and the hardware places four while the occupancy
 	// query still answers five -- the fifth of the persistent grid's blocks then run after the others (+30 % per render,
@@ -826,7 +838,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 	__shared__ float4 stagedNodes[7 * kStagedNodes];
 	__shared__ uint32_t blockNext;
 	const uint32_t nStaged = P.scene.nStaged;
-	for (uint32_t i = threadIdx.x; i < 7 * nStaged; i += kBlock) {
+	for (uint32_t i = threadIdx.x; i < 7 * nStaged; i += kTraceBlock) {
 		const uint32_t v = i / nStaged, n = i - v * nStaged;
 		stagedNodes[v * kStagedNodes + n] = P.scene.quads[8 * n + v];
 	}
@@ -1125,7 +1137,7 @@ __global__ void __launch_bounds__(kBlock, TYR_FLAT_WAVES_PER_EU) k_trace_flat(co
 		// per-wave records for host/driver.cpp's TYR_ANATOMY=2 printout, parked in an array nobody uses during this launch (the NEXT queue's
 		// hit column): microseconds from this wave's start to "queue used up" and to its exit, and how many of its lanes
 		// still held a ray when the queue ran out
-		const uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+		const uint32_t w = blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6);
 		if (w < P.N)
 			P.next.hit[w] = make_float2((float)((tExhausted ? tExhausted : tEnd) - tStart) * 0.01f, (float)(tEnd - tStart) * 0.01f + (float)liveAtExhaustion * 0.0f);
 		if (w < 8192u && 32768u < P.N) { // three more records per wave, further up the same column (host/driver.cpp prints them with TYR_ANATOMY=2)
@@ -1150,7 +1162,10 @@ void launch_trace(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, u
 	launch_trace_kernel(P, maxLive + maxShadowPrev, t, numCUs, lc, stream);
 }
 void launch_trace_kernel(const FrameParams& P, uint32_t items, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
-	hipLaunchKernelGGL((k_trace_flat<TYR_TRACE_STACK>), dim3(persistent_blocks(k_trace_flat<TYR_TRACE_STACK>, items, t, numCUs, lc.perCU[kLcTrace][0])), dim3(kBlock), 0, stream, P);
+	if (t.wideBlockMinItems >= 0 && items >= (uint32_t)t.wideBlockMinItems)
+		hipLaunchKernelGGL((k_trace_flat<TYR_TRACE_STACK, kTraceBlockWide>), dim3(persistent_blocks(k_trace_flat<TYR_TRACE_STACK, kTraceBlockWide>, items, t, numCUs, lc.perCU[kLcTrace][1], kTraceBlockWide)), dim3(kTraceBlockWide), 0, stream, P);
+	else
+		hipLaunchKernelGGL((k_trace_flat<TYR_TRACE_STACK, (uint32_t)kBlock>), dim3(persistent_blocks(k_trace_flat<TYR_TRACE_STACK, (uint32_t)kBlock>, items, t, numCUs, lc.perCU[kLcTrace][0])), dim3(kBlock), 0, stream, P);
 }
 void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream, uint32_t maxLive) {
 	FrameParams Pc = P;

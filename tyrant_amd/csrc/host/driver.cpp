@@ -1746,6 +1746,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_FOLD_SPHERES, 0, 1, &Tuning::foldSpheres },
 		{ TYR_TUNE_RETIRE_SKY, 0, 1, &Tuning::retireSky },
 		{ TYR_TUNE_RESOLVE_SHADOWS, 0, 1, &Tuning::resolveShadows },
+		{ TYR_TUNE_WIDE_BLOCK_MIN_ITEMS, -1, 0x7fffffff, &Tuning::wideBlockMinItems },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)
