@@ -69,7 +69,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 NUM_XCD, NUM_SIMD, NUM_CU = 8, 1024, 256  # MI355X: 8 XCDs x 32 CUs x 4 SIMDs
 REF_N = 2097152  # variables.h:44
-TRACE_KERNEL = "k_trace_flat<12>"  # the traversal kernel: extend(i + 1) + connect(i) in one launch (tyr_render), or one kind of ray alone
+TRACE_KERNEL = "k_trace_flat<12"   # the traversal kernel: extend(i + 1) + connect(i) in one launch (tyr_render), or one kind of ray alone.  A name PREFIX: rocprofv3 lists its two block shapes, k_trace_flat<12, 768u> (launches of 3 Mi rays and more: six waves per SIMD) and k_trace_flat<12, 256u>; both are "the kernel" of the roofline
 SHADE_KERNEL = "k_shade<"            # the second kernel of a render by time
 EXTEND_KERNEL = TRACE_KERNEL
 SHADE_BYTES_PER_RAY = 52 + 24 + 16   # state + e1, e2 + pixel RMW; + 44 per survivor + 48 per shadow ray (added from the counters)
@@ -379,7 +379,7 @@ def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_re
         alg_bytes_per_launch = bytes_per_ext * ext_rays / max(ext_launches, 1)
         alg_gbs = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     out = {
-        "kernel": f"{kernel} " + ("(extend of an iteration + connect of the one before in one persistent launch: quad nodes, closest- and any-hit rays side by side)" if merged else "(the production extend kernel: quad nodes, persistent grid)"),
+        "kernel": f"{kernel}, 768u | 256u> " + ("(768-thread blocks, six waves per SIMD, for launches of at least TYR_TUNE_WIDE_BLOCK_MIN_ITEMS rays, 256-thread blocks at five otherwise; extend of an iteration + connect of the one before in one persistent launch: quad nodes, closest- and any-hit rays side by side)" if merged else "(the production extend kernel: quad nodes, persistent grid)"),
         "avg_launch_ms": round(avg_launch_s * 1e3, 4),
         "launches": ext_launches,
         "launch_time_source": "hipEvent pairs on the ctx stream around the stage (sphere pre-passes + the traversal kernel) inside the timed region",
