@@ -75,6 +75,35 @@ EXTEND_KERNEL = TRACE_KERNEL
 SHADE_BYTES_PER_RAY = 52 + 24 + 16   # state + e1, e2 + pixel RMW; + 44 per survivor + 48 per shadow ray (added from the counters)
 
 
+ORACLE_COUNTER_FIELDS = ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible")
+
+
+def oracle_counters_check(args, world, W, H, spp, N, n_tris, m):
+    """config.oracle_counters_match: the counter deltas of the TIMED renders against the oracle's counters for this very job,
+    committed as tests/golden/bench_c3_counters.json (made by tests/golden/make_bench_counters.py: orc_render, the serial C
+    restatement of kernel.cu:664-748).  Every timed step restarts the frame counter, so K steps must have cast exactly K times
+    the oracle's rays -- extend, shadow, survivors, visible shadow rays, iterations.  None when the job is not the committed one
+    (another workload, resolution, spp, queue size or rank count).  The file is data: nothing under oracle/ is loaded here."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", f"bench_{args.workload}_counters.json")) as f:
+            gold = json.load(f)
+    except (OSError, ValueError):
+        return {"oracle_counters_match": None, "oracle_counters_note": f"no committed oracle counters for workload {args.workload}"}
+    j = gold["job"]
+    if world != 1 or (j["width"], j["height"], j["spp"], j["queue_size"], j["triangles"]) != (W, H, spp, N, n_tris):
+        return {"oracle_counters_match": None, "oracle_counters_note": "this job is not the one the committed oracle counters were made for (tests/golden/make_bench_counters.py: c3, 1920x1080, 8 spp, queue 16,588,800, one rank)"}
+    want = {f: gold["per_render"][f] * args.steps for f in ORACLE_COUNTER_FIELDS}
+    got = m["counter_deltas"]
+    ok = all(int(got[f]) == int(want[f]) for f in ORACLE_COUNTER_FIELDS) and m["iters"] == gold["per_render"]["iterations"] * args.steps
+    out = {"oracle_counters_match": bool(ok),
+           "oracle_counters": {"source": "tests/golden/bench_c3_counters.json (orc_render on this job; tests/test_gpu_configs.py::test_benchmarked_render_path_matches_oracle_at_full_size[bench_shape_16M_8spp] holds the live oracle, the file and the GPU to each other, pixels included)",
+                               "per_render": gold["per_render"], "timed_renders": args.steps}}
+    if not ok:
+        out["oracle_counters"]["timed_deltas"] = {f: int(got[f]) for f in ORACLE_COUNTER_FIELDS}
+        out["oracle_counters"]["timed_iterations"] = m["iters"]
+    return out
+
+
 def dominant_kernel(tune_args) -> str:
     return TRACE_KERNEL
 PMC_PASSES = (
@@ -649,6 +678,9 @@ def main():
                 comm = binding.Dist(r, bytes(idt.cpu().tolist()), rank, world)
 
         def step():
+            # every step is the SAME job: the frame counter all seeds are built from (kernel.cu:667) restarts, so each timed render
+            # casts exactly the rays of the render the oracle's counters were committed for (oracle_counters_match below)
+            r.set_frame(1)
             r.reset_accum()
             it = r.render(spp)
             if ranks > 1:
@@ -740,6 +772,7 @@ def main():
         ext = k1["total_extend_rays"] - k0["total_extend_rays"]
         shd = k1["total_shadow_rays"] - k0["total_shadow_rays"]
         survivors = k1["n_survive"] - k0["n_survive"]
+        deltas = {f: k1[f] - k0[f] for f in ORACLE_COUNTER_FIELDS}
         stats = torch.tensor([float(ext), float(shd), dt], dtype=torch.float64, device=cdev)
         if ranks > 1:
             tmax = stats[2:3].clone()
@@ -762,7 +795,7 @@ def main():
             comm = True if native_used else None  # (only its truth value is reported below)
         r.close()
         per_render = {k: round(v["ms"] / warmup, 3) for k, v in tm_all.items()} if tm_all is not None else {k: round(v["ms"] / steps, 3) for k, v in tm.items()}
-        return {"native_combine": bool(comm is not None and native_ok[0]), "comm_info": comm_info, "ext": ext, "shd": shd, "survivors": survivors, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, **visits}
+        return {"native_combine": bool(comm is not None and native_ok[0]), "comm_info": comm_info, "ext": ext, "shd": shd, "survivors": survivors, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, "counter_deltas": deltas, **visits}
 
     m = measure(N, args.steps, args.warmup, spp_total, shard, world)
     mref = None
@@ -815,6 +848,7 @@ def main():
                 "in_tree_Mrays/s": round(mrays * m["in_tree_frac"], 3),
                 "in_tree_fraction": {"all_rays": round(m["in_tree_frac"], 4), "extend_rays": round(m["in_tree_ext_frac"], 4), "note": "rays whose test of the root box passes (counting build, rank 0's shard); the others cost one box test"},
                 "host_bvh_build_s": round(t_build, 6),
+                **oracle_counters_check(args, world, W, H, spp_total, N, int(prims.shape[0]), m),
                 "render_path": "tyr_render defaults: merged traversal launches (extend(i + 1) + connect(i)), sphere halves folded into shade, rays whose fate is known where they are made (camera rays / survivors that hit nothing, shadow rays that cannot reach a triangle) finished in place -- they count as rays, they never enter a queue; launch-per-iteration (TYR_TUNE_STREAM_TAIL = 0)",
                 **({"tuning": tune} if tune else {}),
                 **({"steady_state": steady} if steady else {}),

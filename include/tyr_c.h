@@ -177,6 +177,12 @@ int tyr_launch_kernels(tyr_ctx* ctx);
 /* Primary-ray budget (extension; the reference streams forever): after `n` more primaries
  * the queue is no longer topped up.  UINT64_MAX = reference behaviour. */
 int tyr_set_budget(tyr_ctx* ctx, uint64_t primary_rays);
+/* The frame counter every seed is built from (`static unsigned frame = 1`, kernel.cu:667; read at kernel.cu:258 and 363,
+ * advanced once per launch_kernels, kernel.cu:736-739).  The reference can only count on; a host that wants the SAME
+ * render again -- a fixed-seed comparison, a benchmark whose steps are one job -- restarts it here (with tyr_reset_accum
+ * and a budget that is a multiple of the pixel count the scan-line cursor is back where it was, too).  0 is not a frame
+ * the reference ever has (it skips it on wrap): TYR_ERR_INVALID. */
+int tyr_set_frame(tyr_ctx* ctx, uint32_t frame);
 
 typedef struct tyr_counters {
 	uint32_t primary_ray_cnt; /* kernel.cu:211 survivors written by the last shade */

@@ -100,6 +100,29 @@ def test_committed_pmc_profiles_parse():
         assert pmc is not None and all(k in pmc["counters"] for g in bench.PMC_PASSES for k in g)
 
 
+def test_oracle_counters_check_compares_the_timed_deltas_with_the_committed_oracle_counters():
+    """config.oracle_counters_match: K timed renders of the committed job must have cast exactly K times the oracle's rays
+    (tests/golden/bench_c3_counters.json, made by tests/golden/make_bench_counters.py); another job -> None, with the reason"""
+    with open(os.path.join(ROOT, "tests", "golden", "bench_c3_counters.json")) as f:
+        gold = json.load(f)
+    j, per = gold["job"], gold["per_render"]
+    assert (j["workload"], j["width"], j["height"], j["spp"], j["queue_size"], j["nranks"]) == ("c3", 1920, 1080, 8, 1920 * 1080 * 8, 1)
+    assert per["total_primary_rays"] == j["spp"] * j["width"] * j["height"] and per["n_survive"] == per["total_extend_rays"] - per["total_primary_rays"]
+    a = bench.parse_args(["--steps", "20"])
+    m = {"counter_deltas": {f: per[f] * 20 for f in bench.ORACLE_COUNTER_FIELDS}, "iters": per["iterations"] * 20}
+    ok = bench.oracle_counters_check(a, 1, 1920, 1080, 8, 1920 * 1080 * 8, j["triangles"], m)
+    assert ok["oracle_counters_match"] is True and ok["oracle_counters"]["timed_renders"] == 20
+    m["counter_deltas"]["total_shadow_rays"] += 1  # one shadow ray too many in twenty renders
+    bad = bench.oracle_counters_check(a, 1, 1920, 1080, 8, 1920 * 1080 * 8, j["triangles"], m)
+    assert bad["oracle_counters_match"] is False and bad["oracle_counters"]["timed_deltas"]["total_shadow_rays"] == per["total_shadow_rays"] * 20 + 1
+    for other in (dict(world=2), dict(N=2097152), dict(spp=4), dict(W=1280)):
+        kw = dict(world=1, W=1920, H=1080, spp=8, N=1920 * 1080 * 8)
+        kw.update(other)
+        r = bench.oracle_counters_check(a, kw["world"], kw["W"], kw["H"], kw["spp"], kw["N"], j["triangles"], m)
+        assert r["oracle_counters_match"] is None and "oracle_counters_note" in r
+    assert bench.oracle_counters_check(bench.parse_args(["--workload", "c2"]), 1, 1920, 1080, 8, 1920 * 1080 * 8, 10036, m)["oracle_counters_match"] is None
+
+
 def _bench_line(stdout: str) -> dict:
     lines = [l for l in stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, stdout[-2000:]
@@ -119,6 +142,7 @@ def test_bench_emits_the_contract_line():
     assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["in_tree_Mrays/s"] <= d["value"]
+    assert d["config"]["oracle_counters_match"] is None  # (only the default job has committed oracle counters; this micro-job says so)
     ss = d["config"]["steady_state"]  # the same kernels with the queue kept full, beside the metric (never instead of it)
     assert ss["Mrays/s"] > 0 and ss["iterations"] == 12 and ss["queue_size"] == d["config"]["queue_size"]
     r = d["roofline"]

@@ -13,6 +13,7 @@ through the C ABI:
   f1  tyr_bvh_build on the GPU box's host: C3's tree, bytes against the oracle's builder.
 """
 import ctypes as C
+import json
 import os
 
 import numpy as np
@@ -245,13 +246,20 @@ def test_stack_bound_of_the_tree_gates_the_wide_drain(orc, hip):
     assert kg["total_extend_rays"] > W * H * spp  # (rays did reach the chains and bounce)
 
 
-@pytest.mark.parametrize("N,spp,knobs", [(W1080 * H1080, 1, {}), (N2M, 2, {}), (W1080 * H1080, 1, dict(stream_tail=1, run_ahead=0)), (N2M, 2, dict(stream_tail=1, run_ahead=0))])
+BENCH_N, BENCH_SPP = 8 * W1080 * H1080, 8  # bench.py's default job: every primary ray of an 8-spp render in flight (job_shape)
+
+
+@pytest.mark.parametrize("N,spp,knobs", [(BENCH_N, BENCH_SPP, {}), (W1080 * H1080, 1, {}), (N2M, 2, {})], ids=["bench_shape_16M_8spp", "queue_WxH_1spp", "queue_2Mi_2spp"])
 def test_benchmarked_render_path_matches_oracle_at_full_size(orc, hip, N, spp, knobs):
     """The code path bench.py times -- `tyr_render` with DEFAULT tuning: merged extend(i+1) + connect(i) launches
-    (`k_trace_flat`), run-ahead where the default enables it, the four-lanes-per-ray drain -- on C3 (996,882 triangles)
-    at 1920x1080 against `orc_render` (main.cpp:164-170 looping kernel.cu:664-748): same iteration count, every counter
-    equal, every pixel exactly `spp` finished paths, radiance within 1e-5 relative.  Once with the GPU-sized queue
-    (every primary ray of the render in flight, the bench's shape) and once at the reference's 2 Mi slots."""
+    (`k_trace_flat`), run-ahead, the four-lanes-per-ray drain -- on C3 (996,882 triangles) at 1920x1080 against `orc_render`
+    (main.cpp:164-170 looping kernel.cu:664-748): same iteration count, every counter equal, every pixel exactly `spp`
+    finished paths, radiance within 1e-5 relative.
+    `bench_shape_16M_8spp` IS the job the driver times (C3, queue 8 x W x H = 16,588,800, 8 spp): its second wavefront is
+    ~10 M rays, so `k_trace_flat<12, 768u>` -- the six-waves-per-SIMD form chosen from TYR_TUNE_WIDE_BLOCK_MIN_ITEMS = 3 Mi
+    items -- meets the oracle on a FULL persistent grid here, not only on partial blocks; its counters are also held against
+    tests/golden/bench_c3_counters.json (what bench.py checks its timed renders with).  The other two stay below 3 Mi rays
+    per launch (the 256-thread form): one ray per pixel in flight, and the reference's own 2 Mi slots."""
     from test_gpu_parity import assert_accum_close
 
     sc, nodes, prims = built_scene("mesh706")
@@ -269,3 +277,67 @@ def test_benchmarked_render_path_matches_oracle_at_full_size(orc, hip, N, spp, k
     bo, bg = o.blit_buffer(), g.blit_buffer()
     assert np.all(bg[:, 3] == spp)
     assert_accum_close(bo, bg, f"C3 render, queue {N}, {spp} spp")
+    if (N, spp) == (BENCH_N, BENCH_SPP):
+        with open(os.path.join(GOLDEN, "bench_c3_counters.json")) as f:
+            gold = json.load(f)
+        assert gold["job"]["queue_size"] == N and gold["job"]["spp"] == spp and gold["job"]["triangles"] == prims.shape[0]
+        assert gold["per_render"]["iterations"] == it_g
+        for f_ in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible"):
+            assert gold["per_render"][f_] == kg[f_] == ko[f_], f_
+        # the same job again from the same frame counter (what every timed step of bench.py is): the same counters
+        g.set_frame(1)
+        g.reset_accum()
+        assert g.render(spp) == it_g
+        k2 = g.counters()
+        for f_ in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible"):
+            assert k2[f_] == 2 * kg[f_], f_
+        assert_accum_close(bo, g.blit_buffer(), "the bench job rendered again from frame 1")
+
+
+def test_c2_render_matches_oracle_at_full_size(orc, hip):
+    """C2 (Cornell box + 10,000 random diffuse triangles) at 1920x1080, the reference's 2 Mi-slot queue, 2 spp: `tyr_render`
+    with default tuning against `orc_render` -- iteration count, every counter, every pixel's path count, radiance <= 1e-5."""
+    from test_gpu_parity import assert_accum_close
+
+    sc, nodes, prims = built_scene("cornell_soup10k")
+    flags = 1 if sc.triangle_materials else 0
+    o = orc.Oracle(W1080, H1080, N2M, flags=flags)
+    g = hip.Renderer(W1080, H1080, N2M, flags=flags)
+    o.load_scene(sc, nodes, prims), g.load_scene(sc, nodes, prims)
+    spp = 2
+    it_o, it_g = o.render(spp), g.render(spp)
+    ko, kg = o.counters(), g.counters()
+    assert kg["device_error"] == 0
+    assert it_o == it_g, (it_o, it_g)
+    for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible", "start_position", "frame", "primary_ray_cnt", "shadow_ray_cnt"):
+        assert ko[f] == kg[f], (f, ko[f], kg[f])
+    bo, bg = o.blit_buffer(), g.blit_buffer()
+    assert np.all(bg[:, 3] == spp)
+    assert_accum_close(bo, bg, "C2 render, queue 2 Mi, 2 spp")
+
+
+def test_set_frame_restarts_the_seed_sequence(orc, hip):
+    """tyr_set_frame (kernel.cu:667's `frame`, which the reference can only count on): after it, tyr_reset_accum and a budget of
+    whole passes over the pixels, a render repeats the render that began at that frame -- counters and radiance; 0 is refused."""
+    from test_gpu_parity import assert_accum_close
+
+    sc, nodes, prims = built_scene("mesh128")
+    W, H, N, spp = 160, 96, 8192, 3
+    g = hip.Renderer(W, H, N, flags=1)
+    g.load_scene(sc, nodes, prims)
+    it1 = g.render(spp)
+    k1, b1 = g.counters(), g.blit_buffer()
+    g.reset_accum()
+    assert g.render(spp) > 0
+    k2 = g.counters()
+    assert k2["total_extend_rays"] - k1["total_extend_rays"] != k1["total_extend_rays"]  # other frames, other random numbers
+    g.set_frame(1)
+    g.reset_accum()
+    assert g.render(spp) == it1
+    k3 = g.counters()
+    for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible"):
+        assert k3[f] - k2[f] == k1[f], f
+    assert k3["frame"] == k1["frame"]
+    assert_accum_close(b1, g.blit_buffer(), "render repeated from frame 1")
+    with pytest.raises(hip.TyrError):
+        g.set_frame(0)

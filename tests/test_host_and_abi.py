@@ -149,3 +149,35 @@ def test_default_spheres_match_oracle(hip, orc):
     orc.lib().orc_default_spheres(o.ctypes.data)
     assert s.tobytes() == o.tobytes() == scenes.reference_spheres().tobytes()
     assert s["refl"][6] == scenes.LIGHT and s["radius"][4] == np.float32(1e4)  # kernel.cu:678, 680
+
+
+def test_hand_declared_rccl_prototypes_are_checked_against_rccl_h(tmp_path):
+    """host/dist.cpp binds RCCL with dlsym through prototypes written by hand (host/rccl_slice.hpp); host/rccl_check.cpp -- part
+    of every build of the library -- static_asserts each of them against <rccl/rccl.h>.  Here: the check compiles as it
+    stands, and a prototype that drifts (ncclSend without its `peer` argument; a 64-byte id) does NOT."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) or not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("hipcc or <rccl/rccl.h> not installed")
+    host = os.path.join(ROOT, "tyrant_amd", "csrc", "host")
+    assert "host/rccl_check.cpp" in open(os.path.join(ROOT, "tyrant_amd", "csrc", "Makefile")).read()  # a drift fails the BUILD
+    check = open(os.path.join(host, "rccl_check.cpp")).read()
+    slice_ = open(os.path.join(host, "rccl_slice.hpp")).read().replace('"../../../include/tyr_c.h"', f'"{ROOT}/include/tyr_c.h"')
+
+    def compiles(slice_text):
+        (tmp_path / "rccl_slice.hpp").write_text(slice_text)
+        (tmp_path / "rccl_check.cpp").write_text(check)
+        p = subprocess.run([hipcc, "-std=c++17", "-fsyntax-only", str(tmp_path / "rccl_check.cpp")], capture_output=True, text=True, timeout=300)
+        return p.returncode == 0, p.stderr
+
+    ok, err = compiles(slice_)
+    assert ok, err[-2000:]
+    assert "NOT checked" not in err  # (<rccl/rccl.h> was found: the assertions were evaluated)
+    drifted = slice_.replace("int (*Send)(const void*, size_t, int, int, nccl_comm, hipStream_t)", "int (*Send)(const void*, size_t, int, nccl_comm, hipStream_t)")
+    assert drifted != slice_
+    ok, err = compiles(drifted)
+    assert not ok and "Rccl::Send no longer matches ncclSend" in err
+    ok, err = compiles(slice_.replace("char internal[TYR_DIST_ID_BYTES];", "char internal[64];"))
+    assert not ok and "ncclUniqueId" in err

@@ -108,6 +108,7 @@ SYMBOLS = {
     "tyr_get_blit_buffer": (P, [P]),
     "tyr_launch_kernels": (C.c_int, [P]),
     "tyr_set_budget": (C.c_int, [P, c_u64]),
+    "tyr_set_frame": (C.c_int, [P, c_u32]),
     "tyr_get_counters": (C.c_int, [P, C.POINTER(Counters)]),
     "tyr_render": (C.c_int, [P, c_u32, c_u32, C.POINTER(c_u32)]),
     "tyr_resolve": (C.c_int, [P, P]),
@@ -318,6 +319,10 @@ class Renderer:
 
     def set_budget(self, n):
         _check(self.L.tyr_set_budget(self.h, n), "tyr_set_budget")
+
+    def set_frame(self, frame=1):
+        """restart the frame counter every seed is built from (kernel.cu:667): the next render repeats the one that began at `frame`"""
+        _check(self.L.tyr_set_frame(self.h, frame), "tyr_set_frame")
 
     def launch_kernels(self):
         _check(self.L.tyr_launch_kernels(self.h), "tyr_launch_kernels")

@@ -31,6 +31,7 @@
 
 #include "ctx.hpp"
 #include "host.hpp"
+#include "rccl_slice.hpp"
 
 namespace tyr {
 void launch_pack_rows(const float4* frame, float4* slab, uint32_t W, uint32_t localRows, uint32_t rank, uint32_t nranks, hipStream_t stream);
@@ -40,30 +41,6 @@ void launch_scatter_rows(const float4* slabs, const float4* own, uint32_t ownRan
 using namespace tyr;
 
 namespace {
-
-// the slice of rccl.h this file needs (types by value: ncclUniqueId is 128 opaque bytes, the enums are ints)
-struct NcclId {
-	char internal[TYR_DIST_ID_BYTES];
-};
-typedef void* nccl_comm;
-constexpr int kNcclSuccess = 0;
-constexpr int kNcclFloat = 7; // ncclFloat32
-constexpr int kNcclSum = 0;
-
-struct Rccl {
-	void* handle = nullptr;
-	int (*GetUniqueId)(NcclId*) = nullptr;
-	int (*CommInitRank)(nccl_comm*, int, NcclId, int) = nullptr;
-	int (*CommDestroy)(nccl_comm) = nullptr;
-	int (*CommCount)(nccl_comm, int*) = nullptr;
-	int (*Send)(const void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
-	int (*Recv)(void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
-	int (*Reduce)(const void*, void*, size_t, int, int, int, nccl_comm, hipStream_t) = nullptr;
-	int (*GroupStart)() = nullptr;
-	int (*GroupEnd)() = nullptr;
-	const char* (*GetErrorString)(int) = nullptr;
-	bool ok = false;
-};
 
 Rccl& rccl() {
 	static Rccl R; // the dynamic loader's handle: process-wide by nature (function-local static: thread-safe init)

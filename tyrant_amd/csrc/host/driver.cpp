@@ -758,6 +758,13 @@ int tyr_set_budget(tyr_ctx* c, uint64_t primary_rays) {
 	return push_counters(c);
 }
 
+int tyr_set_frame(tyr_ctx* c, uint32_t frame) {
+	if (!c || frame == 0)
+		return TYR_ERR_INVALID;
+	c->frame = frame;
+	return TYR_OK;
+}
+
 int tyr_get_counters(tyr_ctx* c, tyr_counters* out) {
 	if (!c || !out)
 		return TYR_ERR_INVALID;
