@@ -656,6 +656,8 @@ def main():
         torch.cuda.synchronize()  # the library launches on its own stream
         r = binding.Renderer(W, H, N, device=local_rank, flags=flags, blit_buffer=accum.data_ptr(), **shard)
         r.load_scene(sc, nodes, prims)
+        info = r.scene_info()
+        upload = {"layout": round(info["upload_layout_s"], 6), "copy": round(info["upload_copy_s"], 6), "device_bytes": info["device_bytes"]}
         if tune:
             r.set_tuning(**tune)
         comm = None
@@ -795,7 +797,7 @@ def main():
             comm = True if native_used else None  # (only its truth value is reported below)
         r.close()
         per_render = {k: round(v["ms"] / warmup, 3) for k, v in tm_all.items()} if tm_all is not None else {k: round(v["ms"] / steps, 3) for k, v in tm.items()}
-        return {"native_combine": bool(comm is not None and native_ok[0]), "comm_info": comm_info, "ext": ext, "shd": shd, "survivors": survivors, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, "counter_deltas": deltas, **visits}
+        return {"native_combine": bool(comm is not None and native_ok[0]), "comm_info": comm_info, "ext": ext, "shd": shd, "survivors": survivors, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, "counter_deltas": deltas, "upload": upload, **visits}
 
     m = measure(N, args.steps, args.warmup, spp_total, shard, world)
     mref = None
@@ -848,6 +850,7 @@ def main():
                 "in_tree_Mrays/s": round(mrays * m["in_tree_frac"], 3),
                 "in_tree_fraction": {"all_rays": round(m["in_tree_frac"], 4), "extend_rays": round(m["in_tree_ext_frac"], 4), "note": "rays whose test of the root box passes (counting build, rank 0's shard); the others cost one box test"},
                 "host_bvh_build_s": round(t_build, 6),
+                "host_scene_upload_s": {**m["upload"], "note": "tyr_scene_upload of the timed renderer (Scene.cpp:53-67's upload half), outside the timed region: `layout` = the host's re-layout of the reference's node array as quad nodes + 48-byte triangles on the builder's threads, `copy` = device allocation + the copies to HBM"},
                 **oracle_counters_check(args, world, W, H, spp_total, N, int(prims.shape[0]), m),
                 "render_path": "tyr_render defaults: merged traversal launches (extend(i + 1) + connect(i)), sphere halves folded into shade, rays whose fate is known where they are made (camera rays / survivors that hit nothing, shadow rays that cannot reach a triangle) finished in place -- they count as rays, they never enter a queue; launch-per-iteration (TYR_TUNE_STREAM_TAIL = 0)",
                 **({"tuning": tune} if tune else {}),

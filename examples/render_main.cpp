@@ -3,7 +3,7 @@
 //     camera.update(); launch_kernels(...); std::swap(ray_buffer_work, ray_buffer_next);
 // written against include/tyrant/*.h, i.e. the reference's own names over libtyrant_hip.so.
 //
-//   render_main [device] [frames] [out.ppm]
+//   render_main [device] [frames] [out.ppm] [scene.ply]
 #define TYRANT_IMPLEMENTATION
 #include <algorithm>
 #include <chrono>
@@ -58,8 +58,13 @@ int main(int argc, char** argv) {
 	tyr_ctx* ctx = nullptr;
 	TYR_CHECK(tyr_create(&ctx, &cfg));
 
+	set_default_ctx(ctx); // the reference's device state is process-wide: the handle-less calls below use this context
+
 	Scene scene;
-	scene.Load(ctx, make_mesh(96)); // main.cpp:112-113
+	if (argc > 4)
+		scene.Load(argv[4]); // main.cpp:112-113: Scene scene; scene.Load("Data/castle.ply");
+	else
+		scene.Load(make_mesh(96));
 
 	// main.cpp:119-130: the caller owns the buffers.  The ray queues are opaque here (see tyrant/interop.h).
 	RayQueue* ray_buffer_work = nullptr;

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TYR_ABI_VERSION 3 /* 2: tyr_counters grows (rays_in_tree_*, debug[16]), tyr_dist_*, per-triangle colours; 3: retired tuning keys removed, tyr_sunsky_probe / tyr_sun_setup */
+#define TYR_ABI_VERSION 4 /* 2: tyr_counters grows (rays_in_tree_*, debug[16]), tyr_dist_*, per-triangle colours; 3: retired tuning keys removed, tyr_sunsky_probe / tyr_sun_setup; 4: tyr_set_frame, tyr_layout_probe, tyr_scene_info grows (upload_*_s) */
 
 /* ---- record layouts (identical to the reference structs) ------------------ */
 
@@ -254,8 +254,21 @@ typedef struct tyr_scene_info {
 	uint32_t max_prim_offset;  /* 1 << 26 */
 	uint32_t quad_max_stack;   /* the most stack entries any traversal of this tree can need (the drain's four-lanes-to-a-ray form holds 48 and is used only below that) */
 	uint64_t device_bytes;     /* quad nodes + pair nodes + 48-byte triangles resident in HBM */
+	double upload_layout_s;    /* the last tyr_scene_upload: seconds in the host's layout passes (on the threads of tyr_set_build_threads) ... */
+	double upload_copy_s;      /* ... and in device allocation + the copies to HBM */
 } tyr_scene_info;
 int tyr_get_scene_info(tyr_ctx* ctx, tyr_scene_info* out);
+
+/* Test / measurement hook, no device needed: the host half of tyr_scene_upload -- the reference's flat node array re-laid out
+ * as 128-byte quad nodes (and, when want_pairs != 0, the counting build's 64-byte pair nodes) plus 48-byte triangles, on the
+ * threads of tyr_set_build_threads -- without the copy to HBM.  Reports sizes, FNV-1a 64-bit hashes of the three arrays (the
+ * layout is byte-identical whatever the thread count: tests/test_host_and_abi.py) and the seconds it took. */
+typedef struct tyr_layout_stats {
+	uint32_t n_pair_nodes, n_quad_nodes, n_staged_nodes, quad_max_stack, root_ref, quad_root_ref;
+	uint64_t hash_pairs, hash_quads, hash_tris;
+	double seconds;
+} tyr_layout_stats;
+int tyr_layout_probe(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims, int32_t want_pairs, tyr_layout_stats* out);
 
 /* The vector functions every kernel is built from (hip/vecmath.hpp: glm's dot, cross, normalize, length, reflect, min,
  * max, clamp, mix, smoothstep and the vec3 operators in glm's evaluation order -- Dependencies/glm-0.9.9.3/glm/detail/

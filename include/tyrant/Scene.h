@@ -1,6 +1,6 @@
-// tyrant/Scene.h -- class Scene and Scene::GPUScene (Scene.h:3-18).  Load() keeps the second half
-// of Scene::Load (Scene.cpp:20-67: per-face Triangle + BBox, BVH build, upload); the assimp
-// import of its first half is a "next" row, so triangles are handed in.
+// tyrant/Scene.h -- class Scene and Scene::GPUScene (Scene.h:3-18).  Load(path) is the reference's call (Scene.h:9): PLY files
+// through tyr_load_ply with Scene::Load's conventions (Scene.cpp:3-47), then the second half of Scene::Load (Scene.cpp:20-67:
+// per-face Triangle + BBox, BVH build, upload).  Other formats: the host imports and hands the per-face vertices in.
 #pragma once
 #include <iostream>
 #include <stdexcept>
@@ -10,11 +10,26 @@
 #include "bvh.h"
 
 namespace tyrant {
+// The context the handle-less calls use.  The reference's Scene::Load(path) (Scene.h:9, called at main.cpp:113) has no handle to
+// pass: its device state is process-wide (kernel.cu:211-224, Scene.cpp:55-67).  A host that wants the reference's one-line
+// call sets its context once, where main.cpp:89-102 picks the device; the overloads that name a ctx remain for hosts with
+// several (one per GPU).
+inline tyr_ctx*& default_ctx_slot() {
+	static tyr_ctx* ctx = nullptr; // (inline function: one object for the whole program)
+	return ctx;
+}
+inline void set_default_ctx(tyr_ctx* ctx) { default_ctx_slot() = ctx; }
+inline tyr_ctx* default_ctx() { return default_ctx_slot(); }
+
 class Scene {
 public:
 	struct GPUScene {
 		CachedBVH CUDACachedBVH; // the reference's member name, Scene.h:6
 	} gpuScene;
+
+	// void Load(const char path[]), Scene.h:9 -- the reference's own signature, on the process-default context
+	void Load(const char path[]) { Load(require_default_ctx(), path); }
+	void Load(const std::vector<vec3>& faceVertices) { Load(require_default_ctx(), faceVertices); }
 
 	// Scene::Load(path), Scene.cpp:3: PLY files through tyr_load_ply (first mesh, fan triangulation)
 	void Load(tyr_ctx* ctx, const char path[]) {
@@ -62,6 +77,12 @@ public:
 	}
 
 private:
+	static tyr_ctx* require_default_ctx() {
+		tyr_ctx* ctx = default_ctx();
+		if (!ctx)
+			throw std::runtime_error("Scene::Load: no context -- call tyrant::set_default_ctx(ctx) once after tyr_create, or use Load(ctx, ...)");
+		return ctx;
+	}
 	std::vector<Triangle> primitives;
 	std::vector<BBox> primitiveBBoxes;
 };

@@ -440,6 +440,20 @@ def test_cpp_host_api_example(hip):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "frame counter 25" in p.stdout, p.stdout  # kernel.cu:667, 739: starts at 1, +1 per call
     assert os.path.getsize(out) > 640 * 360 * 3
+    # ... and with a scene FILE, through the reference's own one-line call `scene.Load(path)` (Scene.h:9, main.cpp:113) on the
+    # process-default context (tyrant::set_default_ctx)
+    ply = os.path.join(ROOT, "gpurun_out", "render_main_scene.ply")
+    n = 24
+    xs = np.linspace(-80.0, 80.0, n + 1)
+    verts = [(x, y, -18.0 + 6.0 * np.sin(0.09 * x) * np.cos(0.08 * y)) for y in xs for x in xs]
+    faces = [(j * (n + 1) + i, j * (n + 1) + i + 1, (j + 1) * (n + 1) + i + 1, (j + 1) * (n + 1) + i) for j in range(n) for i in range(n)]
+    with open(ply, "w") as f:
+        f.write(f"ply\nformat ascii 1.0\nelement vertex {len(verts)}\nproperty float x\nproperty float y\nproperty float z\nelement face {len(faces)}\nproperty list uchar int vertex_indices\nend_header\n")
+        f.write("".join(f"{x:.6f} {y:.6f} {z:.6f}\n" for x, y, z in verts))
+        f.write("".join(f"4 {a} {b} {c} {d}\n" for a, b, c, d in faces))
+    p = subprocess.run([exe, "0", "8", out, ply], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "Loading scene:" in p.stdout and "frame counter 9" in p.stdout, p.stdout
 
 
 @pytest.mark.parametrize("knobs", [

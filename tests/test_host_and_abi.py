@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(hip):
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in tyr_c.h but not exported"
     assert declared == set(hip.SYMBOLS), (declared ^ set(hip.SYMBOLS))
-    assert L.tyr_abi_version() == 3
+    assert L.tyr_abi_version() == 4
 
 
 def test_abi_struct_sizes(hip):
@@ -181,3 +181,92 @@ def test_hand_declared_rccl_prototypes_are_checked_against_rccl_h(tmp_path):
     assert not ok and "Rccl::Send no longer matches ncclSend" in err
     ok, err = compiles(slice_.replace("char internal[TYR_DIST_ID_BYTES];", "char internal[64];"))
     assert not ok and "ncclUniqueId" in err
+
+
+def _layout_cases():
+    from tyrant_amd import scenes
+
+    box = scenes.cornell_box().triangles
+    base = scenes.cornell_soup(500).triangles
+    return {
+        "cornell36": box,
+        "soup10k": scenes.cornell_soup(10000).triangles,
+        "mesh128": scenes.mesh_scene(128).triangles,
+        "longleaf": np.concatenate([base, np.repeat(base[:3], 100, axis=0)]),  # three leaves of 101 identical triangles: chains of synthetic records
+        "one": box[:1].copy(),
+        "two": box[:2].copy(),
+        "only_long": np.repeat(box[:1], 150, axis=0),  # the whole tree is one over-long leaf
+        "mesh706": scenes.mesh_scene(706).triangles,  # C3
+    }
+
+
+def test_device_layout_is_byte_identical_to_the_serial_one_at_every_thread_count(hip):
+    """tyr_scene_upload's host half (host/bvh_layout.cpp; tyr_layout_probe runs it without a device): round 5 made its passes
+    parallel.  The quad-node, pair-node and triangle arrays must equal, byte for byte, what the serial passes of rounds 1-4
+    produced (tests/golden/layout_hashes.json, recorded from that code) -- at 1, 2, 3, 8 and 16 threads, with and without the
+    pair layout, over-long leaves included."""
+    import json
+
+    from conftest import GOLDEN
+
+    with open(os.path.join(GOLDEN, "layout_hashes.json")) as f:
+        gold = json.load(f)["cases"]
+    fields = ("n_quad_nodes", "n_staged_nodes", "quad_max_stack", "root_ref", "quad_root_ref", "hash_quads", "hash_tris")
+    try:
+        for name, tris in _layout_cases().items():
+            hip.set_build_threads(0)
+            nodes, prims = hip.bvh_build(tris.copy())
+            for threads in (1, 2, 3, 8, 16):
+                hip.set_build_threads(threads)
+                st = hip.layout_probe(nodes, prims, True)
+                for f_ in fields + ("n_pair_nodes", "hash_pairs"):
+                    assert st[f_] == gold[name][f_], (name, threads, f_)
+                st = hip.layout_probe(nodes, prims, False)  # what a ctx without the counting flags uploads: no pair nodes, the same quads
+                for f_ in fields:
+                    assert st[f_] == gold[name][f_], (name, threads, f_, "no pairs")
+                assert st["n_pair_nodes"] == 0
+    finally:
+        hip.set_build_threads(0)
+
+
+def test_device_layout_refuses_arrays_that_are_not_a_depth_first_tree(hip):
+    """the layout's parallel passes rely on the reference's array order (bvh.cpp:195-202: first child = index + 1, a subtree is
+    a contiguous range).  Arrays that break it -- a second child outside its parent's range, a node named twice or never, an
+    offset past the end, a non-finite box, a leaf reaching past the primitives -- are refused (TYR_ERR_INVALID), at any thread
+    count, never followed."""
+    from tyrant_amd import scenes
+
+    nodes, prims = hip.bvh_build(scenes.cornell_soup(20000).triangles)
+    interior = np.flatnonzero(nodes["primitiveCount"] == 0)
+    leaves = np.flatnonzero(nodes["primitiveCount"] > 0)
+
+    def refused(mutate):
+        n = nodes.copy()
+        mutate(n)
+        for threads in (1, 8):
+            hip.set_build_threads(threads)
+            try:
+                hip.layout_probe(n, prims)
+            except hip.TyrError as e:
+                assert e.status == -1, e  # TYR_ERR_INVALID
+            else:
+                return False
+        return True
+
+    try:
+        hip.set_build_threads(8)
+        assert hip.layout_probe(nodes, prims)["n_quad_nodes"] > 0  # the array as built is accepted
+        deep = interior[len(interior) // 2]
+        assert refused(lambda n: n["offset"].__setitem__(deep, len(n) - 1))            # second child far outside the parent's subtree (and named twice)
+        assert refused(lambda n: n["offset"].__setitem__(deep, n["offset"][deep] + 1))  # the real second child is never named, its neighbour twice
+        assert refused(lambda n: n["offset"].__setitem__(interior[3], len(n) + 5))      # past the end
+        assert refused(lambda n: n["offset"].__setitem__(interior[3], interior[3] + 1))  # second child == first child
+        assert refused(lambda n: n["bounds"].__setitem__((leaves[7], 1, 2), np.inf))
+        assert refused(lambda n: n["offset"].__setitem__(leaves[5], len(prims)))        # a leaf's primitives past the array
+        assert refused(lambda n: n["splitAxis"].__setitem__(interior[9], 3))
+        t = prims.copy()
+        t["e1"][11, 0] = np.nan
+        with pytest.raises(hip.TyrError):
+            hip.layout_probe(nodes, t)
+    finally:
+        hip.set_build_threads(0)

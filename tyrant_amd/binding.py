@@ -85,7 +85,12 @@ class Counters(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_prims", c_u32), ("n_pair_nodes", c_u32), ("n_quad_nodes", c_u32), ("n_staged_nodes", c_u32), ("n_lights", c_u32), ("max_quad_nodes", c_u32), ("max_prim_offset", c_u32),
-                ("quad_max_stack", c_u32), ("device_bytes", c_u64)]
+                ("quad_max_stack", c_u32), ("device_bytes", c_u64), ("upload_layout_s", C.c_double), ("upload_copy_s", C.c_double)]
+
+
+class LayoutStats(C.Structure):
+    _fields_ = [("n_pair_nodes", c_u32), ("n_quad_nodes", c_u32), ("n_staged_nodes", c_u32), ("quad_max_stack", c_u32), ("root_ref", c_u32), ("quad_root_ref", c_u32),
+                ("hash_pairs", c_u64), ("hash_quads", c_u64), ("hash_tris", c_u64), ("seconds", C.c_double)]
 
 
 class Timings(C.Structure):
@@ -127,6 +132,7 @@ SYMBOLS = {
     "tyr_shadow_export": (C.c_int, [P, P, c_u32]),
     "tyr_shadow_import": (C.c_int, [P, P, c_u32]),
     "tyr_get_scene_info": (C.c_int, [P, C.POINTER(SceneInfo)]),
+    "tyr_layout_probe": (C.c_int, [P, c_i32, P, c_i32, c_i32, C.POINTER(LayoutStats)]),
     "tyr_vecmath_probe": (C.c_int, [c_i32, c_i32, P, P, P, c_u32, P]),
     "tyr_sunsky_probe": (C.c_int, [c_i32, C.c_float, C.c_float, c_i32, P, c_u32, P]),
     "tyr_sun_setup": (C.c_int, [C.c_float, C.c_float, P]),
@@ -209,6 +215,14 @@ def bvh_build(tris: np.ndarray, bboxes: np.ndarray | None = None, algo: int = 2)
     if nn < 0:
         raise TyrError(nn, "tyr_bvh_build")
     return nodes[:nn].copy(), prims
+
+
+def layout_probe(nodes: np.ndarray, prims: np.ndarray, want_pairs: bool = True) -> dict:
+    """the host half of tyr_scene_upload without a device: sizes, FNV-1a hashes of the device arrays, seconds (tyr_layout_probe)"""
+    nodes, prims = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
+    st = LayoutStats()
+    _check(lib().tyr_layout_probe(_ptr(nodes), nodes.shape[0], _ptr(prims), prims.shape[0], int(want_pairs), C.byref(st)), "tyr_layout_probe")
+    return {k: getattr(st, k) for k, _ in st._fields_}
 
 
 def load_ply(path: str) -> np.ndarray:
@@ -388,7 +402,7 @@ class Renderer:
     def scene_info(self) -> dict:
         s = SceneInfo()
         _check(self.L.tyr_get_scene_info(self.h, C.byref(s)), "tyr_get_scene_info")
-        return {k: int(getattr(s, k)) for k, _ in s._fields_}
+        return {k: (float(getattr(s, k)) if k.endswith("_s") else int(getattr(s, k))) for k, _ in s._fields_}
 
     def import_work_queue(self, rays: np.ndarray, n_survivors: int):
         r = np.ascontiguousarray(rays)

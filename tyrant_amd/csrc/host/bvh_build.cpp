@@ -36,6 +36,7 @@ namespace tyr {
 int bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo);
 void triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out);
 void set_build_threads(int threads);
+int build_threads();
 } // namespace tyr
 #else
 #include "host.hpp"
@@ -421,6 +422,14 @@ int bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_no
 			if (!std::isfinite((&bboxes[i].bounds[0][0])[k]))
 				return TYR_ERR_INVALID;
 	std::memset(nodes_out, 0, sizeof(tyr_bvh_node) * (static_cast<size_t>(n) * 2 - 1)); // vector::resize value-initialises, bvh.cpp:11
+	const int threads = build_threads();
+	Builder b(prims, n, bboxes, algo);
+	// every subtree keeps its own ordered copy until all of them are built, so the result can replace `prims` in place (bvh.cpp:24)
+	return b.run(prims, nodes_out, threads);
+}
+
+void set_build_threads(int threads) { g_buildThreads = threads; }
+int build_threads() {
 	int threads = g_buildThreads;
 	if (threads <= 0) {
 		if (const char* e = std::getenv("TYR_BUILD_THREADS"))
@@ -428,12 +437,8 @@ int bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_no
 		if (threads <= 0)
 			threads = static_cast<int>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
 	}
-	Builder b(prims, n, bboxes, algo);
-	// every subtree keeps its own ordered copy until all of them are built, so the result can replace `prims` in place (bvh.cpp:24)
-	return b.run(prims, nodes_out, threads);
+	return threads;
 }
-
-void set_build_threads(int threads) { g_buildThreads = threads; }
 
 // Scene.cpp:22-33: BBox over the three vertices; the stored form gives them as vert, vert+e1, vert+e2
 void triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out) {

@@ -72,6 +72,7 @@ struct tyr_ctx {
 	float4* dPalette = nullptr;                   // TYR_FLAG_TRIANGLE_COLORS: 256 x { colour, emission }
 	DevScene scene{};
 	bool haveScene = false;
+	double uploadLayoutS = 0.0, uploadCopyS = 0.0; // the last tyr_scene_upload: host layout passes, allocation + copies to HBM (tyr_scene_info)
 
 	tyr_sphere spheres[TYR_NUM_SPHERES]{};
 	tyr_camera cam{};

@@ -6,6 +6,7 @@
 // argument block (FrameParams) instead of cudaMemcpyToSymbol (kernel.cu:681-684, 707-709).
 // There is no CPU fallback: without a HIP device tyr_create fails with TYR_ERR_NO_DEVICE.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -604,9 +605,16 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	int rc = use_device(c);
 	if (rc)
 		return rc;
+	// the pair nodes are what the counting build and the BVH_DEBUG picture traverse (the reference's visit counts,
+	// bvh.h:164-209); a ctx without those flags never reads them: they are neither laid out nor kept in HBM (64 MB on C3, 0.4 GB on C5)
+	const bool wantPairs = (c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) != 0;
 	DeviceLayout L;
-	if ((rc = build_device_layout(nodes, nNodes, prims, nPrims, L)))
+	const auto t0 = std::chrono::steady_clock::now();
+	if ((rc = build_device_layout(nodes, nNodes, prims, nPrims, L, wantPairs)))
 		return rc;
+	const auto t1 = std::chrono::steady_clock::now();
+	c->uploadLayoutS = std::chrono::duration<double>(t1 - t0).count();
+	c->uploadCopyS = 0.0;
 	HIPCHK(hipStreamSynchronize(c->stream));
 	dev_free(c->dNodes);
 	dev_free(c->dQuads);
@@ -619,11 +627,6 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	if (L.rootRef == kRefDone)
 		return TYR_OK; // Scene.cpp:49-52
 	// at least one element so the pointers are never null
-	// the pair nodes are what the counting build and the BVH_DEBUG picture traverse (the reference's visit counts,
-	// bvh.h:164-209); a ctx without those flags never reads them and does not keep them in HBM (64 MB on C3, 0.4 GB on C5)
-	const bool wantPairs = (c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) != 0;
-	if (!wantPairs)
-		L.pairNodes.clear();
 	const size_t nodeFloats = std::max<size_t>(L.pairNodes.size(), 16), quadFloats = std::max<size_t>(L.quadNodes.size(), 32), triFloats = L.tris.size();
 	if ((rc = dev_alloc(c->dNodes, nodeFloats / 4)) || (rc = dev_alloc(c->dQuads, quadFloats / 4 + kWhatIfQuadPad)) || (rc = dev_alloc(c->dTris, triFloats / 4)))
 		return rc;
@@ -648,6 +651,7 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	c->scene.rootRef = L.rootRef;
 	c->scene.nPairs = L.nPairs;
 	c->scene.nPrims = static_cast<uint32_t>(nPrims);
+	c->uploadCopyS = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(); // (hipMemcpy from pageable memory returns when the data is on its way from a staging buffer at the latest; the three arrays, allocation included)
 	if (c->cfg.flags & TYR_FLAG_LIGHT_LIST) {
 		// the light array the reference leaves as a TODO (kernel.cu:420): LIGHT triangles in (reordered) array order
 		std::vector<uint32_t> lights;
@@ -1725,6 +1729,37 @@ int tyr_get_scene_info(tyr_ctx* c, tyr_scene_info* out) {
 	out->max_prim_offset = kMaxPrimOffset;
 	const bool havePairs = (c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) != 0;
 	out->device_bytes = static_cast<uint64_t>(c->scene.nQuads) * 128 + (havePairs ? static_cast<uint64_t>(c->scene.nPairs) * 64 : 0) + static_cast<uint64_t>(c->scene.nPrims) * 48;
+	out->upload_layout_s = c->uploadLayoutS;
+	out->upload_copy_s = c->uploadCopyS;
+	return TYR_OK;
+}
+
+int tyr_layout_probe(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims, int32_t want_pairs, tyr_layout_stats* out) {
+	if (!out)
+		return TYR_ERR_INVALID;
+	std::memset(out, 0, sizeof *out);
+	DeviceLayout L;
+	const auto t0 = std::chrono::steady_clock::now();
+	const int rc = build_device_layout(nodes, nNodes, prims, nPrims, L, want_pairs != 0);
+	out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	if (rc)
+		return rc;
+	auto fnv = [](const FloatBuf& v) {
+		uint64_t h = 1469598103934665603ull;
+		const unsigned char* p = reinterpret_cast<const unsigned char*>(v.data());
+		for (size_t i = 0, n = v.size() * sizeof(float); i < n; ++i)
+			h = (h ^ p[i]) * 1099511628211ull;
+		return h;
+	};
+	out->n_pair_nodes = L.nPairs;
+	out->n_quad_nodes = L.nQuads;
+	out->n_staged_nodes = L.nStaged;
+	out->quad_max_stack = L.quadMaxStack;
+	out->root_ref = L.rootRef;
+	out->quad_root_ref = L.quadRootRef;
+	out->hash_pairs = fnv(L.pairNodes);
+	out->hash_quads = fnv(L.quadNodes);
+	out->hash_tris = fnv(L.tris);
 	return TYR_OK;
 }
 

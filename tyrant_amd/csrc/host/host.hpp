@@ -2,6 +2,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "../../../include/tyr_c.h"
@@ -20,20 +21,42 @@ int bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_no
 void triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out);
 void set_build_threads(int threads); // 0 = automatic (TYR_BUILD_THREADS or min(16, cores))
 
-// host/bvh_layout.cpp -- flat reference nodes -> device pair nodes + 48-byte triangles
+int build_threads();                 // what the setting resolves to right now (>= 1)
+
+// host/bvh_layout.cpp -- flat reference nodes -> device quad nodes (+ pair nodes for the counting build) + 48-byte triangles
+// an array of floats that is NOT zeroed when it is sized: every element is written by the layout's (parallel) passes, and a
+// serial memset of C5's 0.9 GB would cost as much as those passes together
+struct FloatBuf {
+	std::unique_ptr<float[]> p;
+	size_t n = 0;
+	void resize(size_t k) {
+		p.reset(k ? new float[k] : nullptr);
+		n = k;
+	}
+	void clear() { resize(0); }
+	float* data() { return p.get(); }
+	const float* data() const { return p.get(); }
+	size_t size() const { return n; }
+	bool empty() const { return n == 0; }
+	float& operator[](size_t i) { return p[i]; }
+	const float& operator[](size_t i) const { return p[i]; }
+};
 struct DeviceLayout {
-	std::vector<float> pairNodes; // 16 floats per pair node
-	std::vector<float> quadNodes; // 32 floats per quad node (hip/traverse.hpp "QuadNode")
+	FloatBuf pairNodes; // 16 floats per pair node (only when asked for)
+	FloatBuf quadNodes; // 32 floats per quad node (hip/traverse.hpp "QuadNode")
 	uint32_t quadRootRef = 0;
 	uint32_t nQuads = 0;
 	uint32_t nStaged = 0; // leading records that are the top of the tree in breadth-first order
 	uint32_t quadMaxStack = 0; // the most entries a traversal of the quad tree can ever have on its stack (whatever the ray)
-	std::vector<float> tris;      // 12 floats per triangle
+	FloatBuf tris;      // 12 floats per triangle
 	float rootMin[3], rootMax[3];
 	uint32_t rootRef;
 	uint32_t nPairs;
 };
-// returns TYR_OK or TYR_ERR_INVALID (malformed tree, non-finite geometry, too many primitives)
-int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims, DeviceLayout& out);
+// returns TYR_OK or TYR_ERR_INVALID (malformed tree -- the array must be the reference's depth-first layout: first child = index
+// + 1, every subtree a contiguous range, bvh.cpp:195-202 --, non-finite geometry, too many primitives).  wantPairs: also lay out
+// the pair nodes (the counting build, BVH_DEBUG); rootRef and nPairs = 0 otherwise.  Runs on build_threads() threads; the bytes
+// do not depend on their number.
+int build_device_layout(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims, DeviceLayout& out, bool wantPairs = true);
 
 } // namespace tyr
