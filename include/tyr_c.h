@@ -213,6 +213,12 @@ int tyr_get_counters(tyr_ctx* ctx, tyr_counters* out);
  * spp * (width*height/nranks) primaries were generated and every path finished.
  * iterations_out may be NULL. */
 int tyr_render(tyr_ctx* ctx, uint32_t spp, uint32_t max_iterations, uint32_t* iterations_out);
+/* max_iterations: UINT32_MAX (exactly) = run to the end.  Only such a render lets shade finish a SURVIVOR in place
+ * (TYR_TUNE_RETIRE_SKY's second half: a bounce ray that can hit nothing gets the next iteration's sky term now) -- any other
+ * limit, however large, could cut the render between the two iterations and show that pixel one iteration early, so it
+ * turns that half off (results are the same numbers either way).  A render that FAILS (non-zero return) leaves the
+ * accumulation buffer undefined: contributions of an iteration that was never counted may already be in it; call
+ * tyr_reset_accum before rendering again. */
 
 /* blit_onto_framebuffer, kernel.cu:648-662: rgb/a -> c/(c+1) -> gamma 1/2.2, written to a linear
  * RGBA32F device buffer (float4[width*height]) instead of a GL surface. */
@@ -232,7 +238,13 @@ int tyr_stage_end(tyr_ctx* ctx);     /* frame++ (kernel.cu:735-745) and the call
 int tyr_sync(tyr_ctx* ctx);
 
 /* AoS import/export of the SoA device queues in the reference's record formats.
- * which: 0 = work queue (input of the next extend), 1 = next queue (survivors of the last shade). */
+ * which: 0 = work queue (input of the next extend), 1 = next queue (survivors of the last shade).
+ * What a queue HOLDS after tyr_render with its default tuning: only the rays that still have to be traced.  TYR_TUNE_RETIRE_SKY
+ * and TYR_TUNE_RESOLVE_SHADOWS finish rays whose fate is known where they are made (camera rays and survivors that can hit
+ * nothing, shadow rays that cannot reach a triangle): such rays are counted (primary_ray_cnt, n_live, shadow_ray_cnt, the
+ * totals) and never written to a queue, so an export of `count` = one of those counters returns the queued records in the
+ * serial order followed by zero-filled records for the ones finished in place.  The stage API (tyr_stage_*,
+ * tyr_launch_kernels) and renders with those two knobs at 0 queue every ray, as the reference does. */
 int tyr_queue_export(tyr_ctx* ctx, int which, tyr_ray_queue* host, uint32_t count);
 /* Test hook: every record of the queue (`which` as tyr_queue_export) is looked up in the DEVICE's rank tables -- the scan of the
  * survive bytes that k_shade resolves virtual slots with -- and the slot found is compared with the record's place in the
@@ -249,7 +261,7 @@ int tyr_shadow_import(tyr_ctx* ctx, const tyr_shadow_queue* host, uint32_t n);
  * reference has 25 index bits, a leaf reference 26 offset bits; bvh.h:124's 64-entry stack is checked at run time and
  * reported through tyr_counters.device_error). */
 typedef struct tyr_scene_info {
-	uint32_t n_prims, n_pair_nodes, n_quad_nodes, n_staged_nodes, n_lights;
+	uint32_t n_prims, n_pair_nodes, n_quad_nodes, n_staged_nodes, n_lights; /* n_pair_nodes: 0 unless the ctx has TYR_FLAG_COUNT_VISITS or TYR_FLAG_DEBUG_BVH (only those traverse pair nodes; others neither lay them out nor upload them) */
 	uint32_t max_quad_nodes;   /* 1 << 25 */
 	uint32_t max_prim_offset;  /* 1 << 26 */
 	uint32_t quad_max_stack;   /* the most stack entries any traversal of this tree can need (the drain's four-lanes-to-a-ray form holds 48 and is used only below that) */
@@ -316,7 +328,7 @@ enum {
 	TYR_TUNE_WIDE_DRAIN = 15,        /* 1 (default) = a wave's last <= 16 rays are finished four lanes to a ray */
 	TYR_TUNE_STREAM_TAIL = 16,       /* tyr_render: 1 = once the primary budget is spent, the remaining iterations run as ONE traversal kernel with shade resident beside it (DESIGN.md "One drain per render": bit-exact, measured slower, hence not the default); 0 (default) = a traversal launch per iteration */
 	TYR_TUNE_STREAM_SHADE_PER_CU = 17, /* streamed tail: shade blocks per CU (1..2, default 1) ... */
-	TYR_TUNE_STREAM_TRACE_PER_CU = 18, /* ... beside this many traversal blocks per CU (1..5, default 4) */
+	TYR_TUNE_STREAM_TRACE_PER_CU = 18, /* ... beside this many traversal blocks per CU (1..4, default 4; a fifth would take the LDS the shade block needs) */
 	TYR_TUNE_RETIRE_SKY = 20,        /* merged path of tyr_render: 1 (default) = a camera ray that hits no sphere and misses the tree's root box is finished by k_primary itself -- its pixel gets sunsky(direction) (kernel.cu:613-617 for a fresh ray; no random number is involved) and it never enters a queue; 0 = shade does it an iteration later */
 	TYR_TUNE_RESOLVE_SHADOWS = 21,   /* merged path of tyr_render, with TYR_TUNE_FOLD_SPHERES: 1 (default) = a shadow ray that a sphere occludes or that fails the tree's root box for its bound is answered by shade itself (visible: its colour joins the pixel's contribution; kernel.cu:630-646 reduced to what is known) and never queued; it still counts as emitted / visible */
 	TYR_TUNE_WIDE_BLOCK_MIN_ITEMS = 22, /* k_trace_flat: a launch of at least this many rays (extend + carried shadow rays) runs as 768-thread blocks -- two per CU, six waves per SIMD, one copy of the staged nodes per three 256-thread parts -- instead of 256-thread blocks at five waves per SIMD; default 3 Mi (the sixth wave feeds a fat launch faster and lengthens the drain of a thin one); -1: never */

@@ -102,3 +102,15 @@ def test_a_render_too_short_for_the_tail_uses_launches(orc, hip):
     for f in FIELDS:
         assert ko[f] == kg[f], f
     assert_accum_close(o.blit_buffer(), g.blit_buffer(), "the rest of the render, streamed")
+
+
+def test_more_traversal_blocks_than_leave_room_for_shade_are_refused(hip):
+    """five traversal blocks of 31.7 KB of LDS per CU leave none for the 27.8 KB shade block that must be resident beside them:
+    the traversal would poll for chunks nobody can publish until its bounded waits expire.  The knob stops at four."""
+    sc, nodes, prims = built_scene("cornell36")
+    g = hip.Renderer(32, 32, 1024)
+    g.load_scene(sc, nodes, prims)
+    g.set_tuning(stream_trace_per_cu=4)
+    with pytest.raises(hip.TyrError):
+        g.set_tuning(stream_trace_per_cu=5)
+    g.close()

@@ -300,9 +300,11 @@ __global__ void __launch_bounds__(kBlock) k_scan_words(const FrameParams P) {
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint4 q = p[k];
-			// read and cleared: a survivor that shade finished in place (P.retireGhosts) occupies a slot of the NEXT iteration's
-			// order that nobody will write -- it must read "did not survive" there
-			p[k] = make_uint4(0u, 0u, 0u, 0u);
+			// read and -- when this iteration's shade finished survivors in place (P.retireGhosts) -- cleared: such a survivor occupies
+			// a slot of the NEXT iteration's order that nobody will write, and it must read "did not survive" there.  (Every other
+			// slot below the next iteration's ray count is written by whoever makes or shades its ray.)
+			if (P.retireGhosts)
+				p[k] = make_uint4(0u, 0u, 0u, 0u);
 			const uint32_t x[4] = { q.x, q.y, q.z, q.w };
 #pragma unroll
 			for (int j = 0; j < 4; ++j) { // four bytes, each 0 or 1 -> four bits

@@ -1215,6 +1215,7 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 // iteration kMaxBounces + 1 - b of the tail; launches beyond the render's end return at once).  The host only waits for
 // the two streams and reads how far the tail went.
 constexpr uint32_t kTailLaunches = static_cast<uint32_t>(kMaxBounces) + 1u;
+static_assert(kTailLaunches + 1u <= tyr::kStreamMaxIters, "the streamed tail writes StreamIter[streamIter + 1] from each of its shade launches");
 static bool stream_tail_eligible(const tyr_ctx* c, uint32_t iterationsLeft) {
 #if defined(TYR_QUAD_STATS) || defined(TYR_LAUNCH_ANATOMY)
 	return false; // the instrumented builds stamp k_trace_flat's launches
@@ -1229,20 +1230,43 @@ static int render_stream_tail(tyr_ctx* c, uint32_t& it) {
 	int rc = stage_begin(c); // (the camera has not moved inside a render: no reset)
 	if (rc)
 		return rc;
+	// What the host will have changed by the time anything can fail: taken back by bail().  From the first launch on a failure
+	// leaves work queued on both streams -- k_trace_stream polls for chunks nobody will publish until its bounded waits
+	// (kStreamTimeoutTicks) run out -- so the way out is always: wait for both streams, put the host's bookkeeping back where the
+	// last completed iteration left it, and have the next tail re-zero its hand-off counters.
+	const uint32_t frame0 = c->frame, iter0 = c->iter, shadowSet0 = c->shadowSet;
+	const int cur0 = c->cur;
+	const bool folded0 = c->lastShadeFolded, carried = c->shadowPending;
+	auto bail = [&](int code) {
+		(void)hipStreamSynchronize(c->side);
+		(void)hipStreamSynchronize(c->stream);
+		c->frame = frame0;
+		c->iter = iter0;
+		c->cur = cur0;
+		c->shadowSet = shadowSet0;
+		c->lastShadeFolded = folded0;
+		c->shadowPending = false; // (the carried shadow rays may or may not have been traced: the render is void either way)
+		c->streamDirty = true;
+		(void)sync_counters(c); // hK follows what the device did, whatever it was
+		(void)hipGetLastError();
+		return code > 0 ? TYR_ERR_DEVICE : code; // (a raw hipError_t of a launch or copy: the device-side failure code of this API)
+	};
+#define TAILCHK(expr)                \
+	do {                             \
+		if ((expr) != hipSuccess)    \
+			return bail(TYR_ERR_DEVICE); \
+	} while (0)
 	const size_t chunks = static_cast<size_t>(c->segCap) * tyr::kSegs / 64 + 8, tiles = static_cast<size_t>(c->segCap) * tyr::kSegs / 256 + 8;
 	if (c->streamDirty) {
 		for (int t = 0; t < 2; ++t) {
-			HIPCHK(hipMemsetAsync(c->fillRay[t], 0, chunks * 4, c->stream));
-			HIPCHK(hipMemsetAsync(c->fillSh[t], 0, chunks * 4, c->stream));
-			HIPCHK(hipMemsetAsync(c->doneRay[t], 0, tiles * 4, c->stream));
+			TAILCHK(hipMemsetAsync(c->fillRay[t], 0, chunks * 4, c->stream));
+			TAILCHK(hipMemsetAsync(c->fillSh[t], 0, chunks * 4, c->stream));
+			TAILCHK(hipMemsetAsync(c->doneRay[t], 0, tiles * 4, c->stream));
 		}
 		c->streamDirty = false;
 	}
-	HIPCHK(hipMemsetAsync(c->dStream, 0, sizeof(StreamState), c->stream));
-	const bool carried = c->shadowPending;
+	TAILCHK(hipMemsetAsync(c->dStream, 0, sizeof(StreamState), c->stream));
 	c->shadowPending = false;
-	const uint32_t frame0 = c->frame, iter0 = c->iter;
-	const int cur0 = c->cur;
 	{
 		FrameParams P = make_params(c);
 		{
@@ -1255,8 +1279,8 @@ static int render_stream_tail(tyr_ctx* c, uint32_t& it) {
 				launch_trace_prepasses(Pp, c->hK->primary_ray_cnt, carried ? c->shadowPendingMax : 0u, c->stream);
 		}
 		launch_stream_begin(P, carried, c->stream);
-		HIPCHK(hipEventRecord(c->evTail, c->stream));
-		HIPCHK(hipStreamWaitEvent(c->side, c->evTail, 0));
+		TAILCHK(hipEventRecord(c->evTail, c->stream));
+		TAILCHK(hipStreamWaitEvent(c->side, c->evTail, 0));
 		KernelTimer t(c, TYR_K_EXTEND);
 		launch_trace_stream(P, c->tuning.streamTracePerCU, c->numCUs, c->stream);
 	}
@@ -1269,9 +1293,11 @@ static int render_stream_tail(tyr_ctx* c, uint32_t& it) {
 		launch_scan(P, c->hK->primary_ray_cnt, c->side); // (an upper bound of every later iteration's rays: nothing is topped up)
 		stage_end(c);
 	}
-	HIPCHK(hipMemcpyAsync(c->hStream, c->dStream, sizeof(StreamState), hipMemcpyDeviceToHost, c->side));
-	HIPCHK(hipGetLastError());
-	const hipError_t e1 = hipStreamSynchronize(c->side), e2 = hipStreamSynchronize(c->stream);
+	TAILCHK(hipMemcpyAsync(c->hStream, c->dStream, sizeof(StreamState), hipMemcpyDeviceToHost, c->side));
+	TAILCHK(hipGetLastError());
+	if (hipStreamSynchronize(c->side) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+		return bail(TYR_ERR_DEVICE);
+#undef TAILCHK
 	// the iterations that had rays of their own are the render's (the one behind them at most traced the last shadow rays)
 	uint32_t real = 0;
 	while (real < kTailLaunches && c->hStream->it[real].nLive != 0)
@@ -1284,10 +1310,6 @@ static int render_stream_tail(tyr_ctx* c, uint32_t& it) {
 	c->shadowSet = (c->iter - 1u) & 1u;
 	c->lastShadeFolded = true;
 	it += real;
-	if (e1 != hipSuccess || e2 != hipSuccess) {
-		c->streamDirty = true;
-		return static_cast<int>(e1 != hipSuccess ? e1 : e2);
-	}
 	rc = sync_counters(c);
 	collect_timings(c);
 	if (!rc)
@@ -1784,7 +1806,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_WIDE_DRAIN, 0, 1, &Tuning::wideDrain },
 		{ TYR_TUNE_STREAM_TAIL, 0, 1, &Tuning::streamTail },
 		{ TYR_TUNE_STREAM_SHADE_PER_CU, 1, 2, &Tuning::streamShadePerCU },
-		{ TYR_TUNE_STREAM_TRACE_PER_CU, 1, 5, &Tuning::streamTracePerCU },
+		{ TYR_TUNE_STREAM_TRACE_PER_CU, 1, 4, &Tuning::streamTracePerCU }, // (five traversal blocks of 31.7 KB leave no LDS for the 27.8 KB shade block beside them: no shade, no progress)
 		{ TYR_TUNE_FOLD_SPHERES, 0, 1, &Tuning::foldSpheres },
 		{ TYR_TUNE_RETIRE_SKY, 0, 1, &Tuning::retireSky },
 		{ TYR_TUNE_RESOLVE_SHADOWS, 0, 1, &Tuning::resolveShadows },
