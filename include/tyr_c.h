@@ -332,6 +332,7 @@ enum {
 	TYR_TUNE_RETIRE_SKY = 20,        /* merged path of tyr_render: 1 (default) = a camera ray that hits no sphere and misses the tree's root box is finished by k_primary itself -- its pixel gets sunsky(direction) (kernel.cu:613-617 for a fresh ray; no random number is involved) and it never enters a queue; 0 = shade does it an iteration later */
 	TYR_TUNE_RESOLVE_SHADOWS = 21,   /* merged path of tyr_render, with TYR_TUNE_FOLD_SPHERES: 1 (default) = a shadow ray that a sphere occludes or that fails the tree's root box for its bound is answered by shade itself (visible: its colour joins the pixel's contribution; kernel.cu:630-646 reduced to what is known) and never queued; it still counts as emitted / visible */
 	TYR_TUNE_WIDE_BLOCK_MIN_ITEMS = 22, /* k_trace_flat: a launch of at least this many rays (extend + carried shadow rays) runs as 768-thread blocks -- two per CU, six waves per SIMD, one copy of the staged nodes per three 256-thread parts -- instead of 256-thread blocks at five waves per SIMD; default 3 Mi (the sixth wave feeds a fat launch faster and lengthens the drain of a thin one); -1: never */
+	TYR_TUNE_FOLD_PROLOGUE = 23,     /* tyr_render, one iteration ahead of the counts (TYR_TUNE_RUN_AHEAD) with TYR_TUNE_FOLD_SPHERES: 1 (default) = once the primary budget is spent, the kernel that ends an iteration (the slot scan) also opens the next one -- set_wavefront_globals (kernel.cu:227-244) and the padding of the queue segments' ends -- instead of a one-block launch each in front of the traversal kernel; 0 = those launches */
 	TYR_TUNE_FOLD_SPHERES = 19       /* merged path of tyr_render: 1 (default) = shade does the sphere pre-passes' work (kernel.cu:127-136, 168-172) for the rays it emits, while they are in registers; 0 = the pre-pass kernels re-read them */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);

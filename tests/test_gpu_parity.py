@@ -491,7 +491,7 @@ def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
     _, g2 = pair(orc, hip, name, W, H, N)
     _, g3 = pair(orc, hip, name, W, H, N)
     g0.set_tuning(merge_trace=0)
-    g1.set_tuning(merge_trace=1, run_ahead=1)
+    g1.set_tuning(merge_trace=1, run_ahead=1, fold_prologue=0)  # every iteration opened by its own k_primary / k_pad_holes launches (round 5's default lets the previous iteration's last kernel do that once the budget is spent)
     g2.set_tuning(merge_trace=1, wide_block_min_items=0)  # (the default) connect(i) inside the launch of extend(i + 1): k_trace_flat, iteration i + 1 queued ahead of iteration i's counts -- and every launch as 768-thread blocks (six waves per SIMD: by default only launches of 3 Mi rays and more; the others here run the 256-thread form)
     g3.set_tuning(merge_trace=1, run_ahead=0, wide_drain=0)  # ... with the host waiting for every iteration's counts, and a wave's last rays left one to a lane
     _, g4 = pair(orc, hip, name, W, H, N)

@@ -84,10 +84,10 @@ struct DevCounters {
 	uint32_t start_position;
 	uint32_t shadow_ray_cnt;
 	uint32_t n_live;
-	uint32_t reserved0;
+	uint32_t reserved0;      // set_wavefront_globals: the survivor count it found (primary_ray_cnt before its reset) ...
 	uint32_t device_error;
 	uint32_t reserved_t;
-	uint32_t reserved1;      // (connect's ticket lives in ConnectCounters)
+	uint32_t reserved1;      // ... and the shadow-ray count: what the host reads of an iteration whose k_scan_words opened the next one (FrameParams::foldNextPrologue)
 	unsigned long long budget_remaining;
 	unsigned long long total_extend_rays;
 	unsigned long long total_shadow_rays;
@@ -217,6 +217,8 @@ struct FrameParams {
 	uint32_t retireGhosts;        // k_shade (with foldSpheres, renders that run to their end): a survivor that will hit nothing is finished in place (it still counts as a survivor and keeps its slot in the next iteration's order)
 	uint32_t resolveShadows;      // k_shade (with foldSpheres): a shadow ray that a sphere occludes, or that cannot enter the tree, is answered in place and never queued
 	uint32_t retireSky;           // k_primary: finish the camera rays that hit nothing (no sphere, not the root box) on the spot instead of queueing them for shade (tyr_render's merged path; the stage API keeps the reference's full queue)
+	uint32_t foldNextPrologue;    // k_scan_words: its last block also opens the NEXT iteration (set_wavefront_globals + the hole padding in front of its traversal launch): tyr_render one iteration ahead of the counts, once the budget is spent (no top-up can follow)
+	uint32_t prologueDone;        // the traversal launchers: the previous iteration's k_scan_words did that (no k_primary launch, no k_pad_holes)
 	uint32_t prevFolded;          // the traversal launchers: the shade launch that made this iteration's survivors and shadow rays did so (only the holes at the segments' ends are left to mark)
 	uint32_t* fillWork;           // fill counters of the work queue's class 0 (what k_trace_stream waits on for iteration j), one per 64-slot chunk
 	uint32_t* fillNext;           // ... of the next queue's class 0 (what this iteration's shade publishes)
@@ -252,6 +254,7 @@ struct Tuning {
 	int resolveShadows = 1;   // merged path of tyr_render (needs foldSpheres): shade answers the shadow rays that cannot reach a triangle itself
 	int retireSky = 1;        // merged path of tyr_render: k_primary finishes the camera rays that hit nothing itself (they never reach a queue)
 	int wideBlockMinItems = 3 << 20; // k_trace_flat: launches of at least this many rays run as 768-thread blocks, six waves per SIMD (< 0: never)
+	int foldPrologue = 1;     // tyr_render one iteration ahead of the counts: once the budget is spent, an iteration's last kernel opens the next one (set_wavefront_globals, hole padding): two launches and two gaps fewer per iteration
 	int foldSpheres = 1;      // merged path of tyr_render: shade does the sphere pre-passes' work for the rays it emits (the streamed tail always does); 0: k_extend_spheres / k_connect_spheres re-read them
 };
 constexpr uint32_t kCountRaysPerBlock = 1024; // the counting build's kernels: queue slots owned by one 256-thread block

@@ -1173,8 +1173,10 @@ void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t 
 	Pc.shadow = P.shadowPrev;
 	if (P.prevFolded) {
 		// the sphere halves were done by the shade launch that made these rays (P.foldSpheres there): only the holes at the
-		// segments' ends are left, of the work queue's class 0 and of the shadow queue in one launch
-		launch_pad_holes(Pc, P.traceShadow != 2u, maxShadowPrev != 0, stream, P.traceShadow == 2u);
+		// segments' ends are left, of the work queue's class 0 and of the shadow queue in one launch -- unless the k_scan_words
+		// launch behind that shade launch has done them too (P.prologueDone)
+		if (!P.prologueDone)
+			launch_pad_holes(Pc, P.traceShadow != 2u, maxShadowPrev != 0, stream, P.traceShadow == 2u);
 		return;
 	}
 	if (P.traceShadow != 2u)

@@ -1069,7 +1069,9 @@ int tyr_launch_kernels(tyr_ctx* c) {
 struct IterationPlan {
 	uint32_t nNew, nLive, nSurvivors, carried; // exact values or upper bounds; carried: shadow rays of the iteration before (0: none to trace)
 };
-static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool begun) {
+// foldNext: this iteration's k_scan_words also opens the next one (no top-up can follow and the next one IS going to be queued);
+// prologueDone: the previous iteration's did that for this one -- no k_primary launch, no k_pad_holes
+static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool begun, bool foldNext = false, bool prologueDone = false) {
 	int rc = begun ? TYR_OK : stage_begin(c);
 	if (rc)
 		return rc;
@@ -1082,7 +1084,10 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 	}
 	if (c->tuning.retireSky)
 		P.retireSky = 1u;
-	enqueue_primary(c, P, p.nNew);
+	P.foldNextPrologue = foldNext ? 1u : 0u;
+	P.prologueDone = prologueDone ? 1u : 0u;
+	if (!prologueDone)
+		enqueue_primary(c, P, p.nNew);
 	enqueue_trace(c, P, p.nLive, p.nSurvivors, p.carried);
 	enqueue_shade(c, P, p.nLive);
 	HIPCHK(hipMemcpyAsync(c->hSnap[set], c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
@@ -1115,7 +1120,14 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 	uint32_t live = static_cast<uint32_t>(s) + nNew; // live(enq - 1), exact
 	budget -= nNew;                                   // budget left behind iteration enq - 1, exact
 	const uint32_t iter0 = c->iter; // iteration j of this render is the ctx's iteration iter0 + j: its events and its counters use set (iter0 + j) & 1
-	if ((rc = enqueue_merged_iteration(c, IterationPlan{ nNew, live, static_cast<uint32_t>(s), 0u }, true)))
+	// Will iteration j + 1 be queued without a look at iteration j's counts, and can it do without a top-up?  Then iteration j's
+	// last kernel opens it (FrameParams::foldNextPrologue): set_wavefront_globals and the hole padding cost a ~5 us launch and a
+	// gap between dependent kernels each, every iteration.  Both answers follow from what the host knows when it queues j: the
+	// budget left behind j (exact once it is zero) and the last iteration that gave birth to rays.
+	const bool mayFold = c->tuning.foldPrologue != 0 && c->tuning.foldSpheres != 0;
+	auto queued_ahead_behind = [&](uint32_t j, uint64_t budgetBehindJ, uint32_t lastBirthAtJ) { return j + 1 < max_iterations && (budgetBehindJ != 0 || j < lastBirthAtJ + static_cast<uint32_t>(kMaxBounces)); };
+	bool folded = mayFold && budget == 0 && queued_ahead_behind(0, budget, 0); // (of the iteration queued last: its k_scan_words has opened the next one)
+	if ((rc = enqueue_merged_iteration(c, IterationPlan{ nNew, live, static_cast<uint32_t>(s), 0u }, true, folded, false)))
 		return rc;
 	uint32_t enq = 1;
 	// The last iteration (of this render) that gave birth to rays: a primary ray survives at most kMaxBounces times
@@ -1126,6 +1138,7 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 	for (;;) {
 		// iterations 0 .. enq - 1 are queued; the counts of 0 .. enq - 2 have arrived
 		bool ahead = false;
+		bool foldedPrev = folded; // whether the iteration whose counts are awaited below (enq - 1) opened its successor
 		uint32_t frameBefore = c->frame;
 		const uint32_t shadowSetBefore = c->shadowSet; // (enqueue_shade of an iteration queued ahead moves it: an iteration that turns out empty must give it back, or tyr_shadow_export would read the empty iteration's counters)
 		const bool foldedBefore = c->lastShadeFolded;
@@ -1133,13 +1146,27 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 		if (enq < max_iterations && canHaveSurvivors) {
 			const uint32_t liveMax = static_cast<uint32_t>(std::min<uint64_t>(N, static_cast<uint64_t>(live) + budget));
 			const uint32_t newMax = static_cast<uint32_t>(std::min<uint64_t>(N, budget));
-			if ((rc = enqueue_merged_iteration(c, IterationPlan{ newMax, liveMax, live, live }, false))) {
+			const bool opened = folded; // iteration enq - 1's k_scan_words has done this one's set_wavefront_globals and hole padding
+			foldedPrev = folded;
+			folded = mayFold && budget == 0 && queued_ahead_behind(enq, 0, lastBirth); // (budget == 0: iteration enq tops nothing up, gives birth to nothing)
+			if ((rc = enqueue_merged_iteration(c, IterationPlan{ newMax, liveMax, live, live }, false, folded, opened))) {
 				(void)hipStreamSynchronize(c->stream); // (the failed iteration may be partly queued; nothing of it is the render's)
 				c->shadowSet = shadowSetBefore;
 				c->lastShadeFolded = foldedBefore;
 				return rc;
 			}
 			ahead = true;
+		}
+		// The render's end is known (the budget is spent, iteration enq - 1 cannot leave a survivor): the launch that traces its last
+		// shadow rays goes out now, sized from an upper bound (at most one shadow ray per ray; the kernel takes its counts from the
+		// device), instead of after the ~25 us it takes the counts to reach the host and the launch to reach the GPU.
+		bool flushedEarly = false;
+		if (!ahead && mayFold && budget == 0 && !canHaveSurvivors) {
+			c->shadowPending = true;
+			c->shadowPendingMax = live;
+			if ((rc = flush_pending_shadow(c)))
+				return rc;
+			flushedEarly = true;
 		}
 		const int set = static_cast<int>((iter0 + enq - 1) & 1u);
 		// a failure from here on leaves an iteration queued that the render will never own: drain the stream and take the
@@ -1162,6 +1189,13 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 				return abandon(static_cast<int>(e));
 		}
 		std::memcpy(c->hK, c->hSnap[set], sizeof(DevCounters));
+		if (foldedPrev) {
+			// iteration enq - 1's k_scan_words ran the next iteration's set_wavefront_globals in front of this snapshot: the two counts
+			// the host steers by were kept aside (DevCounters::reserved0 / reserved1), n_live already reads the next iteration's
+			c->hK->primary_ray_cnt = c->hK->reserved0;
+			c->hK->shadow_ray_cnt = c->hK->reserved1;
+			c->hK->n_live = live;
+		}
 		collect_timings_of(c, set);
 		s = c->hK->primary_ray_cnt; // survivors of iteration enq - 1
 		const uint32_t shadows = c->hK->shadow_ray_cnt;
@@ -1181,13 +1215,13 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 				c->undoLive = live;
 				c->undoShadows = shadows;
 			} else {
-				c->shadowPending = shadows != 0;
+				c->shadowPending = !flushedEarly && shadows != 0;
 				c->shadowPendingMax = shadows;
 			}
 			return TYR_OK;
 		}
 		if (!ahead && enq >= max_iterations) { // max_iterations reached
-			c->shadowPending = shadows != 0;
+			c->shadowPending = !flushedEarly && shadows != 0;
 			c->shadowPendingMax = shadows;
 			return TYR_OK;
 		}
@@ -1200,7 +1234,8 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 		if (!ahead) {
 			// (it was not queued ahead because no survivor was expected, and there are some: cannot happen while a ray survives
 			// at most kMaxBounces times -- queued now, from the exact counts, rather than trusted)
-			if ((rc = enqueue_merged_iteration(c, IterationPlan{ nNew, live, static_cast<uint32_t>(s), shadows }, false)))
+			folded = false;
+			if ((rc = enqueue_merged_iteration(c, IterationPlan{ nNew, live, static_cast<uint32_t>(s), flushedEarly ? 0u : shadows }, false, false, false)))
 				return rc;
 		}
 		++enq;
@@ -1811,6 +1846,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_RETIRE_SKY, 0, 1, &Tuning::retireSky },
 		{ TYR_TUNE_RESOLVE_SHADOWS, 0, 1, &Tuning::resolveShadows },
 		{ TYR_TUNE_WIDE_BLOCK_MIN_ITEMS, -1, 0x7fffffff, &Tuning::wideBlockMinItems },
+		{ TYR_TUNE_FOLD_PROLOGUE, 0, 1, &Tuning::foldPrologue },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)
