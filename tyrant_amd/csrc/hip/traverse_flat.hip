@@ -599,7 +599,14 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 	// needs at all (wave-uniform branches on ballots), state changes are selects, loads of lanes that have nothing to load
 	// go to record 0.  A lane that turns a node into a leaf tests the leaf in the same trip.
 	const bool allRegular = __ballot(gActive && !regular) == 0ull; // (the generic box test is exact for regular rays too: one path for the wave)
+#ifdef TYR_WIDE_LONE_GROUPS
+	// what-if (round 5): the launch's very last rays -- a wave down to TYR_WIDE_LONE_GROUPS groups or fewer -- are bound by the
+	// latency of one step, not by the SIMD's issue slots; they take the loop with branches below, which runs only the blocks a
+	// group needs (a lone ray in a node step: ~150 instead of ~380 instructions)
+	while ((uint32_t)__popcll(__ballot(gActive)) > 4u * (TYR_WIDE_LONE_GROUPS)) {
+#else
 	while (__ballot(gActive) != 0ull) {
+#endif
 		if (kGuardPasses && ++passes > kMaxPasses)
 			break;
 #ifdef TYR_LAUNCH_ANATOMY
@@ -692,7 +699,8 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 			gActive = false;
 		}
 	}
-#else
+#endif
+#if defined(TYR_WIDE_BRANCHY) || defined(TYR_WIDE_LONE_GROUPS)
 	while (__ballot(gActive) != 0ull) {
 		if (kGuardPasses && ++passes > kMaxPasses)
 			break;
