@@ -51,66 +51,24 @@ of the scene by the port and by the reference's own bvh.cpp.
 from __future__ import annotations
 
 import argparse
-import csv
-import glob
 import json
 import os
-import shutil
 import socket
 import subprocess
 import sys
-import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-NUM_XCD, NUM_SIMD, NUM_CU = 8, 1024, 256  # MI355X: 8 XCDs x 32 CUs x 4 SIMDs
-REF_N = 2097152  # variables.h:44
-TRACE_KERNEL = "k_trace_flat<12"   # the traversal kernel: extend(i + 1) + connect(i) in one launch (tyr_render), or one kind of ray alone.  A name PREFIX: rocprofv3 lists its two block shapes, k_trace_flat<12, 768u> (launches of 3 Mi rays and more: six waves per SIMD) and k_trace_flat<12, 256u>; both are "the kernel" of the roofline
-SHADE_KERNEL = "k_shade<"            # the second kernel of a render by time
-EXTEND_KERNEL = TRACE_KERNEL
-SHADE_BYTES_PER_RAY = 52 + 24 + 16   # state + e1, e2 + pixel RMW; + 44 per survivor + 48 per shadow ray (added from the counters)
-
-
-ORACLE_COUNTER_FIELDS = ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible")
-
-
-def oracle_counters_check(args, world, W, H, spp, N, n_tris, m):
-    """config.oracle_counters_match: the counter deltas of the TIMED renders against the oracle's counters for this very job,
-    committed as tests/golden/bench_c3_counters.json (made by tests/golden/make_bench_counters.py: orc_render, the serial C
-    restatement of kernel.cu:664-748).  Every timed step restarts the frame counter, so K steps must have cast exactly K times
-    the oracle's rays -- extend, shadow, survivors, visible shadow rays, iterations.  None when the job is not the committed one
-    (another workload, resolution, spp, queue size or rank count).  The file is data: nothing under oracle/ is loaded here."""
-    try:
-        with open(os.path.join(ROOT, "tests", "golden", f"bench_{args.workload}_counters.json")) as f:
-            gold = json.load(f)
-    except (OSError, ValueError):
-        return {"oracle_counters_match": None, "oracle_counters_note": f"no committed oracle counters for workload {args.workload}"}
-    j = gold["job"]
-    if world != 1 or (j["width"], j["height"], j["spp"], j["queue_size"], j["triangles"]) != (W, H, spp, N, n_tris):
-        return {"oracle_counters_match": None, "oracle_counters_note": "this job is not the one the committed oracle counters were made for (tests/golden/make_bench_counters.py: c3, 1920x1080, 8 spp, queue 16,588,800, one rank)"}
-    want = {f: gold["per_render"][f] * args.steps for f in ORACLE_COUNTER_FIELDS}
-    got = m["counter_deltas"]
-    ok = all(int(got[f]) == int(want[f]) for f in ORACLE_COUNTER_FIELDS) and m["iters"] == gold["per_render"]["iterations"] * args.steps
-    out = {"oracle_counters_match": bool(ok),
-           "oracle_counters": {"source": "tests/golden/bench_c3_counters.json (orc_render on this job; tests/test_gpu_configs.py::test_benchmarked_render_path_matches_oracle_at_full_size[bench_shape_16M_8spp] holds the live oracle, the file and the GPU to each other, pixels included)",
-                               "per_render": gold["per_render"], "timed_renders": args.steps}}
-    if not ok:
-        out["oracle_counters"]["timed_deltas"] = {f: int(got[f]) for f in ORACLE_COUNTER_FIELDS}
-        out["oracle_counters"]["timed_iterations"] = m["iters"]
-    return out
-
-
-def dominant_kernel(tune_args) -> str:
-    return TRACE_KERNEL
-PMC_PASSES = (
-    ("FETCH_SIZE",),
-    ("WRITE_SIZE",),
-    ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"),
-)
+# what is not the measurement itself lives in tyrant_amd/benchkit/ (child-process modes, counters -> roofline arithmetic, the
+# pre-flight of the native exchange); re-exported here: tests/test_bench_contract.py and the tools address them as bench.<name>
+from tyrant_amd.benchkit.children import committed_pmc, drain_block, pmc_child, quad_block, run_pmc_passes  # noqa: E402,F401
+from tyrant_amd.benchkit.common import (EXTEND_KERNEL, HBM_PEAK_GBS, NUM_CU, NUM_SIMD, NUM_XCD, PMC_PASSES, REF_N, SHADE_BYTES_PER_RAY, SHADE_KERNEL, TRACE_KERNEL,  # noqa: E402,F401
+                                        build_workload, dominant_kernel, find_rocprof, job_shape)
+from tyrant_amd.benchkit.preflight import PREFLIGHT_TIMEOUT_S, PREFLIGHT_TORCH_NCCL_ONLY, dist_preflight, run_dist_preflight  # noqa: E402,F401
+from tyrant_amd.benchkit.roofline import ORACLE_COUNTER_FIELDS, oracle_counters_check, roofline_block, shade_block  # noqa: E402,F401
 
 
 def parse_args(argv=None):
@@ -140,7 +98,6 @@ def parse_args(argv=None):
     ap.add_argument("--tune", action="append", default=[], help="launch-shape knob of tyr_set_tuning, e.g. --tune refill_min_idle=8 (never changes results)")
     return ap.parse_args(argv)
 
-
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -155,160 +112,6 @@ def launch_ranks(args) -> int:
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
-
-
-def build_workload(name: str, binding, scenes):
-    if name == "c2":
-        sc = scenes.cornell_soup(10000)
-        label = "C2: Cornell box (36 tris) + 10,000 seeded random diffuse triangles"
-    elif name == "c3":
-        sc = scenes.mesh_scene(706)
-        label = "C3: room + 706x706 height-field mesh (996,882 tris), 70% DIFF / 30% SPEC"
-    elif name == "c5":
-        sc = scenes.glass_dof_scene(2236)
-        label = "C5: room + 2236x2236 height-field mesh (9,999,402 tris), 65% DIFF / 30% SPEC / 5% REFR, thin lens 0.5, sun (0.3,0.2); quoted at --width 3840 --height 2160 --spp 16"
-    elif name == "c1":
-        sc = scenes.cornell_box()
-        label = "C1: Cornell box (36 tris)"
-    else:
-        raise SystemExit(f"unknown workload {name}")
-    t0 = time.perf_counter()
-    nodes, prims = binding.bvh_build(sc.triangles)  # host SAH build (bvh.cpp:3-225), outside the timed region
-    return sc, nodes, prims, label, time.perf_counter() - t0
-
-
-def job_shape(args, world: int):
-    """(spp_total, queue slots per rank)"""
-    if args.spp > 0:
-        spp_total = args.spp * (world if args.scaling == "weak" else 1)
-    elif world == 1:
-        spp_total = 8
-    else:
-        spp_total = 64 if args.scaling == "strong" else 8 * world
-    local_pixels = args.width * (args.height // world)
-    N = args.queue if args.queue > 0 else min(spp_total * local_pixels, 1 << 25)
-    return spp_total, N
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# PMC child passes (N = 1): `rocprofv3 --pmc <counters> -- python3 bench.py --pmc-child ...`, the program itself after
-# `--`, no tracing domain combined with --pmc, one pass per counter group (FETCH_SIZE and WRITE_SIZE do not fit one).
-# ---------------------------------------------------------------------------------------------------------------
-def pmc_child(args) -> int:
-    """one cold + one counted render of the workload, no torch, no timing: what the profiler looks at"""
-    from tyrant_amd import binding, scenes
-
-    spp_total, N = job_shape(args, 1)
-    sc, nodes, prims, _, _ = build_workload(args.workload, binding, scenes)
-    flags = binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0
-    r = binding.Renderer(args.width, args.height, N, flags=flags)
-    r.load_scene(sc, nodes, prims)
-    tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune)}
-    if tune:
-        r.set_tuning(**tune)
-    iters = 0
-    for _ in range(2):
-        r.reset_accum()
-        iters = r.render(spp_total)
-    k = r.counters()
-    assert k["device_error"] == 0
-    r.close()
-    print(json.dumps({"pmc_child_iterations": iters}), flush=True)
-    if os.environ.get("TYR_BENCH_PRINT_DEBUG"):  # the -DTYR_QUAD_STATS build's loop counters (quad_block)
-        print(json.dumps({"child_debug": [int(v) for v in k["debug"]], "renders": 2}), flush=True)
-    return 0
-
-
-def find_rocprof():
-    p = shutil.which("rocprofv3")
-    if p is None and os.path.exists("/opt/rocm/bin/rocprofv3"):
-        p = "/opt/rocm/bin/rocprofv3"
-    return p
-
-
-def run_pmc_passes(args, timeout_s: float = 150.0):
-    """-> {"counters": {name: average per launch of the production extend kernel in the LAST render}, "launches": n} or None"""
-    rocprof = find_rocprof()
-    if rocprof is None:
-        return None
-    out_root = tempfile.mkdtemp(prefix="tyr_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
-    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp),
-             "--queue", str(args.queue)] + [x for kv in args.tune for x in ("--tune", kv)]
-    counters, launches = {}, None
-    shade_counters, shade_launches = {}, None
-    kernel = dominant_kernel(args.tune)
-    try:
-        for i, group in enumerate(PMC_PASSES):
-            d = os.path.join(out_root, f"g{i}")
-            cmd = [rocprof, "--pmc", *group, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=out_root, env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
-            if p.returncode != 0:
-                print(f"[bench] rocprofv3 --pmc {' '.join(group)} failed (rc {p.returncode}): {(p.stderr or p.stdout)[-300:]}", file=sys.stderr)
-                return None
-            iters = None
-            for line in p.stdout.splitlines():
-                if line.startswith('{"pmc_child_iterations"'):
-                    iters = json.loads(line)["pmc_child_iterations"]
-            allrows = []
-            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                with open(path) as f:
-                    allrows += list(csv.DictReader(f))
-            rows = [r for r in allrows if kernel in r["Kernel_Name"]]
-            if not rows or not iters:
-                print(f"[bench] rocprofv3 pass {group}: no rows for {kernel}", file=sys.stderr)
-                return None
-            for name in group:
-                mine = sorted((r for r in rows if r["Counter_Name"] == name), key=lambda r: int(r["Dispatch_Id"]))
-                if len(mine) < 2 or len(mine) % 2:
-                    return None
-                last = mine[len(mine) // 2:]  # the child renders twice: the second (warm) render's launches of this kernel
-                counters[name] = sum(float(r["Counter_Value"]) for r in last) / len(last)
-                launches = len(last)
-                # the same for the shade kernel (summed over the render's launches: its per-render figure)
-                sh = sorted((r for r in allrows if SHADE_KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name), key=lambda r: int(r["Dispatch_Id"]))
-                if sh and len(sh) % 2 == 0:
-                    shade_counters[name] = sum(float(r["Counter_Value"]) for r in sh[len(sh) // 2:])
-                    shade_launches = len(sh) // 2
-    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
-        print(f"[bench] PMC passes abandoned: {e!r}", file=sys.stderr)
-        return None
-    finally:
-        shutil.rmtree(out_root, ignore_errors=True)
-    return {"counters": counters, "launches_averaged": launches, "kernel": kernel, "shade_counters_per_render": shade_counters, "shade_launches_per_render": shade_launches, "source": "live: rocprofv3 --pmc child passes of this command (" + " | ".join(" ".join(g) for g in PMC_PASSES) + ")"}
-
-
-def committed_pmc(workload: str, N: int):
-    try:
-        with open(os.path.join(ROOT, "profiles", f"pmc_{workload}.json")) as f:
-            j = json.load(f)
-        if j.get("queue_size") == N:
-            return {"counters": j["counters"], "launches_averaged": j.get("launches_averaged"), "kernel": j.get("kernel"), "shade_counters_per_render": j.get("shade_counters_per_render", {}), "shade_launches_per_render": j.get("shade_launches_per_render"), "source": f"committed: profiles/pmc_{workload}.json ({j.get('source', '')})"}
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
-
-
-def shade_block(pmc, shade_ms_per_render, rays_per_render, survivors_per_render, shadows_per_render):
-    """the second kernel of a render: k_shade against its byte roofline (52 + 24 + 16 B per ray, 44 per
-    survivor, 48 per shadow ray) and, from the counters, its vector-issue fraction -- it is bound by arithmetic"""
-    alg = SHADE_BYTES_PER_RAY * rays_per_render + 44.0 * survivors_per_render + 48.0 * shadows_per_render
-    t = shade_ms_per_render * 1e-3
-    out = {"kernel": "k_shade<false>", "ms_per_render": round(shade_ms_per_render, 4), "rays_per_render": int(rays_per_render),
-           "algorithmic": {"bytes_per_render": round(alg), "GBps": round(alg / t / 1e9, 2) if t > 0 else None, "frac_of_hbm_peak": round(alg / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None,
-                           "bytes_per_ray": round(alg / max(rays_per_render, 1), 1)}}
-    c = (pmc or {}).get("shade_counters_per_render") or {}
-    if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_ACTIVE_INST_VALU"):
-        cyc = c["GRBM_GUI_ACTIVE"] / NUM_XCD
-        valu = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (NUM_SIMD * cyc)
-        lanes = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
-        out.update({"bound": "valu-issue", "frac": round(valu, 4), "frac_kind": "vector-ALU issue cycles / SIMD cycles while k_shade runs (not an HBM fraction)",
-                    "salu_issue_frac": round(4.0 * c["SQ_ACTIVE_INST_SCA"] / (NUM_SIMD * cyc), 4), "lanes_active_per_valu_inst": round(lanes, 4)})
-        if c.get("FETCH_SIZE") is not None and c.get("WRITE_SIZE") is not None and t > 0:
-            hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-            out["traffic"] = round(hbm / t / 1e9, 2)
-            out["hbm_counter_frac"] = round(hbm / t / 1e9 / HBM_PEAK_GBS, 4)
-    return out
-
 
 def steady_state(binding, sc, nodes, prims, W, H, N, flags, device):
     """The path as the reference's viewer drives it (main.cpp:164-170): launch_kernels without end, every iteration's
@@ -337,241 +140,6 @@ def steady_state(binding, sc, nodes, prims, W, H, N, flags, device):
         return None
     return {"Mrays/s": round(rays / dt / 1e6, 1), "ms_per_iteration": round(dt / iters * 1e3, 3), "iterations": iters, "queue_size": N,
             "note": "tyr_render with a budget that never runs out: every iteration's queue is full (survivors + top-up), the reference viewer's mode; an 8-spp render ends in thin iterations instead"}
-
-
-def drain_block(args):
-    """How much of a traversal launch is its drain: an instrumented build of the library (-DTYR_LAUNCH_ANATOMY: three
-    s_memrealtime stamps per wave) renders the workload once in a CHILD process; per launch, `feed` = first wave's start ->
-    first wave to find the queue used up, `drain` = from there to the last wave's exit."""
-    lib = os.path.join(ROOT, "tyrant_amd", "lib", "libtyrant_hip_anatomy.so")
-    if not os.path.exists(lib):
-        return None
-    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--queue", str(args.queue)]
-    try:
-        p = subprocess.run(child, capture_output=True, text=True, timeout=120, env=dict(os.environ, TYRANT_HIP_LIBRARY=lib, TYR_ANATOMY="1"))
-    except (subprocess.TimeoutExpired, OSError):
-        return None
-    rows = []
-    for line in p.stderr.splitlines():
-        if line.startswith("[anatomy]") and "feed" in line:
-            try:
-                rows.append((float(line.split("feed")[1].split("us")[0]), float(line.split("drain")[1].split("us")[0])))
-            except (IndexError, ValueError):
-                pass
-    if p.returncode != 0 or len(rows) < 2:
-        return None
-    rows = rows[len(rows) // 2:]  # the second (warm) render
-    feed, drain = sum(r[0] for r in rows), sum(r[1] for r in rows)
-    return {"drain_frac": round(drain / (feed + drain), 4), "feed_us_per_launch": [round(r[0], 1) for r in rows], "drain_us_per_launch": [round(r[1], 1) for r in rows],
-            "source": "one render of the same workload by libtyrant_hip_anatomy.so (-DTYR_LAUNCH_ANATOMY) in a child process; the render's last launch (shadow rays only) is not stamped"}
-
-
-def quad_block(args):
-    """What the timed kernel's OWN layout needs, counted by an instrumented build of it (-DTYR_QUAD_STATS) in a child process:
-    quad steps (one 128-byte quad node each, 112 bytes of it read) and triangle tests (48-byte records) per render."""
-    lib = os.path.join(ROOT, "tyrant_amd", "lib", "libtyrant_hip_stats.so")
-    if not os.path.exists(lib):
-        return None
-    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--queue", str(args.queue)]
-    try:
-        p = subprocess.run(child, capture_output=True, text=True, timeout=120, env=dict(os.environ, TYRANT_HIP_LIBRARY=lib, TYR_BENCH_PRINT_DEBUG="1"))
-    except (subprocess.TimeoutExpired, OSError):
-        return None
-    if p.returncode != 0:
-        return None
-    for line in p.stdout.splitlines():
-        if line.startswith('{"child_debug"'):
-            j = json.loads(line)
-            d, renders = j["child_debug"], max(j.get("renders", 1), 1)
-            # tyr_counters.debug of the TYR_QUAD_STATS build: [1] lanes x trips of the quad-test loop, [5] lanes x trips of the triangle loop (traverse_flat.hip TYR_DBG)
-            return {"quad_steps_per_render": d[1] / renders, "triangle_tests_per_render": d[5] / renders,
-                    "source": "one cold + one warm render of the same workload by libtyrant_hip_stats.so (-DTYR_QUAD_STATS) in a child process, averaged"}
-    return None
-
-
-def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_render, kernel=EXTEND_KERNEL, con_ms=0.0, shadow_rays=0.0, quad=None, renders=1):
-    """`bound` = the tightest of the measured resource fractions of the dominant kernel; the algorithmic-bytes figure of
-    SURVEY.md 8d is a separate entry.  Merged launches (kernel = TRACE_KERNEL): the kernel traces this iteration's extend
-    rays and the previous iteration's shadow rays, and the launch that ends a render with the last iteration's shadow rays is
-    the same kernel: ext_ms / ext_launches are ALL its launches (main() adds the one timed as the connect stage; con_ms stays
-    for callers that time a connect launch apart); the algorithmic figure covers the whole traversal stage (all extend + all
-    shadow rays over ext_ms + con_ms)."""
-    avg_launch_s = ext_ms / max(ext_launches, 1) * 1e-3
-    bytes_per_ext = 24 + 8 + 32 * visits["nodes_per_ext"] + 36 * visits["tris_per_ext"]
-    merged = kernel == TRACE_KERNEL
-    if merged:
-        bytes_per_con = 44 + 32 * visits["nodes_per_con"] + 36 * visits["tris_per_con"] + 12 * visits.get("visible_frac", 0.0)
-        alg_total = bytes_per_ext * ext_rays + bytes_per_con * shadow_rays
-        alg_gbs = alg_total / ((ext_ms + con_ms) * 1e-3) / 1e9 if ext_ms + con_ms > 0 else 0.0
-        alg_bytes_per_launch = alg_total / max(ext_launches, 1)
-    else:
-        alg_bytes_per_launch = bytes_per_ext * ext_rays / max(ext_launches, 1)
-        alg_gbs = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-    out = {
-        "kernel": f"{kernel}, 768u | 256u> " + ("(768-thread blocks, six waves per SIMD, for launches of at least TYR_TUNE_WIDE_BLOCK_MIN_ITEMS rays, 256-thread blocks at five otherwise; extend of an iteration + connect of the one before in one persistent launch: quad nodes, closest- and any-hit rays side by side)" if merged else "(the production extend kernel: quad nodes, persistent grid)"),
-        "avg_launch_ms": round(avg_launch_s * 1e3, 4),
-        "launches": ext_launches,
-        "launch_time_source": "hipEvent pairs on the ctx stream around the stage (sphere pre-passes + the traversal kernel) inside the timed region",
-    }
-    fr = {}
-    if pmc:
-        c = pmc["counters"]
-        hbm_bytes = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0  # KB; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM)
-        traffic = hbm_bytes / avg_launch_s / 1e9
-        cyc = c["GRBM_GUI_ACTIVE"] / NUM_XCD  # the counter sums the XCDs' clocks
-        fr["hbm"] = traffic / HBM_PEAK_GBS
-        fr["valu-issue"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (NUM_SIMD * cyc)  # quad-cycles a SIMD spends issuing vector ALU work
-        fr["salu-issue"] = 4.0 * c["SQ_ACTIVE_INST_SCA"] / (NUM_SIMD * cyc)   # = busy cycles of the CU's one scalar unit (shared by 4 SIMDs)
-        lanes = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
-        bound = max(fr, key=fr.get)
-        out.update({
-            "bound": bound,
-            "achieved": round(traffic, 2) if bound == "hbm" else round(100.0 * fr[bound], 2),
-            "peak": HBM_PEAK_GBS if bound == "hbm" else 100.0,
-            "unit": "GB/s" if bound == "hbm" else "% of issue cycles (SQ_ACTIVE_INST_* x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))",
-            "frac": round(fr[bound], 4),
-            "frac_kind": ("HBM bytes by the memory-side counters / 8 TB/s" if bound == "hbm" else ("vector" if bound == "valu-issue" else "scalar") + "-ALU issue cycles / available cycles while the kernel runs: the tightest MEASURED resource fraction -- NOT an HBM fraction (that is hbm_counter_frac; the nominal byte count of SURVEY.md 8d is algorithmic.frac_of_hbm_peak)"),
-            "traffic": round(traffic, 2),
-            "hbm_counter_frac": round(fr["hbm"], 4),
-            "valu_issue_frac": round(fr["valu-issue"], 4),
-            "salu_issue_frac": round(fr["salu-issue"], 4),
-            "lanes_active_per_valu_inst": round(lanes, 4),
-            "useful_lane_issue_frac": round(fr["valu-issue"] * lanes, 4),
-            "wave_wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAVE_CYCLES") else None,
-            "traffic_detail": {"hbm_bytes_per_launch": round(hbm_bytes), "FETCH_SIZE_KB": round(c["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(c["WRITE_SIZE"], 1), "correction": "FETCH_SIZE x 2 (gfx950), WRITE_SIZE as is"},
-            "pmc_source": pmc["source"],
-            "pmc_launches_averaged": pmc["launches_averaged"],
-        })
-    else:
-        # no counters at all: only the nominal figure exists; it is an HBM fraction only while it stays below 1
-        out.update({"bound": "hbm", "achieved": round(min(alg_gbs, HBM_PEAK_GBS), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(min(alg_gbs / HBM_PEAK_GBS, 1.0), 4), "traffic": None,
-                    "note": "no PMC data (rocprofv3 absent and no committed profile): algorithmic bytes, clamped at the peak"})
-    out["algorithmic"] = {
-        "GBps": round(alg_gbs, 2),
-        "frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
-        "bytes_per_extend_ray": round(bytes_per_ext, 1),
-        "bytes_per_launch": round(alg_bytes_per_launch),
-        "covers": "every extend and every shadow ray of the timed renders over the time of all trace launches (the one that ends a render with the last shadow rays included)" if merged else "the extend launches",
-        "nodes_per_ray": round(visits["nodes_per_ext"], 2),
-        "tris_per_ray": round(visits["tris_per_ext"], 3),
-        "connect_nodes_per_ray": round(visits["nodes_per_con"], 2),
-        "connect_tris_per_ray": round(visits["tris_per_con"], 3),
-        "note": "SURVEY.md 8d: 24 + 8 + 32 B x nodes + 36 B x triangles the REFERENCE's binary tree visits per extend ray (44 + 32 x nodes + 36 x triangles + 12 x p_visible per shadow ray), counted by the counting build (k_extend_count / k_connect_count, pair nodes) in an untimed render -- not by the timed quad-node kernel; nominal, exceeds the HBM peak when the tree is cache resident",
-    }
-    # (a) the same nominal count charged to the traversal kernel only for the rays it is handed: extend rays of class 1
-    # (they fail the root box in the kernel that MAKES them, hip/kernels.hpp "Queues") cost it nothing -- their one
-    # box test (32 B of the nominal count) and their 32-byte record belong to k_primary / k_shade
-    t_all = (ext_ms + con_ms) * 1e-3
-    in_ext = visits.get("in_tree_ext_frac")
-    if in_ext is not None and merged and t_all > 0:
-        rays_in = in_ext * ext_rays
-        nodes_in = max(visits["nodes_per_ext"] * ext_rays - (ext_rays - rays_in), 0.0)  # the counting build counts ONE node for a ray that misses the root box
-        alg_in = (24 + 8) * rays_in + 32 * nodes_in + 36 * visits["tris_per_ext"] * ext_rays + bytes_per_con * shadow_rays
-        out["algorithmic"]["class0_only"] = {"GBps": round(alg_in / t_all / 1e9, 2), "frac_of_hbm_peak": round(alg_in / t_all / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": round(alg_in / max(ext_launches, 1)),
-                                             "extend_rays_charged": round(rays_in), "note": "SURVEY.md 8d's count for the rays that reach k_trace_flat: extend rays that pass the root box + every shadow ray"}
-    # (b) what the kernel's own layout needs: 128 B per quad step, 48 B per triangle test, 32 B per ray handed to it
-    if quad and t_all > 0:
-        handed = (in_ext if in_ext is not None else 1.0) * ext_rays + shadow_rays
-        qb = (128.0 * quad["quad_steps_per_render"] + 48.0 * quad["triangle_tests_per_render"]) * renders + 32.0 * handed
-        out["algorithmic"]["quad"] = {"GBps": round(qb / t_all / 1e9, 2), "frac_of_hbm_peak": round(qb / t_all / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": round(qb / max(ext_launches, 1)),
-                                      "quad_steps_per_render": round(quad["quad_steps_per_render"]), "triangle_tests_per_render": round(quad["triangle_tests_per_render"]),
-                                      "note": "bytes the 128-byte quad nodes and 48-byte triangle records of the timed kernel amount to (every step and test counted, cache hits included): " + quad["source"]}
-    # (c) north_star's ">= 50 % of the HBM roofline", answered both ways
-    out["hbm_target_met"] = {"target": 0.5, "nominal": bool(out["algorithmic"]["frac_of_hbm_peak"] >= 0.5), "nominal_class0_only": (bool(out["algorithmic"]["class0_only"]["frac_of_hbm_peak"] >= 0.5) if "class0_only" in out["algorithmic"] else None),
-                             "counters": (bool(out["hbm_counter_frac"] >= 0.5) if out.get("hbm_counter_frac") is not None else None),
-                             "note": "nominal = SURVEY.md 8d's per-ray bytes of the REFERENCE's binary tree over the traversal time (can exceed 1: not traffic); counters = bytes that crossed the fabric (FETCH_SIZE x 2 + WRITE_SIZE) / 8 TB/s -- the tree lives in the 256 MB Infinity Cache and the kernel is bound by instruction issue and by its launches' drains, not by HBM"}
-    out["kernel_ms_per_render"] = kernel_ms_per_render
-    return out
-
-
-PREFLIGHT_TIMEOUT_S = 150.0
-PREFLIGHT_TORCH_NCCL_ONLY = 2  # exit code of the pre-flight child: the native exchange failed, torch's nccl backend works
-
-
-def dist_preflight(args) -> int:
-    """One rank of the pre-flight check of the native exchange (tyr_dist_*: RCCL behind the C ABI), run as a CHILD of the
-    bench rank of the same number before that rank has touched its GPU: a small frame, rows dealt y % world == rank, a
-    2-spp render per rank, GATHER and REDUCE onto rank 0, every pixel must hold exactly 2 finished paths.  The exchange
-    has only met one GPU per box before the driver's multi-GPU run; a hang, a crash or a wrong frame here costs this child,
-    not the measurement: the bench ranks then use torch.distributed for the combine.  Exit code 0 = verified on every rank."""
-    import datetime
-
-    import torch
-    import torch.distributed as dist
-
-    from tyrant_amd import binding, scenes
-
-    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    if os.environ.get("TYR_BENCH_PREFLIGHT_ONE_DEVICE"):
-        local_rank = 0  # rehearsal on a one-GPU box: RCCL refuses two ranks on one device, which is the failure path under test
-    local_rank %= max(torch.cuda.device_count(), 1)  # (fewer GPUs than ranks: the same failure path, not an invalid-device crash)
-    dist.init_process_group("gloo", init_method=f"file://{args.preflight_store}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
-    ok = 1
-    try:
-        torch.cuda.set_device(local_rank)
-        W, H, spp = 64, 8 * world, 2
-        sc = scenes.cornell_box()
-        nodes, prims = binding.bvh_build(sc.triangles)
-        r = binding.Renderer(W, H, 4096, device=local_rank, rank=rank, nranks=world)
-        r.load_scene(sc, nodes, prims)
-        ids = [binding.dist_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm = binding.Dist(r, ids[0], rank, world)
-        frame = torch.zeros(H * W * 4, dtype=torch.float32, device=f"cuda:{local_rank}") if rank == 0 else None
-        torch.cuda.synchronize()
-        for mode in (binding.TYR_DIST_GATHER, binding.TYR_DIST_REDUCE):
-            r.reset_accum()
-            r.render(spp)
-            comm.combine(frame.data_ptr() if frame is not None else None, mode=mode, root=0)
-            comm.wait()
-            torch.cuda.synchronize()
-            if rank == 0:
-                a = frame.view(H * W, 4)[:, 3]
-                if not (float(a.min()) == float(a.max()) == float(spp)):
-                    print(f"[bench preflight] mode {mode}: combined frame holds {float(a.min())}..{float(a.max())} paths per pixel, expected {spp}", file=sys.stderr)
-                    ok = 0
-                frame.zero_()
-        comm.close()
-        r.close()
-    except Exception as e:  # noqa: BLE001
-        print(f"[bench preflight] rank {rank}: {e!r}", file=sys.stderr)
-        ok = 0
-    # ... and torch's own RCCL backend (what the combine falls back to when the native exchange does not verify): one
-    # all-reduce on this rank's device.  If that fails too, the bench ranks combine over gloo, host-staged.
-    nccl_ok = 1
-    if not ok or os.environ.get("TYR_BENCH_PREFLIGHT_PROBE_TORCH_NCCL"):
-        try:
-            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=45))
-            t = torch.ones(4, dtype=torch.float32, device=f"cuda:{local_rank}")
-            dist.all_reduce(t, group=g)
-            torch.cuda.synchronize()
-            nccl_ok = int(float(t[0].item()) == float(world))
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench preflight] rank {rank}: torch's nccl backend: {e!r}", file=sys.stderr)
-            nccl_ok = 0
-    flag = torch.tensor([ok, nccl_ok], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    dist.destroy_process_group()
-    return 0 if int(flag[0].item()) == 1 else (PREFLIGHT_TORCH_NCCL_ONLY if int(flag[1].item()) == 1 else 1)
-
-
-def run_dist_preflight() -> int:
-    """spawn this rank's pre-flight child (this process has not initialised the GPU yet) and wait for it, bounded:
-    0 = the native exchange verified on every rank; PREFLIGHT_TORCH_NCCL_ONLY = it did not, torch's nccl backend does;
-    1 = neither (or the child crashed / ran out of time)"""
-    # the children make their own rendezvous through a FILE (no second port to find free and to agree on): one name per
-    # launch -- the launcher's pid is the parent of every rank, its master port tells concurrent launches apart -- and
-    # without the launcher's TORCHELASTIC_* variables, which would tell them that an agent already hosts a store
-    store = os.path.join(tempfile.gettempdir(), f"tyr_preflight_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}")
-    cmd = [sys.executable, os.path.abspath(__file__), "--dist-preflight", "--preflight-store", store]
-    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
-    try:
-        p = subprocess.run(cmd, timeout=PREFLIGHT_TIMEOUT_S, env=env, stdout=subprocess.DEVNULL)
-        return p.returncode if p.returncode in (0, PREFLIGHT_TORCH_NCCL_ONLY) else 1
-    except subprocess.TimeoutExpired:
-        print(f"[bench] rank {os.environ.get('RANK', '?')}: the native exchange's pre-flight did not finish in {PREFLIGHT_TIMEOUT_S:.0f} s", file=sys.stderr)
-        return 1
-
 
 def main():
     args = parse_args()
