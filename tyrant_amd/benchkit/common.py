@@ -11,7 +11,7 @@ BENCH = os.path.join(ROOT, "bench.py")  # the child modes re-enter through its c
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 NUM_XCD, NUM_SIMD, NUM_CU = 8, 1024, 256  # MI355X: 8 XCDs x 32 CUs x 4 SIMDs
 REF_N = 2097152  # variables.h:44
-TRACE_KERNEL = "k_trace_flat<12"   # the traversal kernel: extend(i + 1) + connect(i) in one launch (tyr_render), or one kind of ray alone.  A name PREFIX: rocprofv3 lists its two block shapes, k_trace_flat<12, 768u> (launches of 3 Mi rays and more: six waves per SIMD) and k_trace_flat<12, 256u>; both are "the kernel" of the roofline
+TRACE_KERNEL = os.environ.get("TYR_BENCH_TRACE_KERNEL", "k_trace_flat<12")   # the traversal kernel: extend(i + 1) + connect(i) in one launch (tyr_render), or one kind of ray alone.  A name PREFIX: rocprofv3 lists its two block shapes, k_trace_flat<12, 768u> (launches of 3 Mi rays and more: six waves per SIMD) and k_trace_flat<12, 256u>; both are "the kernel" of the roofline
 SHADE_KERNEL = "k_shade<"            # the second kernel of a render by time
 EXTEND_KERNEL = TRACE_KERNEL
 SHADE_BYTES_PER_RAY = 52 + 24 + 16   # state + e1, e2 + pixel RMW; + 44 per survivor + 48 per shadow ray (added from the counters)
