@@ -826,35 +826,19 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 // the end of the launch.  Every ray is still answered on its own, into its own slot / pixel: bit-exact as before
 // (shadow rays traverse in the reference's near-first order here; any-hit answers do not depend on the order).
 // ======================================================================================
-// TWO (what-if build -DTYR_WHATIF_TWO_RAYS, round 5; the product instantiates TWO = false only, whose code is untouched): TWO rays per
-// lane.  The lane-state census of the descent trips has half the lanes testing a node while a tenth hold
-// a leaf, a twentieth have popped a stale entry or finished and a quarter hold no ray; the lever round 2 listed and never built:
-// a lane keeps a second ray (registers + its own LDS stack column) and, whenever its current ray is not at a node and the other
-// one is, the two change places -- so that the node trips, four fifths of the kernel's vector instructions, run fuller.  The price:
-// ~20 register moves per trip in which any lane swaps, 16 more vector registers, and two stack columns per lane (8 LDS entries
-// each instead of one of 12: four blocks per CU instead of five); the four-lanes-to-a-ray drain is off (it wants one ray per lane).
-template <int STACK_LDS, uint32_t kTraceBlock, bool TWO = false>
+template <int STACK_LDS, uint32_t kTraceBlock>
 // the arguments read where they lie (device_common.hpp kernarg_view): what the refill, the pixel flush and the kernel's end
 // read of them is loaded there and not held in scalar registers through the descent (24 scalar spills -> 2)
 #define TYR_TRACE_VIEW(name) const FrameParams& name = kernarg_view<FrameParams>();
-__global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ? 6 : TWO ? 4 : TYR_FLAT_WAVES_PER_EU)) k_trace_flat(const FrameParams P) {
+__global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ? 6 : TYR_FLAT_WAVES_PER_EU)) k_trace_flat(const FrameParams P) {
 	constexpr bool COUNT = false; // (TYR_DBG)
-	// the flat kernels' stack (TYR_DECLARE_FLAT_STACK), one [STACK_LDS][256] array per 256-thread part of the block (TWO: two, one per ray of a lane)
-	__shared__ typename LdsStack<STACK_LDS, true>::entry_t smem_[(TWO ? 2 : 1) * STACK_LDS * kTraceBlock];
+	// the flat kernels' stack (TYR_DECLARE_FLAT_STACK), one [STACK_LDS][256] array per 256-thread part of the block
+	__shared__ typename LdsStack<STACK_LDS, true>::entry_t smem_[STACK_LDS * kTraceBlock];
 	uint32_t spillRef_[kStackSize - STACK_LDS];
 	float spillT_[kStackSize - STACK_LDS];
-	[[maybe_unused]] uint32_t spillRef2_[TWO ? kStackSize - STACK_LDS : 1];
-	[[maybe_unused]] float spillT2_[TWO ? kStackSize - STACK_LDS : 1];
 	LdsStack<STACK_LDS, true> st;
 	st.bind(smem_ + (threadIdx.x >> 8) * (STACK_LDS * kBlock) + (threadIdx.x & 255u), spillRef_, spillT_);
 	st.reset();
-	// the other ray of the lane (TWO): its state, and where its stack lives
-	[[maybe_unused]] float o_rox = 0.f, o_roy = 0.f, o_roz = 0.f, o_rdx = 0.f, o_rdy = 0.f, o_rdz = 0.f, o_rix = 0.f, o_riy = 0.f, o_riz = 0.f, o_dist = 0.f;
-	[[maybe_unused]] uint32_t o_ref = kRefDone, o_slot = 0, o_flags = 0; // flags: 1 regular, 2 hitTri, 4 isShadow, 8 occluded, 16 live
-	[[maybe_unused]] int o_prim = 0, o_n = 0;
-	[[maybe_unused]] typename LdsStack<STACK_LDS, true>::lds_column_t o_lds = st.lds + (TWO ? STACK_LDS * kTraceBlock : 0); // (the second set of columns lies behind the first)
-	[[maybe_unused]] uint32_t* o_spillRef = spillRef2_;
-	[[maybe_unused]] float* o_spillT = spillT2_;
 	// LDS: 24,576 B of stack + 7,168 B of staged nodes + 4 = 31,748 B per block, and five blocks per CU are 158,740 of its
 	// 163,840 B: ONE more allocation granule (a 256-byte array was enough) and the hardware places four while the occupancy
 	// query still answers five -- the fifth of the persistent grid's blocks then run after the others (+30 % per render,
@@ -898,34 +882,6 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 	bool isShadow = false, occluded = false;
 	uint32_t visible = 0;
 	uint32_t dbg[16] = {};
-	// TWO: the lane's two rays change places where `sw` says so (a wave-uniform skip when nobody wants to)
-	auto swap_rays = [&](bool sw) {
-		if (!TWO || __ballot(sw) == 0ull)
-			return;
-		if (sw) {
-			float tf;
-#define TYR_SWAPF(a, b) tf = a, a = b, b = tf
-			TYR_SWAPF(rox, o_rox), TYR_SWAPF(roy, o_roy), TYR_SWAPF(roz, o_roz), TYR_SWAPF(rdx, o_rdx), TYR_SWAPF(rdy, o_rdy), TYR_SWAPF(rdz, o_rdz);
-			TYR_SWAPF(rix, o_rix), TYR_SWAPF(riy, o_riy), TYR_SWAPF(riz, o_riz), TYR_SWAPF(dist, o_dist);
-#undef TYR_SWAPF
-			uint32_t tu = ref;
-			ref = o_ref, o_ref = tu;
-			tu = slot, slot = o_slot, o_slot = tu;
-			int ti = prim;
-			prim = o_prim, o_prim = ti;
-			ti = st.n, st.n = o_n, o_n = ti;
-			const uint32_t mine = (regular ? 1u : 0u) | (hitTri ? 2u : 0u) | (isShadow ? 4u : 0u) | (occluded ? 8u : 0u) | (live ? 16u : 0u);
-			regular = (o_flags & 1u) != 0u, hitTri = (o_flags & 2u) != 0u, isShadow = (o_flags & 4u) != 0u, occluded = (o_flags & 8u) != 0u, live = (o_flags & 16u) != 0u;
-			o_flags = mine;
-			auto tl = st.lds;
-			st.lds = o_lds, o_lds = tl;
-			uint32_t* tr = st.spillRef;
-			st.spillRef = o_spillRef, o_spillRef = tr;
-			float* tt = st.spillT;
-			st.spillT = o_spillT, o_spillT = tt;
-		}
-	};
-	[[maybe_unused]] auto other_live = [&]() { return (o_flags & 16u) != 0u; };
 	uint32_t steps = 0; // TYR_QUAD_STATS / TYR_AGE_PRIO: quad steps of this lane's current ray
 	[[maybe_unused]] bool agedWave = false;
 	[[maybe_unused]] unsigned long long tExhausted = 0ull, tWide = 0ull;
@@ -956,23 +912,18 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 	__syncthreads();
 	bool exhausted = nItems == 0;
 	bool wide = false;
-	const uint32_t wideLimit = (!TWO && P.wideDrain != 0u && P.scene.quadMaxStack <= (uint32_t)kWideStackEntries) ? kWideRays : 0u; // (a tree that could need more than the group's 48 entries keeps its rays one to a lane)
+	const uint32_t wideLimit = (P.wideDrain != 0u && P.scene.quadMaxStack <= (uint32_t)kWideStackEntries) ? kWideRays : 0u; // (a tree that could need more than the group's 48 entries keeps its rays one to a lane)
 	uint32_t passes = 0;
 
 	for (;;) {
 		if (kGuardPasses && ++passes > kMaxPasses)
 			break;
 		// ---- refill free lanes from the two queues ----
-		// (TWO: a lane is free when either of its two places is; the empty one becomes the current place, and gets the new ray)
-		unsigned long long idleMask = TWO ? __ballot(!live || !other_live()) : __ballot(!live);
+		const unsigned long long idleMask = __ballot(!live);
 		const uint32_t nIdle = __popcll(idleMask);
 		if (!exhausted && nIdle >= P.refillMinIdle) {
 			TYR_TRACE_VIEW(P) // the refill's reads of the arguments (queue pointers, tickets, the root box): loaded here, not held through the descent
 			const DevScene& sc = P.scene;
-			if (TWO) {
-				swap_rays(live && !other_live());
-				idleMask = __ballot(!live);
-			}
 			const uint32_t rank = __popcll(idleMask & below);
 			uint32_t s = 0;
 			bool fed = false;
@@ -1039,8 +990,6 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 				occluded = blocked;
 				if (kAgePrio)
 					steps = 0;
-				if (TWO)
-					overflow = overflow || st.overflow; // (one flag for the lane's two stacks)
 				st.reset();
 				ref = blocked ? kRefDone : root_ref(sc, nr, dist);
 				if (ref != kRefDone)
@@ -1056,7 +1005,7 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 		{
 			// one way out of the loop: the queue is used up and at most wideLimit rays are left (0: none) -- those are
 			// finished four lanes to a ray below
-			const uint32_t nLiveNow = (uint32_t)__popcll(TWO ? __ballot(live || other_live()) : __ballot(live));
+			const uint32_t nLiveNow = (uint32_t)__popcll(__ballot(live));
 			if (exhausted && nLiveNow <= wideLimit && __ballot(live && st.n > STACK_LDS) == 0ull) {
 				wide = nLiveNow != 0u;
 				if (kAnatomy) {
@@ -1070,7 +1019,7 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 			if (nLiveNow == 0u)
 				continue;
 		}
-		allRegular = (__ballot(live && !regular) == 0ull) && (!TWO || __ballot(other_live() && (o_flags & 1u) == 0u) == 0ull);
+		allRegular = (__ballot(live && !regular) == 0ull);
 		if (kAgePrio) {
 			const bool old = __ballot(live && steps > kAgePrioSteps) != 0ull;
 			if (old != agedWave) {
@@ -1081,21 +1030,16 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 					__builtin_amdgcn_s_setprio(0);
 			}
 		}
-		RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
+		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
 		// ---- descent: one pop attempt + one quad test per lane per trip (the same for both kinds of ray) ----
 		for (;;) {
-			if (TWO) {
-				// a lane whose current ray is not at a node (a leaf, finished, no ray) while its other ray is: change places
-				swap_rays(!(live && ref_is_traversing(ref)) && other_live() && ref_is_traversing(o_ref));
-				r = RayConst{ mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 };
-			}
 			const uint32_t nTrav = __popcll(lanes_traversing(ref));
 			if (nTrav == 0)
 				break;
 			if (nTrav < P.minTraversing) {
 				const bool anyLeaf = lanes_at_leaf(ref) != 0ull;
 				const bool canRefill = !exhausted && (uint32_t)__popcll(__ballot(!live || ref == kRefDone)) >= P.refillMinIdle;
-				if (anyLeaf || canRefill || (TWO && __ballot(other_live() && !ref_is_traversing(o_ref)) != 0ull))
+				if (anyLeaf || canRefill)
 					break;
 			}
 			if (kAnatomy && exhausted)
@@ -1124,11 +1068,6 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 			}
 		}
 		// ---- leaves: bvh.h:129-140 (closest hit) / bvh.h:229-238 (any hit) ----
-		if (TWO) {
-			// the other ray's leaf now, if the current ray has none: the triangle trips run fuller too
-			swap_rays(!(live && ref_is_leaf(ref)) && other_live() && ref_is_leaf(o_ref));
-			r = RayConst{ mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 };
-		}
 		if (ref_is_leaf(ref)) {
 			const uint32_t off = ref & (kMaxPrimOffset - 1);
 			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
@@ -1152,23 +1091,6 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 			ref = found ? kRefDone : kRefPop;
 		}
 		// ---- finished rays ----
-		if (TWO) {
-			// a finished ray in the other place is retired first (a lane reports at most one visible shadow ray per pass: pendIdx)
-			const bool otherDone = other_live() && o_ref == kRefDone;
-			if (__ballot(otherDone) != 0ull) {
-				if (otherDone) {
-					if (o_flags & 4u) {
-						if (!(o_flags & 8u)) {
-							accumulate_pixel(P.blit, __float_as_int(P.shadowPrev.dyz_cd_ix[o_slot].w), mk3(P.shadowPrev.color[o_slot].x, P.shadowPrev.color[o_slot].y, P.shadowPrev.color[o_slot].z), 0);
-							visible += 1;
-						}
-					} else {
-						finish_extend_ray(P.work.hit, o_slot, (o_flags & 2u) != 0u, o_dist, o_prim);
-					}
-					o_flags &= ~16u;
-				}
-			}
-		}
 		if (live && ref == kRefDone) {
 			if (isShadow) {
 				if (!occluded) { // kernel.cu:640-644, added to the pixel at the wave's next refill
@@ -1248,11 +1170,6 @@ void launch_trace(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, u
 	launch_trace_kernel(P, maxLive + maxShadowPrev, t, numCUs, lc, stream);
 }
 void launch_trace_kernel(const FrameParams& P, uint32_t items, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
-#ifdef TYR_WHATIF_TWO_RAYS
-	// what-if: two rays per lane (k_trace_flat's TWO), 256-thread blocks, two 8-entry LDS stack columns per lane
-	hipLaunchKernelGGL((k_trace_flat<8, (uint32_t)kBlock, true>), dim3(persistent_blocks(k_trace_flat<8, (uint32_t)kBlock, true>, items, t, numCUs, lc.perCU[kLcTrace][2])), dim3(kBlock), 0, stream, P);
-	return;
-#endif
 	if (t.wideBlockMinItems >= 0 && items >= (uint32_t)t.wideBlockMinItems)
 		hipLaunchKernelGGL((k_trace_flat<TYR_TRACE_STACK, kTraceBlockWide>), dim3(persistent_blocks(k_trace_flat<TYR_TRACE_STACK, kTraceBlockWide>, items, t, numCUs, lc.perCU[kLcTrace][1], kTraceBlockWide)), dim3(kTraceBlockWide), 0, stream, P);
 	else
