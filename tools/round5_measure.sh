@@ -2,7 +2,7 @@
 set -x
 O=gpurun_out/r5m; mkdir -p $O
 python bench.py --steps 20 --warmup 3 --save-pmc $O/pmc_c3.json > $O/bench_c3.json.log 2> $O/bench_c3.err
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c3_full -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --pmc off --cpu-iterations 0 --no-reference-queue > $GRAFT_REPO_ROOT/$O/bench_c3_under_rocprof.json.log 2> $GRAFT_REPO_ROOT/$O/bench_c3_under_rocprof.err )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c3_full -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --pmc off --cpu-iterations 0 --no-reference-queue --no-steady-state > $GRAFT_REPO_ROOT/$O/bench_c3_under_rocprof.json.log 2> $GRAFT_REPO_ROOT/$O/bench_c3_under_rocprof.err )
 f=$(find /tmp/prof_c3_full -name "*kernel_stats.csv" | head -1); cp $f $O/bench_c3_kernel_stats.csv
 t=$(find /tmp/prof_c3_full -name "*kernel_trace.csv" | head -1); python tools/render_timeline.py $t > $O/timeline_c3.txt
 python bench.py --workload c2 --steps 10 --warmup 2 --save-pmc $O/pmc_c2.json > $O/bench_c2.json.log 2> $O/bench_c2.err
