@@ -22,7 +22,7 @@ Workloads (BASELINE.json configs):
     time of the SAME job, the speed-up and the efficiency.  --scaling weak renders 8*N spp (fixed work per GPU).
 Queue size: the reference's ray_queue_buffer_size (2,097,152, variables.h:44) was chosen for a small GPU and forces 20
 thin wavefront iterations per 8-spp frame.  It is a runtime parameter here and the headline run sizes it for the GPU --
-spp x local pixels slots (16.6 M: 10.4 GB of 288 GB with the queues' eight segments per class sized for the worst case, DESIGN.md 12; capped at 32 Mi), i.e. every primary ray of the render in flight at
+spp x local pixels slots (16.6 M: 10.4 GB of 288 GB with the queues' eight segments per class sized for the worst case, DESIGN.md 4.1; capped at 32 Mi), i.e. every primary ray of the render in flight at
 once.  The same workload at the reference's queue size is measured too (config.reference_queue_size).
 config.steady_state: the same kernels with the queue kept full by top-ups for as long as the measurement lasts (the
 reference's viewer never stops: main.cpp:164-170) -- no thin iterations at the end of a render.  Reported beside the
