@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TYR_ABI_VERSION 4 /* 2: tyr_counters grows (rays_in_tree_*, debug[16]), tyr_dist_*, per-triangle colours; 3: retired tuning keys removed, tyr_sunsky_probe / tyr_sun_setup; 4: tyr_set_frame, tyr_layout_probe, tyr_scene_info grows (upload_*_s) */
+#define TYR_ABI_VERSION 4 /* 2: tyr_counters grows (rays_in_tree_*, debug[16]), tyr_dist_*, per-triangle colours; 3: retired tuning keys removed, tyr_sunsky_probe / tyr_sun_setup; 4: tyr_set_frame, tyr_layout_probe, tyr_bvh_build_device, tyr_scene_info grows (upload_*_s) */
 
 /* ---- record layouts (identical to the reference structs) ------------------ */
 
@@ -389,6 +389,14 @@ int tyr_dist_scatter_rows(const void* slabs_device, void* frame_device, uint32_t
  * deterministic selection yields a valid median split with its own, thread-count-independent, bytes.
  * Returns the node count (>= 0) or a negative status. */
 int tyr_bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo);
+/* The same build -- SAH, the same bytes: every node and the primitive order of the reference's bvh.cpp -- on the DEVICE
+ * (SURVEY.md 8f-1's other alternative; hip/bvh_build_dev.hip): the top of the tree level by level with every primitive in
+ * flight (bounds and the 14 buckets by parallel min / max, the order-dependent SAH arithmetic by one thread per range in the
+ * reference's order, std::partition's permutation from two prefix sums), subtrees of at most 64 primitives by one thread each
+ * running the reference's recursion.  prims / bboxes / nodes_out are HOST arrays as for tyr_bvh_build (prims reordered in
+ * place); seconds_out2 (may be NULL): [0] the device's work, [1] the copies in and out.  Returns the node count or a negative
+ * status (TYR_ERR_UNSUPPORTED: a degenerate range overflowed a task thread's stack -- use tyr_bvh_build). */
+int tyr_bvh_build_device(int32_t device, tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, double* seconds_out2);
 /* Threads tyr_bvh_build may use: the top of the tree fans out into tasks, the output is byte-identical
  * to the serial build.  0 = automatic (env TYR_BUILD_THREADS, else min(16, cores)); 1 = the reference's serial behaviour. */
 int tyr_set_build_threads(int32_t threads);

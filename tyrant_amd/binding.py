@@ -140,6 +140,7 @@ SYMBOLS = {
     "tyr_get_timings": (C.c_int, [P, C.POINTER(Timings), C.c_int]),
     "tyr_set_tuning": (C.c_int, [P, C.c_int, C.c_int]),
     "tyr_bvh_build": (C.c_int, [P, c_i32, P, P, c_i32]),
+    "tyr_bvh_build_device": (C.c_int, [c_i32, P, c_i32, P, P, P]),
     "tyr_triangle_bboxes": (C.c_int, [P, c_i32, P]),
     "tyr_set_build_threads": (C.c_int, [c_i32]),
     "tyr_camera_update": (C.c_int, [C.c_double, C.c_double, C.POINTER(c_f)]),
@@ -215,6 +216,19 @@ def bvh_build(tris: np.ndarray, bboxes: np.ndarray | None = None, algo: int = 2)
     if nn < 0:
         raise TyrError(nn, "tyr_bvh_build")
     return nodes[:nn].copy(), prims
+
+
+def bvh_build_device(tris: np.ndarray, bboxes: np.ndarray | None = None, device: int = 0):
+    """(nodes, prims, (device_seconds, copy_seconds)): tyr_bvh_build_device -- the SAH build on the GPU, the reference's bytes"""
+    prims = np.array(tris, dtype=scenes.TRIANGLE_DTYPE, copy=True)
+    bb = triangle_bboxes(prims) if bboxes is None else np.ascontiguousarray(bboxes)  # (tyr_triangle_bboxes: the same boxes bvh_build() takes)
+    n = prims.shape[0]
+    nodes = np.zeros(max(2 * n - 1, 1), dtype=scenes.NODE_DTYPE)
+    sec = (C.c_double * 2)(0.0, 0.0)
+    rc = lib().tyr_bvh_build_device(device, _ptr(prims), n, _ptr(bb), _ptr(nodes), sec)
+    if rc < 0:
+        raise TyrError(rc, "tyr_bvh_build_device")
+    return nodes[:rc].copy(), prims, (sec[0], sec[1])
 
 
 def layout_probe(nodes: np.ndarray, prims: np.ndarray, want_pairs: bool = True) -> dict:

@@ -1871,6 +1871,14 @@ int tyr_get_timings(tyr_ctx* c, tyr_timings* out, int reset) {
 // ---- host side of the hot path --------------------------------------------------------------
 int tyr_bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo) { return bvh_build(prims, n, bboxes, nodes_out, algo); }
 
+int tyr_bvh_build_device(int32_t device, tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, double* seconds_out2) {
+	for (int32_t i = 0; i < n && bboxes; ++i)
+		for (int k = 0; k < 6; ++k)
+			if (!std::isfinite((&bboxes[i].bounds[0][0])[k]))
+				return TYR_ERR_INVALID;
+	return bvh_build_device(device, prims, n, bboxes, nodes_out, seconds_out2);
+}
+
 int tyr_set_build_threads(int32_t threads) {
 	if (threads < 0 || threads > 256)
 		return TYR_ERR_INVALID;

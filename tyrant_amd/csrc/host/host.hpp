@@ -22,6 +22,8 @@ void triangle_bboxes(const tyr_triangle* prims, int32_t n, tyr_bbox* out);
 void set_build_threads(int threads); // 0 = automatic (TYR_BUILD_THREADS or min(16, cores))
 
 int build_threads();                 // what the setting resolves to right now (>= 1)
+// hip/bvh_build_dev.hip -- the same build (SAH) on the device, the same bytes; host arrays in and out
+int bvh_build_device(int device, tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, double* seconds_out);
 
 // host/bvh_layout.cpp -- flat reference nodes -> device quad nodes (+ pair nodes for the counting build) + 48-byte triangles
 // an array of floats that is NOT zeroed when it is sized: every element is written by the layout's (parallel) passes, and a
