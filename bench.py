@@ -378,6 +378,18 @@ def main():
             solo = measure(min(spp_total * W * H, 1 << 25), max(1, min(args.steps, 2)), 1, spp_total, tdist.shard_spec(0, 1, H), 1)
         dist.barrier()
 
+    # the same tree built on the device (tyr_bvh_build_device: the reference's SAH build as kernels, hip/bvh_build_dev.hip), beside
+    # the host builder's time above: outside the timed region, bytes compared
+    dev_build = None
+    if world == 1 and rank == 0:
+        try:
+            binding.bvh_build_device(sc.triangles[:1024], device=local_rank)  # (code objects)
+            dn, dp, sec = binding.bvh_build_device(sc.triangles, device=local_rank)
+            dev_build = {"device": round(sec[0], 6), "copies": round(sec[1], 6), "same_bytes_as_host_build": bool(dn.tobytes() == nodes.tobytes() and dp.tobytes() == prims.tobytes()),
+                         "note": "tyr_bvh_build_device: host arrays in and out; `device` = first kernel to last (hipEvents), `copies` = triangles + boxes in, nodes + reordered triangles out"}
+        except Exception as e:  # noqa: BLE001
+            dev_build = {"error": repr(e)}
+
     steady = None
     if world == 1 and not args.no_steady_state:
         steady = steady_state(binding, sc, nodes, prims, W, H, N, flags, local_rank)
@@ -418,6 +430,7 @@ def main():
                 "in_tree_Mrays/s": round(mrays * m["in_tree_frac"], 3),
                 "in_tree_fraction": {"all_rays": round(m["in_tree_frac"], 4), "extend_rays": round(m["in_tree_ext_frac"], 4), "note": "rays whose test of the root box passes (counting build, rank 0's shard); the others cost one box test"},
                 "host_bvh_build_s": round(t_build, 6),
+                **({"device_bvh_build_s": dev_build} if dev_build else {}),
                 "host_scene_upload_s": {**m["upload"], "note": "tyr_scene_upload of the timed renderer (Scene.cpp:53-67's upload half), outside the timed region: `layout` = the host's re-layout of the reference's node array as quad nodes + 48-byte triangles on the builder's threads, `copy` = device allocation + the copies to HBM"},
                 **oracle_counters_check(args, world, W, H, spp_total, N, int(prims.shape[0]), m),
                 "render_path": "tyr_render defaults: merged traversal launches (extend(i + 1) + connect(i)), sphere halves folded into shade, rays whose fate is known where they are made (camera rays / survivors that hit nothing, shadow rays that cannot reach a triangle) finished in place -- they count as rays, they never enter a queue; launch-per-iteration (TYR_TUNE_STREAM_TAIL = 0)",

@@ -142,6 +142,7 @@ def test_bench_emits_the_contract_line():
     assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["in_tree_Mrays/s"] <= d["value"]
+    assert d["config"]["device_bvh_build_s"]["same_bytes_as_host_build"] is True and d["config"]["device_bvh_build_s"]["device"] >= 0  # the tree built again on the GPU: the host builder's bytes
     assert d["config"]["oracle_counters_match"] is None  # (only the default job has committed oracle counters; this micro-job says so)
     ss = d["config"]["steady_state"]  # the same kernels with the queue kept full, beside the metric (never instead of it)
     assert ss["Mrays/s"] > 0 and ss["iterations"] == 12 and ss["queue_size"] == d["config"]["queue_size"]

@@ -161,7 +161,8 @@ struct Slot { // an active range of the current level
 	float cb, ct;
 	uint32_t nodeLo[3], nodeHi[3], cLo[3], cHi[3]; // ordered-uint accumulators
 	uint32_t count[kBuckets];
-	uint32_t bLo[kBuckets][3], bHi[kBuckets][3];
+	uint32_t bLo[kBuckets][3], bHi[kBuckets][3];   // the buckets' boxes (bvh.cpp:124-131) ...
+	uint32_t bcLo[kBuckets][3], bcHi[kBuckets][3]; // ... and the bounds of their centroids: a child's node box and centroid box are unions over its buckets, so only the root asks every primitive for them (k_bounds)
 };
 struct Counters {
 	int nNodes;   // top nodes allocated
@@ -184,29 +185,37 @@ __global__ void k_init_info(const tyr_bbox* __restrict__ bb, Info* __restrict__ 
 	slotOf[i] = rootSlot;
 }
 
-__global__ void k_slot_reset(Slot* slots, int nSlots) {
+__global__ void k_slot_reset(Slot* slots, int nSlots, int resetBounds) {
 	const int s = blockIdx.x * kBlockB + threadIdx.x;
 	if (s >= nSlots)
 		return;
 	Slot& S = slots[s];
-	for (int k = 0; k < 3; ++k) {
-		S.nodeLo[k] = S.cLo[k] = 0xffffffffu;
-		S.nodeHi[k] = S.cHi[k] = 0u;
-	}
+	if (resetBounds)
+		for (int k = 0; k < 3; ++k) {
+			S.nodeLo[k] = S.cLo[k] = 0xffffffffu;
+			S.nodeHi[k] = S.cHi[k] = 0u;
+		}
 	for (int b = 0; b < kBuckets; ++b) {
 		S.count[b] = 0;
 		for (int k = 0; k < 3; ++k) {
-			S.bLo[b][k] = 0xffffffffu;
-			S.bHi[b][k] = 0u;
+			S.bLo[b][k] = S.bcLo[b][k] = 0xffffffffu;
+			S.bHi[b][k] = S.bcHi[b][k] = 0u;
 		}
 	}
 }
 
-// node box and centroid box of every active range: a wave whose lanes all sit in one range reduces first
+// node box and centroid box of the ROOT range (every other range inherits them from its parent's buckets): wave reduction, then
+// the block's four waves through LDS, twelve atomics per block (one word serves only ~88 atomics per microsecond: per wave
+// they were 1.4 ms of a 1 M-primitive build)
 __global__ void k_bounds(const Info* __restrict__ info, const int* __restrict__ slotOf, Slot* slots, int n) {
+	__shared__ uint32_t sh[kBlockB / 64][12];
 	const int i = blockIdx.x * kBlockB + threadIdx.x;
 	const int s = i < n ? slotOf[i] : -1;
 	uint32_t v[12];
+	for (int k = 0; k < 3; ++k) { // neutral elements for lanes without a primitive
+		v[k] = v[6 + k] = 0xffffffffu;
+		v[3 + k] = v[9 + k] = 0u;
+	}
 	if (s >= 0) {
 		const Info p = info[i];
 		for (int k = 0; k < 3; ++k) {
@@ -216,35 +225,29 @@ __global__ void k_bounds(const Info* __restrict__ info, const int* __restrict__ 
 			v[9 + k] = v[6 + k];
 		}
 	}
-	const int s0 = __shfl(s, 0, 64);
-	const bool uniform = __all(s == s0);
-	if (uniform) {
-		if (s0 < 0)
-			return;
 #pragma unroll
-		for (int o = 32; o > 0; o >>= 1)
-			for (int k = 0; k < 12; ++k) {
-				const uint32_t w = __shfl_xor(v[k], o, 64);
-				const bool isMin = k < 3 || (k >= 6 && k < 9);
-				v[k] = isMin ? (w < v[k] ? w : v[k]) : (w > v[k] ? w : v[k]);
-			}
-		if ((threadIdx.x & 63) == 0) {
-			Slot& S = slots[s0];
-			for (int k = 0; k < 3; ++k) {
-				atomicMin(&S.nodeLo[k], v[k]);
-				atomicMax(&S.nodeHi[k], v[3 + k]);
-				atomicMin(&S.cLo[k], v[6 + k]);
-				atomicMax(&S.cHi[k], v[9 + k]);
-			}
+	for (int o = 32; o > 0; o >>= 1)
+		for (int k = 0; k < 12; ++k) {
+			const uint32_t w = __shfl_xor(v[k], o, 64);
+			const bool isMin = k < 3 || (k >= 6 && k < 9);
+			v[k] = isMin ? (w < v[k] ? w : v[k]) : (w > v[k] ? w : v[k]);
 		}
-	} else if (s >= 0) {
-		Slot& S = slots[s];
-		for (int k = 0; k < 3; ++k) {
-			atomicMin(&S.nodeLo[k], v[k]);
-			atomicMax(&S.nodeHi[k], v[3 + k]);
-			atomicMin(&S.cLo[k], v[6 + k]);
-			atomicMax(&S.cHi[k], v[9 + k]);
-		}
+	if ((threadIdx.x & 63) == 0)
+		for (int k = 0; k < 12; ++k)
+			sh[threadIdx.x >> 6][k] = v[k];
+	__syncthreads();
+	if (threadIdx.x < 12) {
+		const int k = threadIdx.x;
+		const bool isMin = k < 3 || (k >= 6 && k < 9);
+		uint32_t r = sh[0][k];
+		for (int w = 1; w < kBlockB / 64; ++w)
+			r = isMin ? (sh[w][k] < r ? sh[w][k] : r) : (sh[w][k] > r ? sh[w][k] : r);
+		Slot& S = slots[0]; // the root's slot
+		uint32_t* dst = k < 3 ? &S.nodeLo[k] : k < 6 ? &S.nodeHi[k - 3] : k < 9 ? &S.cLo[k - 6] : &S.cHi[k - 9];
+		if (isMin)
+			atomicMin(dst, r);
+		else
+			atomicMax(dst, r);
 	}
 }
 
@@ -278,7 +281,7 @@ __global__ void k_decide_dim(Slot* slots, TopNode* nodes, int nSlots) {
 
 // bucket of every primitive of a range that is being split, and the buckets' counts and boxes (bvh.cpp:124-131)
 __global__ void k_buckets(const Info* __restrict__ info, const int* __restrict__ slotOf, Slot* slots, uint8_t* __restrict__ bkt, int n) {
-	__shared__ uint32_t shCount[kBuckets], shLo[kBuckets][3], shHi[kBuckets][3];
+	__shared__ uint32_t shCount[kBuckets], shLo[kBuckets][3], shHi[kBuckets][3], shCLo[kBuckets][3], shCHi[kBuckets][3];
 	__shared__ int shSlot, shUniform;
 	const int i = blockIdx.x * kBlockB + threadIdx.x;
 	const int s = i < n ? slotOf[i] : -1;
@@ -289,8 +292,8 @@ __global__ void k_buckets(const Info* __restrict__ info, const int* __restrict__
 	if (threadIdx.x < kBuckets) {
 		shCount[threadIdx.x] = 0;
 		for (int k = 0; k < 3; ++k) {
-			shLo[threadIdx.x][k] = 0xffffffffu;
-			shHi[threadIdx.x][k] = 0u;
+			shLo[threadIdx.x][k] = shCLo[threadIdx.x][k] = 0xffffffffu;
+			shHi[threadIdx.x][k] = shCHi[threadIdx.x][k] = 0u;
 		}
 	}
 	__syncthreads();
@@ -314,6 +317,9 @@ __global__ void k_buckets(const Info* __restrict__ info, const int* __restrict__
 			for (int k = 0; k < 3; ++k) {
 				atomicMin(&shLo[b][k], f2o(p.lo[k]));
 				atomicMax(&shHi[b][k], f2o(p.hi[k]));
+				const uint32_t c = f2o(p.c[k]);
+				atomicMin(&shCLo[b][k], c);
+				atomicMax(&shCHi[b][k], c);
 			}
 		}
 		__syncthreads();
@@ -323,6 +329,8 @@ __global__ void k_buckets(const Info* __restrict__ info, const int* __restrict__
 			for (int k = 0; k < 3; ++k) {
 				atomicMin(&S.bLo[threadIdx.x][k], shLo[threadIdx.x][k]);
 				atomicMax(&S.bHi[threadIdx.x][k], shHi[threadIdx.x][k]);
+				atomicMin(&S.bcLo[threadIdx.x][k], shCLo[threadIdx.x][k]);
+				atomicMax(&S.bcHi[threadIdx.x][k], shCHi[threadIdx.x][k]);
 			}
 		}
 	} else if (live) {
@@ -331,6 +339,9 @@ __global__ void k_buckets(const Info* __restrict__ info, const int* __restrict__
 		for (int k = 0; k < 3; ++k) {
 			atomicMin(&S.bLo[b][k], f2o(p.lo[k]));
 			atomicMax(&S.bHi[b][k], f2o(p.hi[k]));
+			const uint32_t c = f2o(p.c[k]);
+			atomicMin(&S.bcLo[b][k], c);
+			atomicMax(&S.bcHi[b][k], c);
 		}
 	}
 }
@@ -393,7 +404,23 @@ __global__ void k_decide_split(Slot* slots, Slot* next, TopNode* nodes, Counters
 		} else {
 			C.state = kActive;
 			const int ns = atomicAdd(&K->nNext, 1);
-			next[ns].node = first + c;
+			Slot& Nx = next[ns];
+			Nx.node = first + c;
+			// the child's node box and centroid box: the unions over its buckets (min / max: the same values a pass over its
+			// primitives would find)
+			const int b0 = c == 0 ? 0 : minBucket + 1, b1 = c == 0 ? minBucket : kBuckets - 1;
+			for (int k = 0; k < 3; ++k) {
+				uint32_t nl = 0xffffffffu, nh = 0u, cl = 0xffffffffu, ch = 0u;
+				for (int b = b0; b <= b1; ++b) {
+					if (S.count[b] == 0)
+						continue;
+					nl = S.bLo[b][k] < nl ? S.bLo[b][k] : nl;
+					nh = S.bHi[b][k] > nh ? S.bHi[b][k] : nh;
+					cl = S.bcLo[b][k] < cl ? S.bcLo[b][k] : cl;
+					ch = S.bcHi[b][k] > ch ? S.bcHi[b][k] : ch;
+				}
+				Nx.nodeLo[k] = nl, Nx.nodeHi[k] = nh, Nx.cLo[k] = cl, Nx.cHi[k] = ch;
+			}
 			S.childSlot[c] = ns;
 		}
 	}
@@ -725,6 +752,11 @@ struct DevBuf {
 	}
 };
 inline int grid(int n, int b = kBlockB) { return (n + b - 1) / b; }
+struct PoolView { // typed views into one device allocation
+	char* base;
+	template <class T>
+	T* at(size_t off) const { return reinterpret_cast<T*>(base + off); }
+};
 
 } // namespace
 
@@ -747,37 +779,35 @@ int bvh_build_device(int device, tyr_triangle* prims, int32_t n, const tyr_bbox*
 		return TYR_ERR_NO_DEVICE;
 	TYR_D(hipSetDevice(device));
 	const size_t N = static_cast<size_t>(n);
-	DevBuf<tyr_bbox> dBB;
-	DevBuf<tyr_triangle> dPrims, dPrimsOut;
-	DevBuf<Info> dInfo[2];
-	DevBuf<int> dSlotOf[2];
-	DevBuf<uint8_t> dBkt;
-	DevBuf<uint2> dFlags, dExcl, dBlockSums;
-	DevBuf<uint32_t> dPosML, dPosMR;
-	DevBuf<Slot> dSlots[2];
-	DevBuf<TopNode> dNodes;
-	DevBuf<tyr_bvh_node> dScratch, dOut;
-	DevBuf<Counters> dK;
+	// one allocation, carved up (nineteen hipMalloc / hipFree pairs were 35 ms of a 50 ms call around 9 ms of work)
 	const size_t maxSlots = N / (kTaskPrims + 1) + 2, maxTop = 2 * N + 2, nScanBlocks = (N + 1 + kScanPerBlock - 1) / kScanPerBlock;
-	TYR_D(dBB.alloc(N));
-	TYR_D(dPrims.alloc(N));
-	TYR_D(dPrimsOut.alloc(N));
-	TYR_D(dInfo[0].alloc(N));
-	TYR_D(dInfo[1].alloc(N));
-	TYR_D(dSlotOf[0].alloc(N));
-	TYR_D(dSlotOf[1].alloc(N));
-	TYR_D(dBkt.alloc(N));
-	TYR_D(dFlags.alloc(N + 1));
-	TYR_D(dExcl.alloc(N + 4));
-	TYR_D(dBlockSums.alloc(nScanBlocks));
-	TYR_D(dPosML.alloc(N));
-	TYR_D(dPosMR.alloc(N));
-	TYR_D(dSlots[0].alloc(maxSlots));
-	TYR_D(dSlots[1].alloc(maxSlots));
-	TYR_D(dNodes.alloc(maxTop));
-	TYR_D(dScratch.alloc(2 * N));
-	TYR_D(dOut.alloc(2 * N));
-	TYR_D(dK.alloc(1));
+	struct Carve {
+		size_t total = 0;
+		size_t take(size_t bytes) {
+			const size_t at = total;
+			total += (bytes + 255) & ~size_t(255);
+			return at;
+		}
+	} carve;
+	const size_t oBB = carve.take(N * sizeof(tyr_bbox)), oPrims = carve.take(N * sizeof(tyr_triangle)), oPrimsOut = carve.take(N * sizeof(tyr_triangle));
+	const size_t oInfo0 = carve.take(N * sizeof(Info)), oInfo1 = carve.take(N * sizeof(Info)), oSlotOf0 = carve.take(N * sizeof(int)), oSlotOf1 = carve.take(N * sizeof(int));
+	const size_t oBkt = carve.take(N), oFlags = carve.take((N + 1) * sizeof(uint2)), oExcl = carve.take((N + 4) * sizeof(uint2)), oBlockSums = carve.take(nScanBlocks * sizeof(uint2));
+	const size_t oPosML = carve.take(N * sizeof(uint32_t)), oPosMR = carve.take(N * sizeof(uint32_t)), oSlots0 = carve.take(maxSlots * sizeof(Slot)), oSlots1 = carve.take(maxSlots * sizeof(Slot));
+	const size_t oNodes = carve.take(maxTop * sizeof(TopNode)), oScratch = carve.take(2 * N * sizeof(tyr_bvh_node)), oOut = carve.take(2 * N * sizeof(tyr_bvh_node)), oK = carve.take(sizeof(Counters));
+	DevBuf<char> pool;
+	TYR_D(pool.alloc(carve.total));
+	const PoolView mem{ pool.p };
+	struct { tyr_bbox* p; } dBB{ mem.at<tyr_bbox>(oBB) };
+	struct { tyr_triangle* p; } dPrims{ mem.at<tyr_triangle>(oPrims) }, dPrimsOut{ mem.at<tyr_triangle>(oPrimsOut) };
+	struct { Info* p; } dInfo[2] = { { mem.at<Info>(oInfo0) }, { mem.at<Info>(oInfo1) } };
+	struct { int* p; } dSlotOf[2] = { { mem.at<int>(oSlotOf0) }, { mem.at<int>(oSlotOf1) } };
+	struct { uint8_t* p; } dBkt{ mem.at<uint8_t>(oBkt) };
+	struct { uint2* p; } dFlags{ mem.at<uint2>(oFlags) }, dExcl{ mem.at<uint2>(oExcl) }, dBlockSums{ mem.at<uint2>(oBlockSums) };
+	struct { uint32_t* p; } dPosML{ mem.at<uint32_t>(oPosML) }, dPosMR{ mem.at<uint32_t>(oPosMR) };
+	struct { Slot* p; } dSlots[2] = { { mem.at<Slot>(oSlots0) }, { mem.at<Slot>(oSlots1) } };
+	struct { TopNode* p; } dNodes{ mem.at<TopNode>(oNodes) };
+	struct { tyr_bvh_node* p; } dScratch{ mem.at<tyr_bvh_node>(oScratch) }, dOut{ mem.at<tyr_bvh_node>(oOut) };
+	struct { Counters* p; } dK{ mem.at<Counters>(oK) };
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	TYR_D(hipEventCreate(&ev0));
 	TYR_D(hipEventCreate(&ev1));
@@ -819,8 +849,10 @@ int bvh_build_device(int device, tyr_triangle* prims, int32_t n, const tyr_bbox*
 		Slot* Snext = dSlots[cur ^ 1].p;
 		const Info* in = dInfo[cur].p;
 		Info* out = dInfo[cur ^ 1].p;
-		hipLaunchKernelGGL(k_slot_reset, dim3(grid(nSlots)), dim3(kBlockB), 0, st, S, nSlots);
-		hipLaunchKernelGGL(k_bounds, dim3(grid(n)), dim3(kBlockB), 0, st, in, dSlotOf[cur].p, S, n);
+		const bool rootLevel = levelStart.size() == 2;
+		hipLaunchKernelGGL(k_slot_reset, dim3(grid(nSlots)), dim3(kBlockB), 0, st, S, nSlots, rootLevel ? 1 : 0);
+		if (rootLevel) // (every other range got its bounds from its parent's buckets, k_decide_split)
+			hipLaunchKernelGGL(k_bounds, dim3(grid(n)), dim3(kBlockB), 0, st, in, dSlotOf[cur].p, S, n);
 		hipLaunchKernelGGL(k_decide_dim, dim3(grid(nSlots)), dim3(kBlockB), 0, st, S, dNodes.p, nSlots);
 		hipLaunchKernelGGL(k_buckets, dim3(grid(n)), dim3(kBlockB), 0, st, in, dSlotOf[cur].p, S, dBkt.p, n);
 		hipLaunchKernelGGL(k_decide_split, dim3(grid(nSlots)), dim3(kBlockB), 0, st, S, Snext, dNodes.p, dK.p, nSlots);
