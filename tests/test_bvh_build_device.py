@@ -62,6 +62,15 @@ def test_device_build_emits_the_host_builders_bytes(hip):
     neg["e1"][::2, 0] = 0.0
     neg["e2"][::2, 0] = -0.0
     cases["signed_zeros"] = neg
+    # six chains of triangles at +-2^1 .. +-2^40 along the axes: every SAH split peels a few far ones off -- a tree 37 levels deep
+    chains = []
+    for axis in range(3):
+        for sign in (1.0, -1.0):
+            v = np.zeros((40, 3), np.float32)
+            v[:, axis] = (2.0 ** np.arange(1, 41)).astype(np.float32) * np.float32(sign)
+            chains.append(v)
+    v0 = np.concatenate(chains)
+    cases["chains"] = scenes.make_triangles(v0, v0 + np.float32([0.3, 0.9, 0.1]), v0 + np.float32([0.1, 0.4, 1.1]))
     for name, tris in cases.items():
         _same(hip, np.ascontiguousarray(tris), name)
     rng = np.random.default_rng(21)
