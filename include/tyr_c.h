@@ -392,7 +392,7 @@ int tyr_bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bv
 /* The same build -- SAH, the same bytes: every node and the primitive order of the reference's bvh.cpp -- on the DEVICE
  * (SURVEY.md 8f-1's other alternative; hip/bvh_build_dev.hip): the top of the tree level by level with every primitive in
  * flight (bounds and the 14 buckets by parallel min / max, the order-dependent SAH arithmetic by one thread per range in the
- * reference's order, std::partition's permutation from two prefix sums), subtrees of at most 64 primitives by one thread each
+ * reference's order, std::partition's permutation from two prefix sums), subtrees of at most 32 primitives by one thread each
  * running the reference's recursion.  prims / bboxes / nodes_out are HOST arrays as for tyr_bvh_build (prims reordered in
  * place); seconds_out2 (may be NULL): [0] the device's work, [1] the copies in and out.  Returns the node count or a negative
  * status (TYR_ERR_UNSUPPORTED: a degenerate range overflowed a task thread's stack -- use tyr_bvh_build). */

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -40,7 +41,7 @@ constexpr int kBuckets = 14;             // bvh.h:76
 constexpr int kMaxLeafPrims = 4;         // bvh.h:78
 constexpr float kTraversalCost = 1.0f;   // bvh.h:81
 constexpr float kIntersectionCost = 1.0f; // bvh.h:84
-constexpr int kTaskPrims = 64;           // ranges of at most this many primitives are built by one thread
+constexpr int kTaskPrimsDefault = 32;    // ranges of at most this many primitives are built by one thread (C3 on an MI355X: 16 / 32 / 64 / 128 / 256 -> 7.4 / 7.0 / 7.6 / 9.8 / 18.3 ms; TYR_DEVBUILD_TASK_PRIMS overrides)
 constexpr int kTaskStack = 96;           // explicit recursion stack of a task thread (a subtree of kTaskPrims primitives is at most that deep; larger -- degenerate -- tasks may overflow: reported, the host falls back)
 constexpr int kBlockB = 256;
 
@@ -279,28 +280,55 @@ __global__ void k_decide_dim(Slot* slots, TopNode* nodes, int nSlots) {
 	}
 }
 
-// bucket of every primitive of a range that is being split, and the buckets' counts and boxes (bvh.cpp:124-131)
+// bucket of every primitive of a range that is being split, and the buckets' counts, boxes and centroid bounds (bvh.cpp:124-131).
+// Accumulated in LDS per BLOCK while the whole block sits in one range (the top levels: 98 words per range would otherwise take
+// a million atomics each), per WAVE while a wave does (ranges are contiguous and longer than a wave: most waves of the middle
+// levels), lane by lane only in the waves that straddle a boundary.
+constexpr int kBktWords = 13; // count, box lo / hi, centroid lo / hi
+__device__ __forceinline__ void bucket_add(uint32_t* w, const Info& p) { // w: the bucket's 13 words (LDS or global)
+	atomicAdd(&w[0], 1u);
+	for (int k = 0; k < 3; ++k) {
+		atomicMin(&w[1 + k], f2o(p.lo[k]));
+		atomicMax(&w[4 + k], f2o(p.hi[k]));
+		const uint32_t c = f2o(p.c[k]);
+		atomicMin(&w[7 + k], c);
+		atomicMax(&w[10 + k], c);
+	}
+}
+__device__ __forceinline__ void bucket_flush(Slot& S, int b, const uint32_t* w) {
+	atomicAdd(&S.count[b], w[0]);
+	for (int k = 0; k < 3; ++k) {
+		atomicMin(&S.bLo[b][k], w[1 + k]);
+		atomicMax(&S.bHi[b][k], w[4 + k]);
+		atomicMin(&S.bcLo[b][k], w[7 + k]);
+		atomicMax(&S.bcHi[b][k], w[10 + k]);
+	}
+}
 __global__ void k_buckets(const Info* __restrict__ info, const int* __restrict__ slotOf, Slot* slots, uint8_t* __restrict__ bkt, int n) {
-	__shared__ uint32_t shCount[kBuckets], shLo[kBuckets][3], shHi[kBuckets][3], shCLo[kBuckets][3], shCHi[kBuckets][3];
+	__shared__ uint32_t shB[kBuckets][kBktWords];                  // the block's
+	__shared__ uint32_t shW[kBlockB / 64][kBuckets][kBktWords];    // each wave's
 	__shared__ int shSlot, shUniform;
 	const int i = blockIdx.x * kBlockB + threadIdx.x;
 	const int s = i < n ? slotOf[i] : -1;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	if (threadIdx.x == 0) {
 		shSlot = s;
 		shUniform = 1;
 	}
-	if (threadIdx.x < kBuckets) {
-		shCount[threadIdx.x] = 0;
-		for (int k = 0; k < 3; ++k) {
-			shLo[threadIdx.x][k] = shCLo[threadIdx.x][k] = 0xffffffffu;
-			shHi[threadIdx.x][k] = shCHi[threadIdx.x][k] = 0u;
-		}
+	for (int j = threadIdx.x; j < kBuckets * kBktWords; j += kBlockB) {
+		const int w = j % kBktWords;
+		const uint32_t init = w == 0 ? 0u : ((w >= 1 && w <= 3) || (w >= 7 && w <= 9)) ? 0xffffffffu : 0u;
+		(&shB[0][0])[j] = init;
+		for (int v = 0; v < kBlockB / 64; ++v)
+			(&shW[v][0][0])[j] = init;
 	}
 	__syncthreads();
 	if (s != shSlot)
 		shUniform = 0; // (benign race: every writer writes 0)
 	__syncthreads();
-	const bool uniform = shUniform != 0;
+	const bool blockUniform = shUniform != 0;
+	const int s0 = __shfl(s, 0, 64);
+	const bool waveUniform = __all(s == s0) != 0;
 	int b = 0;
 	bool live = false;
 	Info p;
@@ -311,43 +339,35 @@ __global__ void k_buckets(const Info* __restrict__ info, const int* __restrict__
 		bkt[i] = static_cast<uint8_t>(b);
 		live = true;
 	}
-	if (uniform) {
-		if (live) {
-			atomicAdd(&shCount[b], 1u);
-			for (int k = 0; k < 3; ++k) {
-				atomicMin(&shLo[b][k], f2o(p.lo[k]));
-				atomicMax(&shHi[b][k], f2o(p.hi[k]));
-				const uint32_t c = f2o(p.c[k]);
-				atomicMin(&shCLo[b][k], c);
-				atomicMax(&shCHi[b][k], c);
-			}
-		}
+	if (blockUniform) {
+		if (live)
+			bucket_add(shB[b], p);
 		__syncthreads();
-		if (shSlot >= 0 && threadIdx.x < kBuckets && shCount[threadIdx.x] != 0) {
-			Slot& S = slots[shSlot];
-			atomicAdd(&S.count[threadIdx.x], shCount[threadIdx.x]);
-			for (int k = 0; k < 3; ++k) {
-				atomicMin(&S.bLo[threadIdx.x][k], shLo[threadIdx.x][k]);
-				atomicMax(&S.bHi[threadIdx.x][k], shHi[threadIdx.x][k]);
-				atomicMin(&S.bcLo[threadIdx.x][k], shCLo[threadIdx.x][k]);
-				atomicMax(&S.bcHi[threadIdx.x][k], shCHi[threadIdx.x][k]);
-			}
-		}
+		if (shSlot >= 0 && threadIdx.x < kBuckets && shB[threadIdx.x][0] != 0)
+			bucket_flush(slots[shSlot], threadIdx.x, shB[threadIdx.x]);
+	} else if (waveUniform) {
+		if (live)
+			bucket_add(shW[wave][b], p);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (s0 >= 0 && lane < kBuckets && shW[wave][lane][0] != 0)
+			bucket_flush(slots[s0], lane, shW[wave][lane]);
 	} else if (live) {
 		Slot& S = slots[s];
-		atomicAdd(&S.count[b], 1u);
+		uint32_t one[kBktWords];
+		one[0] = 1u;
 		for (int k = 0; k < 3; ++k) {
-			atomicMin(&S.bLo[b][k], f2o(p.lo[k]));
-			atomicMax(&S.bHi[b][k], f2o(p.hi[k]));
-			const uint32_t c = f2o(p.c[k]);
-			atomicMin(&S.bcLo[b][k], c);
-			atomicMax(&S.bcHi[b][k], c);
+			one[1 + k] = f2o(p.lo[k]);
+			one[4 + k] = f2o(p.hi[k]);
+			one[7 + k] = one[10 + k] = f2o(p.c[k]);
 		}
+		bucket_flush(S, b, one);
 	}
 }
 
 // bvh.cpp:132-193: the SAH, leaf or split, the children
-__global__ void k_decide_split(Slot* slots, Slot* next, TopNode* nodes, Counters* K, int nSlots) {
+__global__ void k_decide_split(Slot* slots, Slot* next, TopNode* nodes, Counters* K, int nSlots, int kTaskPrims) {
 	const int s = blockIdx.x * kBlockB + threadIdx.x;
 	if (s >= nSlots)
 		return;
@@ -779,6 +799,9 @@ int bvh_build_device(int device, tyr_triangle* prims, int32_t n, const tyr_bbox*
 		return TYR_ERR_NO_DEVICE;
 	TYR_D(hipSetDevice(device));
 	const size_t N = static_cast<size_t>(n);
+	int kTaskPrims = kTaskPrimsDefault;
+	if (const char* e = std::getenv("TYR_DEVBUILD_TASK_PRIMS"))
+		kTaskPrims = std::max(4, std::min(std::atoi(e), 4096));
 	// one allocation, carved up (nineteen hipMalloc / hipFree pairs were 35 ms of a 50 ms call around 9 ms of work)
 	const size_t maxSlots = N / (kTaskPrims + 1) + 2, maxTop = 2 * N + 2, nScanBlocks = (N + 1 + kScanPerBlock - 1) / kScanPerBlock;
 	struct Carve {
@@ -855,7 +878,7 @@ int bvh_build_device(int device, tyr_triangle* prims, int32_t n, const tyr_bbox*
 			hipLaunchKernelGGL(k_bounds, dim3(grid(n)), dim3(kBlockB), 0, st, in, dSlotOf[cur].p, S, n);
 		hipLaunchKernelGGL(k_decide_dim, dim3(grid(nSlots)), dim3(kBlockB), 0, st, S, dNodes.p, nSlots);
 		hipLaunchKernelGGL(k_buckets, dim3(grid(n)), dim3(kBlockB), 0, st, in, dSlotOf[cur].p, S, dBkt.p, n);
-		hipLaunchKernelGGL(k_decide_split, dim3(grid(nSlots)), dim3(kBlockB), 0, st, S, Snext, dNodes.p, dK.p, nSlots);
+		hipLaunchKernelGGL(k_decide_split, dim3(grid(nSlots)), dim3(kBlockB), 0, st, S, Snext, dNodes.p, dK.p, nSlots, kTaskPrims);
 		hipLaunchKernelGGL(k_flags, dim3(grid(n)), dim3(kBlockB), 0, st, dSlotOf[cur].p, S, dBkt.p, dFlags.p, n);
 		hipLaunchKernelGGL(k_scan_sums, dim3(static_cast<unsigned>(nScanBlocks)), dim3(kBlockB), 0, st, dFlags.p, dBlockSums.p, n);
 		hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kBlockB), 0, st, dBlockSums.p, static_cast<int>(nScanBlocks));
