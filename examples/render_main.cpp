@@ -59,6 +59,8 @@ int main(int argc, char** argv) {
 	TYR_CHECK(tyr_create(&ctx, &cfg));
 
 	set_default_ctx(ctx); // the reference's device state is process-wide: the handle-less calls below use this context
+	if (std::getenv("TYR_BUILD_ON_DEVICE"))
+		set_build_device(device); // `BVH bvh(primitives, bboxes, SAH)` (Scene.cpp:53) on the GPU: the same bytes (tyr_bvh_build_device)
 
 	Scene scene;
 	if (argc > 4)

@@ -4,6 +4,7 @@
 #pragma once
 #include <iostream>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "../tyr_c.h"
@@ -13,6 +14,15 @@
 namespace tyrant {
 
 enum class PartitionAlgorithm { Middle, EqualCounts, SAH }; // bvh.h:45-47
+
+// Where `BVH`'s constructor builds (SAH only): -1 (default) = on the host's threads (tyr_bvh_build), d >= 0 = on device d
+// (tyr_bvh_build_device).  Either way the nodes and the primitive order are the reference's bvh.cpp's, byte for byte; a device
+// build that cannot finish (TYR_ERR_UNSUPPORTED: a degenerate range beyond what one thread's stack holds) falls back to the host.
+inline int& build_device_slot() {
+	static int device = -1; // (inline function: one object for the whole program)
+	return device;
+}
+inline void set_build_device(int device) { build_device_slot() = device; }
 
 class BVH {
 public:
@@ -33,8 +43,13 @@ public:
 		if (primitives.empty())
 			return;
 		nodes.resize(2 * primitives.size() - 1);
-		const int rc = tyr_bvh_build(reinterpret_cast<tyr_triangle*>(primitives.data()), static_cast<int32_t>(primitives.size()),
-			reinterpret_cast<const tyr_bbox*>(primitivesBBoxes.data()), reinterpret_cast<tyr_bvh_node*>(nodes.data()), static_cast<int32_t>(partitionAlgo));
+		int rc = TYR_ERR_UNSUPPORTED;
+		if (partitionAlgo == PartitionAlgorithm::SAH && build_device_slot() >= 0)
+			rc = tyr_bvh_build_device(build_device_slot(), reinterpret_cast<tyr_triangle*>(primitives.data()), static_cast<int32_t>(primitives.size()),
+				reinterpret_cast<const tyr_bbox*>(primitivesBBoxes.data()), reinterpret_cast<tyr_bvh_node*>(nodes.data()), nullptr);
+		if (rc == TYR_ERR_UNSUPPORTED)
+			rc = tyr_bvh_build(reinterpret_cast<tyr_triangle*>(primitives.data()), static_cast<int32_t>(primitives.size()),
+				reinterpret_cast<const tyr_bbox*>(primitivesBBoxes.data()), reinterpret_cast<tyr_bvh_node*>(nodes.data()), static_cast<int32_t>(partitionAlgo));
 		if (rc < 0) // Middle is unimplemented in the reference too (bvh.cpp:190-193 prints an error)
 			throw std::invalid_argument(std::string("BVH: ") + tyr_status_string(rc));
 		nNodes = rc;

@@ -454,6 +454,11 @@ def test_cpp_host_api_example(hip):
     p = subprocess.run([exe, "0", "8", out, ply], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "Loading scene:" in p.stdout and "frame counter 9" in p.stdout, p.stdout
+    # ... and with `BVH bvh(primitives, bboxes, SAH)` built ON THE DEVICE (tyrant::set_build_device): the same tree, so the same picture's ray totals
+    q = subprocess.run([exe, "0", "8", out, ply], capture_output=True, text=True, timeout=300, env=dict(os.environ, TYR_BUILD_ON_DEVICE="1"))
+    assert q.returncode == 0, q.stdout + q.stderr
+    nodes_line = [l for l in p.stdout.splitlines() if "total nodes" in l]
+    assert nodes_line and nodes_line == [l for l in q.stdout.splitlines() if "total nodes" in l], (p.stdout, q.stdout)
 
 
 @pytest.mark.parametrize("knobs", [
