@@ -610,7 +610,14 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	const bool wantPairs = (c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) != 0;
 	DeviceLayout L;
 	const auto t0 = std::chrono::steady_clock::now();
-	if ((rc = build_device_layout(nodes, nNodes, prims, nPrims, L, wantPairs)))
+	try { // (the layout pass allocates and starts threads: nothing may leave a C entry point as an exception)
+		rc = build_device_layout(nodes, nNodes, prims, nPrims, L, wantPairs);
+	} catch (const std::bad_alloc&) {
+		rc = TYR_ERR_OOM;
+	} catch (...) {
+		rc = TYR_ERR_UNSUPPORTED;
+	}
+	if (rc)
 		return rc;
 	const auto t1 = std::chrono::steady_clock::now();
 	c->uploadLayoutS = std::chrono::duration<double>(t1 - t0).count();
@@ -1797,7 +1804,14 @@ int tyr_layout_probe(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triang
 	std::memset(out, 0, sizeof *out);
 	DeviceLayout L;
 	const auto t0 = std::chrono::steady_clock::now();
-	const int rc = build_device_layout(nodes, nNodes, prims, nPrims, L, want_pairs != 0);
+	int rc;
+	try {
+		rc = build_device_layout(nodes, nNodes, prims, nPrims, L, want_pairs != 0);
+	} catch (const std::bad_alloc&) {
+		rc = TYR_ERR_OOM;
+	} catch (...) {
+		rc = TYR_ERR_UNSUPPORTED;
+	}
 	out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	if (rc)
 		return rc;
@@ -1876,7 +1890,13 @@ int tyr_bvh_build_device(int32_t device, tyr_triangle* prims, int32_t n, const t
 		for (int k = 0; k < 6; ++k)
 			if (!std::isfinite((&bboxes[i].bounds[0][0])[k]))
 				return TYR_ERR_INVALID;
-	return bvh_build_device(device, prims, n, bboxes, nodes_out, seconds_out2);
+	try {
+		return bvh_build_device(device, prims, n, bboxes, nodes_out, seconds_out2);
+	} catch (const std::bad_alloc&) {
+		return TYR_ERR_OOM;
+	} catch (...) {
+		return TYR_ERR_UNSUPPORTED;
+	}
 }
 
 int tyr_set_build_threads(int32_t threads) {
