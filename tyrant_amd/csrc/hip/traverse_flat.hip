@@ -509,6 +509,32 @@ __device__ __forceinline__ uint32_t quad_or(uint32_t v) {
 }
 template <int K>
 __device__ __forceinline__ float quad_bcast_f(float v) { return __uint_as_float(quad_perm_u<K * 0x55>(__float_as_uint(v))); }
+// wide_drain is a function of its own (below): its pointer arguments arrive as GENERIC pointers, and a load through one is
+// a flat load -- it counts on vmcnt AND lgkmcnt, so that every wait for a stack entry in LDS also waits for the records in
+// flight.  These say what the kernel knows: the scene and the queues are global memory.
+#ifdef TYR_WIDE_FLAT_LOADS // (what-if: the loads as they were until round 5)
+#define TYR_GLOBAL
+#else
+#define TYR_GLOBAL __attribute__((address_space(1)))
+#endif
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float2 gload_f2(const float* p) {
+	const v2f_t v = *(const TYR_GLOBAL v2f_t*)p;
+	return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float4 gload_f4(const float4* p) {
+	const v4f_t v = *(const TYR_GLOBAL v4f_t*)p;
+	return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t gload_u(const float* p) { return *(const TYR_GLOBAL uint32_t*)p; }
+__device__ __forceinline__ TriData triangle_gload(const float4* tris, uint32_t prim) {
+	TriData d;
+	d.a = gload_f4(tris + 3 * prim + 0);
+	d.b = gload_f4(tris + 3 * prim + 1);
+	d.c = make_float4(__uint_as_float(gload_u(reinterpret_cast<const float*>(tris + 3 * prim + 2))), 0.0f, 0.0f, 0.0f); // (the tests read c.x only)
+	return d;
+}
 constexpr uint32_t kWideRays = 16;        // a wave switches to four lanes per ray once it holds at most this many
 constexpr int kWideStackEntries = 4 * 12; // the four lanes' LDS columns of a group, as one stack
 
@@ -599,6 +625,15 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 	// needs at all (wave-uniform branches on ballots), state changes are selects, loads of lanes that have nothing to load
 	// go to record 0.  A lane that turns a node into a leaf tests the leaf in the same trip.
 	const bool allRegular = __ballot(gActive && !regular) == 0ull; // (the generic box test is exact for regular rays too: one path for the wave)
+#ifdef TYR_WIDE_PREFETCH
+	// what-if (round 5; bit-exact, +-0: profiles/r05_whatif_wide_prefetch.txt).
+	// The record on top of the stack, fetched while a leaf's primitives are: a ray's steps are a chain of dependent fetches
+	// (node -> leaf -> pop -> node ...), and the launch ends on the longest such chain.  What the pop after a leaf will ask for
+	// is known when the leaf is entered -- the top entry -- so this lane's part of THAT record travels beside the primitives
+	// and waits in pf* under the reference it belongs to (records never change: whenever `ref == pfRef` the copy is the record).
+	uint32_t pfRef = kRefDone, pcref = 0u;
+	float2 pbx = make_float2(0.0f, 0.0f), pby = pbx, pbz = pbx;
+#endif
 #ifdef TYR_WIDE_LONE_GROUPS
 	// what-if (round 5): the launch's very last rays -- a wave down to TYR_WIDE_LONE_GROUPS groups or fewer -- are bound by the
 	// latency of one step, not by the SIMD's issue slots; they take the loop with branches below, which runs only the blocks a
@@ -628,10 +663,21 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 			const uint32_t idx = atNode ? (ref & kQuadIndexMask) : 0u, meta = ref >> kQuadOrderShift;
 			const float* qf = reinterpret_cast<const float*>(quads + 8 * idx);
 			const uint32_t at = (sub >> 1) * 4u + (sub & 1u) * 2u;
+#ifdef TYR_WIDE_PREFETCH
+			float2 bx = pbx, by = pby, bz = pbz;
+			uint32_t cref = pcref;
+			if (ref != pfRef) { // (lanes that are at no node load record 0, as before)
+				bx = gload_f2(qf + at);
+				by = gload_f2(qf + 8 + at);
+				bz = gload_f2(qf + 16 + at);
+				cref = gload_u(qf + 24 + sub);
+			}
+#else
 			const float2 bx = *reinterpret_cast<const float2*>(qf + at);
 			const float2 by = *reinterpret_cast<const float2*>(qf + 8 + at);
 			const float2 bz = *reinterpret_cast<const float2*>(qf + 16 + at);
 			const uint32_t cref = __float_as_uint(qf[24 + sub]);
+#endif
 			float t;
 			bool h;
 			if (allRegular)
@@ -662,10 +708,25 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 			const uint32_t off = ref & (kMaxPrimOffset - 1);
 			const uint32_t cnt = atLeaf ? ((ref >> 26) & 31u) + 1u : 0u;
 			bool found = false;
+#ifdef TYR_WIDE_PREFETCH
+			{
+				const int top = n > 0 ? n - 1 : 0;
+				const entry_t e = gstack[(top >> 2) * kBlock + (top & 3)];
+				if (atLeaf && n > 0 && (int)e.x >= 0 && e.x != pfRef && __uint_as_float(e.y) < dist) {
+					const float* pq = reinterpret_cast<const float*>(quads + 8 * (e.x & kQuadIndexMask));
+					const uint32_t at = (sub >> 1) * 4u + (sub & 1u) * 2u;
+					pbx = gload_f2(pq + at);
+					pby = gload_f2(pq + 8 + at);
+					pbz = gload_f2(pq + 16 + at);
+					pcref = gload_u(pq + 24 + sub);
+					pfRef = e.x;
+				}
+			}
+#endif
 			for (uint32_t base = 0; __ballot(base < cnt) != 0ull; base += 4u) {
 				const uint32_t i = base + sub;
 				const bool mine = i < cnt;
-				const TriData td = triangle_load(tris, mine ? off + i : 0u);
+				const TriData td = triangle_gload(tris, mine ? off + i : 0u);
 				float tm = triangle_test_select(td, r);
 				tm = mine ? tm : 0.0f;
 				const float t0 = quad_bcast_f<0>(tm), t1 = quad_bcast_f<1>(tm), t2 = quad_bcast_f<2>(tm), t3 = quad_bcast_f<3>(tm);
