@@ -12,16 +12,21 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tyrant_amd import binding, scenes  # noqa: E402
 
-sc = scenes.mesh_scene(706)
+args = dict(a.split("=") for a in sys.argv[1:])
+if args.pop("scene", "c3") == "c5":  # the config that IS byte-bound (10 M triangles, 4K): 2 spp in flight = the same 16.6 M slots
+    sc = scenes.glass_dof_scene()
+    W, H = 3840, 2160
+    N = 2 * W * H
+else:
+    sc = scenes.mesh_scene(706)
+    W, H = 1920, 1080
+    N = 8 * W * H
 nodes, prims = binding.bvh_build(sc.triangles)
-W, H = 1920, 1080
-N = 8 * W * H
 flags = binding.TYR_FLAG_PROFILE | (binding.TYR_FLAG_TRIANGLE_MATERIALS if sc.triangle_materials else 0)
 r = binding.Renderer(W, H, N, flags=flags)
 r.load_scene(sc, nodes, prims)
 r.set_budget(N)
-for a in sys.argv[1:]:
-    k, v = a.split("=")
+for k, v in args.items():
     r.set_tuning(**{k: int(v)})
 
 tv = sc.triangles["vert"].astype(np.float64)
