@@ -225,7 +225,9 @@ def main():
         r = binding.Renderer(W, H, N, device=local_rank, flags=flags, blit_buffer=accum.data_ptr(), **shard)
         r.load_scene(sc, nodes, prims)
         info = r.scene_info()
-        upload = {"layout": round(info["upload_layout_s"], 6), "copy": round(info["upload_copy_s"], 6), "device_bytes": info["device_bytes"]}
+        upload = {"layout": round(info["upload_layout_s"], 6), "copy": round(info["upload_copy_s"], 6), "layout_on": "device" if info["layout_on_device"] else "host", "device_bytes": info["device_bytes"]}
+        if info["layout_on_device"]:  # ... and the host pass on the same arrays, for the line
+            upload["host_layout"] = round(binding.layout_probe(nodes, prims, want_pairs=False)["seconds"], 6)
         if tune:
             r.set_tuning(**tune)
         comm = None
@@ -387,8 +389,21 @@ def main():
             dn, dp, sec = binding.bvh_build_device(sc.triangles, device=local_rank)
             dev_build = {"device": round(sec[0], 6), "copies": round(sec[1], 6), "same_bytes_as_host_build": bool(dn.tobytes() == nodes.tobytes() and dp.tobytes() == prims.tobytes()),
                          "note": "tyr_bvh_build_device: host arrays in and out; `device` = first kernel to last (hipEvents), `copies` = triangles + boxes in, nodes + reordered triangles out"}
+            # both halves of Scene::Load in one call, nothing but triangles crossing the bus (tyr_scene_build_upload): a ctx of its own
+            r2 = binding.Renderer(64, 48, 64 * 48, device=local_rank, flags=flags)
+            try:
+                r2.build_upload(sc.triangles[:1024], want_nodes=False)
+                _, p2, s3 = r2.build_upload(sc.triangles, want_nodes=False)
+                h2 = r2.scene_hash()
+                r2.upload(nodes, prims)
+                h1 = r2.scene_hash()
+                dev_build["build_upload"] = {"build": round(s3[0], 6), "layout": round(s3[1], 6), "copies": round(s3[2], 6),
+                                             "same_scene_in_hbm_as_build_then_upload": bool(p2.tobytes() == prims.tobytes() and all(h1[k] == h2[k] for k in h1 if k != "seconds")),
+                                             "note": "tyr_scene_build_upload: the tree built AND laid out on the device, the nodes never leave HBM; `copies` = triangles + boxes in, reordered triangles out"}
+            finally:
+                r2.close()
         except Exception as e:  # noqa: BLE001
-            dev_build = {"error": repr(e)}
+            dev_build = {**(dev_build or {}), "error": repr(e)}
 
     steady = None
     if world == 1 and not args.no_steady_state:
@@ -431,7 +446,7 @@ def main():
                 "in_tree_fraction": {"all_rays": round(m["in_tree_frac"], 4), "extend_rays": round(m["in_tree_ext_frac"], 4), "note": "rays whose test of the root box passes (counting build, rank 0's shard); the others cost one box test"},
                 "host_bvh_build_s": round(t_build, 6),
                 **({"device_bvh_build_s": dev_build} if dev_build else {}),
-                "host_scene_upload_s": {**m["upload"], "note": "tyr_scene_upload of the timed renderer (Scene.cpp:53-67's upload half), outside the timed region: `layout` = the host's re-layout of the reference's node array as quad nodes + 48-byte triangles on the builder's threads, `copy` = device allocation + the copies to HBM"},
+                "host_scene_upload_s": {**m["upload"], "note": "tyr_scene_upload of the timed renderer (Scene.cpp:53-67's upload half), outside the timed region.  layout_on device (TYR_TUNE_LAYOUT_ON_DEVICE, the default): `copy` = the reference's node and triangle arrays to HBM as they are, `layout` = hip/bvh_layout_dev.hip making quad nodes + 48-byte triangles there (the same bytes), `host_layout` = the host pass on the builder's threads, for comparison; layout_on host: `layout` = that host pass, `copy` = allocation + the finished records to HBM"},
                 **oracle_counters_check(args, world, W, H, spp_total, N, int(prims.shape[0]), m),
                 "render_path": "tyr_render defaults: merged traversal launches (extend(i + 1) + connect(i)), sphere halves folded into shade, rays whose fate is known where they are made (camera rays / survivors that hit nothing, shadow rays that cannot reach a triangle) finished in place -- they count as rays, they never enter a queue; launch-per-iteration (TYR_TUNE_STREAM_TAIL = 0)",
                 **({"tuning": tune} if tune else {}),

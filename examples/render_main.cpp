@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
 
 	set_default_ctx(ctx); // the reference's device state is process-wide: the handle-less calls below use this context
 	if (std::getenv("TYR_BUILD_ON_DEVICE"))
-		set_build_device(device); // `BVH bvh(primitives, bboxes, SAH)` (Scene.cpp:53) on the GPU: the same bytes (tyr_bvh_build_device)
+		set_build_device(device); // Scene.cpp:53-67 on the GPU: `BVH bvh(...)` builds there (tyr_bvh_build_device), Scene::Load builds AND lays out there (tyr_scene_build_upload): the same bytes
 
 	Scene scene;
 	if (argc > 4)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TYR_ABI_VERSION 4 /* 2: tyr_counters grows (rays_in_tree_*, debug[16]), tyr_dist_*, per-triangle colours; 3: retired tuning keys removed, tyr_sunsky_probe / tyr_sun_setup; 4: tyr_set_frame, tyr_layout_probe, tyr_bvh_build_device, tyr_scene_info grows (upload_*_s) */
+#define TYR_ABI_VERSION 4 /* 2: tyr_counters grows (rays_in_tree_*, debug[16]), tyr_dist_*, per-triangle colours; 3: retired tuning keys removed, tyr_sunsky_probe / tyr_sun_setup; 4: tyr_set_frame, tyr_layout_probe, tyr_bvh_build_device, tyr_scene_build_upload, tyr_scene_hash, tyr_scene_info grows (upload_*_s, layout_on_device) */
 
 /* ---- record layouts (identical to the reference structs) ------------------ */
 
@@ -266,8 +266,10 @@ typedef struct tyr_scene_info {
 	uint32_t max_prim_offset;  /* 1 << 26 */
 	uint32_t quad_max_stack;   /* the most stack entries any traversal of this tree can need (the drain's four-lanes-to-a-ray form holds 48 and is used only below that) */
 	uint64_t device_bytes;     /* quad nodes + pair nodes + 48-byte triangles resident in HBM */
-	double upload_layout_s;    /* the last tyr_scene_upload: seconds in the host's layout passes (on the threads of tyr_set_build_threads) ... */
+	double upload_layout_s;    /* the last tyr_scene_upload / tyr_scene_build_upload: seconds in the layout passes (on the device, or on the threads of tyr_set_build_threads) ... */
 	double upload_copy_s;      /* ... and in device allocation + the copies to HBM */
+	uint32_t layout_on_device; /* 1: that layout ran on the device (TYR_TUNE_LAYOUT_ON_DEVICE; hip/bvh_layout_dev.hip), 0: on the host */
+	uint32_t reserved_;
 } tyr_scene_info;
 int tyr_get_scene_info(tyr_ctx* ctx, tyr_scene_info* out);
 
@@ -281,6 +283,9 @@ typedef struct tyr_layout_stats {
 	double seconds;
 } tyr_layout_stats;
 int tyr_layout_probe(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims, int32_t want_pairs, tyr_layout_stats* out);
+/* The same figures for the scene a ctx HOLDS: the arrays are read back from HBM and hashed like tyr_layout_probe's (pair nodes:
+ * only a ctx that has them).  Equal hashes = the device holds the bytes the host pass makes, wherever the layout ran. */
+int tyr_scene_hash(tyr_ctx* ctx, tyr_layout_stats* out);
 
 /* The vector functions every kernel is built from (hip/vecmath.hpp: glm's dot, cross, normalize, length, reflect, min,
  * max, clamp, mix, smoothstep and the vec3 operators in glm's evaluation order -- Dependencies/glm-0.9.9.3/glm/detail/
@@ -333,6 +338,7 @@ enum {
 	TYR_TUNE_RESOLVE_SHADOWS = 21,   /* merged path of tyr_render, with TYR_TUNE_FOLD_SPHERES: 1 (default) = a shadow ray that a sphere occludes or that fails the tree's root box for its bound is answered by shade itself (visible: its colour joins the pixel's contribution; kernel.cu:630-646 reduced to what is known) and never queued; it still counts as emitted / visible */
 	TYR_TUNE_WIDE_BLOCK_MIN_ITEMS = 22, /* k_trace_flat: a launch of at least this many rays (extend + carried shadow rays) runs as 768-thread blocks -- two per CU, six waves per SIMD, one copy of the staged nodes per three 256-thread parts -- instead of 256-thread blocks at five waves per SIMD; default 3 Mi (the sixth wave feeds a fat launch faster and lengthens the drain of a thin one); -1: never */
 	TYR_TUNE_FOLD_PROLOGUE = 23,     /* tyr_render, one iteration ahead of the counts (TYR_TUNE_RUN_AHEAD) with TYR_TUNE_FOLD_SPHERES: 1 (default) = once the primary budget is spent, the kernel that ends an iteration (the slot scan) also opens the next one -- set_wavefront_globals (kernel.cu:227-244) and the padding of the queue segments' ends -- instead of a one-block launch each in front of the traversal kernel; 0 = those launches */
+	TYR_TUNE_LAYOUT_ON_DEVICE = 24,  /* tyr_scene_upload: 1 (default) = the reference's node and triangle arrays are copied to the device as they are (32 + 40 bytes per node / triangle) and the layout pass runs there (hip/bvh_layout_dev.hip: the same bytes as the host pass; trees it leaves to the host -- pair nodes wanted, leaves of more than 31 primitives, a tree that is one leaf, malformed input -- take the host pass); 0 = always the host pass + a copy of the finished records (128 + 48 bytes) */
 	TYR_TUNE_FOLD_SPHERES = 19       /* merged path of tyr_render: 1 (default) = shade does the sphere pre-passes' work (kernel.cu:127-136, 168-172) for the rays it emits, while they are in registers; 0 = the pre-pass kernels re-read them */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);
@@ -397,6 +403,13 @@ int tyr_bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bv
  * place); seconds_out2 (may be NULL): [0] the device's work, [1] the copies in and out.  Returns the node count or a negative
  * status (TYR_ERR_UNSUPPORTED: a degenerate range overflowed a task thread's stack -- use tyr_bvh_build). */
 int tyr_bvh_build_device(int32_t device, tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, double* seconds_out2);
+/* Scene::Load's two halves in ONE call (Scene.cpp:53 the build, :55-67 the upload): the tree is built on the ctx's device
+ * (tyr_bvh_build_device's kernels) and laid out there (TYR_TUNE_LAYOUT_ON_DEVICE's kernels) -- the nodes never leave HBM unless
+ * asked for.  prims is reordered in place (bvh.cpp:24); nodes_out (may be NULL; else 2n - 1 entries) receives the reference's
+ * node array, *n_nodes_out (may be NULL) its length; seconds_out3 (may be NULL): [0] the build, [1] the layout, [2] the copies
+ * (triangles and boxes in, triangles -- and nodes -- out).  Whatever the device halves leave to the host (see both) is done
+ * there: the scene the ctx ends up with is tyr_bvh_build + tyr_scene_upload's, byte for byte (tyr_scene_hash). */
+int tyr_scene_build_upload(tyr_ctx* ctx, tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t* n_nodes_out, double* seconds_out3);
 /* Threads tyr_bvh_build may use: the top of the tree fans out into tasks, the output is byte-identical
  * to the serial build.  0 = automatic (env TYR_BUILD_THREADS, else min(16, cores)); 1 = the reference's serial behaviour. */
 int tyr_set_build_threads(int32_t threads);

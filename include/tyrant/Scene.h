@@ -69,6 +69,19 @@ public:
 			tyr_scene_upload(ctx, nullptr, 0, nullptr, 0);
 			return;
 		}
+		if (build_device_slot() >= 0) {
+			// tyrant::set_build_device: Scene.cpp:53 and :55-67 in one call -- the tree is built on the ctx's device and laid out there, the
+			// nodes never leave HBM (the reference's `bvh` is a local of this function too: nobody reads it afterwards).  `primitives` comes
+			// back in the builder's order (bvh.cpp:24); what the device leaves to the host is done there, the scene is the same bytes.
+			std::cout << "Creating BVH, total primitives: " << primitives.size() << "\n"; // bvh.cpp:7
+			int32_t nNodes = 0;
+			const int rc = tyr_scene_build_upload(ctx, reinterpret_cast<tyr_triangle*>(primitives.data()), static_cast<int32_t>(primitives.size()),
+				reinterpret_cast<const tyr_bbox*>(primitiveBBoxes.data()), nullptr, &nNodes, nullptr);
+			if (rc)
+				throw std::runtime_error(std::string("Scene::Load: ") + tyr_status_string(rc));
+			std::cout << "Created BVH, total nodes : " << nNodes << "\n"; // bvh.cpp:27
+			return;
+		}
 		BVH bvh(primitives, primitiveBBoxes, PartitionAlgorithm::SAH); // Scene.cpp:53
 		const int rc = tyr_scene_upload(ctx, reinterpret_cast<const tyr_bvh_node*>(bvh.nodes.data()), bvh.nNodes, reinterpret_cast<const tyr_triangle*>(primitives.data()),
 			static_cast<int32_t>(primitives.size()));

@@ -18,6 +18,7 @@ enum class PartitionAlgorithm { Middle, EqualCounts, SAH }; // bvh.h:45-47
 // Where `BVH`'s constructor builds (SAH only): -1 (default) = on the host's threads (tyr_bvh_build), d >= 0 = on device d
 // (tyr_bvh_build_device).  Either way the nodes and the primitive order are the reference's bvh.cpp's, byte for byte; a device
 // build that cannot finish (TYR_ERR_UNSUPPORTED: a degenerate range beyond what one thread's stack holds) falls back to the host.
+// With a build device set, Scene::Load (Scene.h) goes one step further: tyr_scene_build_upload, the tree built AND laid out on the ctx's device.
 inline int& build_device_slot() {
 	static int device = -1; // (inline function: one object for the whole program)
 	return device;

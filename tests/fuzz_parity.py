@@ -52,9 +52,12 @@ for case in range(n_cases):
     nodes, prims = pyorc.bvh_build(sc.triangles, bb)
     o = pyorc.Oracle(W, H, N, rank=rank, nranks=nranks, flags=flags)
     g = binding.Renderer(W, H, N, rank=rank, nranks=nranks, flags=flags)
+    g.set_tuning(layout_on_device=int(rng.integers(0, 2)))  # where tyr_scene_upload's layout pass runs: the same bytes either way
     for r in (o, g):
         r.load_scene(sc, nodes, prims)
         r.set_camera(cam)
+    if rng.random() < 0.25:  # ... or the tree built and laid out on the device in one call (tyr_scene_build_upload): the same scene again
+        g.build_upload(sc.triangles, bb, want_nodes=False)
     sun = (float(rng.uniform(0, 1)), float(rng.uniform(0.05, 0.49)))
     o.set_sun_position(*sun), g.set_sun_position(*sun)
     g.set_tuning(**knobs)

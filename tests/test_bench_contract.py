@@ -143,6 +143,8 @@ def test_bench_emits_the_contract_line():
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["in_tree_Mrays/s"] <= d["value"]
     assert d["config"]["device_bvh_build_s"]["same_bytes_as_host_build"] is True and d["config"]["device_bvh_build_s"]["device"] >= 0  # the tree built again on the GPU: the host builder's bytes
+    assert d["config"]["device_bvh_build_s"]["build_upload"]["same_scene_in_hbm_as_build_then_upload"] is True  # ... and built + laid out there in one call: the same scene in HBM
+    assert d["config"]["host_scene_upload_s"]["layout_on"] == "device"
     assert d["config"]["oracle_counters_match"] is None  # (only the default job has committed oracle counters; this micro-job says so)
     ss = d["config"]["steady_state"]  # the same kernels with the queue kept full, beside the metric (never instead of it)
     assert ss["Mrays/s"] > 0 and ss["iterations"] == 12 and ss["queue_size"] == d["config"]["queue_size"]

@@ -23,7 +23,7 @@ def _same(hip, tris, what, bboxes=None):
     return dn, dp, sec
 
 
-def test_device_build_emits_the_host_builders_bytes(hip):
+def _cases():
     from tyrant_amd import scenes
 
     box = scenes.cornell_box().triangles
@@ -71,8 +71,14 @@ def test_device_build_emits_the_host_builders_bytes(hip):
             chains.append(v)
     v0 = np.concatenate(chains)
     cases["chains"] = scenes.make_triangles(v0, v0 + np.float32([0.3, 0.9, 0.1]), v0 + np.float32([0.1, 0.4, 1.1]))
-    for name, tris in cases.items():
-        _same(hip, np.ascontiguousarray(tris), name)
+    return {k: np.ascontiguousarray(v) for k, v in cases.items()}
+
+
+def test_device_build_emits_the_host_builders_bytes(hip):
+    from tyrant_amd import scenes
+
+    for name, tris in _cases().items():
+        _same(hip, tris, name)
     rng = np.random.default_rng(21)
     for case in range(25):
         n = int(rng.integers(1, 40000))
@@ -104,3 +110,136 @@ def test_device_build_of_the_benchmark_trees_equals_the_reference_bvh_cpp(hip):
         assert hashlib.sha256(nodes.tobytes()).hexdigest() == g["nodes_sha256"], key
         assert hashlib.sha256(np.ascontiguousarray(prims.view(np.uint8).reshape(-1, 40)[:, :37]).tobytes()).hexdigest() == g["prims_sha256"], key  # (bytes 37-39 of a Triangle are padding)
         print(f"{key}: {len(tris)} triangles -> {len(nodes)} nodes in {sec[0] * 1e3:.1f} ms on the device (+ {sec[1] * 1e3:.1f} ms of copies in and out)")
+
+
+# ---- hip/bvh_layout_dev.hip: the upload's layout pass on the device (TYR_TUNE_LAYOUT_ON_DEVICE), and both halves in one call ----
+_LAYOUT_KEYS = ("n_pair_nodes", "n_quad_nodes", "n_staged_nodes", "quad_max_stack", "root_ref", "quad_root_ref", "hash_quads", "hash_tris")
+
+
+def _layout_matches_host(hip, r, nodes, prims, what, expect_on_device=None):
+    """the scene `r` holds in HBM, read back, against the host pass on the same arrays (tyr_scene_hash vs tyr_layout_probe)"""
+    want = hip.layout_probe(nodes, prims, want_pairs=False)
+    got = r.scene_hash()
+    for k in _LAYOUT_KEYS:
+        assert got[k] == want[k], (what, k, got[k], want[k])
+    if expect_on_device is not None:
+        assert r.scene_info()["layout_on_device"] == int(expect_on_device), (what, r.scene_info())
+
+
+def test_layout_on_the_device_writes_the_host_passs_bytes(hip):
+    """every tree of the builder's test list uploaded twice -- layout on the device, layout on the host -- and read back"""
+    from tyrant_amd import scenes
+
+    r = hip.Renderer(64, 48, 64 * 48)
+    host_only = {"one", "two", "longleaf", "only_long", "big_identical"}  # one-leaf trees, leaves of more than 31 primitives
+    for name, tris in _cases().items():
+        nodes, prims = hip.bvh_build(tris)
+        r.set_tuning(layout_on_device=1)
+        r.upload(nodes, prims)
+        on_device = r.scene_info()["layout_on_device"]
+        if name in host_only:
+            assert on_device == 0, name
+        elif len(nodes) >= 3 and int(nodes["primitiveCount"].max()) <= 31:
+            assert on_device == 1, name
+        _layout_matches_host(hip, r, nodes, prims, name)
+        r.set_tuning(layout_on_device=0)
+        r.upload(nodes, prims)
+        _layout_matches_host(hip, r, nodes, prims, name + " (host)", expect_on_device=False)
+    rng = np.random.default_rng(5)
+    r.set_tuning(layout_on_device=1)
+    for case in range(20):
+        t = scenes.random_soup(int(rng.integers(3, 60000)), seed=int(rng.integers(1, 1 << 30)))
+        nodes, prims = hip.bvh_build(t)
+        r.upload(nodes, prims)
+        _layout_matches_host(hip, r, nodes, prims, f"fuzz {case}", expect_on_device=len(nodes) >= 3)
+
+
+def test_layout_on_the_device_leaves_malformed_trees_to_the_host_pass(hip):
+    """the error is the host pass's (TYR_ERR_INVALID), and the scene the ctx held stays"""
+    from tyrant_amd import scenes
+
+    r = hip.Renderer(64, 48, 64 * 48)
+    nodes, prims = hip.bvh_build(scenes.cornell_soup(300).triangles)
+    r.upload(nodes, prims)
+    before = r.scene_hash()
+    interior = np.flatnonzero(nodes["primitiveCount"] == 0)
+    bad = {}
+    b = nodes.copy()
+    b["offset"][interior[3]] = int(interior[3])  # a second child in front of its parent
+    bad["backward child"] = b
+    b = nodes.copy()
+    b["offset"][interior[5]] = b["offset"][interior[2]]  # two parents name one child
+    bad["shared child"] = b
+    b = nodes.copy()
+    b["bounds"][7, 0, 1] = np.nan
+    bad["nan box"] = b
+    b = nodes.copy()
+    leaf = np.flatnonzero(nodes["primitiveCount"] > 0)[4]
+    b["offset"][leaf] = len(prims)  # a leaf past the primitives
+    bad["leaf out of range"] = b
+    for what, arr in bad.items():
+        with pytest.raises(hip.TyrError) as e:
+            r.upload(arr, prims)
+        assert e.value.status == -1, (what, e.value.status)  # TYR_ERR_INVALID
+        assert r.scene_hash() == before, what
+
+
+def test_scene_build_upload_is_build_plus_upload(hip):
+    """tyr_scene_build_upload: nodes, primitive order and the scene in HBM equal tyr_bvh_build + tyr_scene_upload's, whichever
+    half had to fall back to the host; a render on it equals a render on the two-call scene"""
+    from tyrant_amd import scenes
+
+    r = hip.Renderer(64, 48, 64 * 48)
+    for name, tris in _cases().items():
+        hn, hp = hip.bvh_build(tris)
+        nodes, prims, sec = r.build_upload(tris)
+        assert nodes.tobytes() == hn.tobytes() and prims.tobytes() == hp.tobytes(), name
+        _layout_matches_host(hip, r, hn, hp, name)
+        n2, p2, _ = r.build_upload(tris, want_nodes=False)
+        assert n2 is None and p2.tobytes() == hp.tobytes(), name
+        _layout_matches_host(hip, r, hn, hp, name + " (no nodes asked for)")
+    # a counting ctx wants pair nodes: both halves on the host, the same scene as its own upload
+    rc = hip.Renderer(64, 48, 64 * 48, flags=hip.TYR_FLAG_COUNT_VISITS)
+    t = scenes.cornell_soup(700).triangles
+    hn, hp = hip.bvh_build(t)
+    nodes, prims, _ = rc.build_upload(t)
+    assert nodes.tobytes() == hn.tobytes() and prims.tobytes() == hp.tobytes()
+    got = rc.scene_hash()
+    want = hip.layout_probe(hn, hp, want_pairs=True)
+    for k in _LAYOUT_KEYS + ("hash_pairs",):
+        assert got[k] == want[k], k
+    # and a picture: the fused scene renders what the two-call scene renders
+    sc = scenes.cornell_soup(2000)
+    a = hip.Renderer(128, 72, 128 * 72 * 2)
+    b = hip.Renderer(128, 72, 128 * 72 * 2)
+    hn, hp = hip.bvh_build(sc.triangles)
+    a.load_scene(sc, hn, hp)
+    b.load_scene(sc, hn, hp)
+    b.build_upload(sc.triangles)
+    assert a.render(2) == b.render(2)
+    assert np.array_equal(a.blit_buffer()[..., 3], b.blit_buffer()[..., 3])
+    ka, kb = a.counters(), b.counters()
+    for k in ("total_extend_rays", "total_shadow_rays", "n_shadow_visible"):
+        assert ka[k] == kb[k], k
+
+
+def test_layout_of_the_benchmark_trees_on_the_device(hip):
+    """C3 and C5: both halves on the device in one call against the host pass's hashes, and what each way costs"""
+    from tyrant_amd import scenes
+
+    for key, sc in (("c3", scenes.mesh_scene(706)), ("c5", scenes.glass_dof_scene(2236))):
+        hn, hp = hip.bvh_build(sc.triangles)
+        r = hip.Renderer(64, 48, 64 * 48)
+        r.build_upload(sc.triangles[:2000])  # (code objects loaded)
+        nodes, prims, sec = r.build_upload(sc.triangles, want_nodes=False)
+        assert prims.tobytes() == hp.tobytes(), key
+        _layout_matches_host(hip, r, hn, hp, key, expect_on_device=True)
+        r.set_tuning(layout_on_device=1)
+        r.upload(hn, hp)
+        dev = r.scene_info()
+        _layout_matches_host(hip, r, hn, hp, key + " upload", expect_on_device=True)
+        r.set_tuning(layout_on_device=0)
+        r.upload(hn, hp)
+        host = r.scene_info()
+        print(f"{key}: {len(hn)} nodes -> {dev['n_quad_nodes']} records.  tyr_scene_build_upload: build {sec[0] * 1e3:.1f} + layout {sec[1] * 1e3:.1f} + copies {sec[2] * 1e3:.1f} ms; "
+              f"tyr_scene_upload, layout on the device: copies {dev['upload_copy_s'] * 1e3:.1f} + layout {dev['upload_layout_s'] * 1e3:.1f} ms; on the host: layout {host['upload_layout_s'] * 1e3:.1f} + copies {host['upload_copy_s'] * 1e3:.1f} ms")

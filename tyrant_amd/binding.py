@@ -85,7 +85,7 @@ class Counters(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_prims", c_u32), ("n_pair_nodes", c_u32), ("n_quad_nodes", c_u32), ("n_staged_nodes", c_u32), ("n_lights", c_u32), ("max_quad_nodes", c_u32), ("max_prim_offset", c_u32),
-                ("quad_max_stack", c_u32), ("device_bytes", c_u64), ("upload_layout_s", C.c_double), ("upload_copy_s", C.c_double)]
+                ("quad_max_stack", c_u32), ("device_bytes", c_u64), ("upload_layout_s", C.c_double), ("upload_copy_s", C.c_double), ("layout_on_device", c_u32), ("reserved_", c_u32)]
 
 
 class LayoutStats(C.Structure):
@@ -133,6 +133,7 @@ SYMBOLS = {
     "tyr_shadow_import": (C.c_int, [P, P, c_u32]),
     "tyr_get_scene_info": (C.c_int, [P, C.POINTER(SceneInfo)]),
     "tyr_layout_probe": (C.c_int, [P, c_i32, P, c_i32, c_i32, C.POINTER(LayoutStats)]),
+    "tyr_scene_hash": (C.c_int, [P, C.POINTER(LayoutStats)]),
     "tyr_vecmath_probe": (C.c_int, [c_i32, c_i32, P, P, P, c_u32, P]),
     "tyr_sunsky_probe": (C.c_int, [c_i32, C.c_float, C.c_float, c_i32, P, c_u32, P]),
     "tyr_sun_setup": (C.c_int, [C.c_float, C.c_float, P]),
@@ -141,6 +142,7 @@ SYMBOLS = {
     "tyr_set_tuning": (C.c_int, [P, C.c_int, C.c_int]),
     "tyr_bvh_build": (C.c_int, [P, c_i32, P, P, c_i32]),
     "tyr_bvh_build_device": (C.c_int, [c_i32, P, c_i32, P, P, P]),
+    "tyr_scene_build_upload": (C.c_int, [P, P, c_i32, P, P, P, P]),
     "tyr_triangle_bboxes": (C.c_int, [P, c_i32, P]),
     "tyr_set_build_threads": (C.c_int, [c_i32]),
     "tyr_camera_update": (C.c_int, [C.c_double, C.c_double, C.POINTER(c_f)]),
@@ -373,7 +375,7 @@ class Renderer:
         _check(self.L.tyr_get_timings(self.h, C.byref(t), int(reset)), "tyr_get_timings")
         return {n: {"ms": t.ms[i], "launches": int(t.launches[i])} for i, n in enumerate(KERNEL_NAMES)}
 
-    TUNING_KEYS = {"refill_min_idle": 1, "waves_per_simd": 2, "min_traversing": 4, "ticket_chunk": 5, "static_share": 8, "staged_nodes": 9, "profile_mask": 11, "merge_trace": 12, "static_interleave": 13, "run_ahead": 14, "wide_drain": 15, "stream_tail": 16, "stream_shade_per_cu": 17, "stream_trace_per_cu": 18, "fold_spheres": 19, "retire_sky": 20, "resolve_shadows": 21, "wide_block_min_items": 22, "fold_prologue": 23}
+    TUNING_KEYS = {"refill_min_idle": 1, "waves_per_simd": 2, "min_traversing": 4, "ticket_chunk": 5, "static_share": 8, "staged_nodes": 9, "profile_mask": 11, "merge_trace": 12, "static_interleave": 13, "run_ahead": 14, "wide_drain": 15, "stream_tail": 16, "stream_shade_per_cu": 17, "stream_trace_per_cu": 18, "fold_spheres": 19, "retire_sky": 20, "resolve_shadows": 21, "wide_block_min_items": 22, "fold_prologue": 23, "layout_on_device": 24}
 
     def set_tuning(self, **knobs):
         for name, v in knobs.items():
@@ -412,6 +414,23 @@ class Renderer:
     def import_shadow_queue(self, rays: np.ndarray):
         r = np.ascontiguousarray(rays)
         _check(self.L.tyr_shadow_import(self.h, _ptr(r), r.shape[0]), "tyr_shadow_import")
+
+    def scene_hash(self) -> dict:
+        """sizes and FNV-1a hashes of the scene arrays this ctx holds in HBM, read back (tyr_scene_hash): layout_probe()'s figures"""
+        st = LayoutStats()
+        _check(self.L.tyr_scene_hash(self.h, C.byref(st)), "tyr_scene_hash")
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def build_upload(self, tris: np.ndarray, bboxes: np.ndarray | None = None, want_nodes: bool = True):
+        """(nodes or None, prims, (build_s, layout_s, copy_s)): tyr_scene_build_upload -- the tree built and laid out on this ctx's device"""
+        prims = np.array(tris, dtype=scenes.TRIANGLE_DTYPE, copy=True)
+        bb = triangle_bboxes(prims) if bboxes is None else np.ascontiguousarray(bboxes)
+        n = prims.shape[0]
+        nodes = np.zeros(max(2 * n - 1, 1), dtype=scenes.NODE_DTYPE) if want_nodes else None
+        sec = (C.c_double * 3)(0.0, 0.0, 0.0)
+        nn = c_i32(0)
+        _check(self.L.tyr_scene_build_upload(self.h, _ptr(prims), n, _ptr(bb), None if nodes is None else _ptr(nodes), C.byref(nn), sec), "tyr_scene_build_upload")
+        return (None if nodes is None else nodes[: nn.value].copy()), prims, (sec[0], sec[1], sec[2])
 
     def scene_info(self) -> dict:
         s = SceneInfo()

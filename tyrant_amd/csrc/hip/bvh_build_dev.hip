@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "../../../include/tyr_c.h"
+#include "../host/device_build.hpp"
 
 namespace tyr {
 
@@ -780,20 +781,25 @@ struct PoolView { // typed views into one device allocation
 
 } // namespace
 
-// Returns the node count (>= 0) or a negative status.  prims / bboxes / nodes_out are HOST arrays, as tyr_bvh_build's; prims is
-// reordered in place (bvh.cpp:24).  seconds_out (may be null): [0] the device's work (first kernel to last, hipEvents), [1] the
-// copies in and out.  TYR_ERR_UNSUPPORTED: a task thread's stack overflowed (a degenerate range far beyond kTaskPrims): use the host builder.
-int bvh_build_device(int device, tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, double* seconds_out) {
+DeviceBuild::~DeviceBuild() {
+	if (pool)
+		(void)hipFree(pool);
+}
+
 #define TYR_D(expr)                                                     \
 	do {                                                                \
 		const hipError_t e_ = (expr);                                   \
 		if (e_ != hipSuccess)                                           \
 			return e_ == hipErrorOutOfMemory ? TYR_ERR_OOM : static_cast<int>(e_); \
 	} while (0)
-	if (n < 0 || (n > 0 && (!prims || !bboxes || !nodes_out)))
+
+// The build, its results LEFT ON THE DEVICE (out.nodes: the reference's node array, out.prims: the primitives in their final order;
+// both inside out.pool, which out's destructor frees).  prims / bboxes are host arrays and are not touched.  Returns the node count
+// (> 0) or a negative status.  seconds_out (may be null): [0] the device's work (first kernel to last, hipEvents), [1] the copies in.
+// TYR_ERR_UNSUPPORTED: a task thread's stack overflowed (a degenerate range far beyond kTaskPrims): use the host builder.
+int bvh_build_device_keep(int device, const tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, DeviceBuild& out, double* seconds_out) {
+	if (n <= 0 || !prims || !bboxes)
 		return TYR_ERR_INVALID;
-	if (n == 0)
-		return 0; // bvh.cpp:8-10
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
 		return TYR_ERR_NO_DEVICE;
@@ -817,9 +823,14 @@ int bvh_build_device(int device, tyr_triangle* prims, int32_t n, const tyr_bbox*
 	const size_t oBkt = carve.take(N), oFlags = carve.take((N + 1) * sizeof(uint2)), oExcl = carve.take((N + 4) * sizeof(uint2)), oBlockSums = carve.take(nScanBlocks * sizeof(uint2));
 	const size_t oPosML = carve.take(N * sizeof(uint32_t)), oPosMR = carve.take(N * sizeof(uint32_t)), oSlots0 = carve.take(maxSlots * sizeof(Slot)), oSlots1 = carve.take(maxSlots * sizeof(Slot));
 	const size_t oNodes = carve.take(maxTop * sizeof(TopNode)), oScratch = carve.take(2 * N * sizeof(tyr_bvh_node)), oOut = carve.take(2 * N * sizeof(tyr_bvh_node)), oK = carve.take(sizeof(Counters));
-	DevBuf<char> pool;
-	TYR_D(pool.alloc(carve.total));
-	const PoolView mem{ pool.p };
+	if (out.pool)
+		(void)hipFree(out.pool);
+	out.pool = nullptr;
+	out.nodes = nullptr;
+	out.prims = nullptr;
+	out.nNodes = out.n = 0;
+	TYR_D(hipMalloc(&out.pool, carve.total)); // (freed by out's destructor, whichever way this function is left)
+	const PoolView mem{ static_cast<char*>(out.pool) };
 	struct { tyr_bbox* p; } dBB{ mem.at<tyr_bbox>(oBB) };
 	struct { tyr_triangle* p; } dPrims{ mem.at<tyr_triangle>(oPrims) }, dPrimsOut{ mem.at<tyr_triangle>(oPrimsOut) };
 	struct { Info* p; } dInfo[2] = { { mem.at<Info>(oInfo0) }, { mem.at<Info>(oInfo1) } };
@@ -923,10 +934,10 @@ int bvh_build_device(int device, tyr_triangle* prims, int32_t n, const tyr_bbox*
 	const int nNodes = root.size;
 	if (nNodes <= 0 || static_cast<size_t>(nNodes) > 2 * N)
 		return TYR_ERR_DEVICE;
-	const auto tCopy1 = std::chrono::steady_clock::now();
-	TYR_D(hipMemcpy(nodes_out, dOut.p, static_cast<size_t>(nNodes) * sizeof(tyr_bvh_node), hipMemcpyDeviceToHost));
-	TYR_D(hipMemcpy(prims, dPrimsOut.p, N * sizeof(tyr_triangle), hipMemcpyDeviceToHost));
-	copyS += std::chrono::duration<double>(std::chrono::steady_clock::now() - tCopy1).count();
+	out.nodes = dOut.p;
+	out.prims = dPrimsOut.p;
+	out.nNodes = nNodes;
+	out.n = n;
 	if (seconds_out) {
 		float ms = 0.0f;
 		(void)hipEventElapsedTime(&ms, ev0, ev1);
@@ -934,7 +945,30 @@ int bvh_build_device(int device, tyr_triangle* prims, int32_t n, const tyr_bbox*
 		seconds_out[1] = copyS;
 	}
 	return nNodes;
-#undef TYR_D
 }
+
+// Returns the node count (>= 0) or a negative status.  prims / bboxes / nodes_out are HOST arrays, as tyr_bvh_build's; prims is
+// reordered in place (bvh.cpp:24).  seconds_out (may be null): [0] the device's work, [1] the copies in and out.
+int bvh_build_device(int device, tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, double* seconds_out) {
+	if (n < 0 || (n > 0 && (!prims || !bboxes || !nodes_out)))
+		return TYR_ERR_INVALID;
+	if (n == 0)
+		return 0; // bvh.cpp:8-10
+	DeviceBuild B;
+	double secs[2] = { 0.0, 0.0 };
+	const int nNodes = bvh_build_device_keep(device, prims, n, bboxes, B, secs);
+	if (nNodes < 0)
+		return nNodes;
+	const auto tCopy1 = std::chrono::steady_clock::now();
+	TYR_D(hipMemcpy(nodes_out, B.nodes, static_cast<size_t>(nNodes) * sizeof(tyr_bvh_node), hipMemcpyDeviceToHost));
+	TYR_D(hipMemcpy(prims, B.prims, static_cast<size_t>(n) * sizeof(tyr_triangle), hipMemcpyDeviceToHost));
+	secs[1] += std::chrono::duration<double>(std::chrono::steady_clock::now() - tCopy1).count();
+	if (seconds_out) {
+		seconds_out[0] = secs[0];
+		seconds_out[1] = secs[1];
+	}
+	return nNodes;
+}
+#undef TYR_D
 
 } // namespace tyr

@@ -255,6 +255,7 @@ struct Tuning {
 	int retireSky = 1;        // merged path of tyr_render: k_primary finishes the camera rays that hit nothing itself (they never reach a queue)
 	int wideBlockMinItems = 3 << 20; // k_trace_flat: launches of at least this many rays run as 768-thread blocks, six waves per SIMD (< 0: never)
 	int foldPrologue = 1;     // tyr_render one iteration ahead of the counts: once the budget is spent, an iteration's last kernel opens the next one (set_wavefront_globals, hole padding): two launches and two gaps fewer per iteration
+	int layoutOnDevice = 1;   // tyr_scene_upload: the reference's arrays go to the device as they are and hip/bvh_layout_dev.hip makes the records there (the same bytes); 0 = host/bvh_layout.cpp makes them and they are copied
 	int foldSpheres = 1;      // merged path of tyr_render: shade does the sphere pre-passes' work for the rays it emits (the streamed tail always does); 0: k_extend_spheres / k_connect_spheres re-read them
 };
 constexpr uint32_t kCountRaysPerBlock = 1024; // the counting build's kernels: queue slots owned by one 256-thread block

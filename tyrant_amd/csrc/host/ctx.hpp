@@ -73,6 +73,7 @@ struct tyr_ctx {
 	DevScene scene{};
 	bool haveScene = false;
 	double uploadLayoutS = 0.0, uploadCopyS = 0.0; // the last tyr_scene_upload: host layout passes, allocation + copies to HBM (tyr_scene_info)
+	bool layoutOnDevice = false; // ... and where its layout pass ran
 
 	tyr_sphere spheres[TYR_NUM_SPHERES]{};
 	tyr_camera cam{};

@@ -599,6 +599,103 @@ int tyr_destroy(tyr_ctx* c) {
 	return TYR_OK;
 }
 
+namespace {
+
+// the light array the reference leaves as a TODO (kernel.cu:420): LIGHT triangles in (reordered) array order
+int upload_light_list(tyr_ctx* c, const tyr_triangle* prims, int32_t nPrims) {
+	if (!(c->cfg.flags & TYR_FLAG_LIGHT_LIST))
+		return TYR_OK;
+	std::vector<uint32_t> lights;
+	for (int32_t i = 0; i < nPrims; ++i)
+		if (prims[i].materialType == TYR_LIGHT)
+			lights.push_back(static_cast<uint32_t>(i));
+	if (lights.empty())
+		return TYR_OK;
+	int rc;
+	if ((rc = dev_alloc(c->dLights, lights.size())))
+		return rc;
+	HIPCHK(hipMemcpy(c->dLights, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	c->nLights = static_cast<uint32_t>(lights.size());
+	return TYR_OK;
+}
+
+// the ctx lets go of its scene (the stream is idle afterwards)
+int drop_scene(tyr_ctx* c) {
+	HIPCHK(hipStreamSynchronize(c->stream));
+	dev_free(c->dNodes);
+	dev_free(c->dQuads);
+	dev_free(c->dTris);
+	dev_free(c->dLights);
+	c->nLights = 0;
+	c->scene = DevScene{};
+	c->scene.rootRef = kRefDone;
+	c->haveScene = true;
+	return TYR_OK;
+}
+
+// a layout made on the device (hip/bvh_layout_dev.hip) becomes the ctx's scene: L's arrays change owner
+int adopt_device_layout(tyr_ctx* c, DeviceTreeLayout& L, int32_t nPrims) {
+	int rc = drop_scene(c);
+	if (rc == TYR_OK)
+		rc = dev_alloc(c->dNodes, 4); // (no pair nodes; one element so the pointer is never null)
+	if (rc) {
+		(void)hipFree(L.quads);
+		(void)hipFree(L.tris);
+		L.quads = L.tris = nullptr;
+		return rc;
+	}
+	c->dQuads = L.quads;
+	c->dTris = L.tris;
+	L.quads = L.tris = nullptr;
+	c->scene.quads = c->dQuads;
+	c->scene.quadRootRef = L.quadRootRef;
+	c->scene.nQuads = L.nQuads;
+	c->scene.nStaged = L.nStaged;
+	c->scene.quadMaxStack = L.quadMaxStack;
+	c->scene.nodes = c->dNodes;
+	c->scene.tris = c->dTris;
+	std::memcpy(c->scene.rootMin, L.rootMin, 12);
+	std::memcpy(c->scene.rootMax, L.rootMax, 12);
+	c->scene.rootRef = 0u; // the pair layout's root (pair 0), as the host pass answers without pair nodes
+	c->scene.nPairs = 0;
+	c->scene.nPrims = static_cast<uint32_t>(nPrims);
+	return TYR_OK;
+}
+
+// tyr_scene_upload with the layout pass on the device (TYR_TUNE_LAYOUT_ON_DEVICE): the reference's arrays cross the bus as they
+// are -- 32 + 40 bytes per node / triangle instead of 128 + 48 -- and hip/bvh_layout_dev.hip writes the records in HBM.
+// TYR_ERR_UNSUPPORTED: the host pass has to do this tree (and names the error of a malformed one).
+int scene_upload_device_layout(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims) {
+	const auto t0 = std::chrono::steady_clock::now();
+	tyr_bvh_node* dRawNodes = nullptr;
+	tyr_triangle* dRawPrims = nullptr;
+	struct Guard {
+		tyr_bvh_node*& a;
+		tyr_triangle*& b;
+		~Guard() {
+			dev_free(a);
+			dev_free(b);
+		}
+	} guard{ dRawNodes, dRawPrims };
+	int rc;
+	if ((rc = dev_alloc(dRawNodes, static_cast<size_t>(nNodes))) || (rc = dev_alloc(dRawPrims, static_cast<size_t>(nPrims))))
+		return rc;
+	HIPCHK(hipMemcpy(dRawNodes, nodes, static_cast<size_t>(nNodes) * sizeof(tyr_bvh_node), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(dRawPrims, prims, static_cast<size_t>(nPrims) * sizeof(tyr_triangle), hipMemcpyHostToDevice));
+	const auto t1 = std::chrono::steady_clock::now();
+	DeviceTreeLayout L;
+	if ((rc = layout_on_device(dRawNodes, nNodes, dRawPrims, nPrims, L, c->stream)))
+		return rc;
+	if ((rc = adopt_device_layout(c, L, nPrims)))
+		return rc;
+	c->uploadCopyS = std::chrono::duration<double>(t1 - t0).count();
+	c->uploadLayoutS = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+	c->layoutOnDevice = true;
+	return TYR_OK;
+}
+
+} // namespace
+
 int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triangle* prims, int32_t nPrims) {
 	if (!c)
 		return TYR_ERR_INVALID;
@@ -608,6 +705,18 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	// the pair nodes are what the counting build and the BVH_DEBUG picture traverse (the reference's visit counts,
 	// bvh.h:164-209); a ctx without those flags never reads them: they are neither laid out nor kept in HBM (64 MB on C3, 0.4 GB on C5)
 	const bool wantPairs = (c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) != 0;
+	c->layoutOnDevice = false;
+	if (!wantPairs && c->tuning.layoutOnDevice != 0 && kWhatIfQuadPad == 0 && nodes && prims && nNodes >= 3 && nPrims > 0) {
+		try {
+			rc = scene_upload_device_layout(c, nodes, nNodes, prims, nPrims);
+		} catch (...) {
+			rc = TYR_ERR_UNSUPPORTED;
+		}
+		if (rc == TYR_OK)
+			return upload_light_list(c, prims, nPrims);
+		if (rc != TYR_ERR_UNSUPPORTED)
+			return rc;
+	}
 	DeviceLayout L;
 	const auto t0 = std::chrono::steady_clock::now();
 	try { // (the layout pass allocates and starts threads: nothing may leave a C entry point as an exception)
@@ -622,15 +731,8 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	const auto t1 = std::chrono::steady_clock::now();
 	c->uploadLayoutS = std::chrono::duration<double>(t1 - t0).count();
 	c->uploadCopyS = 0.0;
-	HIPCHK(hipStreamSynchronize(c->stream));
-	dev_free(c->dNodes);
-	dev_free(c->dQuads);
-	dev_free(c->dTris);
-	dev_free(c->dLights);
-	c->nLights = 0;
-	c->scene = DevScene{};
-	c->scene.rootRef = kRefDone;
-	c->haveScene = true;
+	if ((rc = drop_scene(c)))
+		return rc;
 	if (L.rootRef == kRefDone)
 		return TYR_OK; // Scene.cpp:49-52
 	// at least one element so the pointers are never null
@@ -659,20 +761,93 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	c->scene.nPairs = L.nPairs;
 	c->scene.nPrims = static_cast<uint32_t>(nPrims);
 	c->uploadCopyS = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(); // (hipMemcpy from pageable memory returns when the data is on its way from a staging buffer at the latest; the three arrays, allocation included)
-	if (c->cfg.flags & TYR_FLAG_LIGHT_LIST) {
-		// the light array the reference leaves as a TODO (kernel.cu:420): LIGHT triangles in (reordered) array order
-		std::vector<uint32_t> lights;
-		for (int32_t i = 0; i < nPrims; ++i)
-			if (prims[i].materialType == TYR_LIGHT)
-				lights.push_back(static_cast<uint32_t>(i));
-		if (!lights.empty()) {
-			if ((rc = dev_alloc(c->dLights, lights.size())))
-				return rc;
-			HIPCHK(hipMemcpy(c->dLights, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-			c->nLights = static_cast<uint32_t>(lights.size());
+	return upload_light_list(c, prims, nPrims);
+}
+
+// Scene::Load's two halves in one call (Scene.cpp:49-67): the tree built on the ctx's device (hip/bvh_build_dev.hip: the reference's
+// bytes) and laid out there (hip/bvh_layout_dev.hip) without the nodes ever leaving HBM.  prims is reordered in place as the
+// reference's BVH constructor does (bvh.cpp:24); nodes_out (may be null, else 2n - 1 entries) receives the reference's node array.
+int tyr_scene_build_upload(tyr_ctx* c, tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t* n_nodes_out, double* seconds_out3) {
+	if (!c || n < 0 || (n > 0 && (!prims || !bboxes)))
+		return TYR_ERR_INVALID;
+	for (int32_t i = 0; i < n; ++i)
+		for (int k = 0; k < 6; ++k)
+			if (!std::isfinite((&bboxes[i].bounds[0][0])[k]))
+				return TYR_ERR_INVALID;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	if (n_nodes_out)
+		*n_nodes_out = 0;
+	if (seconds_out3)
+		seconds_out3[0] = seconds_out3[1] = seconds_out3[2] = 0.0;
+	if (n == 0)
+		return tyr_scene_upload(c, nullptr, 0, nullptr, 0);
+	const bool wantPairs = (c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) != 0;
+	std::vector<tyr_bvh_node> own;
+	auto host_nodes = [&]() -> tyr_bvh_node* {
+		if (nodes_out)
+			return nodes_out;
+		if (own.empty())
+			own.resize(2 * static_cast<size_t>(n) - 1);
+		return own.data();
+	};
+	try {
+		// the ways round the device: both halves on the host (its builder, then tyr_scene_upload) ...
+		auto all_on_host = [&]() -> int {
+			const auto t0 = std::chrono::steady_clock::now();
+			const int nn = bvh_build(prims, n, bboxes, host_nodes(), 2);
+			if (nn < 0)
+				return nn;
+			if (seconds_out3)
+				seconds_out3[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			if (n_nodes_out)
+				*n_nodes_out = nn;
+			return tyr_scene_upload(c, host_nodes(), nn, prims, n);
+		};
+		if (wantPairs || kWhatIfQuadPad != 0)
+			return all_on_host();
+		DeviceBuild B;
+		double secs[2] = { 0.0, 0.0 };
+		const int nNodes = bvh_build_device_keep(c->cfg.device, prims, n, bboxes, B, secs);
+		if (nNodes == TYR_ERR_UNSUPPORTED)
+			return all_on_host();
+		if (nNodes < 0)
+			return nNodes;
+		const auto t1 = std::chrono::steady_clock::now();
+		HIPCHK(hipMemcpy(prims, B.prims, static_cast<size_t>(n) * sizeof(tyr_triangle), hipMemcpyDeviceToHost)); // bvh.cpp:24: the caller's array in its new order
+		if (nodes_out)
+			HIPCHK(hipMemcpy(nodes_out, B.nodes, static_cast<size_t>(nNodes) * sizeof(tyr_bvh_node), hipMemcpyDeviceToHost));
+		double copyS = secs[1] + std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+		if (n_nodes_out)
+			*n_nodes_out = nNodes;
+		if (seconds_out3)
+			seconds_out3[0] = secs[0];
+		const auto t2 = std::chrono::steady_clock::now();
+		DeviceTreeLayout L;
+		rc = c->tuning.layoutOnDevice != 0 ? layout_on_device(B.nodes, nNodes, B.prims, n, L, c->stream) : TYR_ERR_UNSUPPORTED;
+		if (rc == TYR_ERR_UNSUPPORTED) { // ... or the tree built here and laid out there
+			if (!nodes_out)
+				HIPCHK(hipMemcpy(host_nodes(), B.nodes, static_cast<size_t>(nNodes) * sizeof(tyr_bvh_node), hipMemcpyDeviceToHost));
+			return tyr_scene_upload(c, host_nodes(), nNodes, prims, n);
 		}
+		if (rc)
+			return rc;
+		if ((rc = adopt_device_layout(c, L, n)))
+			return rc;
+		c->uploadLayoutS = std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count();
+		c->uploadCopyS = copyS;
+		c->layoutOnDevice = true;
+		if (seconds_out3) {
+			seconds_out3[1] = c->uploadLayoutS;
+			seconds_out3[2] = copyS;
+		}
+		return upload_light_list(c, prims, n);
+	} catch (const std::bad_alloc&) {
+		return TYR_ERR_OOM;
+	} catch (...) {
+		return TYR_ERR_UNSUPPORTED;
 	}
-	return TYR_OK;
 }
 
 int tyr_set_triangle_emission(tyr_ctx* c, const float* rgb) {
@@ -1795,6 +1970,7 @@ int tyr_get_scene_info(tyr_ctx* c, tyr_scene_info* out) {
 	out->device_bytes = static_cast<uint64_t>(c->scene.nQuads) * 128 + (havePairs ? static_cast<uint64_t>(c->scene.nPairs) * 64 : 0) + static_cast<uint64_t>(c->scene.nPrims) * 48;
 	out->upload_layout_s = c->uploadLayoutS;
 	out->upload_copy_s = c->uploadCopyS;
+	out->layout_on_device = c->layoutOnDevice ? 1u : 0u;
 	return TYR_OK;
 }
 
@@ -1834,6 +2010,45 @@ int tyr_layout_probe(const tyr_bvh_node* nodes, int32_t nNodes, const tyr_triang
 	return TYR_OK;
 }
 
+int tyr_scene_hash(tyr_ctx* c, tyr_layout_stats* out) {
+	if (!c || !out)
+		return TYR_ERR_INVALID;
+	if (!c->haveScene)
+		return TYR_ERR_NO_SCENE;
+	int rc = use_device(c);
+	if (rc)
+		return rc;
+	std::memset(out, 0, sizeof *out);
+	out->n_pair_nodes = c->scene.nPairs;
+	out->n_quad_nodes = c->scene.nQuads;
+	out->n_staged_nodes = c->scene.nStaged;
+	out->quad_max_stack = c->scene.quadMaxStack;
+	out->root_ref = c->scene.rootRef;
+	out->quad_root_ref = c->scene.quadRootRef;
+	out->seconds = c->uploadLayoutS;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	try {
+		auto fnv_device = [&](const void* d, size_t bytes, uint64_t& h) -> int {
+			h = 1469598103934665603ull;
+			std::vector<unsigned char> buf(std::min<size_t>(bytes, size_t(64) << 20));
+			for (size_t at = 0; at < bytes; at += buf.size()) {
+				const size_t k = std::min(buf.size(), bytes - at);
+				HIPCHK(hipMemcpy(buf.data(), static_cast<const char*>(d) + at, k, hipMemcpyDeviceToHost));
+				for (size_t i = 0; i < k; ++i)
+					h = (h ^ buf[i]) * 1099511628211ull;
+			}
+			return TYR_OK;
+		};
+		if ((rc = fnv_device(c->dNodes, static_cast<size_t>(c->scene.nPairs) * 64, out->hash_pairs)) ||
+		    (rc = fnv_device(c->dQuads, static_cast<size_t>(c->scene.nQuads) * 128, out->hash_quads)) ||
+		    (rc = fnv_device(c->dTris, static_cast<size_t>(c->scene.nPrims) * 48, out->hash_tris)))
+			return rc;
+	} catch (const std::bad_alloc&) {
+		return TYR_ERR_OOM;
+	}
+	return TYR_OK;
+}
+
 int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 	if (!c)
 		return TYR_ERR_INVALID;
@@ -1861,6 +2076,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_RESOLVE_SHADOWS, 0, 1, &Tuning::resolveShadows },
 		{ TYR_TUNE_WIDE_BLOCK_MIN_ITEMS, -1, 0x7fffffff, &Tuning::wideBlockMinItems },
 		{ TYR_TUNE_FOLD_PROLOGUE, 0, 1, &Tuning::foldPrologue },
+		{ TYR_TUNE_LAYOUT_ON_DEVICE, 0, 1, &Tuning::layoutOnDevice },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)

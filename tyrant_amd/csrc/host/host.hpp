@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../../include/tyr_c.h"
+#include "device_build.hpp"
 #include "../hip/kernels.hpp"
 #include "../hip/sunsky.hpp"
 #include "../hip/traverse.hpp"
@@ -24,6 +25,16 @@ void set_build_threads(int threads); // 0 = automatic (TYR_BUILD_THREADS or min(
 int build_threads();                 // what the setting resolves to right now (>= 1)
 // hip/bvh_build_dev.hip -- the same build (SAH) on the device, the same bytes; host arrays in and out
 int bvh_build_device(int device, tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, double* seconds_out);
+// hip/bvh_layout_dev.hip -- build_device_layout's quad records and triangles made ON the device from device copies of the
+// reference's arrays, the same bytes.  On TYR_OK out.quads / out.tris are hipMalloc'ed and the caller's; TYR_ERR_UNSUPPORTED =
+// a tree the host pass has to do (pair nodes wanted, over-long leaves, one-leaf trees, malformed input: its error codes stay the host's)
+struct DeviceTreeLayout {
+	float4* quads = nullptr;
+	float4* tris = nullptr;
+	uint32_t nQuads = 0, nStaged = 0, quadMaxStack = 0, quadRootRef = 0;
+	float rootMin[3] = { 0.f, 0.f, 0.f }, rootMax[3] = { 0.f, 0.f, 0.f };
+};
+int layout_on_device(const tyr_bvh_node* dNodes, int32_t nNodes, const tyr_triangle* dPrims, int32_t nPrims, DeviceTreeLayout& out, hipStream_t stream);
 
 // host/bvh_layout.cpp -- flat reference nodes -> device quad nodes (+ pair nodes for the counting build) + 48-byte triangles
 // an array of floats that is NOT zeroed when it is sized: every element is written by the layout's (parallel) passes, and a
