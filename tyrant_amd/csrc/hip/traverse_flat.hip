@@ -1129,6 +1129,95 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 			}
 		}
 		// ---- leaves: bvh.h:129-140 (closest hit) / bvh.h:229-238 (any hit) ----
+#ifndef TYR_NO_PACKED_LEAVES
+		// ---- leaves, packed (round 5; -1.0 ... -1.6 % per C3 render, profiles/r05_packed_leaves_ab.txt; -DTYR_NO_PACKED_LEAVES: the loop alone).  The loop below runs max(cnt) rounds over the lanes that are at a leaf -- typically 20 / 12 / 7 / 4
+		// lanes in rounds 0..3: 17 % of the lanes on average, as many rounds as the kernel has node trips.  Here every (lane, primitive)
+		// pair of the phase becomes one ITEM, the items are dealt to the wave's lanes round-major (all first primitives, then all
+		// second ones, ...), each lane tests the item it was dealt with its owner's ray, and the owners take the distances back and
+		// fold them in array order as before (bvh.h:129-140 / 229-238): one round of tests for the whole phase.  Owner -> item lane is a
+		// ds_permute (the owner knows its item's slot: the round's base + its rank among the round's lanes), item lane -> owner
+		// registers are ds_bpermutes: the LDS crossbar, no LDS memory.  Phases with a leaf of more than four primitives or more than 63
+		// items take the loop. ----
+		{
+			const bool atLeaf = ref_is_leaf(ref);
+			const unsigned long long B0 = __ballot(atLeaf);
+			if (B0 != 0ull) {
+				const uint32_t off = ref & (kMaxPrimOffset - 1);
+				const uint32_t cnt = atLeaf ? ((ref >> 26) & 31u) + 1u : 0u;
+				const unsigned long long B1 = __ballot(cnt > 1u), B2 = __ballot(cnt > 2u), B3 = __ballot(cnt > 3u);
+				const uint32_t n0 = (uint32_t)__popcll(B0), n1 = (uint32_t)__popcll(B1), n2 = (uint32_t)__popcll(B2), n3 = (uint32_t)__popcll(B3);
+				if (__ballot(cnt > 4u) == 0ull && n0 + n1 + n2 + n3 <= 63u) {
+					const uint32_t base1 = n0, base2 = n0 + n1, base3 = n0 + n1 + n2;
+					const uint32_t s0 = (uint32_t)__popcll(B0 & below), s1 = base1 + (uint32_t)__popcll(B1 & below), s2 = base2 + (uint32_t)__popcll(B2 & below), s3 = base3 + (uint32_t)__popcll(B3 & below);
+					// an owner tells the lane of each of its items who it is and which primitive it wants (lanes that own nothing in a
+					// round send 0 to lane 63, which holds no item)
+					const uint32_t me = lane + 1u;
+					uint32_t told = (uint32_t)__builtin_amdgcn_ds_permute((int)((cnt > 0u ? s0 : 63u) << 2), (int)(cnt > 0u ? me : 0u));
+					if (n1)
+						told |= (uint32_t)__builtin_amdgcn_ds_permute((int)((cnt > 1u ? s1 : 63u) << 2), (int)(cnt > 1u ? (me | (1u << 8)) : 0u));
+					if (n2)
+						told |= (uint32_t)__builtin_amdgcn_ds_permute((int)((cnt > 2u ? s2 : 63u) << 2), (int)(cnt > 2u ? (me | (2u << 8)) : 0u));
+					if (n3)
+						told |= (uint32_t)__builtin_amdgcn_ds_permute((int)((cnt > 3u ? s3 : 63u) << 2), (int)(cnt > 3u ? (me | (3u << 8)) : 0u));
+					const bool item = lane < n0 + n1 + n2 + n3; // (every slot below the item count was told by exactly one owner)
+					const int from = (int)((item ? (told & 0xffu) - 1u : lane) << 2);
+					auto pull = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)__float_as_uint(v))); };
+					const uint32_t offO = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)off);
+					RayConst ro;
+					ro.o = mk3(pull(rox), pull(roy), pull(roz));
+					ro.d = mk3(pull(rdx), pull(rdy), pull(rdz));
+					// (the test without branches: most lanes hold an item, and three early-outs are three exec-mask sequences; lanes
+					// without an item test record 0 and drop the answer)
+					if ((COUNT || kLoopStats) && item) {
+						TYR_DBG(4)
+					}
+					float tm = triangle_test_select(triangle_load(sc.tris, item ? offO + (told >> 8) : 0u), ro);
+					tm = item ? tm : 0.0f;
+					// the owners take their distances back and accept in array order
+					const float t0 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(s0 << 2), (int)__float_as_uint(tm)));
+					const float t1 = n1 ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(s1 << 2), (int)__float_as_uint(tm))) : 0.0f;
+					const float t2 = n2 ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(s2 << 2), (int)__float_as_uint(tm))) : 0.0f;
+					const float t3 = n3 ? __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(s3 << 2), (int)__float_as_uint(tm))) : 0.0f;
+					const float tk[4] = { t0, t1, t2, t3 };
+					bool found = false;
+#pragma unroll
+					for (uint32_t i = 0; i < 4u; ++i) {
+						const float t = tk[i];
+						const bool in = i < cnt && !found && t > kEpsilon && ((dist - t) > kEpsilon);
+						const bool closer = in && !isShadow && t < dist; // bvh.h:133-137
+						found = found || (in && isShadow);                 // bvh.h:232-236
+						prim = closer ? (int)(off + i) : prim;
+						hitTri = hitTri || closer;
+						dist = closer ? t : dist;
+					}
+					if (atLeaf) {
+						occluded = occluded || found;
+						ref = found ? kRefDone : kRefPop;
+					}
+				}
+			}
+		}
+#endif
+#ifdef TYR_WHATIF_LEAF_ONE_PER_PHASE
+		// what-if (round 5): ONE primitive per lane and leaf phase -- a lane whose leaf holds more keeps the rest (the reference of the
+		// leaf's tail: off + 1, cnt - 1) for the next phase, when more lanes have arrived at leaves, instead of the phase running
+		// max(cnt) rounds at ever fewer lanes.  Same tests in the same order per ray.
+		if (ref_is_leaf(ref)) {
+			const uint32_t off = ref & (kMaxPrimOffset - 1);
+			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+			const float t = triangle_test(triangle_load(sc.tris, off), r);
+			bool found = false;
+			if (isShadow) {
+				found = (t > kEpsilon && ((dist - t) > kEpsilon)); // bvh.h:232-236
+			} else if (t > kEpsilon && t < dist && ((dist - t) > kEpsilon)) {
+				prim = (int)off;
+				dist = t;
+				hitTri = true;
+			}
+			occluded = occluded || found;
+			ref = found ? kRefDone : (cnt > 1u ? (kRefLeaf | ((cnt - 2u) << 26) | (off + 1u)) : kRefPop);
+		}
+#else
 		if (ref_is_leaf(ref)) {
 			const uint32_t off = ref & (kMaxPrimOffset - 1);
 			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
@@ -1151,6 +1240,7 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 			occluded = occluded || found;
 			ref = found ? kRefDone : kRefPop;
 		}
+#endif
 		// ---- finished rays ----
 		if (live && ref == kRefDone) {
 			if (isShadow) {
