@@ -11,6 +11,13 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 prim = [i for i, k in enumerate(ks) if "k_primary" in k[2] and k[4] > 256]  # the launch that generates rays: one per render of bench.py (the queue holds every primary ray); later iterations launch one block (set_wavefront_globals)
 i0 = prim[-back]
 i1 = prim[-back + 1] if back > 1 else len(ks)
+# (bench.py goes on after its last render -- the counting render, the tree built and laid out on the device: the render ends at the
+# first kernel that is not one of tyr_render's)
+RENDER = ("k_primary", "k_pad_holes", "k_trace_flat", "k_trace_stream", "k_stream_begin", "k_shade", "k_scan_words", "k_extend_spheres", "k_connect_spheres")
+for i in range(i0, i1):
+    if not any(r in ks[i][2] for r in RENDER):
+        i1 = i
+        break
 t0 = ks[i0][0]
 for s, e, n, q, _ in ks[i0:i1]:
     short = n.replace("void ", "").replace("tyr::", "").split("(")[0][:34]

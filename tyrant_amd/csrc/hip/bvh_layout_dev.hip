@@ -9,7 +9,8 @@
 //     breadth-first list of the nodes, built with one atomic per BLOCK and level (a single word serves ~88 atomics a microsecond:
 //     one per node would be 0.14 s on C5's 12.6 M nodes); the list also proves the array is a tree (every node reached once);
 //   * the quad numbering is a prefix sum in array order; the 64 records of the top move to the front in breadth-first order
-//     (one thread: 64 records), everything else keeps its order -- new_index() is a search in that 64-entry table;
+//     (one wave walks them, a generation of the queue at a time), everything else keeps its order -- new_index() is a search
+//     in that 64-entry table;
 //   * a record is written once, at its final place with its final references;
 //   * the deepest stack a traversal can need flows UP the same level lists, deepest level first.
 // What it leaves to the host pass (TYR_ERR_UNSUPPORTED, the caller falls back): the pair nodes of the counting build, leaves longer
@@ -263,37 +264,61 @@ __device__ __forceinline__ uint32_t real_meta(const tyr_bvh_node* __restrict__ n
 	return (uint32_t)P.splitAxis | ((X0.primitiveCount > 0 ? 0u : (uint32_t)X0.splitAxis) << 2) | ((X1.primitiveCount > 0 ? 0u : (uint32_t)X1.splitAxis) << 4);
 }
 
-// ---- the top of the tree: the first kStagedNodes records in breadth-first order (one thread) ----
-__global__ void k_lay_top(const tyr_bvh_node* __restrict__ nodes, const uint32_t* __restrict__ quadIndex, const uint32_t* __restrict__ nodeOfQuad, LayState* S) {
-	if (blockIdx.x != 0 || threadIdx.x != 0)
-		return;
-	uint32_t topOld[kStagedNodes];
-	uint32_t n = 1;
-	topOld[0] = 0u; // the root is interior and at depth 0: record 0
-	for (uint32_t head = 0; head < n && n < kStagedNodes; ++head) {
-		const Slots s = real_slots(nodes, quadIndex, (int32_t)nodeOfQuad[topOld[head]]);
-		for (int k = 0; k < 4 && n < kStagedNodes; ++k)
-			if ((int32_t)s.ref[k] >= 0)
-				topOld[n++] = s.ref[k];
-	}
-	// (old index, new index) sorted by old index
-	uint32_t so[kStagedNodes], sn[kStagedNodes];
-	for (uint32_t i = 0; i < n; ++i) {
-		uint32_t j = i;
-		while (j > 0 && so[j - 1] > topOld[i]) {
-			so[j] = so[j - 1];
-			sn[j] = sn[j - 1];
-			--j;
+// ---- the top of the tree: the first kStagedNodes records in breadth-first order.  One wave: a generation of the queue (the
+// records appended by the generation before) is expanded by as many lanes at once, and the children are appended in lane order,
+// slot order within a lane -- the order in which the serial walk (bvh_layout.cpp `topOld`) appends them; it stops at 64 alike.
+// (one thread needed 0.3 ms for its ~450 dependent loads: half of the whole pass on C3) ----
+__global__ void __launch_bounds__(64) k_lay_top(const tyr_bvh_node* __restrict__ nodes, const uint32_t* __restrict__ quadIndex, const uint32_t* __restrict__ nodeOfQuad, LayState* S) {
+	static_assert(kStagedNodes == 64, "one lane per record of the top");
+	__shared__ uint32_t topOld[kStagedNodes];
+	__shared__ uint32_t so[kStagedNodes], sn[kStagedNodes];
+	const uint32_t lane = threadIdx.x;
+	if (lane == 0)
+		topOld[0] = 0u; // the root is interior and at depth 0: record 0
+	__syncthreads();
+	uint32_t head = 0, n = 1;
+	while (head < n && n < kStagedNodes) {
+		const uint32_t gen = n - head;
+		uint32_t kids[4], c = 0;
+		if (lane < gen) {
+			const Slots s = real_slots(nodes, quadIndex, (int32_t)nodeOfQuad[topOld[head + lane]]);
+			for (int k = 0; k < 4; ++k)
+				if ((int32_t)s.ref[k] >= 0)
+					kids[c++] = s.ref[k];
 		}
-		so[j] = topOld[i];
-		sn[j] = i;
+		uint32_t incl = c; // inclusive prefix sum over the lanes
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t y = __shfl_up(incl, o, 64);
+			if ((int)lane >= o)
+				incl += y;
+		}
+		const uint32_t total = __shfl(incl, 63, 64);
+		const uint32_t at = n + incl - c;
+		for (uint32_t k = 0; k < c; ++k)
+			if (at + k < kStagedNodes)
+				topOld[at + k] = kids[k];
+		__syncthreads();
+		head = n;
+		n = min(n + total, kStagedNodes);
 	}
-	for (uint32_t i = 0; i < n; ++i) {
-		S->topSortedOld[i] = so[i];
-		S->topSortedNew[i] = sn[i];
+	// (old index, new index) sorted by old index: lane i's record goes to place #{j : old_j < old_i} (the indices are distinct)
+	const uint32_t mine = lane < n ? topOld[lane] : kNone;
+	uint32_t place = 0;
+	for (uint32_t j = 0; j < n; ++j)
+		place += topOld[j] < mine ? 1u : 0u;
+	if (lane < n) {
+		so[place] = mine;
+		sn[place] = lane;
 	}
-	S->nTop = n;
-	S->quadRootRef = 0u | ((real_meta(nodes, 0) & 63u) << kQuadOrderShift); // new_index(0) = 0
+	__syncthreads();
+	if (lane < n) {
+		S->topSortedOld[lane] = so[lane];
+		S->topSortedNew[lane] = sn[lane];
+	}
+	if (lane == 0) {
+		S->nTop = n;
+		S->quadRootRef = 0u | ((real_meta(nodes, 0) & 63u) << kQuadOrderShift); // new_index(0) = 0
+	}
 }
 // old index -> new index: the top's records by the table, the others keep their order behind the top
 __device__ __forceinline__ uint32_t new_index(const uint32_t* so, const uint32_t* sn, uint32_t nTop, uint32_t old) {
