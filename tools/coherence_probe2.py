@@ -69,11 +69,12 @@ def time_order(q, name, order):
     print(f"    {name:44s} extend  min {best[0]:7.3f}  median {best[2]:7.3f} ms", flush=True)
 
 
+want_first = args_first = bool(int(os.environ.get("TYR_PROBE_FIRST", "0")))  # TYR_PROBE_FIRST=1: also the camera rays (iteration 1), with the orders below
 for it in (1, 2, 3):
     for s in ("begin", "primary"):
         r.stage(s)
     k = r.counters()
-    if it >= 2:
+    if it >= 2 or want_first:
         n = k["n_live"]
         qfull = r.ray_queue(0, n)
         q = qfull[enters_root(qfull)]
@@ -88,6 +89,11 @@ for it in (1, 2, 3):
         time_order(q, "octant, then origin morton 7 bits", np.lexsort((morton(o, 7), octant)))
         time_order(q, "origin morton 7 bits alone", np.argsort(morton(o, 7), kind="stable"))
         time_order(q, "random shuffle", rng.permutation(len(q)))
+        # longest-first guesses (a launch ends on its longest rays: would they finish sooner if they started first?): the most
+        # grazing rays (|d.z| small: along the terrain), the lowest origins, and the same the other way round
+        time_order(q, "most grazing first (|d.z| ascending)", np.argsort(np.abs(d[:, 2]), kind="stable"))
+        time_order(q, "most grazing last (|d.z| descending)", np.argsort(-np.abs(d[:, 2]), kind="stable"))
+        time_order(q, "lowest origin first (o.z ascending)", np.argsort(o[:, 2], kind="stable"))
         # the imports replaced the work queue: put the real one back (every ray, the serial order) before going on
         r.import_work_queue(qfull, n)
         r.stage("primary")
