@@ -95,6 +95,26 @@ def test_device_build_emits_the_host_builders_bytes(hip):
     _same(hip, t, "grown boxes", bb)
 
 
+def test_device_build_refuses_boxes_that_are_not_finite(hip):
+    """the check runs in the first kernel that reads the boxes (a host loop over C5's 60 M floats cost as much as the build):
+    TYR_ERR_INVALID from both entry points, for a small range (one task thread) and a large one (the level loop)"""
+    from tyrant_amd import scenes
+
+    r = hip.Renderer(64, 48, 64 * 48)
+    for n in (20, 5000):
+        t = scenes.random_soup(n, seed=77)
+        for bad in (np.nan, np.inf, -np.inf):
+            bb = scenes.triangle_bboxes(t)
+            bb["bounds"][n // 2, 1, 2] = bad
+            with pytest.raises(hip.TyrError) as e:
+                hip.bvh_build_device(t, bb)
+            assert e.value.status == -1, (n, bad, e.value.status)  # TYR_ERR_INVALID
+            with pytest.raises(hip.TyrError) as e:
+                r.build_upload(t, bb)
+            assert e.value.status == -1, (n, bad, e.value.status)
+        _same(hip, t, f"after the refusals ({n})")  # the library is fine afterwards
+
+
 def test_device_build_of_the_benchmark_trees_equals_the_reference_bvh_cpp(hip):
     """C3 (1,097,453 nodes) and C5 (12,614,891 nodes): the SHA-256 the reference's own bvh.cpp produced in the authoring container
     (tests/golden/ref_build_hashes.json) -- and how long the device took"""

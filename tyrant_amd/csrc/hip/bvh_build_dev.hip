@@ -169,19 +169,27 @@ struct Slot { // an active range of the current level
 struct Counters {
 	int nNodes;   // top nodes allocated
 	int nNext;    // slots of the next level
-	int error;    // 1: a task thread's stack overflowed
+	int error;    // 1: a task thread's stack overflowed; 2: a primitive box that is not finite (TYR_ERR_INVALID)
 };
 
-__global__ void k_init_info(const tyr_bbox* __restrict__ bb, Info* __restrict__ info, int* __restrict__ slotOf, int n, int rootSlot) {
+__global__ void k_init_info(const tyr_bbox* __restrict__ bb, Info* __restrict__ info, int* __restrict__ slotOf, int n, int rootSlot, Counters* K) {
 	const int i = blockIdx.x * kBlockB + threadIdx.x;
 	if (i >= n)
 		return;
 	Info p;
+	bool finite = true;
 	for (int k = 0; k < 3; ++k) {
 		p.lo[k] = bb[i].bounds[0][k];
 		p.hi[k] = bb[i].bounds[1][k];
-		p.c[k] = p.lo[k] * 0.5f + p.hi[k] * 0.5f; // bvh.h:96
+		finite = finite && isfinite(p.lo[k]) && isfinite(p.hi[k]);
 	}
+	if (!finite) { // refused -- and made harmless until the host has read the flag (a bucket index computed from a NaN is anything)
+		K->error = 2;
+		for (int k = 0; k < 3; ++k)
+			p.lo[k] = p.hi[k] = 0.0f;
+	}
+	for (int k = 0; k < 3; ++k)
+		p.c[k] = p.lo[k] * 0.5f + p.hi[k] * 0.5f; // bvh.h:96
 	p.idx = static_cast<uint32_t>(i);
 	info[i] = p;
 	slotOf[i] = rootSlot;
@@ -872,7 +880,7 @@ int bvh_build_device_keep(int device, const tyr_triangle* prims, int32_t n, cons
 		s0.node = 0;
 		TYR_D(hipMemcpyAsync(dSlots[0].p, &s0, sizeof(int), hipMemcpyHostToDevice, st)); // (only `node`: k_slot_reset and k_decide_dim fill the rest)
 	}
-	hipLaunchKernelGGL(k_init_info, dim3(grid(n)), dim3(kBlockB), 0, st, dBB.p, dInfo[0].p, dSlotOf[0].p, n, n <= kTaskPrims ? -1 : 0);
+	hipLaunchKernelGGL(k_init_info, dim3(grid(n)), dim3(kBlockB), 0, st, dBB.p, dInfo[0].p, dSlotOf[0].p, n, n <= kTaskPrims ? -1 : 0, dK.p);
 	int cur = 0, nSlots = n <= kTaskPrims ? 0 : 1;
 	std::vector<int> levelStart{ 0 }; // top-node ids [levelStart[l], levelStart[l + 1]) were made by level l - 1's splits (level 0: the root)
 	int nTop = 1;
@@ -898,6 +906,8 @@ int bvh_build_device_keep(int device, const tyr_triangle* prims, int32_t n, cons
 		hipLaunchKernelGGL(k_scatter, dim3(grid(n)), dim3(kBlockB), 0, st, in, out, dSlotOf[cur].p, dSlotOf[cur ^ 1].p, S, dNodes.p, dFlags.p, dExcl.p, dPosML.p, dPosMR.p, n);
 		TYR_D(hipMemcpyAsync(&hK, dK.p, sizeof hK, hipMemcpyDeviceToHost, st));
 		TYR_D(hipStreamSynchronize(st));
+		if (hK.error == 2)
+			return TYR_ERR_INVALID;
 		nTop = hK.nNodes;
 		nSlots = hK.nNext;
 		if (static_cast<size_t>(nSlots) > maxSlots || static_cast<size_t>(nTop) > maxTop)
@@ -930,7 +940,7 @@ int bvh_build_device_keep(int device, const tyr_triangle* prims, int32_t n, cons
 	TYR_D(hipStreamSynchronize(st));
 	TYR_D(hipGetLastError());
 	if (hK.error)
-		return TYR_ERR_UNSUPPORTED;
+		return hK.error == 2 ? TYR_ERR_INVALID : TYR_ERR_UNSUPPORTED;
 	const int nNodes = root.size;
 	if (nNodes <= 0 || static_cast<size_t>(nNodes) > 2 * N)
 		return TYR_ERR_DEVICE;

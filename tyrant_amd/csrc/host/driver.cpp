@@ -770,10 +770,6 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 int tyr_scene_build_upload(tyr_ctx* c, tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t* n_nodes_out, double* seconds_out3) {
 	if (!c || n < 0 || (n > 0 && (!prims || !bboxes)))
 		return TYR_ERR_INVALID;
-	for (int32_t i = 0; i < n; ++i)
-		for (int k = 0; k < 6; ++k)
-			if (!std::isfinite((&bboxes[i].bounds[0][0])[k]))
-				return TYR_ERR_INVALID;
 	int rc = use_device(c);
 	if (rc)
 		return rc;
@@ -2102,11 +2098,7 @@ int tyr_get_timings(tyr_ctx* c, tyr_timings* out, int reset) {
 int tyr_bvh_build(tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, int32_t algo) { return bvh_build(prims, n, bboxes, nodes_out, algo); }
 
 int tyr_bvh_build_device(int32_t device, tyr_triangle* prims, int32_t n, const tyr_bbox* bboxes, tyr_bvh_node* nodes_out, double* seconds_out2) {
-	for (int32_t i = 0; i < n && bboxes; ++i)
-		for (int k = 0; k < 6; ++k)
-			if (!std::isfinite((&bboxes[i].bounds[0][0])[k]))
-				return TYR_ERR_INVALID;
-	try {
+	try { // (a box that is not finite is refused by the first kernel that reads the boxes: TYR_ERR_INVALID, nothing reordered)
 		return bvh_build_device(device, prims, n, bboxes, nodes_out, seconds_out2);
 	} catch (const std::bad_alloc&) {
 		return TYR_ERR_OOM;
