@@ -866,20 +866,18 @@ int bvh_build_device_keep(int device, const tyr_triangle* prims, int32_t n, cons
 	double copyS = std::chrono::duration<double>(std::chrono::steady_clock::now() - tCopy0).count();
 	hipStream_t st = nullptr;
 	TYR_D(hipEventRecord(ev0, st));
-	// the root
-	{
-		TopNode root{};
-		root.start = 0;
-		root.end = n;
-		root.state = n <= kTaskPrims ? kTask : kActive;
-		root.left = root.right = -1;
-		TYR_D(hipMemcpyAsync(dNodes.p, &root, sizeof root, hipMemcpyHostToDevice, st));
-		Counters k0{ 1, 0, 0 };
-		TYR_D(hipMemcpyAsync(dK.p, &k0, sizeof k0, hipMemcpyHostToDevice, st));
-		Slot s0{};
-		s0.node = 0;
-		TYR_D(hipMemcpyAsync(dSlots[0].p, &s0, sizeof(int), hipMemcpyHostToDevice, st)); // (only `node`: k_slot_reset and k_decide_dim fill the rest)
-	}
+	// the root (sources of asynchronous copies: function scope, they live until the stream has been waited for)
+	TopNode root0{};
+	root0.start = 0;
+	root0.end = n;
+	root0.state = n <= kTaskPrims ? kTask : kActive;
+	root0.left = root0.right = -1;
+	TYR_D(hipMemcpyAsync(dNodes.p, &root0, sizeof root0, hipMemcpyHostToDevice, st));
+	const Counters k0{ 1, 0, 0 };
+	TYR_D(hipMemcpyAsync(dK.p, &k0, sizeof k0, hipMemcpyHostToDevice, st));
+	Slot s0{};
+	s0.node = 0;
+	TYR_D(hipMemcpyAsync(dSlots[0].p, &s0, sizeof(int), hipMemcpyHostToDevice, st)); // (only `node`: k_slot_reset and k_decide_dim fill the rest)
 	hipLaunchKernelGGL(k_init_info, dim3(grid(n)), dim3(kBlockB), 0, st, dBB.p, dInfo[0].p, dSlotOf[0].p, n, n <= kTaskPrims ? -1 : 0, dK.p);
 	int cur = 0, nSlots = n <= kTaskPrims ? 0 : 1;
 	std::vector<int> levelStart{ 0 }; // top-node ids [levelStart[l], levelStart[l + 1]) were made by level l - 1's splits (level 0: the root)

@@ -452,12 +452,10 @@ int layout_on_device(const tyr_bvh_node* dNodes, int32_t nNodes, const tyr_trian
 	if (hS.bad || hS.notHere)
 		return TYR_ERR_UNSUPPORTED;
 	// ---- the levels: the root is level 0 ----
-	{
-		const uint32_t one = 1u, zero = 0u, rootMark = 1u;
-		TYR_L(hipMemcpyAsync(&dS.p->levelCount[0], &one, 4, hipMemcpyHostToDevice, st));
-		TYR_L(hipMemcpyAsync(dList.p, &zero, 4, hipMemcpyHostToDevice, st));
-		TYR_L(hipMemcpyAsync(dSeen.p, &rootMark, 4, hipMemcpyHostToDevice, st));
-	}
+	const uint32_t one = 1u, zero = 0u, rootMark = 1u; // (sources of asynchronous copies: they live until the stream has been waited for)
+	TYR_L(hipMemcpyAsync(&dS.p->levelCount[0], &one, 4, hipMemcpyHostToDevice, st));
+	TYR_L(hipMemcpyAsync(dList.p, &zero, 4, hipMemcpyHostToDevice, st));
+	TYR_L(hipMemcpyAsync(dSeen.p, &rootMark, 4, hipMemcpyHostToDevice, st));
 	const unsigned levelGrid = std::min<unsigned>(blocks_for(nN / 2 + 1), 2048u);
 	uint32_t nLevels = 0;
 	for (uint32_t l0 = 0;; l0 += 16) {
