@@ -625,15 +625,6 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 	// needs at all (wave-uniform branches on ballots), state changes are selects, loads of lanes that have nothing to load
 	// go to record 0.  A lane that turns a node into a leaf tests the leaf in the same trip.
 	const bool allRegular = __ballot(gActive && !regular) == 0ull; // (the generic box test is exact for regular rays too: one path for the wave)
-#ifdef TYR_WIDE_PREFETCH
-	// what-if (round 5; bit-exact, +-0: profiles/r05_whatif_wide_prefetch.txt).
-	// The record on top of the stack, fetched while a leaf's primitives are: a ray's steps are a chain of dependent fetches
-	// (node -> leaf -> pop -> node ...), and the launch ends on the longest such chain.  What the pop after a leaf will ask for
-	// is known when the leaf is entered -- the top entry -- so this lane's part of THAT record travels beside the primitives
-	// and waits in pf* under the reference it belongs to (records never change: whenever `ref == pfRef` the copy is the record).
-	uint32_t pfRef = kRefDone, pcref = 0u;
-	float2 pbx = make_float2(0.0f, 0.0f), pby = pbx, pbz = pbx;
-#endif
 #ifdef TYR_WIDE_LONE_GROUPS
 	// what-if (round 5): the launch's very last rays -- a wave down to TYR_WIDE_LONE_GROUPS groups or fewer -- are bound by the
 	// latency of one step, not by the SIMD's issue slots; they take the loop with branches below, which runs only the blocks a
@@ -663,21 +654,10 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 			const uint32_t idx = atNode ? (ref & kQuadIndexMask) : 0u, meta = ref >> kQuadOrderShift;
 			const float* qf = reinterpret_cast<const float*>(quads + 8 * idx);
 			const uint32_t at = (sub >> 1) * 4u + (sub & 1u) * 2u;
-#ifdef TYR_WIDE_PREFETCH
-			float2 bx = pbx, by = pby, bz = pbz;
-			uint32_t cref = pcref;
-			if (ref != pfRef) { // (lanes that are at no node load record 0, as before)
-				bx = gload_f2(qf + at);
-				by = gload_f2(qf + 8 + at);
-				bz = gload_f2(qf + 16 + at);
-				cref = gload_u(qf + 24 + sub);
-			}
-#else
-			const float2 bx = *reinterpret_cast<const float2*>(qf + at);
-			const float2 by = *reinterpret_cast<const float2*>(qf + 8 + at);
-			const float2 bz = *reinterpret_cast<const float2*>(qf + 16 + at);
-			const uint32_t cref = __float_as_uint(qf[24 + sub]);
-#endif
+			const float2 bx = gload_f2(qf + at);
+			const float2 by = gload_f2(qf + 8 + at);
+			const float2 bz = gload_f2(qf + 16 + at);
+			const uint32_t cref = gload_u(qf + 24 + sub);
 			float t;
 			bool h;
 			if (allRegular)
@@ -708,21 +688,6 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 			const uint32_t off = ref & (kMaxPrimOffset - 1);
 			const uint32_t cnt = atLeaf ? ((ref >> 26) & 31u) + 1u : 0u;
 			bool found = false;
-#ifdef TYR_WIDE_PREFETCH
-			{
-				const int top = n > 0 ? n - 1 : 0;
-				const entry_t e = gstack[(top >> 2) * kBlock + (top & 3)];
-				if (atLeaf && n > 0 && (int)e.x >= 0 && e.x != pfRef && __uint_as_float(e.y) < dist) {
-					const float* pq = reinterpret_cast<const float*>(quads + 8 * (e.x & kQuadIndexMask));
-					const uint32_t at = (sub >> 1) * 4u + (sub & 1u) * 2u;
-					pbx = gload_f2(pq + at);
-					pby = gload_f2(pq + 8 + at);
-					pbz = gload_f2(pq + 16 + at);
-					pcref = gload_u(pq + 24 + sub);
-					pfRef = e.x;
-				}
-			}
-#endif
 			for (uint32_t base = 0; __ballot(base < cnt) != 0ull; base += 4u) {
 				const uint32_t i = base + sub;
 				const bool mine = i < cnt;
@@ -1198,26 +1163,6 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 			}
 		}
 #endif
-#ifdef TYR_WHATIF_LEAF_ONE_PER_PHASE
-		// what-if (round 5): ONE primitive per lane and leaf phase -- a lane whose leaf holds more keeps the rest (the reference of the
-		// leaf's tail: off + 1, cnt - 1) for the next phase, when more lanes have arrived at leaves, instead of the phase running
-		// max(cnt) rounds at ever fewer lanes.  Same tests in the same order per ray.
-		if (ref_is_leaf(ref)) {
-			const uint32_t off = ref & (kMaxPrimOffset - 1);
-			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
-			const float t = triangle_test(triangle_load(sc.tris, off), r);
-			bool found = false;
-			if (isShadow) {
-				found = (t > kEpsilon && ((dist - t) > kEpsilon)); // bvh.h:232-236
-			} else if (t > kEpsilon && t < dist && ((dist - t) > kEpsilon)) {
-				prim = (int)off;
-				dist = t;
-				hitTri = true;
-			}
-			occluded = occluded || found;
-			ref = found ? kRefDone : (cnt > 1u ? (kRefLeaf | ((cnt - 2u) << 26) | (off + 1u)) : kRefPop);
-		}
-#else
 		if (ref_is_leaf(ref)) {
 			const uint32_t off = ref & (kMaxPrimOffset - 1);
 			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
@@ -1240,7 +1185,6 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 			occluded = occluded || found;
 			ref = found ? kRefDone : kRefPop;
 		}
-#endif
 		// ---- finished rays ----
 		if (live && ref == kRefDone) {
 			if (isShadow) {
