@@ -339,6 +339,7 @@ enum {
 	TYR_TUNE_WIDE_BLOCK_MIN_ITEMS = 22, /* k_trace_flat: a launch of at least this many rays (extend + carried shadow rays) runs as 768-thread blocks -- two per CU, six waves per SIMD, one copy of the staged nodes per three 256-thread parts -- instead of 256-thread blocks at five waves per SIMD; default 3 Mi (the sixth wave feeds a fat launch faster and lengthens the drain of a thin one); -1: never */
 	TYR_TUNE_FOLD_PROLOGUE = 23,     /* tyr_render, one iteration ahead of the counts (TYR_TUNE_RUN_AHEAD) with TYR_TUNE_FOLD_SPHERES: 1 (default) = once the primary budget is spent, the kernel that ends an iteration (the slot scan) also opens the next one -- set_wavefront_globals (kernel.cu:227-244) and the padding of the queue segments' ends -- instead of a one-block launch each in front of the traversal kernel; 0 = those launches */
 	TYR_TUNE_LAYOUT_ON_DEVICE = 24,  /* tyr_scene_upload: 1 (default) = the reference's node and triangle arrays are copied to the device as they are (32 + 40 bytes per node / triangle) and the layout pass runs there (hip/bvh_layout_dev.hip: the same bytes as the host pass; trees it leaves to the host -- pair nodes wanted, leaves of more than 31 primitives, a tree that is one leaf, malformed input -- take the host pass); 0 = always the host pass + a copy of the finished records (128 + 48 bytes) */
+	TYR_TUNE_SCAN_IN_TRACE = 25,     /* tyr_render one iteration ahead of the counts (TYR_TUNE_RUN_AHEAD), with TYR_TUNE_FOLD_PROLOGUE: 1 (default) = once the primary budget is spent, an iteration's slot scan -- whose tables only the NEXT shade launch reads -- is not a launch of its own: the shade launch's last block opens the next iteration (set_wavefront_globals, kernel.cu:227-244, and the padding of the queue segments' ends) and that iteration's traversal launch does the scan on its way in, a wave per 16384 slots; 0 = a k_scan_words launch in front of the traversal launch, opening the iteration itself */
 	TYR_TUNE_FOLD_SPHERES = 19       /* merged path of tyr_render: 1 (default) = shade does the sphere pre-passes' work (kernel.cu:127-136, 168-172) for the rays it emits, while they are in registers; 0 = the pre-pass kernels re-read them */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);

@@ -109,7 +109,8 @@ struct DevCounters {
 	uint32_t shade_blocks_done;               // k_shade: blocks that have finished (the last one folds the segment counters into the totals)
 	uint32_t scan_blocks_done;                // k_scan_words: likewise (the last one scans the blocks' totals)
 	uint32_t primary_blocks_done;             // k_primary: likewise (the last one is set_wavefront_globals)
-	uint32_t reserved3[29];
+	uint32_t scan_live[2];                    // n_live of iteration i at [i & 1], kept by k_shade's last block for a slot scan that runs BEHIND the next iteration's prologue (FrameParams::shadeOpensNext, scanPrevInTrace)
+	uint32_t reserved3[27];
 	uint32_t primary_done[kTicketWords * 32]; // k_primary: finished blocks b with b % 8 == w, one word per 128 bytes
 	uint32_t segSurv[kClasses][kSegs];        // seg[next] as shade left it: the records in front of the primary rays a top-up appends (the sphere pre-pass's share)
 	uint32_t reserved4[16];
@@ -219,6 +220,10 @@ struct FrameParams {
 	uint32_t retireSky;           // k_primary: finish the camera rays that hit nothing (no sphere, not the root box) on the spot instead of queueing them for shade (tyr_render's merged path; the stage API keeps the reference's full queue)
 	uint32_t foldNextPrologue;    // k_scan_words: its last block also opens the NEXT iteration (set_wavefront_globals + the hole padding in front of its traversal launch): tyr_render one iteration ahead of the counts, once the budget is spent (no top-up can follow)
 	uint32_t prologueDone;        // the traversal launchers: the previous iteration's k_scan_words did that (no k_primary launch, no k_pad_holes)
+	uint32_t shadeOpensNext;      // k_shade: its last block opens the NEXT iteration (what foldNextPrologue has k_scan_words do) and keeps this iteration's n_live in scan_live[]: the scan is then left to the next traversal launch (scanPrevInTrace; TYR_TUNE_SCAN_IN_TRACE)
+	uint32_t scanSet;             // ... scan_live[scanSet & 1]: the iteration's parity
+	uint32_t scanPrevInTrace;     // k_trace_flat: on its way in, its waves do the slot scan of the iteration BEFORE (n = *scanLivePrev, tables = vPrev): that iteration's shade opened this one (shadeOpensNext) and no k_scan_words was launched
+	const uint32_t* scanLivePrev;
 	uint32_t prevFolded;          // the traversal launchers: the shade launch that made this iteration's survivors and shadow rays did so (only the holes at the segments' ends are left to mark)
 	uint32_t* fillWork;           // fill counters of the work queue's class 0 (what k_trace_stream waits on for iteration j), one per 64-slot chunk
 	uint32_t* fillNext;           // ... of the next queue's class 0 (what this iteration's shade publishes)
@@ -256,6 +261,7 @@ struct Tuning {
 	int wideBlockMinItems = 3 << 20; // k_trace_flat: launches of at least this many rays run as 768-thread blocks, six waves per SIMD (< 0: never)
 	int foldPrologue = 1;     // tyr_render one iteration ahead of the counts: once the budget is spent, an iteration's last kernel opens the next one (set_wavefront_globals, hole padding): two launches and two gaps fewer per iteration
 	int layoutOnDevice = 1;   // tyr_scene_upload: the reference's arrays go to the device as they are and hip/bvh_layout_dev.hip makes the records there (the same bytes); 0 = host/bvh_layout.cpp makes them and they are copied
+	int scanInTrace = 1;      // tyr_render one iteration ahead, the next iteration known to come without a top-up: no k_scan_words launch -- k_shade's last block opens that iteration and its traversal launch's waves do the slot scan on their way in (hip/scan_wave.hpp)
 	int foldSpheres = 1;      // merged path of tyr_render: shade does the sphere pre-passes' work for the rays it emits (the streamed tail always does); 0: k_extend_spheres / k_connect_spheres re-read them
 };
 constexpr uint32_t kCountRaysPerBlock = 1024; // the counting build's kernels: queue slots owned by one 256-thread block

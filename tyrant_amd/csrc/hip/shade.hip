@@ -4,6 +4,7 @@
 // queue), in whatever order the tiles finish.  Rounds 1-2 kept the serial order physically (a stable compaction with a
 // decoupled look-back); that chained every tile to all tiles before it.
 #include "device_common.hpp"
+#include "prologue.hpp"
 
 namespace tyr {
 
@@ -516,6 +517,8 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	f3 pendColor = mk3(0.f, 0.f, 0.f);
 	uint32_t prevSeg = 0, prevS = 0, prevT = 0, prevH = 0;
 	uint32_t mySurvivors = 0, myShadows = 0; // thread 0: what this block appended
+	[[maybe_unused]] bool lastBlock = false;  // thread 0: this block finished last (the kernel's end)
+	[[maybe_unused]] uint32_t survivors = 0;  // ... and the iteration's survivor count it read there
 	uint32_t waveGhosts = 0; // (wave-uniform) survivors finished in place (P.retireGhosts): they count as survivors
 	uint32_t waveResolved = 0, waveVisible = 0; // (wave-uniform) shadow rays answered in place (P.resolveShadows): they count as emitted, the visible ones as visible
 
@@ -913,6 +916,36 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			for (uint32_t c = 0; c < kClasses; ++c) // what the next iteration's sphere pre-pass has to do (a top-up appends behind it)
 				for (uint32_t w = 0; w < kSegs; ++w)
 					PE.k->segSurv[c][w] = __hip_atomic_load(&PE.segNext[c * kClassWords + w * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			lastBlock = true;
+			survivors = s;
+		}
+	}
+	// P.shadeOpensNext (tyr_render one iteration ahead, the next iteration known to come without a top-up; TYR_TUNE_SCAN_IN_TRACE): the
+	// block that finishes last opens that iteration -- the hole padding and set_wavefront_globals, what P.foldNextPrologue has
+	// k_scan_words' last block do -- so that the scan of THIS iteration's survive bytes, which only the next SHADE launch reads, needs no
+	// launch in front of the next traversal launch: that launch's waves do it on their way in (hip/scan_wave.hpp).  Everything read here was written by
+	// agent-scope atomics (the counters) or by this thread; the scan finds its ray count in scan_live[] (n_live is reset below).
+	if (!STREAM) {
+		if (PE.shadeOpensNext != 0u) { // (wave-uniform: a kernel argument)
+			__syncthreads(); // sh[] is free: every wave has left the tile loop
+			if (tid == 0) {
+				sh[16] = lastBlock ? 1u : 0u;
+				sh[17] = survivors;
+			}
+			__syncthreads();
+			if (sh[16] != 0u) {
+				if (tid < kSegs)
+					sh[tid] = __hip_atomic_load(&PE.segNext[tid * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // class 0 of the next work queue
+				else if (tid < 2u * kSegs)
+					sh[tid] = __hip_atomic_load(&PE.kc->seg[(tid - kSegs) * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // this iteration's shadow queue
+				if (tid == 0)
+					PE.k->scan_live[PE.scanSet & 1u] = PE.k->n_live;
+				__syncthreads();
+				pad_work_holes_counts(PE.next, sh);
+				pad_shadow_holes_counts(PE.shadow, sh + kSegs);
+				__syncthreads();
+				wavefront_globals_for(PE, PE.segWork, PE.kcPrev, true, sh[17]);
+			}
 		}
 	}
 #undef TYR_STAMP

@@ -4,6 +4,7 @@
 // same state machine on pair nodes (k_extend_count / k_connect_count), which reproduces the reference's visit counts
 // (bvh.h:164-209).  
 #include "device_common.hpp"
+#include "scan_wave.hpp"
 
 namespace tyr {
 
@@ -936,6 +937,14 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 	if (threadIdx.x == 0)
 		blockNext = blockBegin;
 	__syncthreads();
+	if (P.scanPrevInTrace == 1u) {
+		// the slot scan of the iteration before (scan_wave.hpp): a wave per 16384-slot block, dealt over the BLOCKS first (block b's wave
+		// k takes scan block k * gridDim + b: no block has more than one or two waves at it), behind the barrier -- the block's other
+		// waves are already drawing rays from its share, which waits for nobody
+		const uint32_t wavesPerBlock = kTraceBlock / 64u;
+		scan_blocks_by_wave(P.survFlag, const_cast<unsigned long long*>(P.vPrev.word), const_cast<uint32_t*>(P.vPrev.pre), const_cast<uint32_t*>(P.vPrev.blk), &P.k->scan_blocks_done,
+		                    *P.scanLivePrev, (threadIdx.x >> 6) * gridDim.x + blockIdx.x, gridDim.x * wavesPerBlock, P.retireGhosts != 0u);
+	}
 	bool exhausted = nItems == 0;
 	bool wide = false;
 	const uint32_t wideLimit = (P.wideDrain != 0u && P.scene.quadMaxStack <= (uint32_t)kWideStackEntries) ? kWideRays : 0u; // (a tree that could need more than the group's 48 entries keeps its rays one to a lane)

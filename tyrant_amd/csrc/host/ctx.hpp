@@ -35,6 +35,9 @@ struct tyr_ctx {
 
 	hipStream_t side = nullptr; // second stream of a ctx (shade launches that run beside the traversal)
 	hipEvent_t evSnapshot = nullptr;
+	// TYR_TUNE_SCAN_IN_TRACE
+	bool scanCarried = false;      // the last shade launch left its slot scan to the next traversal launch (hip/scan_wave.hpp)
+	uint32_t scanCarriedSet = 0;
 	// tyr_render with TYR_TUNE_MERGE_TRACE: the shadow rays of the last shaded iteration have not been traced yet (they
 	// ride in the next iteration's trace launch, or in a connect of their own when the render ends)
 	bool shadowPending = false;

@@ -289,6 +289,11 @@ void enqueue_trace(tyr_ctx* c, const FrameParams& P0, uint32_t nLive, uint32_t n
 	FrameParams P = P0;
 	P.traceShadow = maxShadowPrev != 0 ? 1u : 0u;
 	P.prevFolded = c->lastShadeFolded ? 1u : 0u;
+	if (c->scanCarried) { // the iteration before left its slot scan to this launch (TYR_TUNE_SCAN_IN_TRACE)
+		P.scanPrevInTrace = 1u;
+		P.scanLivePrev = &c->dK->scan_live[c->scanCarriedSet];
+		c->scanCarried = false;
+	}
 	KernelTimer t(c, TYR_K_EXTEND);
 	launch_trace(P, nLive, nSurvivors, maxShadowPrev, c->tuning, c->numCUs, c->launchCache, c->stream);
 }
@@ -298,7 +303,14 @@ void enqueue_shade(tyr_ctx* c, const FrameParams& P, uint32_t nLive) {
 	c->lastShadeFolded = P.foldSpheres != 0u;
 	KernelTimer t(c, TYR_K_SHADE);
 	launch_shade(P, nLive, c->numCUs, c->launchCache, c->stream);
-	launch_scan(P, nLive, c->stream);
+	if (P.shadeOpensNext != 0u) {
+		// shade's last block has opened the next iteration, and the scan's tables are read by the NEXT shade launch only: no k_scan_words
+		// launch -- the next traversal launch's waves do the scan on their way in (hip/scan_wave.hpp; enqueue_trace hands it over)
+		c->scanCarried = true;
+		c->scanCarriedSet = P.scanSet & 1u;
+	} else {
+		launch_scan(P, nLive, c->stream);
+	}
 }
 void enqueue_connect(tyr_ctx* c, const FrameParams& P0, uint32_t maxShadow) {
 	FrameParams P = P0;
@@ -1262,7 +1274,13 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 	}
 	if (c->tuning.retireSky)
 		P.retireSky = 1u;
-	P.foldNextPrologue = foldNext ? 1u : 0u;
+	const bool aside = foldNext && c->tuning.scanInTrace != 0;
+	P.foldNextPrologue = (foldNext && !aside) ? 1u : 0u;
+	P.shadeOpensNext = aside ? 1u : 0u; // k_shade's last block opens the next iteration, whose traversal launch does this iteration's slot scan on its way in (TYR_TUNE_SCAN_IN_TRACE)
+	if (aside) {
+		P.scanSet = static_cast<uint32_t>(set);
+		P.scanLive = &c->dK->scan_live[set];
+	}
 	P.prologueDone = prologueDone ? 1u : 0u;
 	if (!prologueDone)
 		enqueue_primary(c, P, p.nNew);
@@ -1329,6 +1347,7 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 			folded = mayFold && budget == 0 && queued_ahead_behind(enq, 0, lastBirth); // (budget == 0: iteration enq tops nothing up, gives birth to nothing)
 			if ((rc = enqueue_merged_iteration(c, IterationPlan{ newMax, liveMax, live, live }, false, folded, opened))) {
 				(void)hipStreamSynchronize(c->stream); // (the failed iteration may be partly queued; nothing of it is the render's)
+				c->scanCarried = false;
 				c->shadowSet = shadowSetBefore;
 				c->lastShadeFolded = foldedBefore;
 				return rc;
@@ -1352,6 +1371,7 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 		auto abandon = [&](int code) {
 			if (ahead) {
 				(void)hipStreamSynchronize(c->stream);
+				c->scanCarried = false;
 				c->frame = frameBefore;
 				c->cur ^= 1;
 				c->iter--;
@@ -2073,6 +2093,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_WIDE_BLOCK_MIN_ITEMS, -1, 0x7fffffff, &Tuning::wideBlockMinItems },
 		{ TYR_TUNE_FOLD_PROLOGUE, 0, 1, &Tuning::foldPrologue },
 		{ TYR_TUNE_LAYOUT_ON_DEVICE, 0, 1, &Tuning::layoutOnDevice },
+		{ TYR_TUNE_SCAN_IN_TRACE, 0, 1, &Tuning::scanInTrace },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)
