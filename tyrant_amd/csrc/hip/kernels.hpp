@@ -79,6 +79,13 @@ constexpr uint32_t kTicketWords = 8; // = XCDs: block b draws from word b % 8 fi
 // only sound while everything the finishing block READS of the others' output was written with agent-scope atomics (the
 // counters, vBlkOut) or is only OVERWRITTEN by it (counts the others have finished reading).  A plain store added to
 // something a finaliser reads would race silently across the XCDs' L2s: use __hip_atomic_store / atomicAdd there.
+// what k_shade's last block tells the host directly (FrameParams::hostSnap): the counts of the iteration, then -- behind a system-scope
+// fence -- the stamp the host is waiting for
+struct HostSnap {
+	uint32_t survivors, shadows, device_error, n_live;
+	uint32_t pad[11];
+	uint32_t seq;
+};
 struct DevCounters {
 	uint32_t primary_ray_cnt;
 	uint32_t start_position;
@@ -222,6 +229,8 @@ struct FrameParams {
 	uint32_t prologueDone;        // the traversal launchers: the previous iteration's k_scan_words did that (no k_primary launch, no k_pad_holes)
 	uint32_t shadeOpensNext;      // k_shade: its last block opens the NEXT iteration (what foldNextPrologue has k_scan_words do) and keeps this iteration's n_live in scan_live[]: the scan is then left to the next traversal launch (scanPrevInTrace; TYR_TUNE_SCAN_IN_TRACE)
 	uint32_t scanSet;             // ... scan_live[scanSet & 1]: the iteration's parity
+	HostSnap* hostSnap;           // k_shade: its last block writes what the host's render loop steers by here (pinned host memory) -- no copy and no event between this launch and the next (TYR_TUNE_KERNEL_SNAPSHOT)
+	uint32_t snapSeq;             // ... stamped with this number, written last
 	uint32_t scanPrevInTrace;     // k_trace_flat: on its way in, its waves do the slot scan of the iteration BEFORE (n = *scanLivePrev, tables = vPrev): that iteration's shade opened this one (shadeOpensNext) and no k_scan_words was launched
 	const uint32_t* scanLivePrev;
 	uint32_t prevFolded;          // the traversal launchers: the shade launch that made this iteration's survivors and shadow rays did so (only the holes at the segments' ends are left to mark)
@@ -262,6 +271,7 @@ struct Tuning {
 	int foldPrologue = 1;     // tyr_render one iteration ahead of the counts: once the budget is spent, an iteration's last kernel opens the next one (set_wavefront_globals, hole padding): two launches and two gaps fewer per iteration
 	int layoutOnDevice = 1;   // tyr_scene_upload: the reference's arrays go to the device as they are and hip/bvh_layout_dev.hip makes the records there (the same bytes); 0 = host/bvh_layout.cpp makes them and they are copied
 	int scanInTrace = 1;      // tyr_render one iteration ahead, the next iteration known to come without a top-up: no k_scan_words launch -- k_shade's last block opens that iteration and its traversal launch's waves do the slot scan on their way in (hip/scan_wave.hpp)
+	int kernelSnapshot = 1;   // tyr_render one iteration ahead: the counts the host waits for are written to pinned host memory by k_shade's last block instead of copied behind it and signalled by an event (two packets in the stream between this iteration's shade and the next traversal launch)
 	int foldSpheres = 1;      // merged path of tyr_render: shade does the sphere pre-passes' work for the rays it emits (the streamed tail always does); 0: k_extend_spheres / k_connect_spheres re-read them
 };
 constexpr uint32_t kCountRaysPerBlock = 1024; // the counting build's kernels: queue slots owned by one 256-thread block

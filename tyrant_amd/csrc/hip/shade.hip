@@ -519,6 +519,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	uint32_t mySurvivors = 0, myShadows = 0; // thread 0: what this block appended
 	[[maybe_unused]] bool lastBlock = false;  // thread 0: this block finished last (the kernel's end)
 	[[maybe_unused]] uint32_t survivors = 0;  // ... and the iteration's survivor count it read there
+	[[maybe_unused]] uint32_t snapShadows = 0;
 	uint32_t waveGhosts = 0; // (wave-uniform) survivors finished in place (P.retireGhosts): they count as survivors
 	uint32_t waveResolved = 0, waveVisible = 0; // (wave-uniform) shadow rays answered in place (P.resolveShadows): they count as emitted, the visible ones as visible
 
@@ -918,6 +919,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 					PE.k->segSurv[c][w] = __hip_atomic_load(&PE.segNext[c * kClassWords + w * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			lastBlock = true;
 			survivors = s;
+			snapShadows = h;
 		}
 	}
 	// P.shadeOpensNext (tyr_render one iteration ahead, the next iteration known to come without a top-up; TYR_TUNE_SCAN_IN_TRACE): the
@@ -946,6 +948,16 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 				__syncthreads();
 				wavefront_globals_for(PE, PE.segWork, PE.kcPrev, true, sh[17]);
 			}
+		}
+	}
+	// the counts the host's render loop waits for, straight into its (pinned) memory: four stores, a fence, the stamp
+	if (!STREAM) {
+		if (tid == 0 && lastBlock && PE.hostSnap != nullptr) {
+			HostSnap* const hs = PE.hostSnap;
+			__hip_atomic_store(&hs->survivors, survivors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&hs->shadows, snapShadows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&hs->device_error, __hip_atomic_load(&PE.k->device_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&hs->seq, PE.snapSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 	}
 #undef TYR_STAMP

@@ -29,6 +29,10 @@ struct tyr_ctx {
 	DevCounters* hK = nullptr; // pinned host mirror
 	DevCounters* hSnap[2] = { nullptr, nullptr }; // tyr_render one iteration ahead: where the counters of iteration i land (set i & 1)
 	hipEvent_t evSnap[2] = { nullptr, nullptr };
+	tyr::HostSnap* hostSnap[2] = { nullptr, nullptr }; // TYR_TUNE_KERNEL_SNAPSHOT: written by k_shade's last block (pinned, device-visible)
+	tyr::HostSnap* hostSnapDev[2] = { nullptr, nullptr }; // ... as the device addresses them
+	uint32_t snapSeq = 0;                               // stamp of the last iteration queued with a kernel-written snapshot
+	uint32_t snapSeqOf[2] = { 0, 0 };                   // ... per set (0: that iteration uses the copy + event)
 	ConnectCounters* dKc = nullptr; // two sets, iteration i uses set i & 1
 	uint32_t iter = 0;
 	uint32_t shadowSet = 0; // which of the two sets holds the counts of the shadow queue's current content (tyr_shadow_export)

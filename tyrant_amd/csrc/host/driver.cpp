@@ -541,6 +541,11 @@ int tyr_create(tyr_ctx** out, const tyr_config* cfg) {
 		std::memset(c->hSnap[s], 0, sizeof(DevCounters));
 		if (hipEventCreateWithFlags(&c->evSnap[s], hipEventDisableTiming) != hipSuccess)
 			return fail(TYR_ERR_NO_DEVICE);
+		if (hipHostMalloc(reinterpret_cast<void**>(&c->hostSnap[s]), sizeof(tyr::HostSnap), hipHostMallocMapped) != hipSuccess)
+			return fail(TYR_ERR_OOM);
+		std::memset(c->hostSnap[s], 0, sizeof(tyr::HostSnap));
+		if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->hostSnapDev[s]), c->hostSnap[s], 0) != hipSuccess)
+			return fail(TYR_ERR_NO_DEVICE);
 	}
 	c->scene.rootRef = kRefDone;
 	*out = c;
@@ -599,6 +604,8 @@ int tyr_destroy(tyr_ctx* c) {
 			(void)hipHostFree(c->hSnap[s]);
 		if (c->evSnap[s])
 			(void)hipEventDestroy(c->evSnap[s]);
+		if (c->hostSnap[s])
+			(void)hipHostFree(c->hostSnap[s]);
 	}
 	if (c->evSnapshot)
 		(void)hipEventDestroy(c->evSnapshot);
@@ -1282,12 +1289,25 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 		P.scanLive = &c->dK->scan_live[set];
 	}
 	P.prologueDone = prologueDone ? 1u : 0u;
+	// the counts the loop waits for: written by k_shade's last block into pinned host memory (nothing in the stream between this shade
+	// launch and the next traversal launch), unless the stages are being timed (their event pairs want a real wait)
+	const bool kernelSnap = c->tuning.kernelSnapshot != 0 && !(c->cfg.flags & TYR_FLAG_PROFILE);
+	c->snapSeqOf[set] = 0;
+	if (kernelSnap) {
+		if (++c->snapSeq == 0u)
+			++c->snapSeq;
+		c->snapSeqOf[set] = c->snapSeq;
+		P.hostSnap = c->hostSnapDev[set];
+		P.snapSeq = c->snapSeq;
+	}
 	if (!prologueDone)
 		enqueue_primary(c, P, p.nNew);
 	enqueue_trace(c, P, p.nLive, p.nSurvivors, p.carried);
 	enqueue_shade(c, P, p.nLive);
-	HIPCHK(hipMemcpyAsync(c->hSnap[set], c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipEventRecord(c->evSnap[set], c->stream));
+	if (!kernelSnap) {
+		HIPCHK(hipMemcpyAsync(c->hSnap[set], c->dK, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipEventRecord(c->evSnap[set], c->stream));
+	}
 	HIPCHK(hipGetLastError());
 	stage_end(c);
 	return TYR_OK;
@@ -1381,13 +1401,34 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 			}
 			return code;
 		};
-		{
+		if (c->snapSeqOf[set] != 0u) {
+			// the kernel-written snapshot: poll its stamp (the stream is looked at now and then: a fault must not hang the host)
+			volatile tyr::HostSnap* const hs = c->hostSnap[set];
+			const uint32_t want = c->snapSeqOf[set];
+			const auto t0 = std::chrono::steady_clock::now();
+			for (uint32_t spins = 0; __atomic_load_n(&hs->seq, __ATOMIC_ACQUIRE) != want; ++spins) {
+				if ((spins & 0x3fffu) == 0x3fffu) {
+					const hipError_t q = hipStreamQuery(c->stream);
+					if (q != hipErrorNotReady && __atomic_load_n(&hs->seq, __ATOMIC_ACQUIRE) != want) // idle (or failed) without the stamp
+						return abandon(q == hipSuccess ? TYR_ERR_DEVICE : static_cast<int>(q));
+					if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+						return abandon(TYR_ERR_DEVICE);
+				}
+#if defined(__x86_64__)
+				__builtin_ia32_pause();
+#endif
+			}
+			c->hK->primary_ray_cnt = hs->survivors;
+			c->hK->shadow_ray_cnt = hs->shadows;
+			c->hK->device_error = hs->device_error;
+			c->hK->n_live = live;
+		} else {
 			const hipError_t e = hipEventSynchronize(c->evSnap[set]);
 			if (e != hipSuccess)
 				return abandon(static_cast<int>(e));
+			std::memcpy(c->hK, c->hSnap[set], sizeof(DevCounters));
 		}
-		std::memcpy(c->hK, c->hSnap[set], sizeof(DevCounters));
-		if (foldedPrev) {
+		if (c->snapSeqOf[set] == 0u && foldedPrev) {
 			// iteration enq - 1's k_scan_words ran the next iteration's set_wavefront_globals in front of this snapshot: the two counts
 			// the host steers by were kept aside (DevCounters::reserved0 / reserved1), n_live already reads the next iteration's
 			c->hK->primary_ray_cnt = c->hK->reserved0;
@@ -2094,6 +2135,7 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_FOLD_PROLOGUE, 0, 1, &Tuning::foldPrologue },
 		{ TYR_TUNE_LAYOUT_ON_DEVICE, 0, 1, &Tuning::layoutOnDevice },
 		{ TYR_TUNE_SCAN_IN_TRACE, 0, 1, &Tuning::scanInTrace },
+		{ TYR_TUNE_KERNEL_SNAPSHOT, 0, 1, &Tuning::kernelSnapshot },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)
