@@ -207,7 +207,13 @@ void collect_timings_of(tyr_ctx* c, int set) {
 		if (!c->evUsed[set][k])
 			continue;
 		float ms = 0.0f;
-		if (hipEventElapsedTime(&ms, c->ev[set][2 * k], c->ev[set][2 * k + 1]) == hipSuccess) {
+		hipError_t e = hipEventElapsedTime(&ms, c->ev[set][2 * k], c->ev[set][2 * k + 1]);
+		if (e == hipErrorNotReady) { // (TYR_TUNE_KERNEL_SNAPSHOT: the host may be here a moment before the stage's closing event has been processed)
+			(void)hipGetLastError();
+			if (hipEventSynchronize(c->ev[set][2 * k + 1]) == hipSuccess)
+				e = hipEventElapsedTime(&ms, c->ev[set][2 * k], c->ev[set][2 * k + 1]);
+		}
+		if (e == hipSuccess) {
 			c->timings.ms[k] += ms;
 			c->timings.launches[k] += 1;
 		}
@@ -1290,8 +1296,8 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 	}
 	P.prologueDone = prologueDone ? 1u : 0u;
 	// the counts the loop waits for: written by k_shade's last block into pinned host memory (nothing in the stream between this shade
-	// launch and the next traversal launch), unless the stages are being timed (their event pairs want a real wait)
-	const bool kernelSnap = c->tuning.kernelSnapshot != 0 && !(c->cfg.flags & TYR_FLAG_PROFILE);
+	// launch and the next traversal launch; a ctx that times its stages still has their event pairs there)
+	const bool kernelSnap = c->tuning.kernelSnapshot != 0;
 	c->snapSeqOf[set] = 0;
 	if (kernelSnap) {
 		if (++c->snapSeq == 0u)
