@@ -500,13 +500,6 @@ __device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, 
 	const float4* q = quads + 8 * idx;
 	const uint32_t meta = ref >> kQuadOrderShift; // bit 31 of an interior reference is clear
 	float4 x01, x23, y01, y23, z01, z23, rf;
-#ifdef TYR_WHATIF_DOUBLE_NODE
-	// diagnostic build only: every node is fetched twice, from two copies 128 MiB apart, and merged with min()
-	// (equal values, so the traversal is unchanged) -- measures how much of the kernel's time is node bytes
-	const float4* q2 = q + (size_t(8) << 20);
-	auto mg = [](float4 a, float4 b) { return make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)); };
-	x01 = mg(q[0], q2[0]), x23 = mg(q[1], q2[1]), y01 = mg(q[2], q2[2]), y23 = mg(q[3], q2[3]), z01 = mg(q[4], q2[4]), z23 = mg(q[5], q2[5]), rf = q[6];
-#else
 	if (STAGED && idx < nStaged) {
 		// an explicit LDS pointer: as a generic pointer the compiler selected between the two bases and issued
 		// 28 flat_load_dword per node
@@ -524,7 +517,6 @@ __device__ __forceinline__ QuadHits test_quad(const float4* __restrict__ quads, 
 	} else {
 		x01 = q[0], x23 = q[1], y01 = q[2], y23 = q[3], z01 = q[4], z23 = q[5], rf = q[6];
 	}
-#endif
 	const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
 	float t0, t1, t2, t3;
 	const lanemask H0 = slab_any<FAST>(r, x01.x, x01.y, y01.x, y01.y, z01.x, z01.y, dist, t0);

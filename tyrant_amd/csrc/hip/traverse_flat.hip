@@ -11,18 +11,13 @@ namespace tyr {
 // Register budget of the flat traversal kernels, as waves per SIMD.  Five (<= 96 VGPRs) measured 7-10 % faster in
 // extend than the four the allocator picks by itself (99 VGPRs); six (80 VGPRs) spills 32 registers in the descent
 // loop and is 40 % slower.  Deeper LDS stacks cap the occupancy below five anyway.
-#ifndef TYR_CONNECT_ORDERED
-#define TYR_CONNECT_ORDERED false
-#endif
 // Threads per block of k_trace_flat (template parameter): 256 -- five blocks per CU, five waves per SIMD -- or 768 = three
 // 256-thread parts that share ONE copy of the staged nodes: two such blocks per CU are SIX waves per SIMD with all 64 staged
 // nodes (2 x (73,728 B of stacks + 7,168 + 4) = the CU's 160 KB in 1,280-byte granules; 75 vector registers under that
 // bound, no spill).  The sixth wave feeds a fat launch faster (-2.3 % per C3 render at 16.6 M slots) and lengthens the drain
 // of a thin one (+0.7 % at 2 Mi slots): launch_trace_kernel picks by the launch's item count (Tuning::wideBlockMinItems).
 constexpr uint32_t kTraceBlockWide = 768;
-#ifndef TYR_FLAT_WAVES_PER_EU
 #define TYR_FLAT_WAVES_PER_EU (STACK_LDS <= 8 ? 6 : STACK_LDS <= 12 ? 5 : STACK_LDS <= 16 ? 3 : 2)
-#endif
 
 // ======================================================================================
 // Flat traversal: persistent waves, lane refill, and NO nested divergent loops.
@@ -54,16 +49,6 @@ constexpr bool kLoopStats = false;
 constexpr bool kAnatomy = true; // three s_memrealtime stamps per wave (start, queue used up, exit): tools/launch_tail.py
 #else
 constexpr bool kAnatomy = false;
-#endif
-// -DTYR_AGE_PRIO=<quad steps>: a wave that holds a ray older than this many quad steps raises its issue priority
-// (s_setprio 3) until that ray is done: the launch ends on its longest rays, and during the feed phase their steps take
-// 3.5 us apiece because five waves per SIMD take turns (DESIGN.md section 4.4 "the drain, wave by wave")
-#ifdef TYR_AGE_PRIO
-constexpr bool kAgePrio = true;
-constexpr uint32_t kAgePrioSteps = TYR_AGE_PRIO;
-#else
-constexpr bool kAgePrio = false;
-constexpr uint32_t kAgePrioSteps = 0;
 #endif
 #define TYR_DBG(i)                                                     \
 	if (COUNT || kLoopStats) {                                         \
@@ -513,11 +498,7 @@ __device__ __forceinline__ float quad_bcast_f(float v) { return __uint_as_float(
 // wide_drain is a function of its own (below): its pointer arguments arrive as GENERIC pointers, and a load through one is
 // a flat load -- it counts on vmcnt AND lgkmcnt, so that every wait for a stack entry in LDS also waits for the records in
 // flight.  These say what the kernel knows: the scene and the queues are global memory.
-#ifdef TYR_WIDE_FLAT_LOADS // (what-if: the loads as they were until round 5)
-#define TYR_GLOBAL
-#else
 #define TYR_GLOBAL __attribute__((address_space(1)))
-#endif
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float2 gload_f2(const float* p) {
@@ -616,7 +597,6 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 	const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 };
 	const uint32_t signBits = (r.nx ? 1u : 0u) | (r.ny ? 2u : 0u) | (r.nz ? 4u : 0u);
 	bool wideOverflow = false;
-#ifndef TYR_WIDE_BRANCHY
 	// The loop below is written with SELECTS, not branches.  A SIMD issues one scalar instruction per four cycles whichever of
 	// its waves it comes from; the first form of this loop (lane-varying `if`s: pop / node / leaf / four accepts per leaf /
 	// fast or generic box test) compiled to ~300 scalar instructions per step -- exec-mask save, branch, restore around
@@ -626,14 +606,7 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 	// needs at all (wave-uniform branches on ballots), state changes are selects, loads of lanes that have nothing to load
 	// go to record 0.  A lane that turns a node into a leaf tests the leaf in the same trip.
 	const bool allRegular = __ballot(gActive && !regular) == 0ull; // (the generic box test is exact for regular rays too: one path for the wave)
-#ifdef TYR_WIDE_LONE_GROUPS
-	// what-if (round 5): the launch's very last rays -- a wave down to TYR_WIDE_LONE_GROUPS groups or fewer -- are bound by the
-	// latency of one step, not by the SIMD's issue slots; they take the loop with branches below, which runs only the blocks a
-	// group needs (a lone ray in a node step: ~150 instead of ~380 instructions)
-	while ((uint32_t)__popcll(__ballot(gActive)) > 4u * (TYR_WIDE_LONE_GROUPS)) {
-#else
 	while (__ballot(gActive) != 0ull) {
-#endif
 		if (kGuardPasses && ++passes > kMaxPasses)
 			break;
 #ifdef TYR_LAUNCH_ANATOMY
@@ -726,100 +699,233 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 			gActive = false;
 		}
 	}
-#endif
-#if defined(TYR_WIDE_BRANCHY) || defined(TYR_WIDE_LONE_GROUPS)
-	while (__ballot(gActive) != 0ull) {
+	return visible | (wideOverflow ? 0x80000000u : 0u) | (kGuardPasses && passes > kMaxPasses ? 0x40000000u : 0u);
+}
+
+#ifdef TYR_WIDE_STEAL
+// ==== what-if (round 6): the drain four lanes to a ray, with HAND-OFFS ====
+// A launch ends on its longest rays (140-260 quad steps against a mean of 12) and a wave leaves wide_drain with its
+// longest ray, whatever the other fifteen groups do meanwhile.  Here a group that holds nothing takes the BOTTOM entry
+// off another group's stack -- the subtree the owner would visit last -- and traverses it with the owner's bound at the
+// time of the hand-off; when it is through it reports to the group it took the entry from, which folds the answer into
+// its own.  TYR_WIDE_STEAL = 1: the fold is "nearer wins" (closest hit) / "or" (any hit): NOT the reference's accept
+// order (bvh.h:134) -- this build prices the idea, it is not a mode.
+// The group's 48-entry stack is circular: entry i (0 = bottom) lies at physical index (bot + i) % 48.
+template <int STACK_LDS>
+__device__ __attribute__((noinline, cold)) uint32_t wide_drain_steal(const float4* __restrict__ quads, const float4* __restrict__ tris, const float4* __restrict__ shadowColor, const float4* __restrict__ shadowDyzCdIx,
+                                                               float2* __restrict__ workHit, float4* __restrict__ blit, typename LdsStack<STACK_LDS, true>::entry_t* smem_, WideState w, uint32_t passes TYR_WIDE_STEPS_PARAM) {
+	const uint32_t lane = lane_id();
+	const unsigned long long below = (1ull << lane) - 1ull;
+	float rox = w.rox, roy = w.roy, roz = w.roz, rdx = w.rdx, rdy = w.rdy, rdz = w.rdz, rix = w.rix, riy = w.riy, riz = w.riz, dist = w.dist;
+	uint32_t ref = w.ref, slot = w.slot;
+	int prim = w.prim;
+	bool regular = (w.flags & 1u) != 0u, hitTri = (w.flags & 2u) != 0u, isShadow = (w.flags & 4u) != 0u, occluded = (w.flags & 8u) != 0u;
+	const bool live = (w.flags & 16u) != 0u;
+	uint32_t visible = 0;
+	const uint32_t sub = lane & 3u, grp = lane >> 2;
+	const unsigned long long lm = __ballot(live);
+	const uint32_t nl = (uint32_t)__popcll(lm);
+	const uint32_t told = (uint32_t)__builtin_amdgcn_ds_permute(live ? (int)(__popcll(lm & below) << 2) : 63 * 4, (int)lane);
+	bool gActive = grp < nl; // this group is traversing
+	const uint32_t asked = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(grp << 2), (int)told);
+	const uint32_t srcLane = gActive ? asked : lane;
+	{
+		const int pull = (int)(srcLane << 2);
+		auto pull_f = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)__float_as_uint(v))); };
+		auto pull_u = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v); };
+		rox = pull_f(rox), roy = pull_f(roy), roz = pull_f(roz);
+		rdx = pull_f(rdx), rdy = pull_f(rdy), rdz = pull_f(rdz);
+		rix = pull_f(rix), riy = pull_f(riy), riz = pull_f(riz);
+		dist = pull_f(dist);
+		ref = pull_u(ref);
+		slot = pull_u(slot);
+		prim = (int)pull_u((uint32_t)prim);
+		const uint32_t fl = pull_u((regular ? 1u : 0u) | (hitTri ? 2u : 0u) | (isShadow ? 4u : 0u) | (occluded ? 8u : 0u));
+		regular = (fl & 1u) != 0u, hitTri = (fl & 2u) != 0u, isShadow = (fl & 4u) != 0u, occluded = (fl & 8u) != 0u;
+	}
+	int n = (int)__builtin_amdgcn_ds_bpermute((int)(srcLane << 2), w.n);
+	typedef typename LdsStack<STACK_LDS, true>::entry_t entry_t;
+	entry_t* const column0 = smem_ + (threadIdx.x >> 8) * (STACK_LDS * kBlock) + (threadIdx.x & 255u & ~63u);
+	entry_t moved[STACK_LDS / 4];
+#pragma unroll
+	for (int row = 0; row < STACK_LDS / 4; ++row) {
+		const int e = 4 * row + (int)sub;
+		moved[row] = (gActive && e < n) ? column0[e * kBlock + srcLane] : entry_t{};
+	}
+	wave_lds_order();
+#pragma unroll
+	for (int row = 0; row < STACK_LDS / 4; ++row)
+		if (gActive && 4 * row + (int)sub < n)
+			column0[row * kBlock + lane] = moved[row];
+	wave_lds_order();
+	entry_t* const gstack = column0 + (lane & ~3u); // physical entry e: gstack[(e >> 2) * kBlock + (e & 3)]
+	auto phys = [](int i) { return i >= kWideStackEntries ? i - kWideStackEntries : i; };
+	bool wideOverflow = false;
+	int bot = 0;               // physical index of the stack's bottom entry
+	uint32_t pending = 0;      // entries handed off whose answers are still out
+	uint32_t parent = 0xffu;   // first lane of the group this group reports to (0xff: it holds the ray itself and writes its answer out)
+	bool holds = gActive;      // traversing, or through and waiting for answers
+	const unsigned long long grpBelow = (1ull << (lane & ~3u)) - 1ull;
+	bool allRegular = __ballot(gActive && !regular) == 0ull;
+	uint32_t stepsWide = 0;
+	while (__ballot(holds) != 0ull) {
 		if (kGuardPasses && ++passes > kMaxPasses)
 			break;
+		stepsWide += 1;
 #ifdef TYR_LAUNCH_ANATOMY
 		wideSteps += 1;
 #endif
-		if (gActive && ref == kRefPop) {
-			if (n == 0) {
-				ref = kRefDone;
-			} else {
-				--n;
-				const entry_t e = gstack[(n >> 2) * kBlock + (n & 3)];
-				if (__uint_as_float(e.y) < dist) // the pop-time half of Bbox.h:61
-					ref = e.x;
+		// ---- hand-offs: the k-th free group takes the bottom entry of the k-th group that has one ----
+		{
+#ifndef TYR_STEAL_AFTER
+#define TYR_STEAL_AFTER 0 // hand-offs begin after this many steps of the wave four lanes to a ray: whoever is still going then is long
+#endif
+#ifndef TYR_STEAL_MIN_N
+#define TYR_STEAL_MIN_N 1 // a group gives its bottom entry away when it holds at least this many (and something to do besides)
+#endif
+			const bool freeG = !holds, victimOK = gActive && (n > TYR_STEAL_MIN_N || (n == TYR_STEAL_MIN_N && ref != kRefPop));
+			const unsigned long long T = __ballot(freeG && sub == 0u), V = __ballot(victimOK && sub == 0u);
+			if (T != 0ull && V != 0ull && stepsWide >= (uint32_t)(TYR_STEAL_AFTER)) {
+				const uint32_t nT = (uint32_t)__popcll(T), nV = (uint32_t)__popcll(V), nP = nT < nV ? nT : nV;
+				const uint32_t trank = (uint32_t)__popcll(T & grpBelow), vrank = (uint32_t)__popcll(V & grpBelow);
+				const bool robbed = victimOK && vrank < nP, thief = freeG && trank < nP;
+				const uint32_t toldV = (uint32_t)__builtin_amdgcn_ds_permute((robbed && sub == 0u) ? (int)(vrank << 2) : 63 * 4, (int)lane);
+				const uint32_t vlane = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(trank << 2), (int)toldV) & 60u;
+				const int pull = (int)((thief ? vlane : lane) << 2);
+				auto pull_f = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)__float_as_uint(v))); };
+				auto pull_u = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v); };
+				rox = pull_f(rox), roy = pull_f(roy), roz = pull_f(roz);
+				rdx = pull_f(rdx), rdy = pull_f(rdy), rdz = pull_f(rdz);
+				rix = pull_f(rix), riy = pull_f(riy), riz = pull_f(riz);
+				dist = pull_f(dist);
+				slot = pull_u(slot);
+				const uint32_t fl = pull_u((regular ? 1u : 0u) | (isShadow ? 4u : 0u));
+				const int vbot = (int)pull_u((uint32_t)bot);
+				wave_lds_order();
+				const entry_t e = column0[(vbot >> 2) * kBlock + (thief ? vlane : (lane & ~3u)) + (vbot & 3)];
+				wave_lds_order();
+				if (robbed) {
+					bot = phys(bot + 1);
+					n -= 1;
+					pending += 1;
+				}
+#ifdef TYR_LAUNCH_ANATOMY
+				wideSteps += nP << 16; // (anatomy build: hand-offs of this wave in the upper half)
+#endif
+				if (thief) {
+					regular = (fl & 1u) != 0u, isShadow = (fl & 4u) != 0u;
+					ref = __uint_as_float(e.y) < dist ? e.x : kRefPop;
+					n = 0, bot = 0, prim = 0, pending = 0;
+					hitTri = false, occluded = false;
+					parent = vlane;
+					holds = true, gActive = true;
+				}
+				allRegular = __ballot(gActive && !regular) == 0ull;
 			}
 		}
-		if (gActive && (int)ref >= 0) {
-			// ---- one quad node: this lane's child box ----
-			const uint32_t idx = ref & kQuadIndexMask, meta = ref >> kQuadOrderShift;
+		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 };
+		const uint32_t signBits = (r.nx ? 1u : 0u) | (r.ny ? 2u : 0u) | (r.nz ? 4u : 0u);
+		// ---- pop: the group's top entry ----
+		{
+			const bool popping = gActive && ref == kRefPop;
+			const bool has = n > 0;
+			const int top = phys(bot + (has ? n - 1 : 0));
+			const entry_t e = gstack[(top >> 2) * kBlock + (top & 3)];
+			const uint32_t popped = !has ? kRefDone : (__uint_as_float(e.y) < dist ? e.x : kRefPop); // the pop-time half of Bbox.h:61
+			ref = popping ? popped : ref;
+			n = (popping && has) ? n - 1 : n;
+		}
+		// ---- one quad node: this lane's child box ----
+		const bool atNode = gActive && (int)ref >= 0;
+		if (__ballot(atNode) != 0ull) {
+			const uint32_t idx = atNode ? (ref & kQuadIndexMask) : 0u, meta = ref >> kQuadOrderShift;
 			const float* qf = reinterpret_cast<const float*>(quads + 8 * idx);
 			const uint32_t at = (sub >> 1) * 4u + (sub & 1u) * 2u;
-			const float2 bx = *reinterpret_cast<const float2*>(qf + at);
-			const float2 by = *reinterpret_cast<const float2*>(qf + 8 + at);
-			const float2 bz = *reinterpret_cast<const float2*>(qf + 16 + at);
-			const uint32_t cref = __float_as_uint(qf[24 + sub]);
+			const float2 bx = gload_f2(qf + at);
+			const float2 by = gload_f2(qf + 8 + at);
+			const float2 bz = gload_f2(qf + 16 + at);
+			const uint32_t cref = gload_u(qf + 24 + sub);
 			float t;
 			bool h;
-			if (regular)
+			if (allRegular)
 				h = slab_fast(r, bx.x, bx.y, by.x, by.y, bz.x, bz.y, dist, t);
 			else
 				h = slab_test(r, r.nx ? bx.y : bx.x, r.nx ? bx.x : bx.y, r.ny ? by.y : by.x, r.ny ? by.x : by.y, r.nz ? bz.y : bz.x, r.nz ? bz.x : bz.y, dist, t);
-			// this slot's place in the reference's visit order (test_quad: near slot first inside each group, near group first)
+			h = h && atNode;
 			const uint32_t aT = meta & 3u, aL = (meta >> 2) & 3u, aR = (meta >> 4) & 3u;
 			const uint32_t bT = (signBits >> aT) & 1u, bG = (signBits >> ((sub >> 1) ? aR : aL)) & 1u;
 			const uint32_t rank = 2u * ((sub >> 1) ^ bT) + ((sub & 1u) ^ bG);
 			const uint32_t hr = quad_or(h ? (1u << rank) : 0u); // the group's hits, in visit order
-			if (hr == 0u) {
-				ref = kRefPop;
-			} else {
-				const uint32_t first = (uint32_t)__ffs((int)hr) - 1u;
-				// the others go onto the stack farthest first, so that the nearest pops first (push3's order)
-				if (h && rank != first) {
-					const int e = n + (int)__popc(hr >> (rank + 1u));
-					if (e < kWideStackEntries)
-						gstack[(e >> 2) * kBlock + (e & 3)] = make_uint2(cref, __float_as_uint(t));
-				}
-				n += (int)__popc(hr) - 1;
-				if (n > kWideStackEntries) {
-					wideOverflow = true;
-					n = kWideStackEntries;
-				}
-				ref = quad_or(rank == first ? cref : 0u);
+			const uint32_t first = (uint32_t)__ffs((int)(hr | 16u)) - 1u;
+			const int e = n + (int)__popc(hr >> (rank + 1u));
+			if (h && rank != first && e < kWideStackEntries) {
+				const int pe = phys(bot + e);
+				gstack[(pe >> 2) * kBlock + (pe & 3)] = make_uint2(cref, __float_as_uint(t));
 			}
-		} else if (gActive && ref_is_leaf(ref)) {
-			// ---- a leaf: four primitives per trip, accepted in array order (bvh.h:129-140 / 229-238) ----
+			int n2 = n + (int)__popc(hr) - (hr != 0u ? 1 : 0);
+			wideOverflow = wideOverflow || (atNode && n2 > kWideStackEntries);
+			n2 = n2 > kWideStackEntries ? kWideStackEntries : n2;
+			const uint32_t nearest = quad_or((h && rank == first) ? cref : 0u);
+			ref = atNode ? (hr == 0u ? kRefPop : nearest) : ref;
+			n = atNode ? n2 : n;
+		}
+		// ---- a leaf: four primitives per round ----
+		const bool atLeaf = gActive && ref_is_leaf(ref);
+		if (__ballot(atLeaf) != 0ull) {
 			const uint32_t off = ref & (kMaxPrimOffset - 1);
-			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
+			const uint32_t cnt = atLeaf ? ((ref >> 26) & 31u) + 1u : 0u;
 			bool found = false;
-			for (uint32_t base = 0; base < cnt; base += 4u) {
+			for (uint32_t base = 0; __ballot(base < cnt) != 0ull; base += 4u) {
 				const uint32_t i = base + sub;
-				float tm = 0.0f;
-				if (i < cnt) {
-					// all three vectors of the record before the test starts: left alone, the compiler sinks the loads of
-					// `vert` and e2.z behind Moeller-Trumbore's first early-out -- a second dependent round trip per leaf on
-					// the launch's critical path
-					const TriData td = triangle_load(tris, off + i);
-#ifndef TYR_WHATIF_NO_TRI_HOIST
-					__asm__ volatile("" ::"v"(td.a.x), "v"(td.b.x), "v"(td.c.x));
-#endif
-					tm = triangle_test(td, r);
-				}
+				const bool mine = i < cnt;
+				const TriData td = triangle_gload(tris, mine ? off + i : 0u);
+				float tm = triangle_test_select(td, r);
+				tm = mine ? tm : 0.0f;
 				const float t0 = quad_bcast_f<0>(tm), t1 = quad_bcast_f<1>(tm), t2 = quad_bcast_f<2>(tm), t3 = quad_bcast_f<3>(tm);
 				const float tk[4] = { t0, t1, t2, t3 };
 #pragma unroll
 				for (uint32_t k = 0; k < 4u; ++k) {
 					const float t = tk[k];
-					if (base + k < cnt) {
-						if (isShadow) {
-							found = found || (t > kEpsilon && ((dist - t) > kEpsilon));
-						} else if (t > kEpsilon && t < dist && ((dist - t) > kEpsilon)) {
-							prim = (int)(off + base + k);
-							dist = t;
-							hitTri = true;
-						}
-					}
+					const bool in = (base + k < cnt) && t > kEpsilon && ((dist - t) > kEpsilon);
+					found = found || (in && isShadow);
+					const bool closer = in && !isShadow && t < dist;
+					prim = closer ? (int)(off + base + k) : prim;
+					hitTri = hitTri || closer;
+					dist = closer ? t : dist;
 				}
 			}
 			occluded = occluded || found;
-			ref = found ? kRefDone : kRefPop;
+			ref = atLeaf ? (found ? kRefDone : kRefPop) : ref;
 		}
-		if (gActive && ref == kRefDone) {
-			if (sub == 0u) {
+		// ---- through: a group that waits for nothing answers; one that reports does so through the scalar unit ----
+		gActive = gActive && ref != kRefDone;
+		const bool through = holds && !gActive && pending == 0u;
+		const unsigned long long R = __ballot(through && parent != 0xffu && sub == 0u);
+		if (R != 0ull) {
+			const uint32_t packed = (hitTri ? 1u : 0u) | (occluded ? 2u : 0u) | (parent << 8);
+			unsigned long long todo = R;
+			while (todo != 0ull) {
+				const int l = (int)__ffsll((long long)todo) - 1;
+				todo &= todo - 1ull;
+				const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)packed, l);
+				const float cd = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dist), l));
+				const int cp = __builtin_amdgcn_readlane(prim, l);
+				if ((lane & ~3u) == (pk >> 8)) {
+					pending -= 1u;
+					if (isShadow) {
+						if (pk & 2u) {
+							occluded = true;
+							ref = kRefDone; // (any hit: nothing left to look for; entries handed off earlier run to their end)
+							gActive = false;
+						}
+					} else if ((pk & 1u) && cd < dist) {
+						dist = cd, prim = cp, hitTri = true;
+					}
+				}
+			}
+		}
+		if (through) {
+			if (parent == 0xffu && sub == 0u) {
 				if (isShadow) {
 					if (!occluded) { // kernel.cu:640-644
 						const float4 c = shadowColor[slot];
@@ -830,12 +936,16 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 					finish_extend_ray(workHit, slot, hitTri, dist, prim);
 				}
 			}
-			gActive = false;
+			holds = false;
+			parent = 0xffu;
 		}
 	}
-#endif
 	return visible | (wideOverflow ? 0x80000000u : 0u) | (kGuardPasses && passes > kMaxPasses ? 0x40000000u : 0u);
 }
+#define TYR_WIDE_DRAIN wide_drain_steal
+#else
+#define TYR_WIDE_DRAIN wide_drain
+#endif
 
 // ======================================================================================
 // k_trace_flat: extend(i + 1) and connect(i) in ONE persistent launch (tyr_render only).
@@ -880,21 +990,6 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 	const uint32_t lane = lane_id();
 	const unsigned long long below = (1ull << lane) - 1ull;
 	[[maybe_unused]] uint32_t tripsFeed = 0; // (anatomy build) descent trips before the queue ran out
-	[[maybe_unused]] bool quietCU = false;
-#ifdef TYR_WHATIF_QUIET_CUS
-	// what-if (with -DTYR_LAUNCH_ANATOMY): on one CU in TYR_WHATIF_QUIET_CUS only the first wave of every block works -- five
-	// waves on the CU instead of twenty -- and every wave reports its feed-phase trips: how fast does a trip go on a quiet CU
-	// while the rest of the chip is as busy as ever (is the 3.5 us per trip a property of the CU or of the chip)?
-	{
-		const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
-		const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20); // HW_REG_XCC_ID [3:0]
-		const uint32_t cuKey = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
-		quietCU = (cuKey % (uint32_t)(TYR_WHATIF_QUIET_CUS)) == 0u;
-		__syncthreads();
-		if (quietCU && (threadIdx.x >> 6) != 0u)
-			return;
-	}
-#endif
 	// items = physical slots: the work queue's [0, nExt), then the shadow queue's; the few slots at the segments' ends that
 	// hold no record are handed out like the others: the pre-passes (and k_primary) have made them rays that enter nothing
 	const uint32_t nExt = P.traceShadow == 2u ? 0u : queue_extent(P.segWork);
@@ -909,8 +1004,7 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 	bool isShadow = false, occluded = false;
 	uint32_t visible = 0;
 	uint32_t dbg[16] = {};
-	uint32_t steps = 0; // TYR_QUAD_STATS / TYR_AGE_PRIO: quad steps of this lane's current ray
-	[[maybe_unused]] bool agedWave = false;
+	uint32_t steps = 0; // TYR_QUAD_STATS: quad steps of this lane's current ray
 	[[maybe_unused]] unsigned long long tExhausted = 0ull, tWide = 0ull;
 	[[maybe_unused]] uint32_t liveAtExhaustion = 0, liveAtWide = 0, tripsAfter = 0, passesAfter = 0, wideSteps = 0; // (anatomy build)
 	const unsigned long long tStart = kAnatomy ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1023,8 +1117,6 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 				dist = bound;
 				hitTri = false;
 				occluded = blocked;
-				if (kAgePrio)
-					steps = 0;
 				st.reset();
 				ref = blocked ? kRefDone : root_ref(sc, nr, dist);
 				if (ref != kRefDone)
@@ -1055,16 +1147,6 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 				continue;
 		}
 		allRegular = (__ballot(live && !regular) == 0ull);
-		if (kAgePrio) {
-			const bool old = __ballot(live && steps > kAgePrioSteps) != 0ull;
-			if (old != agedWave) {
-				agedWave = old;
-				if (old)
-					__builtin_amdgcn_s_setprio(3);
-				else
-					__builtin_amdgcn_s_setprio(0);
-			}
-		}
 		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 }; // bvh.h:120-121
 		// ---- descent: one pop attempt + one quad test per lane per trip (the same for both kinds of ray) ----
 		for (;;) {
@@ -1094,7 +1176,7 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 			}
 			if ((int)ref >= 0) {
 				TYR_DBG(0)
-				if (kLoopStats || kAgePrio)
+				if (kLoopStats)
 					steps += 1;
 				const QuadHits q = allRegular ? test_quad<true, true, true>(sc.quads, ref, r, dist, stagedNodes, nStaged) : test_quad<false, true, true>(sc.quads, ref, r, dist, stagedNodes, nStaged);
 				const lanemask any01 = q.hit[0] | q.hit[1], any012 = any01 | q.hit[2];
@@ -1103,8 +1185,7 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 			}
 		}
 		// ---- leaves: bvh.h:129-140 (closest hit) / bvh.h:229-238 (any hit) ----
-#ifndef TYR_NO_PACKED_LEAVES
-		// ---- leaves, packed (round 5; -1.0 ... -1.6 % per C3 render, profiles/r05_packed_leaves_ab.txt; -DTYR_NO_PACKED_LEAVES: the loop alone).  The loop below runs max(cnt) rounds over the lanes that are at a leaf -- typically 20 / 12 / 7 / 4
+		// ---- leaves, packed (round 5; -1.0 ... -1.6 % per C3 render, profiles/r05_packed_leaves_ab.txt).  The loop below runs max(cnt) rounds over the lanes that are at a leaf -- typically 20 / 12 / 7 / 4
 		// lanes in rounds 0..3: 17 % of the lanes on average, as many rounds as the kernel has node trips.  Here every (lane, primitive)
 		// pair of the phase becomes one ITEM, the items are dealt to the wave's lanes round-major (all first primitives, then all
 		// second ones, ...), each lane tests the item it was dealt with its owner's ray, and the owners take the distances back and
@@ -1171,7 +1252,6 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 				}
 			}
 		}
-#endif
 		if (ref_is_leaf(ref)) {
 			const uint32_t off = ref & (kMaxPrimOffset - 1);
 			const uint32_t cnt = ((ref >> 26) & 31u) + 1u;
@@ -1226,7 +1306,7 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 		w.rox = rox, w.roy = roy, w.roz = roz, w.rdx = rdx, w.rdy = rdy, w.rdz = rdz, w.rix = rix, w.riy = riy, w.riz = riz, w.dist = dist;
 		w.ref = ref, w.slot = slot, w.prim = prim, w.n = st.n;
 		w.flags = (regular ? 1u : 0u) | (hitTri ? 2u : 0u) | (isShadow ? 4u : 0u) | (occluded ? 8u : 0u) | (live ? 16u : 0u);
-		const uint32_t res = wide_drain<STACK_LDS>(PE.scene.quads, PE.scene.tris, PE.shadowPrev.color, PE.shadowPrev.dyz_cd_ix, PE.work.hit, PE.blit, smem_, w, passes TYR_WIDE_STEPS_ARG);
+		const uint32_t res = TYR_WIDE_DRAIN<STACK_LDS>(PE.scene.quads, PE.scene.tris, PE.shadowPrev.color, PE.shadowPrev.dyz_cd_ix, PE.work.hit, PE.blit, smem_, w, passes TYR_WIDE_STEPS_ARG);
 		visible += res & 0x3fffffffu;
 		overflow = overflow || (res & 0x80000000u) != 0u;
 		if (res & 0x40000000u)
@@ -1254,8 +1334,10 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 			P.next.hit[w] = make_float2((float)((tExhausted ? tExhausted : tEnd) - tStart) * 0.01f, (float)(tEnd - tStart) * 0.01f + (float)liveAtExhaustion * 0.0f);
 		if (w < 8192u && 32768u < P.N) { // three more records per wave, further up the same column (host/driver.cpp prints them with TYR_ANATOMY=2)
 			P.next.hit[8192u + w] = make_float2(tWide ? (float)(tWide - tStart) * 0.01f : 0.0f, (float)(liveAtExhaustion + 256u * liveAtWide));
-			P.next.hit[16384u + w] = make_float2((float)tripsAfter, (float)wideSteps); // trips after the queue ran out one ray to a lane, steps four lanes to a ray
-			P.next.hit[24576u + w] = make_float2((float)passesAfter, quietCU ? -(float)tripsFeed : (float)tripsFeed);
+			P.next.hit[16384u + w] = make_float2((float)tripsAfter, (float)(wideSteps & 0xffffu)); // trips after the queue ran out one ray to a lane, steps four lanes to a ray
+			if (40960u < P.N)
+				P.next.hit[32768u + w] = make_float2((float)(wideSteps >> 16), 0.0f); // (-DTYR_WIDE_STEAL) hand-offs inside this wave
+			P.next.hit[24576u + w] = make_float2((float)passesAfter, (float)tripsFeed);
 		}
 	}
 }
@@ -1266,9 +1348,7 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 
 // extend of this iteration + connect of the previous one in one launch.  P.kc must be this iteration's set, P.kcPrev the
 // set of the iteration whose shadow rays ride along (P.traceShadow: 0 none, 1 beside the extend rays, 2 they are all of it).
-#ifndef TYR_TRACE_STACK
-#define TYR_TRACE_STACK 12 // LDS stack entries per lane of k_trace_flat (a what-if build may pair 8 with TYR_FLAT_WAVES_PER_EU=6)
-#endif
+#define TYR_TRACE_STACK 12 // LDS stack entries per lane of k_trace_flat
 void launch_trace(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, uint32_t maxShadowPrev, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream) {
 	launch_trace_prepasses(P, nSurvivors, maxShadowPrev, stream, maxLive); // (the shadow rays' pre-pass reads its counts in kcPrev)
 	launch_trace_kernel(P, maxLive + maxShadowPrev, t, numCUs, lc, stream);

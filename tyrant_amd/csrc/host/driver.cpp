@@ -28,12 +28,6 @@ using namespace tyr;
 			return static_cast<int>(e_);   \
 	} while (0)
 
-#ifdef TYR_WHATIF_DOUBLE_NODE
-constexpr size_t kWhatIfQuadPad = size_t(8) << 20; // float4s: 1 Mi quad nodes
-#else
-constexpr size_t kWhatIfQuadPad = 0;
-#endif
-
 namespace {
 
 template <class T>
@@ -731,7 +725,7 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 	// bvh.h:164-209); a ctx without those flags never reads them: they are neither laid out nor kept in HBM (64 MB on C3, 0.4 GB on C5)
 	const bool wantPairs = (c->cfg.flags & (TYR_FLAG_COUNT_VISITS | TYR_FLAG_DEBUG_BVH)) != 0;
 	c->layoutOnDevice = false;
-	if (!wantPairs && c->tuning.layoutOnDevice != 0 && kWhatIfQuadPad == 0 && nodes && prims && nNodes >= 3 && nPrims > 0) {
+	if (!wantPairs && c->tuning.layoutOnDevice != 0 && nodes && prims && nNodes >= 3 && nPrims > 0) {
 		try {
 			rc = scene_upload_device_layout(c, nodes, nNodes, prims, nPrims);
 		} catch (...) {
@@ -762,16 +756,12 @@ int tyr_scene_upload(tyr_ctx* c, const tyr_bvh_node* nodes, int32_t nNodes, cons
 		return TYR_OK; // Scene.cpp:49-52
 	// at least one element so the pointers are never null
 	const size_t nodeFloats = std::max<size_t>(L.pairNodes.size(), 16), quadFloats = std::max<size_t>(L.quadNodes.size(), 32), triFloats = L.tris.size();
-	if ((rc = dev_alloc(c->dNodes, nodeFloats / 4)) || (rc = dev_alloc(c->dQuads, quadFloats / 4 + kWhatIfQuadPad)) || (rc = dev_alloc(c->dTris, triFloats / 4)))
+	if ((rc = dev_alloc(c->dNodes, nodeFloats / 4)) || (rc = dev_alloc(c->dQuads, quadFloats / 4)) || (rc = dev_alloc(c->dTris, triFloats / 4)))
 		return rc;
 	if (!L.pairNodes.empty())
 		HIPCHK(hipMemcpy(c->dNodes, L.pairNodes.data(), L.pairNodes.size() * sizeof(float), hipMemcpyHostToDevice));
 	if (!L.quadNodes.empty())
 		HIPCHK(hipMemcpy(c->dQuads, L.quadNodes.data(), L.quadNodes.size() * sizeof(float), hipMemcpyHostToDevice));
-#ifdef TYR_WHATIF_DOUBLE_NODE
-	if (!L.quadNodes.empty()) // second copy of the node array at a fixed distance: see tools/whatif_node_bytes.sh
-		HIPCHK(hipMemcpy(c->dQuads + kWhatIfQuadPad, L.quadNodes.data(), L.quadNodes.size() * sizeof(float), hipMemcpyHostToDevice));
-#endif
 	c->scene.quads = c->dQuads;
 	c->scene.quadRootRef = L.quadRootRef;
 	c->scene.nQuads = L.nQuads;
@@ -826,7 +816,7 @@ int tyr_scene_build_upload(tyr_ctx* c, tyr_triangle* prims, int32_t n, const tyr
 				*n_nodes_out = nn;
 			return tyr_scene_upload(c, host_nodes(), nn, prims, n);
 		};
-		if (wantPairs || kWhatIfQuadPad != 0)
+		if (wantPairs)
 			return all_on_host();
 		DeviceBuild B;
 		double secs[2] = { 0.0, 0.0 };
@@ -1099,10 +1089,10 @@ int tyr_sync(tyr_ctx* c) {
 #ifdef TYR_LAUNCH_ANATOMY
 // TYR_ANATOMY=2: the per-wave records k_trace_flat's anatomy build leaves in the next queue's hit column
 static void print_wave_anatomy(const float2* dHit, unsigned long long feedTicks) {
-	std::vector<float2> rec(4 * 8192);
+	std::vector<float2> rec(5 * 8192);
 	if (hipMemcpy(rec.data(), dHit, rec.size() * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess)
 		return;
-	std::vector<float> drain, normal, wide, perTrip, perStep, liveExh, liveWide, trips, steps, passes;
+	std::vector<float> drain, normal, wide, perTrip, perStep, liveExh, liveWide, trips, steps, passes, handoffs;
 	for (uint32_t w = 0; w < 8192; ++w) {
 		const float tExh = rec[w].x, tEnd = rec[w].y, tWide = rec[8192 + w].x;
 		if (!(tExh > 0.0f) || !(tEnd >= tExh) || !(tEnd < 1e5f))
@@ -1121,6 +1111,7 @@ static void print_wave_anatomy(const float2* dHit, unsigned long long feedTicks)
 		trips.push_back(nTrips);
 		steps.push_back(nSteps);
 		passes.push_back(rec[24576 + w].x);
+		handoffs.push_back(rec[32768 + w].x);
 	}
 	auto pct = [](std::vector<float>& v, double p) {
 		if (v.empty())
@@ -1139,21 +1130,19 @@ static void print_wave_anatomy(const float2* dHit, unsigned long long feedTicks)
 	line("descent trips one ray to a lane", trips);
 	line("outer passes (leaf rounds) one ray to a lane", passes);
 	line("steps four lanes to a ray", steps);
+	line("hand-offs four lanes to a ray (steal build)", handoffs);
 	line("us per trip, one ray to a lane", perTrip);
 	line("us per step, four lanes to a ray", perStep);
 	{
-		// the feed phase: microseconds per descent trip while the queue lasted; with -DTYR_WHATIF_QUIET_CUS the waves of the quiet
-		// CUs (negative trip counts) apart from the others
-		std::vector<float> feedBusy, feedQuiet;
+		// the feed phase: microseconds per descent trip while the queue lasted
+		std::vector<float> feedBusy;
 		for (uint32_t w = 0; w < 8192; ++w) {
 			const float tExh = rec[w].x, n = rec[24576 + w].y;
-			if (!(tExh > 0.0f) || n == 0.0f)
+			if (!(tExh > 0.0f) || !(n > 0.0f))
 				continue;
-			(n < 0.0f ? feedQuiet : feedBusy).push_back(tExh / std::fabs(n));
+			feedBusy.push_back(tExh / n);
 		}
 		line("feed phase: us per trip", feedBusy);
-		if (!feedQuiet.empty())
-			line("feed phase: us per trip, waves of the QUIET CUs", feedQuiet);
 	}
 	// the launch ends with these: the five waves that left last
 	std::vector<uint32_t> order;
@@ -1194,9 +1183,6 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 		P.foldSpheres = 1u; // this iteration's shade does the sphere halves for the rays it emits
 		P.resolveShadows = c->tuning.resolveShadows ? 1u : 0u; // ... and answers the shadow rays that cannot reach a triangle
 		P.retireGhosts = (c->tuning.retireSky && c->unboundedRender) ? 1u : 0u; // ... and finishes the survivors that will hit nothing (a render cut short would see their pixels an iteration early)
-#ifdef TYR_WHATIF_NO_GHOSTS
-		P.retireGhosts = 0u;
-#endif
 	}
 	if (merge && c->tuning.retireSky)
 		P.retireSky = 1u;   // ... and k_primary finishes the camera rays that hit nothing
@@ -1231,7 +1217,7 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 #endif
 			std::fprintf(stderr, "\n");
 #ifdef TYR_LAUNCH_ANATOMY
-			if (std::getenv("TYR_ANATOMY")[0] == '2' && P.N > 32768u)
+			if (std::getenv("TYR_ANATOMY")[0] == '2' && P.N > 40960u)
 				print_wave_anatomy(P.next.hit, tx - t0);
 #endif
 		}
