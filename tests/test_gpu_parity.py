@@ -580,6 +580,47 @@ def test_bench_two_ranks_on_one_gpu(hip):
     assert d["n_gpus"] == 2 and d["config"]["spp_total"] == 4 and d["scaling"] == "weak" and d["value"] > 0
 
 
+def test_shadow_queue_after_a_render_that_ends_early(orc, hip):
+    """ADVICE (round 5): a run-ahead render whose rays all die before kMaxBounces ends on an EMPTY iteration that was queued ahead -- and,
+    the budget being spent, folded (its shade launch would open a successor).  That fold must not happen: it zeroes the counters of the
+    last REAL iteration's shadow queue, which tyr_shadow_export hands out after the render.  A nearly black ground ends most paths by
+    Russian roulette at once: six 16 x 16 renders in a row end after 3 to 6 iterations, some with shadow rays left in the last one.
+    Default tuning except resolve_shadows = 0 (so that every shadow ray is queued and the export is the reference's queue)."""
+    import dataclasses
+
+    from tyrant_amd import scenes
+
+    sc0 = scenes.tyrant_default()
+    sp = sc0.spheres.copy()
+    sp["color"][4] = (0.06, 0.05, 0.04)
+    sp["color"][0] = (0.1, 0.1, 0.1)
+    sc = dataclasses.replace(sc0, spheres=sp)
+    nodes, prims = hip.bvh_build(sc.triangles)
+    W = H = 16
+    N = 256
+    o, g = orc.Oracle(W, H, N), hip.Renderer(W, H, N)
+    o.load_scene(sc, nodes, prims), g.load_scene(sc, nodes, prims)
+    g.set_tuning(resolve_shadows=0)
+    early = with_shadows = 0
+    for rep in range(6):
+        io, ig = o.render(1), g.render(1)
+        ko, kg = o.counters(), g.counters()
+        assert kg["device_error"] == 0 and io == ig, (rep, io, ig)
+        for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible", "start_position", "frame", "n_live", "shadow_ray_cnt", "primary_ray_cnt"):
+            assert ko[f] == kg[f], (rep, f, ko[f], kg[f])
+        nh = ko["shadow_ray_cnt"]
+        so, sg = o.shadow_queue(nh), g.shadow_queue(nh)
+        for f in ("origin", "direction", "color", "closestDistance"):
+            assert np.array_equal(bits(so[f]), bits(sg[f])), f"render {rep} ({io} iterations): shadow queue after the render, {f}"
+        early += io < 6
+        with_shadows += (io < 6 and nh > 0)
+    assert early >= 2 and with_shadows >= 1  # (the oracle's run: renders of 5, 5, 3 (2 shadow rays), 6, 6, 4 iterations)
+    # ... and the ctx is where the reference's loop would have left it: one more iteration, stage by stage
+    for st in ("begin", "primary", "extend", "shade", "connect", "end"):
+        o.stage(st), g.stage(st)
+    assert_accum_close(o.blit_buffer(), g.blit_buffer(), "staged iteration after renders that ended early")
+
+
 def test_triangle_colors_defaults_and_errors(orc, hip):
     """TYR_FLAG_TRIANGLE_COLORS (per-triangle colour / emission, the reference's commented-out Scene.cpp:44): needs
     TRIANGLE_MATERIALS; with the default palette (white, (3,3,3)) it is the run without the flag, bit for bit in the

@@ -811,7 +811,26 @@ int bvh_build_device_keep(int device, const tyr_triangle* prims, int32_t n, cons
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
 		return TYR_ERR_NO_DEVICE;
+	// The caller's current device is put back on every way out, and the build runs on a stream of its own: hosts that call this also
+	// use torch or other HIP code, and the legacy NULL stream synchronises implicitly with every blocking stream of the process.  The
+	// guard's destructor WAITS for the stream first -- asynchronous copies below read and write locals of this function (root0, k0, s0,
+	// hK, root), which must outlive them on the early returns too.
+	struct DeviceAndStream {
+		int prev = -1;
+		hipStream_t st = nullptr;
+		~DeviceAndStream() {
+			if (st) {
+				(void)hipStreamSynchronize(st);
+				(void)hipStreamDestroy(st);
+			}
+			if (prev >= 0)
+				(void)hipSetDevice(prev);
+		}
+	} scope;
+	if (hipGetDevice(&scope.prev) != hipSuccess)
+		scope.prev = -1;
 	TYR_D(hipSetDevice(device));
+	TYR_D(hipStreamCreateWithFlags(&scope.st, hipStreamNonBlocking));
 	const size_t N = static_cast<size_t>(n);
 	int kTaskPrims = kTaskPrimsDefault;
 	if (const char* e = std::getenv("TYR_DEVBUILD_TASK_PRIMS"))
@@ -864,7 +883,7 @@ int bvh_build_device_keep(int device, const tyr_triangle* prims, int32_t n, cons
 	TYR_D(hipMemcpy(dBB.p, bboxes, N * sizeof(tyr_bbox), hipMemcpyHostToDevice));
 	TYR_D(hipMemcpy(dPrims.p, prims, N * sizeof(tyr_triangle), hipMemcpyHostToDevice));
 	double copyS = std::chrono::duration<double>(std::chrono::steady_clock::now() - tCopy0).count();
-	hipStream_t st = nullptr;
+	const hipStream_t st = scope.st;
 	TYR_D(hipEventRecord(ev0, st));
 	// the root (sources of asynchronous copies: function scope, they live until the stream has been waited for)
 	TopNode root0{};

@@ -251,7 +251,9 @@ __global__ void __launch_bounds__(kBlock) k_scan_words(const FrameParams P) {
 	const uint32_t n = *P.scanLive; // &k->n_live, or the streamed tail's StreamIter::nLive
 	const uint32_t e = blockIdx.x * kBlock + threadIdx.x, first = e * 64u;
 	if (blockIdx.x * kScanBlockSlots >= n)
-		return; // (the whole block: the host sized the grid from an upper bound)
+		return; // (the whole block: the host sized the grid from an upper bound.  With n == 0 that is EVERY block, block 0 and the fold below
+		        // included: an iteration without rays opens no successor -- k_shade's shadeOpensNext agrees, host/driver.cpp render_run_ahead
+		        // states the invariant: nothing is ever queued behind an empty iteration)
 	unsigned long long word = 0ull;
 	if (first < n) {
 		uint4* p = reinterpret_cast<uint4*>(P.survFlag + first);

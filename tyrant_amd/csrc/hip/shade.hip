@@ -931,7 +931,10 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		if (PE.shadeOpensNext != 0u) { // (wave-uniform: a kernel argument)
 			__syncthreads(); // sh[] is free: every wave has left the tile loop
 			if (tid == 0) {
-				sh[16] = lastBlock ? 1u : 0u;
+				// (an iteration without rays opens nothing: it is the one a run-ahead render queued behind its last real iteration, the host
+				// never queues a successor behind it, and the counters of the iteration before -- kcPrev's segments and shadow count, which
+				// set_wavefront_globals would zero -- are what tyr_shadow_export hands out after the render; k_scan_words' fold skips it likewise)
+				sh[16] = (lastBlock && PE.k->n_live != 0u) ? 1u : 0u;
 				sh[17] = survivors;
 			}
 			__syncthreads();

@@ -22,6 +22,9 @@
 #include <thread>
 #include <vector>
 
+#include <exception>
+#include <mutex>
+
 #include "host.hpp"
 
 namespace tyr {
@@ -36,10 +39,30 @@ inline float bits(uint32_t u) {
 }
 inline bool finite3(const float* p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
 
-// f(chunk, begin, end) over [0, n) cut into at most `threads` contiguous chunks of at least `grain` items
+// f(chunk, begin, end) over [0, n) cut into at most `threads` contiguous chunks of at least `grain` items.
+// No exception leaves a worker thread (that would be std::terminate, whatever the C entry point catches): a worker's exception is
+// kept, every thread is joined -- also when the calling thread's share or a std::thread constructor throws -- and the first one is
+// rethrown on the calling thread, where tyr_scene_upload / tyr_layout_probe / tyr_scene_build_upload turn it into TYR_ERR_OOM.
 struct Par {
 	int threads;
 	size_t chunks(size_t n, size_t grain) const { return std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(std::max(threads, 1)), n / std::max<size_t>(grain, 1))); }
+	struct Joined { // joins what was started, whatever happens between the first emplace_back and the end of the scope
+		std::vector<std::thread> pool;
+		~Joined() {
+			for (std::thread& th : pool)
+				if (th.joinable())
+					th.join();
+		}
+	};
+	struct FirstError {
+		std::mutex m;
+		std::exception_ptr e;
+		void keep() noexcept {
+			std::lock_guard<std::mutex> g(m);
+			if (!e)
+				e = std::current_exception();
+		}
+	};
 	template <class F>
 	void run(size_t n, size_t grain, F&& f) const {
 		const size_t c = chunks(n, grain);
@@ -47,29 +70,55 @@ struct Par {
 			f(size_t(0), size_t(0), n);
 			return;
 		}
-		std::vector<std::thread> pool;
-		pool.reserve(c - 1);
-		for (size_t t = 1; t < c; ++t)
-			pool.emplace_back([&f, t, c, n] { f(t, n * t / c, n * (t + 1) / c); });
-		f(size_t(0), size_t(0), n / c);
-		for (std::thread& th : pool)
-			th.join();
+		FirstError err;
+		{
+			Joined j;
+			j.pool.reserve(c - 1);
+			try {
+				for (size_t t = 1; t < c; ++t)
+					j.pool.emplace_back([&f, &err, t, c, n]() noexcept {
+						try {
+							f(t, n * t / c, n * (t + 1) / c);
+						} catch (...) {
+							err.keep();
+						}
+					});
+				f(size_t(0), size_t(0), n / c);
+			} catch (...) {
+				err.keep();
+			}
+		} // (joined)
+		if (err.e)
+			std::rethrow_exception(err.e);
 	}
 	// run f over a list of independent tasks (dynamic: the tasks differ in size)
 	template <class F>
 	void tasks(size_t nTasks, F&& f) const {
 		const size_t c = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(std::max(threads, 1)), nTasks));
 		std::atomic<size_t> next{ 0 };
-		auto body = [&] {
-			for (size_t i = next.fetch_add(1); i < nTasks; i = next.fetch_add(1))
-				f(i);
+		FirstError err;
+		auto body = [&]() noexcept {
+			try {
+				for (size_t i = next.fetch_add(1); i < nTasks; i = next.fetch_add(1))
+					f(i);
+			} catch (...) {
+				err.keep();
+				next.store(nTasks); // (the others stop at their next draw)
+			}
 		};
-		std::vector<std::thread> pool;
-		for (size_t t = 1; t < c; ++t)
-			pool.emplace_back(body);
-		body();
-		for (std::thread& th : pool)
-			th.join();
+		{
+			Joined j;
+			try {
+				j.pool.reserve(c - 1);
+				for (size_t t = 1; t < c; ++t)
+					j.pool.emplace_back(body);
+			} catch (...) {
+				err.keep();
+			}
+			body();
+		} // (joined)
+		if (err.e)
+			std::rethrow_exception(err.e);
 	}
 };
 constexpr size_t kGrain = 1 << 14;

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 
 #include "ctx.hpp"
+#include <thread>
+
 #include "host.hpp"
 
 using namespace tyr;
@@ -1333,6 +1335,10 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 	// gap between dependent kernels each, every iteration.  Both answers follow from what the host knows when it queues j: the
 	// budget left behind j (exact once it is zero) and the last iteration that gave birth to rays.
 	const bool mayFold = c->tuning.foldPrologue != 0 && c->tuning.foldSpheres != 0;
+	// INVARIANT the kernels rely on: an iteration that turns out to have no rays (n_live == 0: the one queued ahead of its predecessor's
+	// counts for nothing) is never followed by another -- the loop below returns when it sees "budget == 0 && s == 0" -- so the kernels that
+	// would open its successor (k_scan_words' and k_shade's last blocks) skip that when n_live is 0, and the counters of the last real
+	// iteration stay what tyr_shadow_export reads.
 	auto queued_ahead_behind = [&](uint32_t j, uint64_t budgetBehindJ, uint32_t lastBirthAtJ) { return j + 1 < max_iterations && (budgetBehindJ != 0 || j < lastBirthAtJ + static_cast<uint32_t>(kMaxBounces)); };
 	bool folded = mayFold && budget == 0 && queued_ahead_behind(0, budget, 0); // (of the iteration queued last: its k_scan_words has opened the next one)
 	if ((rc = enqueue_merged_iteration(c, IterationPlan{ nNew, live, static_cast<uint32_t>(s), 0u }, true, folded, false)))
@@ -1381,9 +1387,11 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 		// a failure from here on leaves an iteration queued that the render will never own: drain the stream and take the
 		// host's bookkeeping of it back, so that the ctx is where its last completed iteration left it
 		auto abandon = [&](int code) {
+			// (also when nothing was queued ahead: kernels of iteration enq - 1 may still be running and would go on writing the snapshot
+			// record and the blit buffer behind an error return)
+			(void)hipStreamSynchronize(c->stream);
+			c->scanCarried = false;
 			if (ahead) {
-				(void)hipStreamSynchronize(c->stream);
-				c->scanCarried = false;
 				c->frame = frameBefore;
 				c->cur ^= 1;
 				c->iter--;
@@ -1397,14 +1405,16 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 			// the kernel-written snapshot: poll its stamp (the stream is looked at now and then: a fault must not hang the host)
 			volatile tyr::HostSnap* const hs = c->hostSnap[set];
 			const uint32_t want = c->snapSeqOf[set];
-			const auto t0 = std::chrono::steady_clock::now();
+			// An iteration is tens to hundreds of microseconds: spin.  The stream is looked at every 16 K spins -- idle (or failed)
+			// without the stamp is the only verdict; a slow iteration (a serialising profiler, a very large scene) is waited for as
+			// hipStreamSynchronize would, and once the wait is past a few milliseconds the core is given back between looks.
 			for (uint32_t spins = 0; __atomic_load_n(&hs->seq, __ATOMIC_ACQUIRE) != want; ++spins) {
 				if ((spins & 0x3fffu) == 0x3fffu) {
 					const hipError_t q = hipStreamQuery(c->stream);
 					if (q != hipErrorNotReady && __atomic_load_n(&hs->seq, __ATOMIC_ACQUIRE) != want) // idle (or failed) without the stamp
 						return abandon(q == hipSuccess ? TYR_ERR_DEVICE : static_cast<int>(q));
-					if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
-						return abandon(TYR_ERR_DEVICE);
+					if (spins >= (1u << 20))
+						std::this_thread::sleep_for(std::chrono::microseconds(50));
 				}
 #if defined(__x86_64__)
 				__builtin_ia32_pause();
@@ -1442,6 +1452,7 @@ static int render_run_ahead(tyr_ctx* c, uint32_t max_iterations, uint32_t& it) {
 				c->shadowPending = false;
 				c->shadowSet = shadowSetBefore;
 				c->lastShadeFolded = foldedBefore;
+				c->scanCarried = false; // (the empty iteration's shade launch left no scan behind: its last block opens nothing when n_live is 0)
 				c->runAheadUndo = true;
 				c->undoLive = live;
 				c->undoShadows = shadows;
