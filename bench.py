@@ -448,7 +448,7 @@ def main():
                 **({"device_bvh_build_s": dev_build} if dev_build else {}),
                 "host_scene_upload_s": {**m["upload"], "note": "tyr_scene_upload of the timed renderer (Scene.cpp:53-67's upload half), outside the timed region.  layout_on device (TYR_TUNE_LAYOUT_ON_DEVICE, the default): `copy` = the reference's node and triangle arrays to HBM as they are, `layout` = hip/bvh_layout_dev.hip making quad nodes + 48-byte triangles there (the same bytes), `host_layout` = the host pass on the builder's threads, for comparison; layout_on host: `layout` = that host pass, `copy` = allocation + the finished records to HBM"},
                 **oracle_counters_check(args, world, W, H, spp_total, N, int(prims.shape[0]), m),
-                "render_path": "tyr_render defaults: merged traversal launches (extend(i + 1) + connect(i)), sphere halves folded into shade, rays whose fate is known where they are made (camera rays / survivors that hit nothing, shadow rays that cannot reach a triangle) finished in place -- they count as rays, they never enter a queue; launch-per-iteration (TYR_TUNE_STREAM_TAIL = 0)",
+                "render_path": "tyr_render defaults: merged traversal launches (extend(i + 1) + connect(i)), sphere halves folded into shade, rays whose fate is known where they are made (camera rays / survivors that hit nothing, shadow rays that cannot reach a triangle) finished in place -- they count as rays, they never enter a queue",
                 **({"tuning": tune} if tune else {}),
                 **({"steady_state": steady} if steady else {}),
                 **(

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TYR_ABI_VERSION 4 /* 2: tyr_counters grows (rays_in_tree_*, debug[16]), tyr_dist_*, per-triangle colours; 3: retired tuning keys removed, tyr_sunsky_probe / tyr_sun_setup; 4: tyr_set_frame, tyr_layout_probe, tyr_bvh_build_device, tyr_scene_build_upload, tyr_scene_hash, tyr_scene_info grows (upload_*_s, layout_on_device) */
+#define TYR_ABI_VERSION 5 /* 2: tyr_counters grows (rays_in_tree_*, debug[16]), tyr_dist_*, per-triangle colours; 3: retired tuning keys removed, tyr_sunsky_probe / tyr_sun_setup; 4: tyr_set_frame, tyr_layout_probe, tyr_bvh_build_device, tyr_scene_build_upload, tyr_scene_hash, tyr_scene_info grows (upload_*_s, layout_on_device); 5: the streamed tail's tuning keys (16, 17, 18) retired with its kernels */
 
 /* ---- record layouts (identical to the reference structs) ------------------ */
 
@@ -331,9 +331,8 @@ enum {
 	TYR_TUNE_STATIC_INTERLEAVE = 13, /* the fixed per-block part as interleaved 64-slot chunks (1, default) or one contiguous range per block (0) */
 	TYR_TUNE_RUN_AHEAD = 14,         /* tyr_render: queue iteration i + 1 before iteration i's counts reach the host: 0 never, 1 or 2 (default) always -- nothing is queued behind the iteration that is known to end the render (budget spent, kMaxBounces iterations since the last top-up) */
 	TYR_TUNE_WIDE_DRAIN = 15,        /* 1 (default) = a wave's last <= 16 rays are finished four lanes to a ray */
-	TYR_TUNE_STREAM_TAIL = 16,       /* tyr_render: 1 = once the primary budget is spent, the remaining iterations run as ONE traversal kernel with shade resident beside it (DESIGN.md "One drain per render": bit-exact, measured slower, hence not the default); 0 (default) = a traversal launch per iteration */
-	TYR_TUNE_STREAM_SHADE_PER_CU = 17, /* streamed tail: shade blocks per CU (1..2, default 1) ... */
-	TYR_TUNE_STREAM_TRACE_PER_CU = 18, /* ... beside this many traversal blocks per CU (1..4, default 4; a fifth would take the LDS the shade block needs) */
+	/* 16, 17, 18: STREAM_TAIL, STREAM_SHADE_PER_CU, STREAM_TRACE_PER_CU -- retired in ABI 5 with the streamed tail (round 4: one traversal kernel across a render's last iterations,
+	   bit-exact, 30 % slower; branch experiment/stream-tail, docs/HISTORY.md section 4.8); tyr_set_tuning answers TYR_ERR_INVALID for them */
 	TYR_TUNE_RETIRE_SKY = 20,        /* merged path of tyr_render: 1 (default) = a camera ray that hits no sphere and misses the tree's root box is finished by k_primary itself -- its pixel gets sunsky(direction) (kernel.cu:613-617 for a fresh ray; no random number is involved) and it never enters a queue; 0 = shade does it an iteration later */
 	TYR_TUNE_RESOLVE_SHADOWS = 21,   /* merged path of tyr_render, with TYR_TUNE_FOLD_SPHERES: 1 (default) = a shadow ray that a sphere occludes or that fails the tree's root box for its bound is answered by shade itself (visible: its colour joins the pixel's contribution; kernel.cu:630-646 reduced to what is known) and never queued; it still counts as emitted / visible */
 	TYR_TUNE_WIDE_BLOCK_MIN_ITEMS = 22, /* k_trace_flat: a launch of at least this many rays (extend + carried shadow rays) runs as 768-thread blocks -- two per CU, six waves per SIMD, one copy of the staged nodes per three 256-thread parts -- instead of 256-thread blocks at five waves per SIMD; default 3 Mi (the sixth wave feeds a fat launch faster and lengthens the drain of a thin one); -1: never */

@@ -39,7 +39,7 @@ def pytest_configure(config):
 # else runs at all.  Kernel parity therefore comes first, host / scene / camera tests next, and tests that only check the
 # FORMAT of bench.py's line (child processes, timings of micro-jobs) last: a bench-format assertion can never again
 # stand in front of the parity tests (round 3: one rounded timing, `0.0 > 0`, left 101 parity tests unreached).
-_ORDER = ("test_gpu_parity", "test_gpu_configs", "test_stream_tail", "test_ref_pins", "test_bvh_build_device", "test_glm_pinning", "test_debug_bvh", "test_dist_native", "test_scene_io",
+_ORDER = ("test_gpu_parity", "test_gpu_configs", "test_ref_pins", "test_bvh_build_device", "test_glm_pinning", "test_debug_bvh", "test_dist_native", "test_scene_io",
           "test_camera_input", "test_oracle_golden", "test_oracle_math", "test_oracle_wavefront", "test_host_and_abi", "test_dist_gloo")
 _LAST = ("test_bench_contract",)
 

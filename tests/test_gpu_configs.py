@@ -269,7 +269,7 @@ def test_benchmarked_render_path_matches_oracle_at_full_size(orc, hip, N, spp, k
     o = orc.Oracle(W1080, H1080, N, flags=1)
     g = hip.Renderer(W1080, H1080, N, flags=1)
     o.load_scene(sc, nodes, prims), g.load_scene(sc, nodes, prims)
-    g.set_tuning(**knobs)  # {}: the defaults bench.py times; stream_tail: the remaining iterations as ONE traversal kernel once the budget is spent (opt-in)
+    g.set_tuning(**knobs)  # {}: the defaults bench.py times
     it_o, it_g = o.render(spp), g.render(spp)
     ko, kg = o.counters(), g.counters()
     assert kg["device_error"] == 0

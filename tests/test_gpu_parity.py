@@ -501,7 +501,7 @@ def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
     g3.set_tuning(merge_trace=1, run_ahead=0, wide_drain=0)  # ... with the host waiting for every iteration's counts, and a wave's last rays left one to a lane
     _, g4 = pair(orc, hip, name, W, H, N)
     _, g5 = pair(orc, hip, name, W, H, N)
-    g4.set_tuning(merge_trace=1, run_ahead=0, stream_tail=1)  # once the budget is spent: ONE traversal kernel across the remaining iterations, shade resident beside it (k_trace_stream / k_shade<.., true>)
+    g4.set_tuning(merge_trace=1, run_ahead=1, scan_in_trace=0, kernel_snapshot=0)  # one iteration ahead with round 5's two later steps off: the slot scan a launch of its own (its last block opens the next iteration), the counts copied behind shade and signalled by an event
     g3.set_tuning(resolve_shadows=0)  # (and one merged path that queues every shadow ray although shade has done their sphere halves)
     g5.set_tuning(merge_trace=1, fold_spheres=0, retire_sky=0)  # the sphere pre-pass kernels instead of shade doing their work for the rays it emits; camera rays that hit nothing queued for shade instead of finished by k_primary
     from tyrant_amd import scenes
@@ -518,7 +518,7 @@ def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
         # (n_live, shadow_ray_cnt: the iteration a run-ahead render queues for nothing must not show in the counters)
         for f in ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible", "start_position", "frame", "n_live", "shadow_ray_cnt", "primary_ray_cnt"):
             assert ko[f] == k0[f] == k1[f] == k2[f] == k3[f] == k4[f] == k5[f], (name, f)
-        assert_accum_close(o.blit_buffer(), g4.blit_buffer(), name + " streamed tail")
+        assert_accum_close(o.blit_buffer(), g4.blit_buffer(), name + " run-ahead, scan launch + copied snapshot")
         assert_accum_close(o.blit_buffer(), g5.blit_buffer(), name + " sphere pre-pass kernels")
         # the last iteration's shadow queue, whatever path made it (the run-ahead path once exported the EMPTY look-ahead iteration's)
         nh = ko["shadow_ray_cnt"]
@@ -536,7 +536,7 @@ def test_render_with_and_without_merged_launches(orc, hip, name, W, H, N, spp):
         o.stage(st), g1.stage(st), g2.stage(st), g4.stage(st)
     assert_accum_close(o.blit_buffer(), g1.blit_buffer(), name + " staged iteration after the render")
     assert_accum_close(o.blit_buffer(), g2.blit_buffer(), name + " staged iteration after the merged render")
-    assert_accum_close(o.blit_buffer(), g4.blit_buffer(), name + " staged iteration after a streamed tail")
+    assert_accum_close(o.blit_buffer(), g4.blit_buffer(), name + " staged iteration after a render with the scan launch + copied snapshot")
     # a render cut short by max_iterations still settles its last shadow rays before it returns
     o.reset_accum(), g2.reset_accum()
     assert o.render(spp, 2) == g2.render(spp, 2) == 2

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(hip):
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in tyr_c.h but not exported"
     assert declared == set(hip.SYMBOLS), (declared ^ set(hip.SYMBOLS))
-    assert L.tyr_abi_version() == 4
+    assert L.tyr_abi_version() == 5
 
 
 def test_abi_struct_sizes(hip):

@@ -3,7 +3,7 @@
 rounds=$1; shift
 for r in $(seq $rounds); do
   for k in "$@"; do
-    echo -n "[${k:-defaults}] "; timeout -k 10 100 python3 tools/stream_probe.py stream_tail=0 renders=4 $k 2>&1 | grep "^render" | sort -t: -k2 -n | head -1 | sed 's/render [0-9]*: //; s/ ms.*//'
+    echo -n "[${k:-defaults}] "; timeout -k 10 100 python3 tools/stream_probe.py renders=4 $k 2>&1 | grep "^render" | sort -t: -k2 -n | head -1 | sed 's/render [0-9]*: //; s/ ms.*//'
   done
 done | python3 -c "
 import sys, collections, statistics

@@ -4,6 +4,6 @@ for round in 1 2; do
   for tag in product "$@"; do
     lib=$PWD/tyrant_amd/lib/libtyrant_hip.so
     [ "$tag" != product ] && lib=$PWD/tyrant_amd/lib/libtyrant_hip_$tag.so
-    echo -n "$tag: "; TYRANT_HIP_LIBRARY=$lib timeout -k 10 100 python3 tools/stream_probe.py stream_tail=0 renders=4 ${PROBE_KNOBS} 2>&1 | grep "^render" | sort -t: -k2 -n | head -1
+    echo -n "$tag: "; TYRANT_HIP_LIBRARY=$lib timeout -k 10 100 python3 tools/stream_probe.py renders=4 ${PROBE_KNOBS} 2>&1 | grep "^render" | sort -t: -k2 -n | head -1
   done
 done

@@ -4,7 +4,7 @@ for r in $(seq $rounds); do
   for tag in product "$@"; do
     lib=$PWD/tyrant_amd/lib/libtyrant_hip.so
     [ "$tag" != product ] && lib=$PWD/tyrant_amd/lib/libtyrant_hip_$tag.so
-    echo -n "$tag "; TYRANT_HIP_LIBRARY=$lib timeout -k 10 100 python3 tools/stream_probe.py stream_tail=0 renders=4 ${PROBE_KNOBS} 2>&1 | grep "^render" | sort -t: -k2 -n | head -1 | sed 's/render [0-9]*: //; s/ ms.*//'
+    echo -n "$tag "; TYRANT_HIP_LIBRARY=$lib timeout -k 10 100 python3 tools/stream_probe.py renders=4 ${PROBE_KNOBS} 2>&1 | grep "^render" | sort -t: -k2 -n | head -1 | sed 's/render [0-9]*: //; s/ ms.*//'
   done
 done | python3 -c "
 import sys, collections, statistics

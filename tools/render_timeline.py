@@ -13,7 +13,7 @@ i0 = prim[-back]
 i1 = prim[-back + 1] if back > 1 else len(ks)
 # (bench.py goes on after its last render -- the counting render, the tree built and laid out on the device: the render ends at the
 # first kernel that is not one of tyr_render's)
-RENDER = ("k_primary", "k_pad_holes", "k_trace_flat", "k_trace_stream", "k_stream_begin", "k_shade", "k_scan_words", "k_extend_spheres", "k_connect_spheres")
+RENDER = ("k_primary", "k_pad_holes", "k_trace_flat", "k_shade", "k_scan_words", "k_extend_spheres", "k_connect_spheres")
 for i in range(i0, i1):
     if not any(r in ks[i][2] for r in RENDER):
         i1 = i

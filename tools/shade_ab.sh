@@ -9,5 +9,5 @@ PROBE_KNOBS="queue=2097152" bash tools/lib_ab.sh "$@"
 for tag in product "$@"; do
   lib=$PWD/tyrant_amd/lib/libtyrant_hip.so
   [ "$tag" != product ] && lib=$PWD/tyrant_amd/lib/libtyrant_hip_$tag.so
-  echo -n "$tag: "; TYRANT_HIP_LIBRARY=$lib timeout -k 10 100 python3 tools/stream_probe.py stream_tail=0 renders=3 profile=1 2>&1 | grep "^stages"
+  echo -n "$tag: "; TYRANT_HIP_LIBRARY=$lib timeout -k 10 100 python3 tools/stream_probe.py renders=3 profile=1 2>&1 | grep "^stages"
 done

@@ -1,6 +1,5 @@
 """tools/stream_probe.py [knob=value ...] -- three C3 renders (1080p, 8 spp, every primary ray in flight) with the given tuning
-knobs, for `rocprofv3 --kernel-trace` (tools/render_timeline.py prints the last render's kernels): what runs beside what
-in the streamed tail."""
+knobs, for `rocprofv3 --kernel-trace` (tools/render_timeline.py prints the last render's kernels)."""
 import os
 import sys
 import time

@@ -150,35 +150,6 @@ __device__ __forceinline__ uint32_t v_lookup(const VTable& T, uint32_t key) {
 	return T.blk[e >> 8] + T.pre[e] + (uint32_t)__popcll(T.word[e] & ((1ull << (v & 63u)) - 1ull));
 }
 
-// ---- agent-scope ("sc1") accesses: the streamed tail's hand-offs between kernels that run side by side ----------------
-// (MI355X_MICROARCH.md, inter-workgroup visibility: relaxed agent-scope atomic loads / stores lower to global_load / store
-// ... sc1: stores write through and drop the line from the XCD's L2, loads bypass the CU's L1.)  8-byte pieces: the
-// compiler tracks them like any other access (inline-asm dwordx4 forms would need hand-placed waits).
-__device__ __forceinline__ uint32_t ld_sc1_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-union Sc1Pair {
-	unsigned long long u;
-	float2 f;
-};
-__device__ __forceinline__ float2 ld_sc1_f2(const float2* p) {
-	Sc1Pair v;
-	v.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	return v.f;
-}
-__device__ __forceinline__ void st_sc1_f2(float2* p, float2 x) {
-	Sc1Pair v;
-	v.f = x;
-	__hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float4 ld_sc1_f4(const float4* p) {
-	const float2 a = ld_sc1_f2(reinterpret_cast<const float2*>(p)), b = ld_sc1_f2(reinterpret_cast<const float2*>(p) + 1);
-	return make_float4(a.x, a.y, b.x, b.y);
-}
-__device__ __forceinline__ void st_sc1_f4(float4* p, float4 x) {
-	st_sc1_f2(reinterpret_cast<float2*>(p), make_float2(x.x, x.y));
-	st_sc1_f2(reinterpret_cast<float2*>(p) + 1, make_float2(x.z, x.w));
-}
-
 // bits of a wave mask below this lane (v_mbcnt: no per-lane copy of the 64-bit "lanes below me" mask to keep in two vector registers)
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

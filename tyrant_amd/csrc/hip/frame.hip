@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_spheres(const FrameParams P)
 constexpr uint32_t kScanBlockSlots = 64u * kBlock;
 __global__ void __launch_bounds__(kBlock) k_scan_words(const FrameParams P) {
 	__shared__ uint32_t waveSum[kBlock / 64];
-	const uint32_t n = *P.scanLive; // &k->n_live, or the streamed tail's StreamIter::nLive
+	const uint32_t n = *P.scanLive; // &k->n_live
 	const uint32_t e = blockIdx.x * kBlock + threadIdx.x, first = e * 64u;
 	if (blockIdx.x * kScanBlockSlots >= n)
 		return; // (the whole block: the host sized the grid from an upper bound.  With n == 0 that is EVERY block, block 0 and the fold below
@@ -354,49 +354,6 @@ __global__ void __launch_bounds__(kBlock) k_scan_words(const FrameParams P) {
 	}
 }
 
-// ======================================================================================
-// The streamed tail's first iteration (kernels.hpp "the STREAMED TAIL"): what set_wavefront_globals (kernel.cu:227-244) does
-// for an iteration without a top-up, and the iteration's StreamIter -- closed from the start: its rays were made by a
-// shade LAUNCH that has ended.  One wave.  (The StreamState has been zeroed by the host.)
-// ======================================================================================
-__global__ void __launch_bounds__(64) k_stream_begin(const FrameParams P, uint32_t traceShadowPrev) {
-	const uint32_t i = threadIdx.x;
-	StreamIter* const I = &P.stream->it[0];
-	uint32_t n = 0, h = 0;
-	if (i < kClasses * kSegs) {
-		const uint32_t c = i / kSegs, w = i % kSegs;
-		n = P.segWork[c * kClassWords + w * kSegStride];
-		I->segWork[c][w] = n;
-		P.segNext[c * kClassWords + w * kSegStride] = 0; // what this iteration's shade appends to
-	}
-	if (i < kSegs) {
-		h = traceShadowPrev ? P.kcPrev->seg[i * kSegStride] : 0u;
-		I->segShadowPrev[i] = h;
-		P.kc->seg[i * kSegStride] = 0;
-	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		n += __shfl_xor(n, o, 64);
-		h += __shfl_xor(h, o, 64);
-	}
-	if (i == 0) {
-		DevCounters* k = P.k;
-		n = k->primary_ray_cnt; // the survivors, those the last shade launch finished in place included (P.retireGhosts: they hold slots of this iteration's order without lying in a queue)
-		I->nLive = n;
-		I->nShadowPrev = h;
-		k->n_live = n;
-		k->total_extend_rays += n;
-		k->primary_ray_cnt = 0;
-		k->shadow_ray_cnt = 0;
-		k->scan_blocks_done = 0;
-		P.kc->shadow_cnt = 0;
-		__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		I->closed = 1u;
-	}
-}
-void launch_stream_begin(const FrameParams& P, bool traceShadowPrev, hipStream_t stream) {
-	hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(64), 0, stream, P, traceShadowPrev ? 1u : 0u);
-}
 
 // ======================================================================================
 // blit_onto_framebuffer, kernel.cu:648-662 -> linear RGBA32F

@@ -132,53 +132,9 @@ struct ConnectCounters {
 	uint32_t chunks[kTicketWords * 32]; // (unused since the traversal launches are one kernel: extend_chunks serves them)
 	uint32_t seg[kSegs * kSegStride];   // records in segment w of this iteration's shadow queue
 };
-// ---- the STREAMED TAIL of a render (round 4; DESIGN.md "One drain per render") --------------------------------------
-// Once a render's primary budget is spent every iteration is thinner than the one before, and each of them used to be
-// a traversal launch that ends in ~300 us of drain, a shade launch, a scan and a host round trip.  In the streamed tail
-// ONE traversal kernel (k_trace_stream) lives across all remaining iterations: a wave that runs dry does not exit, it draws
-// the next 64-slot chunk of whatever iteration has one ready -- chunks of iteration j + 1 become ready while the stragglers
-// of iteration j are still out, because k_shade_stream (one launch per iteration, resident BESIDE the traversal grid: four
-// traversal blocks + one shade block per CU) shades a tile as soon as the traversal has finished its 256 rays and publishes
-// the survivors chunk by chunk.  What still orders the iterations is the serial order itself: shade(j + 1) needs the scan of
-// iteration j's survive bytes (rank(v), kernels.hpp "Queues"), i.e. all of shade(j) -- which the side stream's launch order
-// gives for free (k_shade_stream(j), k_scan_words(j), k_shade_stream(j + 1), ...).
-//   hand-offs (MI355X_MICROARCH.md "inter-workgroup visibility"): payload stored sc1 (write-through), every storing wave
-//   waits vmcnt(0), then agent-scope atomic adds on a counter; the consumer polls the counter with sc1 loads and reads the
-//   payload with sc1 loads.  Two kinds of counter:
-//     fill[chunk]  (shade -> trace)  records of a 64-slot chunk of the next ray queue's class 0 / of the shadow queue
-//                                    that have been written; a chunk is ready at 64, or -- once the iteration is closed --
-//                                    at what the final segment count leaves it
-//     done[tile]   (trace -> shade)  rays of a 256-slot tile of the work queue's class 0 the traversal has finished
-//   Every wait is bounded by the wall clock (kStreamTimeoutTicks of s_memrealtime): a waiter that runs out raises
-//   kErrNoProgress and everybody leaves; nothing in here can hold the GPU.
-constexpr uint32_t kStreamMaxIters = 16;   // iterations a streamed tail can span (kMaxBounces + 2 are ever needed)
-struct StreamIter {
-	uint32_t closed;                     // 1: the work queue of this iteration and the shadow queue of the one before are complete (their producers have all finished)
-	uint32_t nLive;                      // rays of this iteration, both classes (= the virtual slots its scan covers)
-	uint32_t nShadowPrev;                // shadow rays of the iteration before (traced beside this iteration's rays)
-	uint32_t unused0;
-	uint32_t shadeBlocksDone;            // k_shade_stream of this iteration: blocks that have finished
-	uint32_t pad0[3];
-	uint32_t segWork[kClasses][kSegs];   // final record counts of this iteration's work queue
-	uint32_t segShadowPrev[kSegs];       // ... and of the shadow queue of the iteration before
-	uint32_t pad1[64 - 8 - kClasses * kSegs - kSegs];
-	uint32_t tick[2][kSegs * kSegStride]; // the traversal's chunk tickets, one word per 128 bytes: [0] work rays of class 0, [1] shadow rays; word w hands out the chunks of segment w
-	uint32_t shadeTiles[kSegs * kSegStride]; // k_shade_stream's tile tickets
-	// shadow rays of the iteration before that the traversal has finished: eight partial counts, 128 bytes apart (a wave adds to
-	// word blockIdx % 8 whenever it has 64 to report, runs dry or moves on -- one word would be a serial queue of atomics,
-	// ~12 ns each: the first build reported per refill and spent 5 ms per iteration there)
-	uint32_t shadowDone[kSegs * kSegStride];
-};
-struct StreamState {
-	uint32_t ended;                      // set when an iteration closes with no ray of either kind: the render is over
-	uint32_t pad[31];
-	StreamIter it[kStreamMaxIters];
-};
-constexpr unsigned long long kStreamTimeoutTicks = 20ull * 100000ull; // 20 ms of s_memrealtime (100 MHz): far beyond any wait of a working render
-
 constexpr uint32_t kErrStackOverflow = 1u;
 // (bit 2 was the look-back time-out of rounds 1-2's stable compaction: no longer raised, not reused)
-constexpr uint32_t kErrNoProgress = 4u; // a wait of the streamed tail ran into its wall-clock bound (kStreamTimeoutTicks); -DTYR_GUARD_PASSES builds: a wave of a flat traversal kernel ran out of passes (kMaxPasses)
+constexpr uint32_t kErrNoProgress = 4u; // -DTYR_GUARD_PASSES builds: a wave of a flat traversal kernel ran out of passes (kMaxPasses)
 constexpr uint32_t kErrQueueOverflow = 8u; // a queue segment ran out of room (the records beyond it were dropped); cannot happen with segCap as host/driver.cpp sizes it, kept as a check
 
 struct FrameParams {
@@ -218,9 +174,6 @@ struct FrameParams {
 	uint32_t traceShadow;         // k_trace_flat: the previous iteration's shadow rays ride in this launch (0: a render's first launch; 2: they are ALL of it -- the launch that ends a render)
 	uint32_t staticInterleave;    // ... as 64-slot chunks b, b + G, ... (1) or as one contiguous range per block (0)
 	uint32_t wideDrain;           // k_trace_flat: finish a wave's last <= 16 rays four lanes to a ray
-	// the streamed tail (StreamState above); all zero / null in the launch-per-iteration path
-	StreamState* stream;
-	uint32_t streamIter;          // k_shade_stream: which StreamIter this launch shades; k_trace_stream: 0 (it starts at the tail's first iteration)
 	uint32_t foldSpheres;         // k_shade: also do the sphere half of extend / connect for the rays it emits (kernel.cu:125-136, 168-172), as k_primary does for its own: no sphere pre-pass follows
 	uint32_t retireGhosts;        // k_shade (with foldSpheres, renders that run to their end): a survivor that will hit nothing is finished in place (it still counts as a survivor and keeps its slot in the next iteration's order)
 	uint32_t resolveShadows;      // k_shade (with foldSpheres): a shadow ray that a sphere occludes, or that cannot enter the tree, is answered in place and never queued
@@ -234,13 +187,7 @@ struct FrameParams {
 	uint32_t scanPrevInTrace;     // k_trace_flat: on its way in, its waves do the slot scan of the iteration BEFORE (n = *scanLivePrev, tables = vPrev): that iteration's shade opened this one (shadeOpensNext) and no k_scan_words was launched
 	const uint32_t* scanLivePrev;
 	uint32_t prevFolded;          // the traversal launchers: the shade launch that made this iteration's survivors and shadow rays did so (only the holes at the segments' ends are left to mark)
-	uint32_t* fillWork;           // fill counters of the work queue's class 0 (what k_trace_stream waits on for iteration j), one per 64-slot chunk
-	uint32_t* fillNext;           // ... of the next queue's class 0 (what this iteration's shade publishes)
-	uint32_t* fillShadow;         // ... of this iteration's shadow queue
-	uint32_t* fillShadowPrev;     // ... of the previous iteration's
-	uint32_t* doneWork;           // done counters of the work queue's class 0, one per 256-slot tile
-	uint32_t* doneNext;
-	const uint32_t* scanLive;     // k_scan_words: where this iteration's ray count is (&k->n_live, or the StreamIter's)
+	const uint32_t* scanLive;     // k_scan_words: where this iteration's ray count is (&k->n_live)
 	// TYR_FLAG_LIGHT_LIST (extension): emissive triangles, as indices into scene.tris in array order
 	const uint32_t* lights;
 	uint32_t nLights;
@@ -262,9 +209,6 @@ struct Tuning {
 	int runAhead = 2;         // tyr_render: queue iteration i + 1 before iteration i's counts are on the host: 0 never, 1 / 2 always
 	int mergeTrace = 1;       // tyr_render: connect(i) rides in the launch of extend(i + 1)
 	int profileMask = 31;     // TYR_FLAG_PROFILE: which stages (bit TYR_K_*) get a hipEvent pair
-	int streamTail = 0;       // tyr_render: once the budget is spent, ONE traversal kernel across the remaining iterations with shade resident beside it (0, the default: a launch per iteration -- the streamed form is bit-exact and slower, DESIGN.md "One drain per render")
-	int streamShadePerCU = 1; // streamed tail: k_shade_stream blocks per CU ...
-	int streamTracePerCU = 4; // ... beside this many blocks of k_trace_stream
 	int resolveShadows = 1;   // merged path of tyr_render (needs foldSpheres): shade answers the shadow rays that cannot reach a triangle itself
 	int retireSky = 1;        // merged path of tyr_render: k_primary finishes the camera rays that hit nothing itself (they never reach a queue)
 	int wideBlockMinItems = 3 << 20; // k_trace_flat: launches of at least this many rays run as 768-thread blocks, six waves per SIMD (< 0: never)
@@ -272,7 +216,7 @@ struct Tuning {
 	int layoutOnDevice = 1;   // tyr_scene_upload: the reference's arrays go to the device as they are and hip/bvh_layout_dev.hip makes the records there (the same bytes); 0 = host/bvh_layout.cpp makes them and they are copied
 	int scanInTrace = 1;      // tyr_render one iteration ahead, the next iteration known to come without a top-up: no k_scan_words launch -- k_shade's last block opens that iteration and its traversal launch's waves do the slot scan on their way in (hip/scan_wave.hpp)
 	int kernelSnapshot = 1;   // tyr_render one iteration ahead: the counts the host waits for are written to pinned host memory by k_shade's last block instead of copied behind it and signalled by an event (two packets in the stream between this iteration's shade and the next traversal launch)
-	int foldSpheres = 1;      // merged path of tyr_render: shade does the sphere pre-passes' work for the rays it emits (the streamed tail always does); 0: k_extend_spheres / k_connect_spheres re-read them
+	int foldSpheres = 1;      // merged path of tyr_render: shade does the sphere pre-passes' work for the rays it emits ; 0: k_extend_spheres / k_connect_spheres re-read them
 };
 constexpr uint32_t kCountRaysPerBlock = 1024; // the counting build's kernels: queue slots owned by one 256-thread block
 
@@ -280,7 +224,7 @@ constexpr int kBlock = 256; // 4 wave64 per workgroup
 
 // Per-context cache of the occupancy queries that size the persistent grids (a slow host call: asked once per
 // kernel, not once per launch).  Lives in tyr_ctx -- one ctx per device, no process-wide statics.
-enum { kLcShade = 0, kLcTrace, kLcTraceStream, kLcKinds };
+enum { kLcShade = 0, kLcTrace, kLcKinds };
 struct LaunchCache {
 	int perCU[kLcKinds][6] = {};
 };
@@ -293,10 +237,6 @@ void launch_scan(const FrameParams& P, uint32_t maxLive, hipStream_t stream); //
 // nSurvivors: upper bound of the slots the sphere pre-pass still has to do (primary rays get theirs in k_primary)
 void launch_extend(const FrameParams& P, uint32_t maxLive, uint32_t nSurvivors, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);
 void launch_shade(const FrameParams& P, uint32_t maxLive, int numCUs, LaunchCache& lc, hipStream_t stream);
-// the streamed tail: the traversal kernel that lives across iterations (blocksPerCU resident blocks per CU), and one iteration's shade beside it
-void launch_stream_begin(const FrameParams& P, bool traceShadowPrev, hipStream_t stream); // the tail's first StreamIter from the device's counts (+ what set_wavefront_globals does for an iteration without a top-up)
-void launch_trace_stream(const FrameParams& P, int blocksPerCU, int numCUs, hipStream_t stream);
-void launch_shade_stream(const FrameParams& P, int blocksPerCU, int numCUs, hipStream_t stream);
 void launch_trace_prepasses(const FrameParams& P, uint32_t nSurvivors, uint32_t maxShadowPrev, hipStream_t stream, uint32_t maxLive = 0);
 void launch_trace_kernel(const FrameParams& P, uint32_t items, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream); // k_trace_flat alone (launch_trace = pre-passes + this)
 void launch_connect(const FrameParams& P, uint32_t maxShadow, bool countVisits, const Tuning& t, int numCUs, LaunchCache& lc, hipStream_t stream);

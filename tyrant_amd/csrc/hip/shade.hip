@@ -482,24 +482,13 @@ struct ShadeStage { // one tile's output, waiting for the tile's place in the qu
 // queue on the counter of segment (tile / 2) % 8, issued as soon as the tile's counts are known; the records wait in LDS at
 // their rank inside the tile and leave as coalesced stores (thread t writes record t) AFTER the next tile has been
 // shaded -- by then the atomics have long returned.
-//
-// STREAM = the streamed tail's form (kernels.hpp "the STREAMED TAIL"): this launch shades ONE iteration while k_trace_stream
-// -- resident beside it -- is still tracing it: a class-0 tile is shaded once the traversal has finished its rays
-// (done[tile]), class 1 (nothing to wait for) goes first; the records it emits for the traversal are stored sc1 and
-// published chunk by chunk (fill[chunk]); the block that finishes last closes the next iteration (StreamIter).
-template <bool LIGHTS, bool STREAM>
+template <bool LIGHTS>
 __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const FrameParams P_) {
 	const FrameParams& P = P_;
 	__shared__ uint32_t sh[32];
 	__shared__ ShadeStage stage;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u, wave = tid >> 6;
-	StreamIter* const SI = STREAM ? &P.stream->it[P.streamIter] : nullptr;
-	if (STREAM && P.stream->ended)
-		return; // the render ended in an earlier iteration (the host queues a launch per iteration the tail can have)
-	if (STREAM)
-		__builtin_amdgcn_s_setprio(3); // one wave per SIMD beside four of the traversal kernel's, which wait for what this one makes
-	bool gaveUp = false; // STREAM: a wait ran into its bound (kErrNoProgress is raised): leave without shading further tiles
 	// class 0's tiles, then class 1's (from the device's counts: the host may have sized the grid from an upper bound)
 	const uint32_t tiles0 = queue_extent(P.segWork) / kBlock;
 	const uint32_t nTiles = tiles0 + queue_extent(P.segWork + kClassWords) / kBlock;
@@ -535,22 +524,13 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			const uint32_t base = isTree ? baseT : baseK;
 			if (tid < prevS && base != 0xffffffffu) {
 				const uint32_t d = isTree ? seg_phys(prevSeg, base + tid) : P.classStride + seg_phys(prevSeg, base + (tid - prevT));
-				const bool through = STREAM && isTree; // what the traversal kernel reads while this launch is still running: write-through
-				if (through) {
-					st_sc1_f4(&P.next.o_dx[d], stage.sv_o_dx[tid]);
-					st_sc1_f2(&P.next.dyz[d], stage.sv_dyz[tid]);
-					st_sc1_f2(&P.next.hit[d], stage.sv_hit[tid]);
-				} else {
-					P.next.o_dx[d] = stage.sv_o_dx[tid];
-				}
+				P.next.o_dx[d] = stage.sv_o_dx[tid];
 				__asm__ volatile("" ::: "memory");
 				P.next.direct_ix[d] = stage.sv_direct_ix[tid];
 				__asm__ volatile("" ::: "memory");
-				if (!through) {
-					P.next.dyz[d] = stage.sv_dyz[tid];
-					if (P.foldSpheres)
-						P.next.hit[d] = stage.sv_hit[tid];
-				}
+				P.next.dyz[d] = stage.sv_dyz[tid];
+				if (P.foldSpheres)
+					P.next.hit[d] = stage.sv_hit[tid];
 				P.next.flags[d] = stage.sv_flags[tid];
 				P.next.key[d] = stage.sv_key[tid];
 			}
@@ -558,81 +538,31 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		__asm__ volatile("" ::: "memory");
 		if (tid < prevH && baseH != 0xffffffffu) {
 			const uint32_t d = seg_phys(prevSeg, baseH + tid);
-			if (STREAM) {
-				st_sc1_f4(&P.shadow.o_dx[d], stage.sh_o_dx[tid]);
-				st_sc1_f4(&P.shadow.dyz_cd_ix[d], stage.sh_dyz_cd_ix[tid]);
-				st_sc1_f4(&P.shadow.color[d], stage.sh_color[tid]);
-			} else {
-				P.shadow.o_dx[d] = stage.sh_o_dx[tid];
-				__asm__ volatile("" ::: "memory");
-				P.shadow.dyz_cd_ix[d] = stage.sh_dyz_cd_ix[tid];
-				__asm__ volatile("" ::: "memory");
-				P.shadow.color[d] = stage.sh_color[tid];
-			}
+			P.shadow.o_dx[d] = stage.sh_o_dx[tid];
+			__asm__ volatile("" ::: "memory");
+			P.shadow.dyz_cd_ix[d] = stage.sh_dyz_cd_ix[tid];
+			__asm__ volatile("" ::: "memory");
+			P.shadow.color[d] = stage.sh_color[tid];
 			P.shadow.key[d] = stage.sh_key[tid];
 		}
-		if (STREAM)
-			__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave, before anybody signals for it
 		__syncthreads(); // `stage` and sh[] are free again
-		if (STREAM) {
-			// publish: the records [base, base + n) of segment prevSeg lie in the chunks of rows base / 64 .. (base + n - 1) / 64
-			// (at most five); one thread per chunk adds what this tile wrote there
-			auto publish = [&](uint32_t* fill, uint32_t base, uint32_t n, uint32_t k) {
-				if (n == 0u || base == 0xffffffffu)
-					return;
-				const uint32_t row = (base >> 6) + k, lastRow = (base + n - 1u) >> 6;
-				if (row > lastRow)
-					return;
-				const uint32_t lo = base > row * 64u ? base : row * 64u, hi = base + n < (row + 1u) * 64u ? base + n : (row + 1u) * 64u;
-				__hip_atomic_fetch_add(&fill[row * kSegs + prevSeg], hi - lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			};
-			if (tid < 8u)
-				publish(P.fillNext, baseT, prevT, tid);
-			else if (tid >= 64u && tid < 72u)
-				publish(P.fillShadow, baseH, prevH, tid - 64u);
-		}
 		TYR_STAMP(4)
 	};
 
 	uint32_t word = blockIdx.x % kTicketWords, tried = 0;
-	uint32_t* const tickets = STREAM ? SI->shadeTiles : P.k->shade_tiles;
+	uint32_t* const tickets = P.k->shade_tiles;
 	auto draw_tile = [&]() -> uint32_t { // block-uniform; nTiles when nothing is left
-		const FrameParams& P = kernarg_view<FrameParams>();
 		uint32_t vbNext = nTiles;
 		if (tid == 0) {
-			while (tried < kTicketWords && !gaveUp) {
+			while (tried < kTicketWords) {
 				const uint32_t t = atomicAdd(&tickets[word * 32], 1u);
 				const unsigned long long cand = (unsigned long long)t * kTicketWords + word;
 				if (cand < nTiles) {
 					vbNext = (uint32_t)cand;
-					if (STREAM) // class 1 first (its rays wait for nobody), then class 0 in the order the traversal hands it out
-						vbNext = vbNext < nTiles - tiles0 ? vbNext + tiles0 : vbNext - (nTiles - tiles0);
 					break;
 				}
 				word = (word + 1) % kTicketWords;
 				++tried;
-			}
-			if (STREAM && vbNext < tiles0) {
-				// the traversal's answers for this tile: done[tile] counts the rays it has finished (agent-scope adds behind the
-				// storing wave's vmcnt(0)); the barrier below stands between this poll and every load of the answers
-				const uint32_t s0 = vbNext * kBlock;
-				uint32_t want = 0;
-#pragma unroll
-				for (uint32_t q = 0; q < 4u; ++q)
-					want += chunk_valid(P.segWork, s0 + 64u * q);
-				const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-				uint32_t polls = 0;
-				while (ld_sc1_u32(&P.doneWork[vbNext]) != want) {
-					__builtin_amdgcn_s_sleep(8);
-					if ((++polls & 63u) == 0u && (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks || ld_sc1_u32(&P.k->device_error) != 0u)) {
-						atomicOr(&P.k->device_error, kErrNoProgress);
-						vbNext = nTiles;
-						gaveUp = true;
-						break;
-					}
-				}
-				if (!gaveUp)
-					st_sc1_u32(&P.doneWork[vbNext], 0u); // the counter is its reader's to reset (the slot's next use is two iterations away)
 			}
 			sh[3] = vbNext;
 		}
@@ -643,7 +573,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	};
 	// (no tile at all -- a launch for an iteration without rays: no ticket is drawn, eight round trips saved per block)
 	for (uint32_t vb = nTiles != 0u ? draw_tile() : nTiles; vb < nTiles; vb = draw_tile()) { // vb = tile id = 256 physical slots of one class
-		TYR_STAMP(3) // (the draw: ticket, and in the streamed tail the wait for the traversal's answers)
+		TYR_STAMP(3) // (the draw: ticket)
 		const FrameParams& P = kernarg_view<FrameParams>(); // this tile's reads of the arguments: loaded where they are used (device_common.hpp; 113 scalar spills -> 2, 128 vector registers -> 96)
 		const uint32_t cls = vb >= tiles0 ? 1u : 0u;
 		const uint32_t inClass = (vb - cls * tiles0) * kBlock + tid; // slot inside the class
@@ -663,7 +593,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		const bool valid = lane < chunk_valid(P.segWork + cls * kClassWords, inClass & ~63u);
 		float2 hitRecord = make_float2(kVeryFar, 0.f);
 		if (valid)
-			hitRecord = (STREAM && cls == 0u) ? ld_sc1_f2(&P.work.hit[slot]) : P.work.hit[slot];
+			hitRecord = P.work.hit[slot];
 		if (valid)
 			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
 		shade_ray<LIGHTS>(P, slot, valid, hitRecord, out, vslot, flush_pixels);
@@ -821,81 +751,6 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		atomicAdd(&PE.k->debug[7], ntiles_);
 	}
 #endif
-	if (STREAM) {
-		// The block that finishes last closes the NEXT iteration for the traversal kernel: final counts, then the flag.  Its
-		// own records and fill adds are out (flush_prev waits and publishes); the other blocks' likewise before they counted
-		// as done.
-		if (tid == 0) {
-			if (myResolved)
-				atomicAdd(&PE.kc->shadow_cnt, myResolved); // (here: only the shadow rays answered in place; the queued ones are counted by the segments)
-			__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (atomicAdd(&SI->shadeBlocksDone, 1u) + 1u == PE.shadeBlocks && !gaveUp && ld_sc1_u32(&PE.k->device_error) == 0u) {
-				StreamIter* const NI = SI + 1; // (PE.streamIter + 1 < kStreamMaxIters: the host queues at most kMaxBounces + 1 of these launches)
-				uint32_t s = 0, h = 0;
-				for (uint32_t c = 0; c < kClasses; ++c)
-					for (uint32_t w = 0; w < kSegs; ++w) {
-						const uint32_t n = ld_sc1_u32(&PE.segNext[c * kClassWords + w * kSegStride]);
-						st_sc1_u32(&NI->segWork[c][w], n);
-						s += n;
-					}
-				for (uint32_t w = 0; w < kSegs; ++w) {
-					const uint32_t n = ld_sc1_u32(&PE.kc->seg[w * kSegStride]);
-					st_sc1_u32(&NI->segShadowPrev[w], n);
-					h += n;
-				}
-				st_sc1_u32(&NI->nLive, s);
-				st_sc1_u32(&NI->nShadowPrev, h);
-				// the iteration's totals (what set_wavefront_globals and the last shade block keep in the launch-per-iteration path)
-				const uint32_t hAll = h + __hip_atomic_load(&PE.kc->shadow_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // + the shadow rays answered in place
-				PE.kc->shadow_cnt = 0;
-				PE.k->n_live = SI->nLive;
-				PE.k->shadow_ray_cnt = hAll;
-				PE.k->total_shadow_rays += hAll;
-				PE.k->n_survive += s;
-				PE.k->total_extend_rays += s;
-				// what the next iteration's shade appends to: this iteration's work queue (two iterations on it is `next` again)
-				// and the other set of shadow counters; nobody reads either any more (every shade block is done, the traversal
-				// kernel works from the StreamIter copies)
-				for (uint32_t c = 0; c < kClasses; ++c)
-					for (uint32_t w = 0; w < kSegs; ++w)
-						st_sc1_u32(&PE.segWork[c * kClassWords + w * kSegStride], 0u);
-				for (uint32_t w = 0; w < kSegs; ++w)
-					st_sc1_u32(&PE.kcPrev->seg[w * kSegStride], 0u);
-				PE.kcPrev->shadow_cnt = 0;
-				PE.k->scan_blocks_done = 0;
-				// the shadow rays that were traced beside this iteration's rays lie in the buffers the next iteration's shade
-				// writes: it may not start (= this launch may not end) before the traversal has finished them
-				{
-					const uint32_t want = SI->nShadowPrev;
-					const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-					uint32_t polls = 0;
-					auto shadows_done = [&]() {
-						uint32_t n = 0;
-						for (uint32_t w = 0; w < kSegs; ++w)
-							n += ld_sc1_u32(&SI->shadowDone[w * kSegStride]);
-						return n;
-					};
-					while (shadows_done() != want) {
-						__builtin_amdgcn_s_sleep(8);
-						if ((++polls & 63u) == 0u && (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks || ld_sc1_u32(&PE.k->device_error) != 0u)) {
-							atomicOr(&PE.k->device_error, kErrNoProgress);
-							break;
-						}
-					}
-				}
-				__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				st_sc1_u32(&NI->closed, 1u);
-				if (s == 0u) {
-					// no survivors: the next iteration is the last shadow rays alone (or nothing); the one after it is empty and
-					// closed (its counts are the zeros the tail started with) -- the traversal kernel ends there
-					if (h != 0u && PE.streamIter + 2u < kStreamMaxIters)
-						st_sc1_u32(&(NI + 1)->closed, 1u);
-					st_sc1_u32(&PE.stream->ended, 1u);
-				}
-			}
-		}
-		return;
-	}
 	if (tid == 0) {
 		if (mySurvivors)
 			atomicAdd(&PE.k->primary_ray_cnt, mySurvivors);
@@ -927,41 +782,37 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 	// k_scan_words' last block do -- so that the scan of THIS iteration's survive bytes, which only the next SHADE launch reads, needs no
 	// launch in front of the next traversal launch: that launch's waves do it on their way in (hip/scan_wave.hpp).  Everything read here was written by
 	// agent-scope atomics (the counters) or by this thread; the scan finds its ray count in scan_live[] (n_live is reset below).
-	if (!STREAM) {
-		if (PE.shadeOpensNext != 0u) { // (wave-uniform: a kernel argument)
-			__syncthreads(); // sh[] is free: every wave has left the tile loop
-			if (tid == 0) {
-				// (an iteration without rays opens nothing: it is the one a run-ahead render queued behind its last real iteration, the host
-				// never queues a successor behind it, and the counters of the iteration before -- kcPrev's segments and shadow count, which
-				// set_wavefront_globals would zero -- are what tyr_shadow_export hands out after the render; k_scan_words' fold skips it likewise)
-				sh[16] = (lastBlock && PE.k->n_live != 0u) ? 1u : 0u;
-				sh[17] = survivors;
-			}
+	if (PE.shadeOpensNext != 0u) { // (wave-uniform: a kernel argument)
+		__syncthreads(); // sh[] is free: every wave has left the tile loop
+		if (tid == 0) {
+			// (an iteration without rays opens nothing: it is the one a run-ahead render queued behind its last real iteration, the host
+			// never queues a successor behind it, and the counters of the iteration before -- kcPrev's segments and shadow count, which
+			// set_wavefront_globals would zero -- are what tyr_shadow_export hands out after the render; k_scan_words' fold skips it likewise)
+			sh[16] = (lastBlock && PE.k->n_live != 0u) ? 1u : 0u;
+			sh[17] = survivors;
+		}
+		__syncthreads();
+		if (sh[16] != 0u) {
+			if (tid < kSegs)
+				sh[tid] = __hip_atomic_load(&PE.segNext[tid * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // class 0 of the next work queue
+			else if (tid < 2u * kSegs)
+				sh[tid] = __hip_atomic_load(&PE.kc->seg[(tid - kSegs) * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // this iteration's shadow queue
+			if (tid == 0)
+				PE.k->scan_live[PE.scanSet & 1u] = PE.k->n_live;
 			__syncthreads();
-			if (sh[16] != 0u) {
-				if (tid < kSegs)
-					sh[tid] = __hip_atomic_load(&PE.segNext[tid * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // class 0 of the next work queue
-				else if (tid < 2u * kSegs)
-					sh[tid] = __hip_atomic_load(&PE.kc->seg[(tid - kSegs) * kSegStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // this iteration's shadow queue
-				if (tid == 0)
-					PE.k->scan_live[PE.scanSet & 1u] = PE.k->n_live;
-				__syncthreads();
-				pad_work_holes_counts(PE.next, sh);
-				pad_shadow_holes_counts(PE.shadow, sh + kSegs);
-				__syncthreads();
-				wavefront_globals_for(PE, PE.segWork, PE.kcPrev, true, sh[17]);
-			}
+			pad_work_holes_counts(PE.next, sh);
+			pad_shadow_holes_counts(PE.shadow, sh + kSegs);
+			__syncthreads();
+			wavefront_globals_for(PE, PE.segWork, PE.kcPrev, true, sh[17]);
 		}
 	}
 	// the counts the host's render loop waits for, straight into its (pinned) memory: four stores, a fence, the stamp
-	if (!STREAM) {
-		if (tid == 0 && lastBlock && PE.hostSnap != nullptr) {
-			HostSnap* const hs = PE.hostSnap;
-			__hip_atomic_store(&hs->survivors, survivors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			__hip_atomic_store(&hs->shadows, snapShadows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			__hip_atomic_store(&hs->device_error, __hip_atomic_load(&PE.k->device_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			__hip_atomic_store(&hs->seq, PE.snapSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
+	if (tid == 0 && lastBlock && PE.hostSnap != nullptr) {
+		HostSnap* const hs = PE.hostSnap;
+		__hip_atomic_store(&hs->survivors, survivors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(&hs->shadows, snapShadows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(&hs->device_error, __hip_atomic_load(&PE.k->device_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(&hs->seq, PE.snapSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 #undef TYR_STAMP
 }
@@ -975,7 +826,7 @@ uint32_t shade_grid(const FrameParams& P, uint32_t maxSlots, int numCUs, LaunchC
 	int* perCU = lc.perCU[kLcShade]; // [0] default kernel, [1] the light-list instantiation
 	if (perCU[lights] == 0) {
 		int q = 0;
-		const hipError_t e = lights ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<true, false>, kBlock, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<false, false>, kBlock, 0);
+		const hipError_t e = lights ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<true>, kBlock, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<false>, kBlock, 0);
 		if (e != hipSuccess || q < 1)
 			q = 2;
 		perCU[lights] = q > 6 ? 6 : q;
@@ -987,21 +838,9 @@ void launch_shade(const FrameParams& P0, uint32_t maxSlots, int numCUs, LaunchCa
 	FrameParams P = P0;
 	P.shadeBlocks = shade_grid(P, maxSlots, numCUs, lc);
 	if (P.flags & TYR_FLAG_LIGHT_LIST)
-		hipLaunchKernelGGL((k_shade<true, false>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
+		hipLaunchKernelGGL((k_shade<true>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
 	else
-		hipLaunchKernelGGL((k_shade<false, false>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
-}
-// one iteration of the streamed tail: resident beside the traversal kernel (blocksPerCU blocks per CU; the grid must
-// not exceed what fits there, or its late blocks would only start when the early ones -- which wait for the traversal -- end:
-// slower, never wrong, every wait is bounded)
-void launch_shade_stream(const FrameParams& P0, int blocksPerCU, int numCUs, hipStream_t stream) {
-	FrameParams P = P0;
-	P.shadeBlocks = (uint32_t)(blocksPerCU < 1 ? 1 : blocksPerCU) * (uint32_t)numCUs;
-	P.foldSpheres = 1u;
-	if (P.flags & TYR_FLAG_LIGHT_LIST)
-		hipLaunchKernelGGL((k_shade<true, true>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
-	else
-		hipLaunchKernelGGL((k_shade<false, true>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
+		hipLaunchKernelGGL((k_shade<false>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
 }
 
 } // namespace tyr

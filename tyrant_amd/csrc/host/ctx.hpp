@@ -12,7 +12,6 @@ using tyr::DevScene;
 using tyr::LaunchCache;
 using tyr::RayQ;
 using tyr::ShadowQ;
-using tyr::StreamState;
 using tyr::SunParams;
 using tyr::Tuning;
 
@@ -37,7 +36,6 @@ struct tyr_ctx {
 	uint32_t iter = 0;
 	uint32_t shadowSet = 0; // which of the two sets holds the counts of the shadow queue's current content (tyr_shadow_export)
 
-	hipStream_t side = nullptr; // second stream of a ctx (shade launches that run beside the traversal)
 	hipEvent_t evSnapshot = nullptr;
 	// TYR_TUNE_SCAN_IN_TRACE
 	bool scanCarried = false;      // the last shade launch left its slot scan to the next traversal launch (hip/scan_wave.hpp)
@@ -56,17 +54,8 @@ struct tyr_ctx {
 	unsigned long long* vWord[2] = { nullptr, nullptr };
 	uint32_t* vPre[2] = { nullptr, nullptr };
 	uint32_t* vBlk[2] = { nullptr, nullptr };
-	// the streamed tail (hip/kernels.hpp "the STREAMED TAIL"): per-iteration state, fill counters per 64-slot chunk of the two ray
-	// queues' class 0 and of the two shadow queues, done counters per 256-slot tile of the ray queues' class 0
-	StreamState* dStream = nullptr;
-	StreamState* hStream = nullptr; // pinned: where the tail's state lands for the host to count its iterations
-	uint32_t* fillRay[2] = { nullptr, nullptr };
-	uint32_t* fillSh[2] = { nullptr, nullptr };
-	uint32_t* doneRay[2] = { nullptr, nullptr };
 	bool unboundedRender = false; // tyr_render was called without an iteration limit: contributions may arrive an iteration early (TYR_TUNE_RETIRE_SKY's survivors)
 	bool lastShadeFolded = false; // the shade launch that filled the current work / shadow queues did the sphere pre-passes' work too (TYR_TUNE_FOLD_SPHERES)
-	bool streamDirty = false; // a tail ended in an error: the counters above are re-zeroed before the next one
-	hipEvent_t evTail = nullptr;
 	float4* blit = nullptr;
 	bool ownBlit = false;
 
