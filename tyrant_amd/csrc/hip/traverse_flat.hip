@@ -702,251 +702,6 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 	return visible | (wideOverflow ? 0x80000000u : 0u) | (kGuardPasses && passes > kMaxPasses ? 0x40000000u : 0u);
 }
 
-#ifdef TYR_WIDE_STEAL
-// ==== what-if (round 6): the drain four lanes to a ray, with HAND-OFFS ====
-// A launch ends on its longest rays (140-260 quad steps against a mean of 12) and a wave leaves wide_drain with its
-// longest ray, whatever the other fifteen groups do meanwhile.  Here a group that holds nothing takes the BOTTOM entry
-// off another group's stack -- the subtree the owner would visit last -- and traverses it with the owner's bound at the
-// time of the hand-off; when it is through it reports to the group it took the entry from, which folds the answer into
-// its own.  TYR_WIDE_STEAL = 1: the fold is "nearer wins" (closest hit) / "or" (any hit): NOT the reference's accept
-// order (bvh.h:134) -- this build prices the idea, it is not a mode.
-// The group's 48-entry stack is circular: entry i (0 = bottom) lies at physical index (bot + i) % 48.
-template <int STACK_LDS>
-__device__ __attribute__((noinline, cold)) uint32_t wide_drain_steal(const float4* __restrict__ quads, const float4* __restrict__ tris, const float4* __restrict__ shadowColor, const float4* __restrict__ shadowDyzCdIx,
-                                                               float2* __restrict__ workHit, float4* __restrict__ blit, typename LdsStack<STACK_LDS, true>::entry_t* smem_, WideState w, uint32_t passes TYR_WIDE_STEPS_PARAM) {
-	const uint32_t lane = lane_id();
-	const unsigned long long below = (1ull << lane) - 1ull;
-	float rox = w.rox, roy = w.roy, roz = w.roz, rdx = w.rdx, rdy = w.rdy, rdz = w.rdz, rix = w.rix, riy = w.riy, riz = w.riz, dist = w.dist;
-	uint32_t ref = w.ref, slot = w.slot;
-	int prim = w.prim;
-	bool regular = (w.flags & 1u) != 0u, hitTri = (w.flags & 2u) != 0u, isShadow = (w.flags & 4u) != 0u, occluded = (w.flags & 8u) != 0u;
-	const bool live = (w.flags & 16u) != 0u;
-	uint32_t visible = 0;
-	const uint32_t sub = lane & 3u, grp = lane >> 2;
-	const unsigned long long lm = __ballot(live);
-	const uint32_t nl = (uint32_t)__popcll(lm);
-	const uint32_t told = (uint32_t)__builtin_amdgcn_ds_permute(live ? (int)(__popcll(lm & below) << 2) : 63 * 4, (int)lane);
-	bool gActive = grp < nl; // this group is traversing
-	const uint32_t asked = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(grp << 2), (int)told);
-	const uint32_t srcLane = gActive ? asked : lane;
-	{
-		const int pull = (int)(srcLane << 2);
-		auto pull_f = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)__float_as_uint(v))); };
-		auto pull_u = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v); };
-		rox = pull_f(rox), roy = pull_f(roy), roz = pull_f(roz);
-		rdx = pull_f(rdx), rdy = pull_f(rdy), rdz = pull_f(rdz);
-		rix = pull_f(rix), riy = pull_f(riy), riz = pull_f(riz);
-		dist = pull_f(dist);
-		ref = pull_u(ref);
-		slot = pull_u(slot);
-		prim = (int)pull_u((uint32_t)prim);
-		const uint32_t fl = pull_u((regular ? 1u : 0u) | (hitTri ? 2u : 0u) | (isShadow ? 4u : 0u) | (occluded ? 8u : 0u));
-		regular = (fl & 1u) != 0u, hitTri = (fl & 2u) != 0u, isShadow = (fl & 4u) != 0u, occluded = (fl & 8u) != 0u;
-	}
-	int n = (int)__builtin_amdgcn_ds_bpermute((int)(srcLane << 2), w.n);
-	typedef typename LdsStack<STACK_LDS, true>::entry_t entry_t;
-	entry_t* const column0 = smem_ + (threadIdx.x >> 8) * (STACK_LDS * kBlock) + (threadIdx.x & 255u & ~63u);
-	entry_t moved[STACK_LDS / 4];
-#pragma unroll
-	for (int row = 0; row < STACK_LDS / 4; ++row) {
-		const int e = 4 * row + (int)sub;
-		moved[row] = (gActive && e < n) ? column0[e * kBlock + srcLane] : entry_t{};
-	}
-	wave_lds_order();
-#pragma unroll
-	for (int row = 0; row < STACK_LDS / 4; ++row)
-		if (gActive && 4 * row + (int)sub < n)
-			column0[row * kBlock + lane] = moved[row];
-	wave_lds_order();
-	entry_t* const gstack = column0 + (lane & ~3u); // physical entry e: gstack[(e >> 2) * kBlock + (e & 3)]
-	auto phys = [](int i) { return i >= kWideStackEntries ? i - kWideStackEntries : i; };
-	bool wideOverflow = false;
-	int bot = 0;               // physical index of the stack's bottom entry
-	uint32_t pending = 0;      // entries handed off whose answers are still out
-	uint32_t parent = 0xffu;   // first lane of the group this group reports to (0xff: it holds the ray itself and writes its answer out)
-	bool holds = gActive;      // traversing, or through and waiting for answers
-	const unsigned long long grpBelow = (1ull << (lane & ~3u)) - 1ull;
-	bool allRegular = __ballot(gActive && !regular) == 0ull;
-	uint32_t stepsWide = 0;
-	while (__ballot(holds) != 0ull) {
-		if (kGuardPasses && ++passes > kMaxPasses)
-			break;
-		stepsWide += 1;
-#ifdef TYR_LAUNCH_ANATOMY
-		wideSteps += 1;
-#endif
-		// ---- hand-offs: the k-th free group takes the bottom entry of the k-th group that has one ----
-		{
-#ifndef TYR_STEAL_AFTER
-#define TYR_STEAL_AFTER 0 // hand-offs begin after this many steps of the wave four lanes to a ray: whoever is still going then is long
-#endif
-#ifndef TYR_STEAL_MIN_N
-#define TYR_STEAL_MIN_N 1 // a group gives its bottom entry away when it holds at least this many (and something to do besides)
-#endif
-			const bool freeG = !holds, victimOK = gActive && (n > TYR_STEAL_MIN_N || (n == TYR_STEAL_MIN_N && ref != kRefPop));
-			const unsigned long long T = __ballot(freeG && sub == 0u), V = __ballot(victimOK && sub == 0u);
-			if (T != 0ull && V != 0ull && stepsWide >= (uint32_t)(TYR_STEAL_AFTER)) {
-				const uint32_t nT = (uint32_t)__popcll(T), nV = (uint32_t)__popcll(V), nP = nT < nV ? nT : nV;
-				const uint32_t trank = (uint32_t)__popcll(T & grpBelow), vrank = (uint32_t)__popcll(V & grpBelow);
-				const bool robbed = victimOK && vrank < nP, thief = freeG && trank < nP;
-				const uint32_t toldV = (uint32_t)__builtin_amdgcn_ds_permute((robbed && sub == 0u) ? (int)(vrank << 2) : 63 * 4, (int)lane);
-				const uint32_t vlane = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(trank << 2), (int)toldV) & 60u;
-				const int pull = (int)((thief ? vlane : lane) << 2);
-				auto pull_f = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)__float_as_uint(v))); };
-				auto pull_u = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v); };
-				rox = pull_f(rox), roy = pull_f(roy), roz = pull_f(roz);
-				rdx = pull_f(rdx), rdy = pull_f(rdy), rdz = pull_f(rdz);
-				rix = pull_f(rix), riy = pull_f(riy), riz = pull_f(riz);
-				dist = pull_f(dist);
-				slot = pull_u(slot);
-				const uint32_t fl = pull_u((regular ? 1u : 0u) | (isShadow ? 4u : 0u));
-				const int vbot = (int)pull_u((uint32_t)bot);
-				wave_lds_order();
-				const entry_t e = column0[(vbot >> 2) * kBlock + (thief ? vlane : (lane & ~3u)) + (vbot & 3)];
-				wave_lds_order();
-				if (robbed) {
-					bot = phys(bot + 1);
-					n -= 1;
-					pending += 1;
-				}
-#ifdef TYR_LAUNCH_ANATOMY
-				wideSteps += nP << 16; // (anatomy build: hand-offs of this wave in the upper half)
-#endif
-				if (thief) {
-					regular = (fl & 1u) != 0u, isShadow = (fl & 4u) != 0u;
-					ref = __uint_as_float(e.y) < dist ? e.x : kRefPop;
-					n = 0, bot = 0, prim = 0, pending = 0;
-					hitTri = false, occluded = false;
-					parent = vlane;
-					holds = true, gActive = true;
-				}
-				allRegular = __ballot(gActive && !regular) == 0ull;
-			}
-		}
-		const RayConst r = { mk3(rox, roy, roz), mk3(rdx, rdy, rdz), mk3(rix, riy, riz), rix < 0, riy < 0, riz < 0 };
-		const uint32_t signBits = (r.nx ? 1u : 0u) | (r.ny ? 2u : 0u) | (r.nz ? 4u : 0u);
-		// ---- pop: the group's top entry ----
-		{
-			const bool popping = gActive && ref == kRefPop;
-			const bool has = n > 0;
-			const int top = phys(bot + (has ? n - 1 : 0));
-			const entry_t e = gstack[(top >> 2) * kBlock + (top & 3)];
-			const uint32_t popped = !has ? kRefDone : (__uint_as_float(e.y) < dist ? e.x : kRefPop); // the pop-time half of Bbox.h:61
-			ref = popping ? popped : ref;
-			n = (popping && has) ? n - 1 : n;
-		}
-		// ---- one quad node: this lane's child box ----
-		const bool atNode = gActive && (int)ref >= 0;
-		if (__ballot(atNode) != 0ull) {
-			const uint32_t idx = atNode ? (ref & kQuadIndexMask) : 0u, meta = ref >> kQuadOrderShift;
-			const float* qf = reinterpret_cast<const float*>(quads + 8 * idx);
-			const uint32_t at = (sub >> 1) * 4u + (sub & 1u) * 2u;
-			const float2 bx = gload_f2(qf + at);
-			const float2 by = gload_f2(qf + 8 + at);
-			const float2 bz = gload_f2(qf + 16 + at);
-			const uint32_t cref = gload_u(qf + 24 + sub);
-			float t;
-			bool h;
-			if (allRegular)
-				h = slab_fast(r, bx.x, bx.y, by.x, by.y, bz.x, bz.y, dist, t);
-			else
-				h = slab_test(r, r.nx ? bx.y : bx.x, r.nx ? bx.x : bx.y, r.ny ? by.y : by.x, r.ny ? by.x : by.y, r.nz ? bz.y : bz.x, r.nz ? bz.x : bz.y, dist, t);
-			h = h && atNode;
-			const uint32_t aT = meta & 3u, aL = (meta >> 2) & 3u, aR = (meta >> 4) & 3u;
-			const uint32_t bT = (signBits >> aT) & 1u, bG = (signBits >> ((sub >> 1) ? aR : aL)) & 1u;
-			const uint32_t rank = 2u * ((sub >> 1) ^ bT) + ((sub & 1u) ^ bG);
-			const uint32_t hr = quad_or(h ? (1u << rank) : 0u); // the group's hits, in visit order
-			const uint32_t first = (uint32_t)__ffs((int)(hr | 16u)) - 1u;
-			const int e = n + (int)__popc(hr >> (rank + 1u));
-			if (h && rank != first && e < kWideStackEntries) {
-				const int pe = phys(bot + e);
-				gstack[(pe >> 2) * kBlock + (pe & 3)] = make_uint2(cref, __float_as_uint(t));
-			}
-			int n2 = n + (int)__popc(hr) - (hr != 0u ? 1 : 0);
-			wideOverflow = wideOverflow || (atNode && n2 > kWideStackEntries);
-			n2 = n2 > kWideStackEntries ? kWideStackEntries : n2;
-			const uint32_t nearest = quad_or((h && rank == first) ? cref : 0u);
-			ref = atNode ? (hr == 0u ? kRefPop : nearest) : ref;
-			n = atNode ? n2 : n;
-		}
-		// ---- a leaf: four primitives per round ----
-		const bool atLeaf = gActive && ref_is_leaf(ref);
-		if (__ballot(atLeaf) != 0ull) {
-			const uint32_t off = ref & (kMaxPrimOffset - 1);
-			const uint32_t cnt = atLeaf ? ((ref >> 26) & 31u) + 1u : 0u;
-			bool found = false;
-			for (uint32_t base = 0; __ballot(base < cnt) != 0ull; base += 4u) {
-				const uint32_t i = base + sub;
-				const bool mine = i < cnt;
-				const TriData td = triangle_gload(tris, mine ? off + i : 0u);
-				float tm = triangle_test_select(td, r);
-				tm = mine ? tm : 0.0f;
-				const float t0 = quad_bcast_f<0>(tm), t1 = quad_bcast_f<1>(tm), t2 = quad_bcast_f<2>(tm), t3 = quad_bcast_f<3>(tm);
-				const float tk[4] = { t0, t1, t2, t3 };
-#pragma unroll
-				for (uint32_t k = 0; k < 4u; ++k) {
-					const float t = tk[k];
-					const bool in = (base + k < cnt) && t > kEpsilon && ((dist - t) > kEpsilon);
-					found = found || (in && isShadow);
-					const bool closer = in && !isShadow && t < dist;
-					prim = closer ? (int)(off + base + k) : prim;
-					hitTri = hitTri || closer;
-					dist = closer ? t : dist;
-				}
-			}
-			occluded = occluded || found;
-			ref = atLeaf ? (found ? kRefDone : kRefPop) : ref;
-		}
-		// ---- through: a group that waits for nothing answers; one that reports does so through the scalar unit ----
-		gActive = gActive && ref != kRefDone;
-		const bool through = holds && !gActive && pending == 0u;
-		const unsigned long long R = __ballot(through && parent != 0xffu && sub == 0u);
-		if (R != 0ull) {
-			const uint32_t packed = (hitTri ? 1u : 0u) | (occluded ? 2u : 0u) | (parent << 8);
-			unsigned long long todo = R;
-			while (todo != 0ull) {
-				const int l = (int)__ffsll((long long)todo) - 1;
-				todo &= todo - 1ull;
-				const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)packed, l);
-				const float cd = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dist), l));
-				const int cp = __builtin_amdgcn_readlane(prim, l);
-				if ((lane & ~3u) == (pk >> 8)) {
-					pending -= 1u;
-					if (isShadow) {
-						if (pk & 2u) {
-							occluded = true;
-							ref = kRefDone; // (any hit: nothing left to look for; entries handed off earlier run to their end)
-							gActive = false;
-						}
-					} else if ((pk & 1u) && cd < dist) {
-						dist = cd, prim = cp, hitTri = true;
-					}
-				}
-			}
-		}
-		if (through) {
-			if (parent == 0xffu && sub == 0u) {
-				if (isShadow) {
-					if (!occluded) { // kernel.cu:640-644
-						const float4 c = shadowColor[slot];
-						accumulate_pixel(blit, __float_as_int(shadowDyzCdIx[slot].w), mk3(c.x, c.y, c.z), 0);
-						visible += 1;
-					}
-				} else {
-					finish_extend_ray(workHit, slot, hitTri, dist, prim);
-				}
-			}
-			holds = false;
-			parent = 0xffu;
-		}
-	}
-	return visible | (wideOverflow ? 0x80000000u : 0u) | (kGuardPasses && passes > kMaxPasses ? 0x40000000u : 0u);
-}
-#define TYR_WIDE_DRAIN wide_drain_steal
-#else
-#define TYR_WIDE_DRAIN wide_drain
-#endif
-
 // ======================================================================================
 // k_trace_flat: extend(i + 1) and connect(i) in ONE persistent launch (tyr_render only).
 //
@@ -1306,7 +1061,7 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 		w.rox = rox, w.roy = roy, w.roz = roz, w.rdx = rdx, w.rdy = rdy, w.rdz = rdz, w.rix = rix, w.riy = riy, w.riz = riz, w.dist = dist;
 		w.ref = ref, w.slot = slot, w.prim = prim, w.n = st.n;
 		w.flags = (regular ? 1u : 0u) | (hitTri ? 2u : 0u) | (isShadow ? 4u : 0u) | (occluded ? 8u : 0u) | (live ? 16u : 0u);
-		const uint32_t res = TYR_WIDE_DRAIN<STACK_LDS>(PE.scene.quads, PE.scene.tris, PE.shadowPrev.color, PE.shadowPrev.dyz_cd_ix, PE.work.hit, PE.blit, smem_, w, passes TYR_WIDE_STEPS_ARG);
+		const uint32_t res = wide_drain<STACK_LDS>(PE.scene.quads, PE.scene.tris, PE.shadowPrev.color, PE.shadowPrev.dyz_cd_ix, PE.work.hit, PE.blit, smem_, w, passes TYR_WIDE_STEPS_ARG);
 		visible += res & 0x3fffffffu;
 		overflow = overflow || (res & 0x80000000u) != 0u;
 		if (res & 0x40000000u)
@@ -1334,9 +1089,7 @@ __global__ void __launch_bounds__(kTraceBlock, (kTraceBlock == kTraceBlockWide ?
 			P.next.hit[w] = make_float2((float)((tExhausted ? tExhausted : tEnd) - tStart) * 0.01f, (float)(tEnd - tStart) * 0.01f + (float)liveAtExhaustion * 0.0f);
 		if (w < 8192u && 32768u < P.N) { // three more records per wave, further up the same column (host/driver.cpp prints them with TYR_ANATOMY=2)
 			P.next.hit[8192u + w] = make_float2(tWide ? (float)(tWide - tStart) * 0.01f : 0.0f, (float)(liveAtExhaustion + 256u * liveAtWide));
-			P.next.hit[16384u + w] = make_float2((float)tripsAfter, (float)(wideSteps & 0xffffu)); // trips after the queue ran out one ray to a lane, steps four lanes to a ray
-			if (40960u < P.N)
-				P.next.hit[32768u + w] = make_float2((float)(wideSteps >> 16), 0.0f); // (-DTYR_WIDE_STEAL) hand-offs inside this wave
+			P.next.hit[16384u + w] = make_float2((float)tripsAfter, (float)wideSteps); // trips after the queue ran out one ray to a lane, steps four lanes to a ray
 			P.next.hit[24576u + w] = make_float2((float)passesAfter, (float)tripsFeed);
 		}
 	}

@@ -27,10 +27,10 @@ extern "C" {
 #ifdef TYR_LAUNCH_ANATOMY
 // TYR_ANATOMY=2: the per-wave records k_trace_flat's anatomy build leaves in the next queue's hit column
 static void print_wave_anatomy(const float2* dHit, unsigned long long feedTicks) {
-	std::vector<float2> rec(5 * 8192);
+	std::vector<float2> rec(4 * 8192);
 	if (hipMemcpy(rec.data(), dHit, rec.size() * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess)
 		return;
-	std::vector<float> drain, normal, wide, perTrip, perStep, liveExh, liveWide, trips, steps, passes, handoffs;
+	std::vector<float> drain, normal, wide, perTrip, perStep, liveExh, liveWide, trips, steps, passes;
 	for (uint32_t w = 0; w < 8192; ++w) {
 		const float tExh = rec[w].x, tEnd = rec[w].y, tWide = rec[8192 + w].x;
 		if (!(tExh > 0.0f) || !(tEnd >= tExh) || !(tEnd < 1e5f))
@@ -49,7 +49,6 @@ static void print_wave_anatomy(const float2* dHit, unsigned long long feedTicks)
 		trips.push_back(nTrips);
 		steps.push_back(nSteps);
 		passes.push_back(rec[24576 + w].x);
-		handoffs.push_back(rec[32768 + w].x);
 	}
 	auto pct = [](std::vector<float>& v, double p) {
 		if (v.empty())
@@ -68,7 +67,6 @@ static void print_wave_anatomy(const float2* dHit, unsigned long long feedTicks)
 	line("descent trips one ray to a lane", trips);
 	line("outer passes (leaf rounds) one ray to a lane", passes);
 	line("steps four lanes to a ray", steps);
-	line("hand-offs four lanes to a ray (steal build)", handoffs);
 	line("us per trip, one ray to a lane", perTrip);
 	line("us per step, four lanes to a ray", perStep);
 	{
@@ -155,7 +153,7 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 #endif
 			std::fprintf(stderr, "\n");
 #ifdef TYR_LAUNCH_ANATOMY
-			if (std::getenv("TYR_ANATOMY")[0] == '2' && P.N > 40960u)
+			if (std::getenv("TYR_ANATOMY")[0] == '2' && P.N > 32768u)
 				print_wave_anatomy(P.next.hit, tx - t0);
 #endif
 		}
