@@ -68,7 +68,7 @@ from tyrant_amd.benchkit.children import committed_pmc, drain_block, pmc_child, 
 from tyrant_amd.benchkit.common import (EXTEND_KERNEL, HBM_PEAK_GBS, NUM_CU, NUM_SIMD, NUM_XCD, PMC_PASSES, REF_N, SHADE_BYTES_PER_RAY, SHADE_KERNEL, TRACE_KERNEL,  # noqa: E402,F401
                                         build_workload, dominant_kernel, find_rocprof, job_shape)
 from tyrant_amd.benchkit.preflight import PREFLIGHT_TIMEOUT_S, PREFLIGHT_TORCH_NCCL_ONLY, dist_preflight, run_dist_preflight  # noqa: E402,F401
-from tyrant_amd.benchkit.roofline import ORACLE_COUNTER_FIELDS, oracle_counters_check, roofline_block, shade_block  # noqa: E402,F401
+from tyrant_amd.benchkit.roofline import ORACLE_COUNTER_FIELDS, nominal_step_frac, oracle_counters_check, roofline_block, shade_block  # noqa: E402,F401
 
 
 def parse_args(argv=None):
@@ -76,7 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c3_framed", "c5"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel: 0 = the configuration's (8 at one GPU; N > 1: 64 in total when --scaling strong, 8 per GPU when weak)")
@@ -84,6 +84,8 @@ def parse_args(argv=None):
     ap.add_argument("--queue", type=int, default=0, help="ray_queue_buffer_size (variables.h:44); 0 = sized for the GPU: spp x local pixels, at most 32 Mi slots")
     ap.add_argument("--no-reference-queue", action="store_true", help="skip the second measurement at the reference's queue size (2,097,152)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-framed", action="store_true", help="workload c3 at one GPU: skip the secondary workload c3_framed (config.framed: the same scene from where the room's opening fills the frame)")
+    ap.add_argument("--no-spread", action="store_true", help="one GPU: skip config.spread (ten blocks of twenty more renders behind the timed region: ms per render p50 / p95 / max)")
     ap.add_argument("--no-steady-state", action="store_true", help="skip config.steady_state (the queue kept full by top-ups, as the reference's viewer runs: no thin iterations)")
     ap.add_argument("--no-one-gpu-job", action="store_true", help="N > 1, strong: skip rank 0's solo render of the same job (strong_scaling block)")
     ap.add_argument("--cpu-iterations", type=int, default=2)
@@ -216,8 +218,13 @@ def main():
     if world > 1 and not native and args.combine == "gather":
         use_torch_gather = tdist.agree_gather_works(cdev)
 
-    def measure(N, steps, warmup, spp, shard, ranks):
-        """one renderer at queue size N: untimed counting render, warm-up, `steps` timed renders (ranks > 1: + the combine)"""
+    def pct(v, p):
+        v = sorted(v)
+        return v[min(len(v) - 1, int(round(p * (len(v) - 1))))] if v else None
+
+    def measure(N, steps, warmup, spp, shard, ranks, sc=sc, spread_blocks=0):
+        """one renderer at queue size N: untimed counting render, warm-up, `steps` timed renders (ranks > 1: + the combine);
+        spread_blocks: that many blocks of twenty more renders BEHIND the timed region, each render timed by itself"""
         # the caller owns blit_buffer (main.cpp:129-130): a torch tensor here (device memory is torch's job in this script)
         accum = torch.zeros(H * W * 4, dtype=torch.float32, device=dev)
         frame = torch.zeros(H * W * 4, dtype=torch.float32, device=dev) if (ranks > 1 and rank == 0) else None
@@ -334,8 +341,13 @@ def main():
         fence()
         t0 = time.perf_counter()
         iters = 0
+        step_ms = []  # (tyr_render returns when the render's counters are on the host: a step's end needs no extra wait to be timed)
+        ts = t0
         for _ in range(steps):
             iters += step()
+            tn = time.perf_counter()
+            step_ms.append((tn - ts) * 1e3)
+            ts = tn
         fence()
         dt = time.perf_counter() - t0
         k1 = r.counters()
@@ -356,6 +368,19 @@ def main():
             # sanity of the combined frame: every pixel has exactly spp completed paths
             a = (frame if frame is not None else accum).view(H * W, 4)[:, 3]
             assert float(a.min()) == float(a.max()) == float(spp), (float(a.min()), float(a.max()), spp)
+        spread = None
+        if spread_blocks > 0 and ranks == 1:
+            # behind the timed region: the job is 5 ms and boxes differ by 1-3 %; K steps say little about a render's spread
+            per, blocks = [], []
+            for _ in range(spread_blocks):
+                tb = time.perf_counter()
+                for _ in range(20):
+                    t1 = time.perf_counter()
+                    step()
+                    per.append((time.perf_counter() - t1) * 1e3)
+                blocks.append((time.perf_counter() - tb) * 1e3 / 20.0)
+            spread = {"renders": len(per), "ms_min": round(min(per), 3), "ms_p50": round(pct(per, 0.5), 3), "ms_p95": round(pct(per, 0.95), 3), "ms_max": round(max(per), 3),
+                      "block_means_ms": [round(b, 3) for b in blocks], "note": f"{spread_blocks} blocks of 20 renders of the same job behind the timed region, each render timed by itself (host clock around tyr_render, which returns with the render's counters on the host)"}
         native_used = comm is not None and native_ok[0]
         comm_info = None
         if comm is not None:
@@ -367,9 +392,21 @@ def main():
             comm = True if native_used else None  # (only its truth value is reported below)
         r.close()
         per_render = {k: round(v["ms"] / warmup, 3) for k, v in tm_all.items()} if tm_all is not None else {k: round(v["ms"] / steps, 3) for k, v in tm.items()}
-        return {"native_combine": bool(comm is not None and native_ok[0]), "comm_info": comm_info, "ext": ext, "shd": shd, "survivors": survivors, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, "counter_deltas": deltas, "upload": upload, **visits}
+        return {"native_combine": bool(comm is not None and native_ok[0]), "comm_info": comm_info, "ext": ext, "shd": shd, "survivors": survivors, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, "counter_deltas": deltas, "upload": upload, "step_ms": step_ms, "spread": spread, **visits}
 
-    m = measure(N, args.steps, args.warmup, spp_total, shard, world)
+    m = measure(N, args.steps, args.warmup, spp_total, shard, world, spread_blocks=0 if (world > 1 or args.no_spread) else 10)
+    # the secondary workload (NOT the metric): the same scene and job from where the room's opening fills the frame
+    framed = None
+    if world == 1 and args.workload == "c3" and not args.no_framed and (W, H, spp_total) == (1920, 1080, 8):
+        fsteps = max(1, min(args.steps, 10))
+        mf = measure(N, fsteps, 1, spp_total, shard, 1, sc=scenes.mesh_scene_framed(706))
+        fr_rate = (mf["ext_all"] + mf["shd_all"]) / mf["dt_all"] / 1e6
+        framed = {"workload": "c3_framed: the C3 scene from (0, -87.5, 50) -- kernel.cu:698-699's 1.5 x W/H by 1.5 extents make the frame exactly as wide as the room's opening there: every camera ray enters the room (from SURVEY.md 8d's (0, -190, 50) the opening covers 12.7 % of the frame)",
+                  "Mrays/s": round(fr_rate, 3), "ms_per_step": round(mf["dt_all"] / fsteps * 1e3, 3), "steps": fsteps, "in_tree_Mrays/s": round(fr_rate * mf["in_tree_frac"], 3),
+                  "in_tree_fraction": {"all_rays": round(mf["in_tree_frac"], 4), "extend_rays": round(mf["in_tree_ext_frac"], 4)},
+                  "wavefront_iterations_per_step": mf["iters"] / fsteps, "nodes_per_extend_ray": round(mf["nodes_per_ext"], 2), "tris_per_extend_ray": round(mf["tris_per_ext"], 3),
+                  "kernel_ms_per_render": mf["kernel_ms_per_render"],
+                  **oracle_counters_check(args, 1, W, H, spp_total, N, int(prims.shape[0]), mf, workload="c3_framed", steps=fsteps)}
     mref = None
     if not args.no_reference_queue and N != REF_N:
         mref = measure(REF_N, max(1, min(args.steps, 2)), 1, spp_total, shard, world)
@@ -420,6 +457,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(m["dt_all"] / args.steps * 1e3, 3),
+            "ms_per_step_spread": {"min": round(min(m["step_ms"]), 3), "p50": round(pct(m["step_ms"], 0.5), 3), "p95": round(pct(m["step_ms"], 0.95), 3), "max": round(max(m["step_ms"]), 3), "of": "the timed steps (host clock per tyr_render)"},
             "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None,
@@ -427,6 +465,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": label + (f"; as BASELINE config C4: {spp_total} spp in total shared by {world} GPUs" if world > 1 and args.scaling == "strong" else ""),
+                # what `value` is made of, first: the rays that actually enter the tree (the others cost one box test where they are made)
+                "in_tree_Mrays/s": round(mrays * m["in_tree_frac"], 3),
+                "in_tree_fraction": {"all_rays": round(m["in_tree_frac"], 4), "extend_rays": round(m["in_tree_ext_frac"], 4), "note": "rays whose test of the root box passes (counting build, rank 0's shard); the others cost one box test.  SURVEY.md 8d's camera sees the room's opening in 12.7 % of the frame: config.framed is the same job from where it fills the frame"},
+                **({"framed": framed} if framed else {}),
+                **({"spread": m["spread"]} if m.get("spread") else {}),
                 "resolution": f"{W}x{H}",
                 "spp_total": spp_total,
                 "queue_size": N,
@@ -442,8 +485,6 @@ def main():
                 "wavefront_iterations_per_step": m["iters"] / args.steps,
                 "extend_Mrays/s": round(m["ext_all"] / m["dt_all"] / 1e6, 3),
                 "shadow_Mrays/s": round(m["shd_all"] / m["dt_all"] / 1e6, 3),
-                "in_tree_Mrays/s": round(mrays * m["in_tree_frac"], 3),
-                "in_tree_fraction": {"all_rays": round(m["in_tree_frac"], 4), "extend_rays": round(m["in_tree_ext_frac"], 4), "note": "rays whose test of the root box passes (counting build, rank 0's shard); the others cost one box test"},
                 "host_bvh_build_s": round(t_build, 6),
                 **({"device_bvh_build_s": dev_build} if dev_build else {}),
                 "host_scene_upload_s": {**m["upload"], "note": "tyr_scene_upload of the timed renderer (Scene.cpp:53-67's upload half), outside the timed region.  layout_on device (TYR_TUNE_LAYOUT_ON_DEVICE, the default): `copy` = the reference's node and triangle arrays to HBM as they are, `layout` = hip/bvh_layout_dev.hip making quad nodes + 48-byte triangles there (the same bytes), `host_layout` = the host pass on the builder's threads, for comparison; layout_on host: `layout` = that host pass, `copy` = allocation + the finished records to HBM"},
@@ -474,6 +515,9 @@ def main():
         per_render = 1.0 / args.steps
         k_sh = tm["shade"]
         out["roofline"]["shade"] = shade_block(pmc, k_sh["ms"] * per_render if k_sh["launches"] else m["kernel_ms_per_render"].get("shade", 0.0), m["ext"] * per_render, m["survivors"] * per_render, m["shd"] * per_render)
+        nf = nominal_step_frac(out["roofline"], args.steps, m["counter_deltas"]["total_primary_rays"], m["dt_all"])
+        if nf:
+            out["roofline"].update(nf)
         if world == 1 and args.pmc != "off":
             d = drain_block(args)
             if d:

@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 BENCH = os.path.join(ROOT, "bench.py")  # the child modes re-enter through its command line (--pmc-child, --dist-preflight)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+GATHER_CEILING_GBS = 7400.0  # ibid., "Indexed rows: gather into LDS": uniformly random rows out of the Infinity Cache, 7.4-7.9 TB/s (151 MB table) ... 8.6 TB/s (38 MB)
 NUM_XCD, NUM_SIMD, NUM_CU = 8, 1024, 256  # MI355X: 8 XCDs x 32 CUs x 4 SIMDs
 REF_N = 2097152  # variables.h:44
 TRACE_KERNEL = os.environ.get("TYR_BENCH_TRACE_KERNEL", "k_trace_flat<12")   # the traversal kernel: extend(i + 1) + connect(i) in one launch (tyr_render), or one kind of ray alone.  A name PREFIX: rocprofv3 lists its two block shapes, k_trace_flat<12, 768u> (launches of 3 Mi rays and more: six waves per SIMD) and k_trace_flat<12, 256u>; both are "the kernel" of the roofline
@@ -32,6 +33,9 @@ def build_workload(name: str, binding, scenes):
     elif name == "c3":
         sc = scenes.mesh_scene(706)
         label = "C3: room + 706x706 height-field mesh (996,882 tris), 70% DIFF / 30% SPEC"
+    elif name == "c3_framed":
+        sc = scenes.mesh_scene_framed(706)
+        label = "C3 framed: the C3 scene from (0, -87.5, 50), where the room's opening fills the 16:9 frame (kernel.cu:698-699's 1.5 x W/H by 1.5 extents): every camera ray enters the room"
     elif name == "c5":
         sc = scenes.glass_dof_scene(2236)
         label = "C5: room + 2236x2236 height-field mesh (9,999,402 tris), 65% DIFF / 30% SPEC / 5% REFR, thin lens 0.5, sun (0.3,0.2); quoted at --width 3840 --height 2160 --spp 16"

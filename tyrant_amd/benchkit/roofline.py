@@ -4,31 +4,34 @@ from __future__ import annotations
 import json
 import os
 
-from .common import EXTEND_KERNEL, HBM_PEAK_GBS, NUM_SIMD, NUM_XCD, ROOT, SHADE_BYTES_PER_RAY, TRACE_KERNEL
+from .common import EXTEND_KERNEL, GATHER_CEILING_GBS, HBM_PEAK_GBS, NUM_SIMD, NUM_XCD, ROOT, SHADE_BYTES_PER_RAY, TRACE_KERNEL
 
 ORACLE_COUNTER_FIELDS = ("total_primary_rays", "total_extend_rays", "total_shadow_rays", "n_survive", "n_shadow_visible")
 
 
-def oracle_counters_check(args, world, W, H, spp, N, n_tris, m):
+def oracle_counters_check(args, world, W, H, spp, N, n_tris, m, workload=None, steps=None):
     """config.oracle_counters_match: the counter deltas of the TIMED renders against the oracle's counters for this very job,
     committed as tests/golden/bench_c3_counters.json (made by tests/golden/make_bench_counters.py: orc_render, the serial C
     restatement of kernel.cu:664-748).  Every timed step restarts the frame counter, so K steps must have cast exactly K times
     the oracle's rays -- extend, shadow, survivors, visible shadow rays, iterations.  None when the job is not the committed one
-    (another workload, resolution, spp, queue size or rank count).  The file is data: nothing under oracle/ is loaded here."""
+    (another workload, resolution, spp, queue size or rank count).  The file is data: nothing under oracle/ is loaded here.
+    `workload` / `steps`: the secondary workload's (c3_framed: tests/golden/bench_c3_framed_counters.json) instead of the command line's."""
+    workload = workload or args.workload
+    steps = args.steps if steps is None else steps
     try:
-        with open(os.path.join(ROOT, "tests", "golden", f"bench_{args.workload}_counters.json")) as f:
+        with open(os.path.join(ROOT, "tests", "golden", f"bench_{workload}_counters.json")) as f:
             gold = json.load(f)
     except (OSError, ValueError):
-        return {"oracle_counters_match": None, "oracle_counters_note": f"no committed oracle counters for workload {args.workload}"}
+        return {"oracle_counters_match": None, "oracle_counters_note": f"no committed oracle counters for workload {workload}"}
     j = gold["job"]
     if world != 1 or (j["width"], j["height"], j["spp"], j["queue_size"], j["triangles"]) != (W, H, spp, N, n_tris):
         return {"oracle_counters_match": None, "oracle_counters_note": "this job is not the one the committed oracle counters were made for (tests/golden/make_bench_counters.py: c3, 1920x1080, 8 spp, queue 16,588,800, one rank)"}
-    want = {f: gold["per_render"][f] * args.steps for f in ORACLE_COUNTER_FIELDS}
+    want = {f: gold["per_render"][f] * steps for f in ORACLE_COUNTER_FIELDS}
     got = m["counter_deltas"]
-    ok = all(int(got[f]) == int(want[f]) for f in ORACLE_COUNTER_FIELDS) and m["iters"] == gold["per_render"]["iterations"] * args.steps
+    ok = all(int(got[f]) == int(want[f]) for f in ORACLE_COUNTER_FIELDS) and m["iters"] == gold["per_render"]["iterations"] * steps
     out = {"oracle_counters_match": bool(ok),
-           "oracle_counters": {"source": "tests/golden/bench_c3_counters.json (orc_render on this job; tests/test_gpu_configs.py::test_benchmarked_render_path_matches_oracle_at_full_size[bench_shape_16M_8spp] holds the live oracle, the file and the GPU to each other, pixels included)",
-                               "per_render": gold["per_render"], "timed_renders": args.steps}}
+           "oracle_counters": {"source": f"tests/golden/bench_{workload}_counters.json (orc_render on this job; tests/test_gpu_configs.py::test_benchmarked_render_path_matches_oracle_at_full_size[bench_shape_16M_8spp] holds the live oracle, the file and the GPU to each other, pixels included)",
+                               "per_render": gold["per_render"], "timed_renders": steps}}
     if not ok:
         out["oracle_counters"]["timed_deltas"] = {f: int(got[f]) for f in ORACLE_COUNTER_FIELDS}
         out["oracle_counters"]["timed_iterations"] = m["iters"]
@@ -99,6 +102,8 @@ def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_re
             "frac_kind": ("HBM bytes by the memory-side counters / 8 TB/s" if bound == "hbm" else ("vector" if bound == "valu-issue" else "scalar") + "-ALU issue cycles / available cycles while the kernel runs: the tightest MEASURED resource fraction -- NOT an HBM fraction (that is hbm_counter_frac; the nominal byte count of SURVEY.md 8d is algorithmic.frac_of_hbm_peak)"),
             "traffic": round(traffic, 2),
             "hbm_counter_frac": round(fr["hbm"], 4),
+            "fabric_vs_gather_ceiling": round(traffic / GATHER_CEILING_GBS, 4),
+            "fabric_vs_gather_ceiling_note": f"counter bytes per second / {GATHER_CEILING_GBS:.0f} GB/s -- the rate at which MI355X_MICROARCH.md 'Indexed rows' measured uniformly random rows gathered out of a table that lives in the Infinity Cache (7.4-7.9 TB/s for 151 MB, 8.6 TB/s for 38 MB; the lower end is used): the roofline that applies to a cache-resident scene (C3: 83 MB), which the 8 TB/s HBM figure is not",
             "valu_issue_frac": round(fr["valu-issue"], 4),
             "salu_issue_frac": round(fr["salu-issue"], 4),
             "lanes_active_per_valu_inst": round(lanes, 4),
@@ -148,3 +153,18 @@ def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_re
                              "note": "nominal = SURVEY.md 8d's per-ray bytes of the REFERENCE's binary tree over the traversal time (can exceed 1: not traffic); counters = bytes that crossed the fabric (FETCH_SIZE x 2 + WRITE_SIZE) / 8 TB/s -- the tree lives in the 256 MB Infinity Cache and the kernel is bound by instruction issue and by its launches' drains, not by HBM"}
     out["kernel_ms_per_render"] = kernel_ms_per_render
     return out
+
+
+def nominal_step_frac(roofline, steps, primary_rays, dt_s):
+    """SURVEY.md 8d's nominal bytes of the WHOLE step (every traversal launch + every shade launch + 44 B per primary ray) over the
+    timed region's wall time, as a fraction of the HBM peak: the one nominal figure that is bounded by 1 as long as no work is skipped
+    (the traversal kernel's own nominal fraction exceeds 1 on a cache-resident scene)."""
+    try:
+        trace = roofline["algorithmic"]["bytes_per_launch"] * roofline["launches"]
+        shade = roofline["shade"]["algorithmic"]["bytes_per_render"] * steps
+    except (KeyError, TypeError):
+        return None
+    total = trace + shade + 44.0 * primary_rays
+    return {"nominal_step_frac": round(total / dt_s / 1e9 / HBM_PEAK_GBS, 4) if dt_s > 0 else None,
+            "nominal_step_bytes": {"traversal": round(trace), "shade": round(shade), "primary": round(44.0 * primary_rays), "timed_s": round(dt_s, 6),
+                                   "note": "SURVEY.md 8d per-unit bytes x the units of the timed renders / wall time of the timed region / 8 TB/s; nominal: most of these bytes are served by the Infinity Cache and LDS (hbm_counter_frac is what crossed the fabric)"}}

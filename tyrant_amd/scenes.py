@@ -310,6 +310,20 @@ def mesh_scene(cells: int = 706, seed: int = 12345, spec_fraction: float = 0.3, 
     return SceneData(f"room+heightfield{cells}", tris, cornell_spheres(), CORNELL_CAMERA, triangle_materials=True)
 
 
+# The view from which the room's opening fills a 16:9 frame.  kernel.cu:698-699 scales camera_right by 1.5 * W / H and camera_up by
+# 1.5, and kernel.cu:274-278 spans them over [-0.5, 0.5]: at distance d along the view direction the frame is 2.667 d wide and 1.5 d
+# high.  From SURVEY.md 8d's Cornell camera (0, -190, 50) the 100 x 100 opening at y = -50 (d = 140) covers 0.268 x 0.476 = 12.7 % of a
+# 1080p frame -- 61 % of a C3 render's extend rays never enter the tree.  From d = 37.5 the frame is exactly as wide as the opening
+# (and 56 high, inside its 100): every camera ray enters the room.
+FRAMED_CAMERA = Camera(position=(0.0, -87.5, 50.0), direction=(0.0, 1.0, 0.0), up=(0.0, 0.0, 1.0), focalDistance=1.0, lensRadius=0.0)
+
+
+def mesh_scene_framed(cells: int = 706, seed: int = 12345) -> SceneData:
+    """bench.py's secondary workload `c3_framed`: the C3 scene (same triangles, same tree) seen from FRAMED_CAMERA."""
+    sc = mesh_scene(cells, seed)
+    return dataclasses.replace(sc, name=sc.name + "_framed", camera=FRAMED_CAMERA)
+
+
 def glass_dof_scene(cells: int = 2236, seed: int = 12345) -> SceneData:
     """C5: the C3 generator with 5 % REFR triangles, a thin lens (lensRadius 0.5) focused on the
     height field from the Cornell camera (kernel.cu:286-293 multiplies focalDistance by 3), and a high sun."""
