@@ -340,7 +340,6 @@ enum {
 	TYR_TUNE_LAYOUT_ON_DEVICE = 24,  /* tyr_scene_upload: 1 (default) = the reference's node and triangle arrays are copied to the device as they are (32 + 40 bytes per node / triangle) and the layout pass runs there (hip/bvh_layout_dev.hip: the same bytes as the host pass; trees it leaves to the host -- pair nodes wanted, leaves of more than 31 primitives, a tree that is one leaf, malformed input -- take the host pass); 0 = always the host pass + a copy of the finished records (128 + 48 bytes) */
 	TYR_TUNE_SCAN_IN_TRACE = 25,     /* tyr_render one iteration ahead of the counts (TYR_TUNE_RUN_AHEAD), with TYR_TUNE_FOLD_PROLOGUE: 1 (default) = once the primary budget is spent, an iteration's slot scan -- whose tables only the NEXT shade launch reads -- is not a launch of its own: the shade launch's last block opens the next iteration (set_wavefront_globals, kernel.cu:227-244, and the padding of the queue segments' ends) and that iteration's traversal launch does the scan on its way in, a wave per 16384 slots; 0 = a k_scan_words launch in front of the traversal launch, opening the iteration itself */
 	TYR_TUNE_KERNEL_SNAPSHOT = 26,   /* tyr_render one iteration ahead of the counts (TYR_TUNE_RUN_AHEAD): 1 (default) = the counts the host's loop waits for (survivors, shadow rays, the error word) are written to pinned host memory by the shade launch's last block and the host polls their stamp -- no copy and no event in the stream between an iteration's shade launch and the next traversal launch; 0 = a copy of the counters behind the shade launch + an event */
-	TYR_TUNE_FRESH_SHADE = 27,       /* (round 6) 1 (default) = an iteration whose work queue holds nothing but the camera rays k_primary has just made -- the first wavefront of a render whose queue takes all its primaries, and whenever no ray survived the iteration before -- is shaded by an instantiation of the shade kernel in which what kernel.cu:295 initialises is constant: direct (1, 1, 1), bounces 0, lastSpecular, the key the slot itself (no throughput / flags loads, no rank lookup); 0 = the general kernel.  Same results bit for bit */
 	TYR_TUNE_FOLD_SPHERES = 19       /* merged path of tyr_render: 1 (default) = shade does the sphere pre-passes' work (kernel.cu:127-136, 168-172) for the rays it emits, while they are in registers; 0 = the pre-pass kernels re-read them */
 };
 int tyr_set_tuning(tyr_ctx* ctx, int key, int value);

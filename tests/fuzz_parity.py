@@ -34,7 +34,7 @@ for case in range(n_cases):
                         focalDistance=float(rng.uniform(1, 80)), lensRadius=float(rng.choice([0.0, 0.0, rng.uniform(0.1, 3.0)])))
     knobs = dict(refill_min_idle=int(rng.integers(1, 65)), min_traversing=int(rng.integers(1, 65)), ticket_chunk=int(rng.choice([64, 128, 1024])), static_share=int(rng.integers(0, 16)),
                  staged_nodes=int(rng.integers(0, 65)), merge_trace=int(rng.integers(0, 2)), static_interleave=int(rng.integers(0, 2)), run_ahead=int(rng.integers(0, 3)), wide_drain=int(rng.integers(0, 2)),
-                 waves_per_simd=int(rng.choice([0, 0, 1, 3])), fold_spheres=int(rng.integers(0, 2)), retire_sky=int(rng.integers(0, 2)), fresh_shade=int(rng.integers(0, 2)), resolve_shadows=int(rng.integers(0, 2)),
+                 waves_per_simd=int(rng.choice([0, 0, 1, 3])), fold_spheres=int(rng.integers(0, 2)), retire_sky=int(rng.integers(0, 2)), resolve_shadows=int(rng.integers(0, 2)),
                  wide_block_min_items=int(rng.choice([-1, 0, 0, 3 << 20])), fold_prologue=int(rng.integers(0, 2)), scan_in_trace=int(rng.integers(0, 2)), kernel_snapshot=int(rng.integers(0, 2)))  # (0: every traversal launch as 768-thread blocks, six waves per SIMD)
     if sc.triangle_materials and rng.random() < 0.5:  # emissive triangles + light list (TYR_FLAG_LIGHT_LIST)
         lit = rng.choice(len(sc.triangles), size=int(rng.integers(1, min(40, len(sc.triangles)))), replace=False)

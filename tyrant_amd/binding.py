@@ -375,7 +375,7 @@ class Renderer:
         _check(self.L.tyr_get_timings(self.h, C.byref(t), int(reset)), "tyr_get_timings")
         return {n: {"ms": t.ms[i], "launches": int(t.launches[i])} for i, n in enumerate(KERNEL_NAMES)}
 
-    TUNING_KEYS = {"refill_min_idle": 1, "waves_per_simd": 2, "min_traversing": 4, "ticket_chunk": 5, "static_share": 8, "staged_nodes": 9, "profile_mask": 11, "merge_trace": 12, "static_interleave": 13, "run_ahead": 14, "wide_drain": 15, "fold_spheres": 19, "retire_sky": 20, "resolve_shadows": 21, "wide_block_min_items": 22, "fold_prologue": 23, "layout_on_device": 24, "scan_in_trace": 25, "kernel_snapshot": 26, "fresh_shade": 27}
+    TUNING_KEYS = {"refill_min_idle": 1, "waves_per_simd": 2, "min_traversing": 4, "ticket_chunk": 5, "static_share": 8, "staged_nodes": 9, "profile_mask": 11, "merge_trace": 12, "static_interleave": 13, "run_ahead": 14, "wide_drain": 15, "fold_spheres": 19, "retire_sky": 20, "resolve_shadows": 21, "wide_block_min_items": 22, "fold_prologue": 23, "layout_on_device": 24, "scan_in_trace": 25, "kernel_snapshot": 26}
 
     def set_tuning(self, **knobs):
         for name, v in knobs.items():

@@ -186,7 +186,6 @@ struct FrameParams {
 	uint32_t snapSeq;             // ... stamped with this number, written last
 	uint32_t scanPrevInTrace;     // k_trace_flat: on its way in, its waves do the slot scan of the iteration BEFORE (n = *scanLivePrev, tables = vPrev): that iteration's shade opened this one (shadeOpensNext) and no k_scan_words was launched
 	const uint32_t* scanLivePrev;
-	uint32_t allFresh;            // launch_shade (host side only): every ray of the work queue was made by k_primary in THIS iteration (no survivors in front of the top-up, exactly): the k_shade<.., true> instantiation -- bounces 0, lastSpecular, direct (1, 1, 1), direct keys folded at compile time
 	uint32_t prevFolded;          // the traversal launchers: the shade launch that made this iteration's survivors and shadow rays did so (only the holes at the segments' ends are left to mark)
 	const uint32_t* scanLive;     // k_scan_words: where this iteration's ray count is (&k->n_live)
 	// TYR_FLAG_LIGHT_LIST (extension): emissive triangles, as indices into scene.tris in array order
@@ -216,7 +215,6 @@ struct Tuning {
 	int foldPrologue = 1;     // tyr_render one iteration ahead of the counts: once the budget is spent, an iteration's last kernel opens the next one (set_wavefront_globals, hole padding): two launches and two gaps fewer per iteration
 	int layoutOnDevice = 1;   // tyr_scene_upload: the reference's arrays go to the device as they are and hip/bvh_layout_dev.hip makes the records there (the same bytes); 0 = host/bvh_layout.cpp makes them and they are copied
 	int scanInTrace = 1;      // tyr_render one iteration ahead, the next iteration known to come without a top-up: no k_scan_words launch -- k_shade's last block opens that iteration and its traversal launch's waves do the slot scan on their way in (hip/scan_wave.hpp)
-	int freshShade = 1;       // an iteration whose work queue holds nothing but the camera rays k_primary has just made is shaded by k_shade<.., true> (their throughput, bounce count and key form are constants there)
 	int kernelSnapshot = 1;   // tyr_render one iteration ahead: the counts the host waits for are written to pinned host memory by k_shade's last block instead of copied behind it and signalled by an event (two packets in the stream between this iteration's shade and the next traversal launch)
 	int foldSpheres = 1;      // merged path of tyr_render: shade does the sphere pre-passes' work for the rays it emits ; 0: k_extend_spheres / k_connect_spheres re-read them
 };

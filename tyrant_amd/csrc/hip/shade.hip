@@ -127,34 +127,26 @@ __device__ __forceinline__ EmitterSample sample_emitter(const FrameParams& P, ui
 // before).
 // Lanes past the end of the queue come along with valid = false (they load nothing and produce nothing) so that
 // afterLoads is reached by the whole wave.
-// FRESH: every ray of the launch was made by k_primary in this iteration (the first wavefront of a render whose queue holds all
-// its primaries: 0.40 of a C3 render's 1.17 ms of shade).  kernel.cu:295 aggregate-initialises such a ray -- direct (1, 1, 1),
-// bounces 0, lastSpecular true -- and its key is its slot (kernel.cu:254): the throughput and the flags are not loaded (4 of the
-// record's 24 bytes are: the pixel index), x * 1.0f folds away exactly, the rank lookup and the Russian-roulette history go.
-template <bool LIGHTS, bool FRESH, class AfterLoads>
+template <bool LIGHTS, class AfterLoads>
 __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, bool valid, float2 hitRecord, ShadeOut& out, uint32_t& vslotOut, AfterLoads&& afterLoads) {
-	float4 a = make_float4(0.f, 0.f, 0.f, 0.f), dq = make_float4(1.f, 1.f, 1.f, 0.f);
+	float4 a = make_float4(0.f, 0.f, 0.f, 0.f), dq = a;
 	float2 b = make_float2(0.f, 0.f), h = make_float2(kVeryFar, 0.f);
-	uint32_t fl = 1u << 8, key = 0;
+	uint32_t fl = 0, key = 0;
 	if (valid) {
 		key = P.work.key[slot];
 		a = P.work.o_dx[slot];
 		b = P.work.dyz[slot];
 		h = hitRecord; // loaded by the caller (an early launch reads it past the caches, once)
-		if (FRESH) {
-			dq.w = reinterpret_cast<const float*>(&P.work.direct_ix[slot])[3];
-		} else {
-			dq = P.work.direct_ix[slot];
-			fl = P.work.flags[slot];
-		}
+		dq = P.work.direct_ix[slot];
+		fl = P.work.flags[slot];
 	}
 
-	f3 origin = mk3(a.x, a.y, a.z), direction = mk3(a.w, b.x, b.y), direct = FRESH ? mk3(1.f, 1.f, 1.f) : mk3(dq.x, dq.y, dq.z);
+	f3 origin = mk3(a.x, a.y, a.z), direction = mk3(a.w, b.x, b.y), direct = mk3(dq.x, dq.y, dq.z);
 	const int pixel = __float_as_int(dq.w);
 	const float distance = h.x;
 	const uint32_t ident = __float_as_uint(h.y);
-	int bounces = FRESH ? 0 : (int)(fl & 0xffu);
-	bool lastSpecular = FRESH ? true : ((fl >> 8) & 1u) != 0;
+	int bounces = (int)(fl & 0xffu);
+	bool lastSpecular = ((fl >> 8) & 1u) != 0;
 
 	int new_frame = 0;
 	f3 color = mk3(0.f, 0.f, 0.f);
@@ -162,7 +154,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 #ifdef TYR_WHATIF_NO_LOOKUP
 	const uint32_t vslot = key & kKeyMask;
 #else
-	const uint32_t vslot = valid ? (FRESH ? (key & kKeyMask) : v_lookup(P.vPrev, key)) : 0u; // the ray's slot by the serial order
+	const uint32_t vslot = valid ? v_lookup(P.vPrev, key) : 0u; // the ray's slot by the serial order
 #endif
 	vslotOut = vslot;
 	uint32_t seed = (P.frame * (uint32_t)pixel * 147565741u) * 720898027u * vslot; // kernel.cu:363
@@ -490,7 +482,7 @@ struct ShadeStage { // one tile's output, waiting for the tile's place in the qu
 // queue on the counter of segment (tile / 2) % 8, issued as soon as the tile's counts are known; the records wait in LDS at
 // their rank inside the tile and leave as coalesced stores (thread t writes record t) AFTER the next tile has been
 // shaded -- by then the atomics have long returned.
-template <bool LIGHTS, bool FRESH>
+template <bool LIGHTS>
 __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const FrameParams P_) {
 	const FrameParams& P = P_;
 	__shared__ uint32_t sh[32];
@@ -604,7 +596,7 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			hitRecord = P.work.hit[slot];
 		if (valid)
 			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
-		shade_ray<LIGHTS, FRESH>(P, slot, valid, hitRecord, out, vslot, flush_pixels);
+		shade_ray<LIGHTS>(P, slot, valid, hitRecord, out, vslot, flush_pixels);
 #ifndef TYR_WHATIF_NO_SURVFLAG
 		if (valid)
 			P.survFlag[vslot] = out.survive ? 1 : 0; // what k_scan_words turns into next iteration's slots
@@ -834,7 +826,7 @@ uint32_t shade_grid(const FrameParams& P, uint32_t maxSlots, int numCUs, LaunchC
 	int* perCU = lc.perCU[kLcShade]; // [0] default kernel, [1] the light-list instantiation
 	if (perCU[lights] == 0) {
 		int q = 0;
-		const hipError_t e = lights ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<true, false>, kBlock, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<false, false>, kBlock, 0);
+		const hipError_t e = lights ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<true>, kBlock, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_shade<false>, kBlock, 0);
 		if (e != hipSuccess || q < 1)
 			q = 2;
 		perCU[lights] = q > 6 ? 6 : q;
@@ -845,18 +837,10 @@ uint32_t shade_grid(const FrameParams& P, uint32_t maxSlots, int numCUs, LaunchC
 void launch_shade(const FrameParams& P0, uint32_t maxSlots, int numCUs, LaunchCache& lc, hipStream_t stream) {
 	FrameParams P = P0;
 	P.shadeBlocks = shade_grid(P, maxSlots, numCUs, lc);
-	// P.allFresh (the host knows it exactly or says 0): every ray of this iteration's work queue is a camera ray k_primary has just made
-	if (P.flags & TYR_FLAG_LIGHT_LIST) {
-		if (P.allFresh)
-			hipLaunchKernelGGL((k_shade<true, true>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
-		else
-			hipLaunchKernelGGL((k_shade<true, false>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
-	} else {
-		if (P.allFresh)
-			hipLaunchKernelGGL((k_shade<false, true>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
-		else
-			hipLaunchKernelGGL((k_shade<false, false>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
-	}
+	if (P.flags & TYR_FLAG_LIGHT_LIST)
+		hipLaunchKernelGGL((k_shade<true>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
+	else
+		hipLaunchKernelGGL((k_shade<false>), dim3(P.shadeBlocks), dim3(kBlock), 0, stream, P);
 }
 
 } // namespace tyr

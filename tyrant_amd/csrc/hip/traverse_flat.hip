@@ -658,14 +658,7 @@ __device__ __attribute__((noinline, cold)) uint32_t wide_drain(const float4* __r
 		}
 		// ---- a leaf: four primitives per round, accepted in array order (bvh.h:129-140 / 229-238) ----
 		const bool atLeaf = gActive && ref_is_leaf(ref);
-#ifdef TYR_WIDE_LEAF_MIN_GROUPS
-		// what-if (round 6): the drain is bound by vector issue, and a leaf round costs the wave ~170 instructions however few groups are at a
-		// leaf: groups at a leaf wait until at least TYR_WIDE_LEAF_MIN_GROUPS of them are, or until nobody is at a node any more
-		const unsigned long long leafLanes = __ballot(atLeaf);
-		if (leafLanes != 0ull && ((uint32_t)__popcll(leafLanes) >= 4u * (TYR_WIDE_LEAF_MIN_GROUPS) || __ballot(gActive && !atLeaf) == 0ull)) {
-#else
 		if (__ballot(atLeaf) != 0ull) {
-#endif
 			const uint32_t off = ref & (kMaxPrimOffset - 1);
 			const uint32_t cnt = atLeaf ? ((ref >> 26) & 31u) + 1u : 0u;
 			bool found = false;

@@ -122,7 +122,6 @@ static int launch_iteration(tyr_ctx* c, bool pipelined) {
 	}
 	if (merge && c->tuning.retireSky)
 		P.retireSky = 1u;   // ... and k_primary finishes the camera rays that hit nothing
-	P.allFresh = (c->tuning.freshShade != 0 && c->hK->primary_ray_cnt == 0u && nNew != 0u) ? 1u : 0u; // (hK is current: the queue holds nothing but what k_primary is about to make)
 	enqueue_primary(c, P, nNew);
 	if (merge) { // every traversal launch of a merged render is k_trace_flat; the first one has no shadow rays to carry yet
 		const uint32_t carried = c->shadowPending ? c->shadowPendingMax : 0u;
@@ -229,7 +228,6 @@ static int enqueue_merged_iteration(tyr_ctx* c, const IterationPlan& p, bool beg
 		P.hostSnap = c->hostSnapDev[set];
 		P.snapSeq = c->snapSeq;
 	}
-	P.allFresh = (c->tuning.freshShade != 0 && p.nSurvivors == 0u && p.nNew != 0u && !prologueDone) ? 1u : 0u; // (nSurvivors is exact or an upper bound: zero is exact)
 	if (!prologueDone)
 		enqueue_primary(c, P, p.nNew);
 	enqueue_trace(c, P, p.nLive, p.nSurvivors, p.carried);

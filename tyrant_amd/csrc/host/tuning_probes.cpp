@@ -213,7 +213,6 @@ int tyr_set_tuning(tyr_ctx* c, int key, int value) {
 		{ TYR_TUNE_LAYOUT_ON_DEVICE, 0, 1, &Tuning::layoutOnDevice },
 		{ TYR_TUNE_SCAN_IN_TRACE, 0, 1, &Tuning::scanInTrace },
 		{ TYR_TUNE_KERNEL_SNAPSHOT, 0, 1, &Tuning::kernelSnapshot },
-		{ TYR_TUNE_FRESH_SHADE, 0, 1, &Tuning::freshShade },
 	};
 	for (const Knob& k : knobs) {
 		if (k.key != key)
