@@ -30,7 +30,7 @@ def oracle_counters_check(args, world, W, H, spp, N, n_tris, m, workload=None, s
     got = m["counter_deltas"]
     ok = all(int(got[f]) == int(want[f]) for f in ORACLE_COUNTER_FIELDS) and m["iters"] == gold["per_render"]["iterations"] * steps
     out = {"oracle_counters_match": bool(ok),
-           "oracle_counters": {"source": f"tests/golden/bench_{workload}_counters.json (orc_render on this job; tests/test_gpu_configs.py::test_benchmarked_render_path_matches_oracle_at_full_size[bench_shape_16M_8spp] holds the live oracle, the file and the GPU to each other, pixels included)",
+           "oracle_counters": {"source": f"tests/golden/bench_{workload}_counters.json (orc_render on this job; tests/test_gpu_configs.py::test_benchmarked_render_path_matches_oracle_at_full_size[{'framed_16M_8spp' if workload == 'c3_framed' else 'bench_shape_16M_8spp'}] holds the live oracle, the file and the GPU to each other, pixels included)",
                                "per_render": gold["per_render"], "timed_renders": steps}}
     if not ok:
         out["oracle_counters"]["timed_deltas"] = {f: int(got[f]) for f in ORACLE_COUNTER_FIELDS}
