@@ -121,6 +121,29 @@ def test_oracle_counters_check_compares_the_timed_deltas_with_the_committed_orac
         r = bench.oracle_counters_check(a, kw["world"], kw["W"], kw["H"], kw["spp"], kw["N"], j["triangles"], m)
         assert r["oracle_counters_match"] is None and "oracle_counters_note" in r
     assert bench.oracle_counters_check(bench.parse_args(["--workload", "c2"]), 1, 1920, 1080, 8, 1920 * 1080 * 8, 10036, m)["oracle_counters_match"] is None
+    # the secondary workload (config.framed) is checked against its own file, with its own number of timed renders
+    with open(os.path.join(ROOT, "tests", "golden", "bench_c3_framed_counters.json")) as f:
+        fr = json.load(f)
+    assert fr["job"]["workload"] == "c3_framed" and fr["job"]["triangles"] == j["triangles"] and fr["bvh_nodes_sha256"] == gold["bvh_nodes_sha256"]  # the same scene and tree, another camera
+    assert fr["per_render"]["total_extend_rays"] > 2 * per["total_extend_rays"]  # ... from which the rays actually enter the room
+    mf = {"counter_deltas": {f: fr["per_render"][f] * 10 for f in bench.ORACLE_COUNTER_FIELDS}, "iters": fr["per_render"]["iterations"] * 10}
+    ok = bench.oracle_counters_check(a, 1, 1920, 1080, 8, 1920 * 1080 * 8, j["triangles"], mf, workload="c3_framed", steps=10)
+    assert ok["oracle_counters_match"] is True and ok["oracle_counters"]["timed_renders"] == 10 and "framed_16M_8spp" in ok["oracle_counters"]["source"]
+    assert bench.oracle_counters_check(a, 1, 1920, 1080, 8, 1920 * 1080 * 8, j["triangles"], m, workload="c3_framed", steps=10)["oracle_counters_match"] is False  # (C3's own counters are not the framed job's)
+
+
+def test_nominal_step_fraction_and_gather_ceiling():
+    """roofline.nominal_step_frac = SURVEY.md 8d's bytes of the whole step / wall time / 8 TB/s; roofline.fabric_vs_gather_ceiling = the
+    counters' bytes per second / the guide's Infinity-Cache random-row rate (round 5's review recomputed both by hand: 0.96 and ~0.5)"""
+    roof = {"algorithmic": {"bytes_per_launch": 5.064e9}, "launches": 140, "shade": {"algorithmic": {"bytes_per_render": 4.205e9}}}
+    nf = bench.nominal_step_frac(roof, 20, 20 * 16588800, 0.10538)
+    assert abs(nf["nominal_step_frac"] - 0.96) < 0.01 and nf["nominal_step_bytes"]["primary"] == round(44.0 * 20 * 16588800)
+    assert bench.nominal_step_frac({}, 20, 1, 1.0) is None
+    pmc = {"counters": {"FETCH_SIZE": 900000.0, "WRITE_SIZE": 202000.0, "GRBM_GUI_ACTIVE": 8 * 1.2e6, "SQ_ACTIVE_INST_VALU": 2.0e8, "SQ_ACTIVE_INST_SCA": 1.4e8, "SQ_THREAD_CYCLES_VALU": 64 * 2.0e8 * 0.68,
+                        "SQ_WAVE_CYCLES": 1.0e9, "SQ_WAIT_ANY": 5.0e8}, "source": "test", "launches_averaged": 7}
+    visits = {"nodes_per_ext": 21.56, "tris_per_ext": 1.66, "nodes_per_con": 28.06, "tris_per_con": 1.957, "visible_frac": 0.678}
+    r = bench.roofline_block(pmc, ext_ms=3.7, ext_launches=7, ext_rays=32.9e6, visits=visits, kernel_ms_per_render={}, kernel=bench.TRACE_KERNEL, shadow_rays=9.5e6)
+    assert abs(r["fabric_vs_gather_ceiling"] - r["traffic"] / 7400.0) < 1e-3 and r["fabric_vs_gather_ceiling"] > r["hbm_counter_frac"]
 
 
 def _bench_line(stdout: str) -> dict:
@@ -142,6 +165,10 @@ def test_bench_emits_the_contract_line():
     assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["in_tree_Mrays/s"] <= d["value"]
+    assert list(d["config"])[:3] == ["workload", "in_tree_Mrays/s", "in_tree_fraction"]  # what `value` is made of comes first
+    sp = d["ms_per_step_spread"]
+    assert sp["min"] <= sp["p50"] <= sp["p95"] <= sp["max"] and d["config"]["spread"]["renders"] == 200 and "framed" not in d["config"]  # (the framed view belongs to the default C3 job)
+    assert d["roofline"]["nominal_step_frac"] > 0
     assert d["config"]["device_bvh_build_s"]["same_bytes_as_host_build"] is True and d["config"]["device_bvh_build_s"]["device"] >= 0  # the tree built again on the GPU: the host builder's bytes
     assert d["config"]["device_bvh_build_s"]["build_upload"]["same_scene_in_hbm_as_build_then_upload"] is True  # ... and built + laid out there in one call: the same scene in HBM
     assert d["config"]["host_scene_upload_s"]["layout_on"] == "device"
