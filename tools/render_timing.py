@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """tools/render_timing.py -- per-kernel milliseconds per render (1080p, 8 spp, queue sized for the GPU) on C2 and C3,
-through whichever library TYRANT_HIP_LIBRARY names: the quick A/B for what-if builds, e.g.
-  hipcc ... -DTYR_WHATIF_NO_ATOMICS -c hip/kernels.hip   (pixel atomics left out: wrong picture, right timing)
+through whichever library TYRANT_HIP_LIBRARY names: the quick A/B for tagged builds (make -C tyrant_amd/csrc tagged TAG=...).
 No oracle, no assertions on the picture."""
 import sys, os
 sys.path.insert(0, os.getcwd())

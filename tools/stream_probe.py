@@ -33,8 +33,3 @@ if os.environ.get("TYR_PROBE_DEBUG"):
     tiles = max(d[7], 1)
     names = ["load+shade", "ranks+barrier", "places arrive", "draw (+ wait for the traversal)", "copy out+barrier(+publish)", "stage+pixel atomics"]
     print(f"shade tiles (all renders, all launches) {tiles}; ticks (10 ns) per tile: " + ", ".join(f"{n} {d[i] / tiles:.0f}" for i, n in enumerate(names)) + f"; sum {sum(d[:6]) / tiles:.0f}")
-if os.environ.get("TYR_PROBE_CENSUS"):  # -DTYR_SHADE_CENSUS build: how full the atmosphere model's two passes of k_shade run
-    d = g.counters()["debug"]
-    w = max(d[8], 1)
-    print(f"shade wave-tiles {d[8]}, rays per wave {d[9] / w:.1f}; first pass: {d[10] / w:.1f} rays per wave ask ({d[14] / w:.1f} of them sun samples), {d[11] / w:.3f} of the waves run it; "
-          f"second pass (rays finished in place): {d[12] / w:.1f} per wave, {d[13] / w:.3f} of the waves run it")

@@ -72,9 +72,6 @@ __device__ __forceinline__ double exp_poly(double r) {
 }
 
 __device__ __forceinline__ float expf_det(float xf) {
-#ifdef TYR_WHATIF_FAST_MATH // upper bound of what cheaper transcendentals could save (results differ: a measurement, not a mode)
-	return __expf(xf);
-#endif
 	if (xf != xf)
 		return xf;
 	const double x = (double)xf;
@@ -134,11 +131,6 @@ __device__ __forceinline__ float cosf_det(float xf) {
 }
 // both at once (shares the reduction; each result is bit-identical to the single calls)
 __device__ __forceinline__ void sincosf_det(float xf, float& s_out, float& c_out) {
-#ifdef TYR_WHATIF_FAST_MATH
-	s_out = __sinf(xf);
-	c_out = __cosf(xf);
-	return;
-#endif
 	if (!(fabsf(xf) < 1048576.0f)) {
 		s_out = c_out = xf - xf;
 		return;

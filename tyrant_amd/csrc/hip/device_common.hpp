@@ -194,10 +194,6 @@ __device__ __forceinline__ float2 sphere_hit_record(const FrameParams& P, f3 o, 
 // issued matters: in front of a barrier every wave sits out its own scattered atomics (~3000 cycles under load).
 __device__ __forceinline__ void accumulate_pixel(float4* blit, int pixel, f3 color, int new_frame) {
 	float* px = reinterpret_cast<float*>(&blit[pixel]);
-#ifdef TYR_WHATIF_NO_ATOMICS
-	if (pixel != 12345)
-		return;
-#endif
 	if (color.x != 0.0f)
 		atomicAdd(px + 0, color.x);
 	if (color.y != 0.0f)

@@ -32,9 +32,6 @@ struct ShadeOut {
 	// the path ends; no random number).  It still SURVIVES this iteration (its survive byte, the counts, its slot in the
 	// next iteration's order -- every other ray's random numbers depend on that), it just never enters a queue.
 	bool ghost;
-#ifdef TYR_SHADE_CENSUS
-	int atmoKind; // (diagnostic build) what the ray asked of the atmosphere model: 0 nothing, 1 sun, 2 sky, 3 sunsky
-#endif
 };
 
 // NEE toward spheres[6], kernel.cu:419-447 / 559-590 (common part)
@@ -151,11 +148,7 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 	int new_frame = 0;
 	f3 color = mk3(0.f, 0.f, 0.f);
 	f3 albedo = mk3(0.f, 0.f, 0.f);
-#ifdef TYR_WHATIF_NO_LOOKUP
-	const uint32_t vslot = key & kKeyMask;
-#else
 	const uint32_t vslot = valid ? v_lookup(P.vPrev, key) : 0u; // the ray's slot by the serial order
-#endif
 	vslotOut = vslot;
 	uint32_t seed = (P.frame * (uint32_t)pixel * 147565741u) * 720898027u * vslot; // kernel.cu:363
 	int material = TYR_DIFF;
@@ -368,9 +361,6 @@ __device__ __forceinline__ void shade_ray(const FrameParams& P, uint32_t slot, b
 	// miss (sky / sunsky(direction), kernel.cu:613-617).  A ray asks at most once, nothing random is drawn in
 	// between, so all of them evaluate it HERE, in one pass of the wave, instead of one pass per place of call; every
 	// lane still performs exactly the operations the reference's order of evaluation prescribes.
-#ifdef TYR_SHADE_CENSUS
-	out.atmoKind = atmo;
-#endif
 	if (atmo != kAtmoNone) {
 		const bool miss = !hit;
 		const f3 viewDir = miss ? direction : out.sDir;
@@ -468,9 +458,7 @@ struct ShadeStage { // one tile's output, waiting for the tile's place in the qu
 	uint32_t sh_key[kBlock];
 };
 
-#ifndef TYR_SHADE_BLOCKS_PER_CU
 #define TYR_SHADE_BLOCKS_PER_CU 5 // tiles in flight per CU: 102 vector registers each (96 used; 5 x 27.8 KB of the CU's 160 KB LDS)
-#endif
 // One tile = 256 consecutive physical slots of the work queue = four 64-slot chunks (one per wave), each the tail or
 // the middle of one segment: a wave's valid lanes are the first chunk_valid() of its chunk.
 //
@@ -597,28 +585,9 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 		if (valid)
 			pixelBits = __float_as_uint(P.work.direct_ix[slot].w);
 		shade_ray<LIGHTS>(P, slot, valid, hitRecord, out, vslot, flush_pixels);
-#ifndef TYR_WHATIF_NO_SURVFLAG
 		if (valid)
 			P.survFlag[vslot] = out.survive ? 1 : 0; // what k_scan_words turns into next iteration's slots
-#endif
 		TYR_STAMP(0)
-#ifdef TYR_SHADE_CENSUS
-		{
-			// diagnostic build: how full the atmosphere model's two passes run (debug[8] wave-tiles, [9] rays, [10] rays asking in the
-			// first pass -- for themselves --, [11] waves in which any does, [12] rays finished in place (the second pass: for the
-			// survivor), [13] waves with any, [14] sun samples among [10])
-			const unsigned long long bm = __ballot(out.atmoKind != 0), bg = __ballot(out.ghost), bv = __ballot(valid), bs = __ballot(out.atmoKind == 1);
-			if (lane == 0) {
-				atomicAdd(&P.k->debug[8], 1ull);
-				atomicAdd(&P.k->debug[9], (unsigned long long)__popcll(bv));
-				atomicAdd(&P.k->debug[10], (unsigned long long)__popcll(bm));
-				atomicAdd(&P.k->debug[11], bm ? 1ull : 0ull);
-				atomicAdd(&P.k->debug[12], (unsigned long long)__popcll(bg));
-				atomicAdd(&P.k->debug[13], bg ? 1ull : 0ull);
-				atomicAdd(&P.k->debug[14], (unsigned long long)__popcll(bs));
-			}
-		}
-#endif
 
 		// ---- ranks inside the tile: survivors that may enter the tree, survivors that cannot, shadow rays ----
 		const bool sT = out.survive && out.tree, sS = out.survive && !out.tree && !out.ghost;
@@ -756,13 +725,9 @@ __global__ void __launch_bounds__(kBlock, TYR_SHADE_BLOCKS_PER_CU) k_shade(const
 			atomicAdd(&PE.k->primary_ray_cnt, mySurvivors);
 		if (myShadows + myResolved)
 			atomicAdd(&PE.kc->shadow_cnt, myShadows + myResolved);
-#ifdef TYR_WHATIF_SHADE_FENCE
-		__threadfence();
-#else
 		// the counts above must have arrived before this block counts as done; they are device-scope atomics, so waiting for
 		// them is enough (a release fence here is an L2 write-back per block)
 		__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
 		if (atomicAdd(&PE.k->shade_blocks_done, 1u) + 1u == PE.shadeBlocks) {
 			const uint32_t s = __hip_atomic_load(&PE.k->primary_ray_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const uint32_t h = __hip_atomic_load(&PE.kc->shadow_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
