@@ -120,7 +120,17 @@ def test_oracle_counters_check_compares_the_timed_deltas_with_the_committed_orac
         kw.update(other)
         r = bench.oracle_counters_check(a, kw["world"], kw["W"], kw["H"], kw["spp"], kw["N"], j["triangles"], m)
         assert r["oracle_counters_match"] is None and "oracle_counters_note" in r
-    assert bench.oracle_counters_check(bench.parse_args(["--workload", "c2"]), 1, 1920, 1080, 8, 1920 * 1080 * 8, 10036, m)["oracle_counters_match"] is None
+    assert bench.oracle_counters_check(bench.parse_args(["--workload", "c1"]), 1, 1920, 1080, 8, 1920 * 1080 * 8, 36, m)["oracle_counters_match"] is None  # (no committed counters for c1)
+    for wl in ("c2", "c5"):  # round 6: the other two bench workloads have their oracle counters too
+        with open(os.path.join(ROOT, "tests", "golden", f"bench_{wl}_counters.json")) as f:
+            g2 = json.load(f)
+        j2, p2 = g2["job"], g2["per_render"]
+        assert j2["workload"] == wl and p2["total_primary_rays"] == j2["spp"] * j2["width"] * j2["height"] and p2["n_survive"] == p2["total_extend_rays"] - p2["total_primary_rays"]
+        m2 = {"counter_deltas": {f: p2[f] * 2 for f in bench.ORACLE_COUNTER_FIELDS}, "iters": p2["iterations"] * 2}
+        a2 = bench.parse_args(["--workload", wl, "--steps", "2"])
+        assert bench.oracle_counters_check(a2, 1, j2["width"], j2["height"], j2["spp"], j2["queue_size"], j2["triangles"], m2)["oracle_counters_match"] is True
+    a5 = bench.parse_args(["--workload", "c5", "--width", "3840", "--height", "2160", "--spp", "16"])
+    assert bench.job_shape(a5, 1) == (16, 1 << 25)  # the queue size the committed C5 counters were made for
     # the secondary workload (config.framed) is checked against its own file, with its own number of timed renders
     with open(os.path.join(ROOT, "tests", "golden", "bench_c3_framed_counters.json")) as f:
         fr = json.load(f)

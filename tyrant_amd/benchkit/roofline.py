@@ -11,8 +11,8 @@ ORACLE_COUNTER_FIELDS = ("total_primary_rays", "total_extend_rays", "total_shado
 
 def oracle_counters_check(args, world, W, H, spp, N, n_tris, m, workload=None, steps=None):
     """config.oracle_counters_match: the counter deltas of the TIMED renders against the oracle's counters for this very job,
-    committed as tests/golden/bench_c3_counters.json (made by tests/golden/make_bench_counters.py: orc_render, the serial C
-    restatement of kernel.cu:664-748).  Every timed step restarts the frame counter, so K steps must have cast exactly K times
+    committed as tests/golden/bench_<workload>_counters.json (made by tests/golden/make_bench_counters.py: orc_render, the serial C
+    restatement of kernel.cu:664-748; round 6: also for c2, c5 at 4K / 16 spp and the framed view of c3).  Every timed step restarts the frame counter, so K steps must have cast exactly K times
     the oracle's rays -- extend, shadow, survivors, visible shadow rays, iterations.  None when the job is not the committed one
     (another workload, resolution, spp, queue size or rank count).  The file is data: nothing under oracle/ is loaded here.
     `workload` / `steps`: the secondary workload's (c3_framed: tests/golden/bench_c3_framed_counters.json) instead of the command line's."""
@@ -25,7 +25,7 @@ def oracle_counters_check(args, world, W, H, spp, N, n_tris, m, workload=None, s
         return {"oracle_counters_match": None, "oracle_counters_note": f"no committed oracle counters for workload {workload}"}
     j = gold["job"]
     if world != 1 or (j["width"], j["height"], j["spp"], j["queue_size"], j["triangles"]) != (W, H, spp, N, n_tris):
-        return {"oracle_counters_match": None, "oracle_counters_note": "this job is not the one the committed oracle counters were made for (tests/golden/make_bench_counters.py: c3, 1920x1080, 8 spp, queue 16,588,800, one rank)"}
+        return {"oracle_counters_match": None, "oracle_counters_note": f"this job is not the one the committed oracle counters were made for (tests/golden/bench_{workload}_counters.json: {j['width']}x{j['height']}, {j['spp']} spp, queue {j['queue_size']}, one rank)"}
     want = {f: gold["per_render"][f] * steps for f in ORACLE_COUNTER_FIELDS}
     got = m["counter_deltas"]
     ok = all(int(got[f]) == int(want[f]) for f in ORACLE_COUNTER_FIELDS) and m["iters"] == gold["per_render"]["iterations"] * steps
