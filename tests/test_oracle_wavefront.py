@@ -223,3 +223,32 @@ def test_resolve_tonemap(orc):
     want = (c / (c + 1.0)) ** (1 / 2.2)
     assert np.allclose(img[:, :3], want, rtol=2e-6, atol=1e-7)
     assert np.allclose(img[:, 3], 0.5 ** (1 / 2.2), rtol=1e-6)
+
+
+def test_framed_camera_sees_the_room_through_its_opening(orc):
+    """scenes.FRAMED_CAMERA (bench.py's secondary workload `c3_framed`): kernel.cu:698-699 scales camera_right by 1.5 * W / H and camera_up
+    by 1.5, kernel.cu:274-278 spans them over [-0.5, 0.5] -- so from d = 37.5 in front of the room's 100 x 100 opening (y = -50, x in
+    [-50, 50], z in [0, 100]) a 16:9 frame is exactly as wide as the opening and 56.25 high, inside it.  Checked on the oracle's own camera
+    rays (primary_rays, kernel.cu:247-297): they cross the plane y = -50 inside the opening -- all but the leftmost pixel column, whose jitter
+    (kernel.cu:268: `x - sample.x`) reaches one pixel beyond the frame's edge --; from SURVEY.md 8d's camera (0, -190, 50) one in eight does
+    (0.268 x 0.476 = 12.7 % of the frame)."""
+    from tyrant_amd import scenes
+
+    W, H = 320, 180
+    inside = {}
+    for name, cam in (("framed", scenes.FRAMED_CAMERA), ("cornell", scenes.CORNELL_CAMERA)):
+        sc = scenes.SceneData("opening", scenes.room_walls(), scenes.cornell_spheres(), cam)
+        nodes, prims = orc.bvh_build(sc.triangles, scenes.triangle_bboxes(sc.triangles))
+        o = orc.Oracle(W, H, W * H)
+        o.load_scene(sc, nodes, prims)
+        o.stage("begin"), o.stage("primary")
+        q = o.ray_queue(0, W * H)
+        org, d = q["origin"].astype(np.float64), q["direction"].astype(np.float64)
+        assert np.all(d[:, 1] > 0)
+        t = (-50.0 - org[:, 1]) / d[:, 1]
+        x, z = org[:, 0] + t * d[:, 0], org[:, 2] + t * d[:, 2]
+        inside[name] = float(np.mean((np.abs(x) <= 50.0) & (z >= 0.0) & (z <= 100.0)))
+        if name == "framed":
+            assert abs(np.abs(x).max() - 50.0) < 0.5 and 20.0 < z.min() and z.max() < 80.0  # as wide as the opening, 56 of its 100 high
+    assert inside["framed"] >= 1.0 - 1.0 / W  # (everything but part of one jittered pixel column)
+    assert abs(inside["cornell"] - 0.127) < 0.01

@@ -314,7 +314,7 @@ def mesh_scene(cells: int = 706, seed: int = 12345, spec_fraction: float = 0.3, 
 # 1.5, and kernel.cu:274-278 spans them over [-0.5, 0.5]: at distance d along the view direction the frame is 2.667 d wide and 1.5 d
 # high.  From SURVEY.md 8d's Cornell camera (0, -190, 50) the 100 x 100 opening at y = -50 (d = 140) covers 0.268 x 0.476 = 12.7 % of a
 # 1080p frame -- 61 % of a C3 render's extend rays never enter the tree.  From d = 37.5 the frame is exactly as wide as the opening
-# (and 56 high, inside its 100): every camera ray enters the room.
+# (and 56 high, inside its 100): every camera ray enters the room (but for the leftmost pixel column, whose jitter reaches a pixel further).
 FRAMED_CAMERA = Camera(position=(0.0, -87.5, 50.0), direction=(0.0, 1.0, 0.0), up=(0.0, 0.0, 1.0), focalDistance=1.0, lensRadius=0.0)
 
 
