@@ -113,6 +113,10 @@ def roofline_block(pmc, ext_ms, ext_launches, ext_rays, visits, kernel_ms_per_re
             "pmc_source": pmc["source"],
             "pmc_launches_averaged": pmc["launches_averaged"],
         })
+        if bound == "hbm":
+            out["bound_note"] = ("the largest of the measured resource fractions, not a wall the launch stands at: profiles/r06_whatif_ray_order_c5.txt -- the same launch with its rays laid out "
+                                 "by the triangle they will hit moves 24 % fewer bytes across the fabric and is 8.7 % shorter; with a region of the tree per XCD, 38 % fewer bytes and LONGER.  The fabric's "
+                                 "rate is what six latency-bound waves per SIMD ask of it (wave_wait_frac, valu_issue_frac)")
     else:
         # no counters at all: only the nominal figure exists; it is an HBM fraction only while it stays below 1
         out.update({"bound": "hbm", "achieved": round(min(alg_gbs, HBM_PEAK_GBS), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(min(alg_gbs / HBM_PEAK_GBS, 1.0), 4), "traffic": None,
