@@ -154,6 +154,11 @@ def test_nominal_step_fraction_and_gather_ceiling():
     visits = {"nodes_per_ext": 21.56, "tris_per_ext": 1.66, "nodes_per_con": 28.06, "tris_per_con": 1.957, "visible_frac": 0.678}
     r = bench.roofline_block(pmc, ext_ms=3.7, ext_launches=7, ext_rays=32.9e6, visits=visits, kernel_ms_per_render={}, kernel=bench.TRACE_KERNEL, shadow_rays=9.5e6)
     assert abs(r["fabric_vs_gather_ceiling"] - r["traffic"] / 7400.0) < 1e-3 and r["fabric_vs_gather_ceiling"] > r["hbm_counter_frac"]
+    assert r["bound"] == "valu-issue" and "bound_note" not in r
+    # a launch whose largest measured fraction is the fabric's (C5) says what that fraction is and is not
+    hot = dict(pmc, counters=dict(pmc["counters"], FETCH_SIZE=8.7e6, WRITE_SIZE=3.2e5))
+    r5 = bench.roofline_block(hot, ext_ms=3.7 * 5, ext_launches=7, ext_rays=32.9e6, visits=visits, kernel_ms_per_render={}, kernel=bench.TRACE_KERNEL, shadow_rays=9.5e6)
+    assert r5["bound"] == "hbm" and r5["unit"] == "GB/s" and "r06_whatif_ray_order_c5" in r5["bound_note"]
 
 
 def _bench_line(stdout: str) -> dict:
