@@ -368,6 +368,9 @@ def main():
             # sanity of the combined frame: every pixel has exactly spp completed paths
             a = (frame if frame is not None else accum).view(H * W, 4)[:, 3]
             assert float(a.min()) == float(a.max()) == float(spp), (float(a.min()), float(a.max()), spp)
+        # what the last timed render left in the accumulation buffer (every step resets it and renders the same job): the sums the committed
+        # oracle file holds for this job are compared with it below (oracle_counters_check: oracle_radiance_match)
+        radiance = [float(x) for x in accum.view(H * W, 4)[:, :3].to(torch.float64).sum(0).tolist()] if ranks == 1 else None
         spread = None
         if spread_blocks > 0 and ranks == 1:
             # behind the timed region: the job is 5 ms and boxes differ by 1-3 %; K steps say little about a render's spread
@@ -392,7 +395,7 @@ def main():
             comm = True if native_used else None  # (only its truth value is reported below)
         r.close()
         per_render = {k: round(v["ms"] / warmup, 3) for k, v in tm_all.items()} if tm_all is not None else {k: round(v["ms"] / steps, 3) for k, v in tm.items()}
-        return {"native_combine": bool(comm is not None and native_ok[0]), "comm_info": comm_info, "ext": ext, "shd": shd, "survivors": survivors, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, "counter_deltas": deltas, "upload": upload, "step_ms": step_ms, "spread": spread, **visits}
+        return {"native_combine": bool(comm is not None and native_ok[0]), "comm_info": comm_info, "ext": ext, "shd": shd, "survivors": survivors, "ext_all": ext_all, "shd_all": shd_all, "dt_all": dt_all, "iters": iters, "tm": tm, "kernel_ms_per_render": per_render, "counter_deltas": deltas, "upload": upload, "step_ms": step_ms, "spread": spread, "radiance_sum_rgb": radiance, **visits}
 
     m = measure(N, args.steps, args.warmup, spp_total, shard, world, spread_blocks=0 if (world > 1 or args.no_spread) else 10)
     # the secondary workload (NOT the metric): the same scene and job from where the room's opening fills the frame

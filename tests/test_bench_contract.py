@@ -115,6 +115,14 @@ def test_oracle_counters_check_compares_the_timed_deltas_with_the_committed_orac
     m["counter_deltas"]["total_shadow_rays"] += 1  # one shadow ray too many in twenty renders
     bad = bench.oracle_counters_check(a, 1, 1920, 1080, 8, 1920 * 1080 * 8, j["triangles"], m)
     assert bad["oracle_counters_match"] is False and bad["oracle_counters"]["timed_deltas"]["total_shadow_rays"] == per["total_shadow_rays"] * 20 + 1
+    # the picture too: the accumulation buffer's sums after the last timed render against the oracle's (same file), 1e-5
+    assert "oracle_radiance_match" not in ok
+    m["counter_deltas"]["total_shadow_rays"] -= 1
+    m["radiance_sum_rgb"] = [x * (1.0 + 2e-7) for x in gold["radiance_sum_rgb"]]
+    ok = bench.oracle_counters_check(a, 1, 1920, 1080, 8, 1920 * 1080 * 8, j["triangles"], m)
+    assert ok["oracle_counters_match"] is True and ok["oracle_radiance_match"] is True and ok["oracle_radiance"]["rel_err"] < 1e-6
+    m["radiance_sum_rgb"][1] *= 1.0 + 1e-4
+    assert bench.oracle_counters_check(a, 1, 1920, 1080, 8, 1920 * 1080 * 8, j["triangles"], m)["oracle_radiance_match"] is False
     for other in (dict(world=2), dict(N=2097152), dict(spp=4), dict(W=1280)):
         kw = dict(world=1, W=1920, H=1080, spp=8, N=1920 * 1080 * 8)
         kw.update(other)

@@ -35,6 +35,13 @@ def oracle_counters_check(args, world, W, H, spp, N, n_tris, m, workload=None, s
     if not ok:
         out["oracle_counters"]["timed_deltas"] = {f: int(got[f]) for f in ORACLE_COUNTER_FIELDS}
         out["oracle_counters"]["timed_iterations"] = m["iters"]
+    # ... and the picture: the sums over the accumulation buffer the last timed render left, against the oracle's for this job (the same additions
+    # per pixel in another order: 1e-5, the tolerance of the full-size GPU tests)
+    want_rgb, got_rgb = gold.get("radiance_sum_rgb"), m.get("radiance_sum_rgb")
+    if want_rgb and got_rgb:
+        rel = max(abs(g - w) / max(abs(w), 1e-30) for g, w in zip(got_rgb, want_rgb))
+        out["oracle_radiance_match"] = bool(rel <= 1e-5)
+        out["oracle_radiance"] = {"rel_err": float(f"{rel:.3e}"), "tolerance": 1e-5, "of": "sum over the accumulation buffer's r, g, b after the last timed render (float64 sums of the fp32 pixels) against radiance_sum_rgb of the same file"}
     return out
 
 def shade_block(pmc, shade_ms_per_render, rays_per_render, survivors_per_render, shadows_per_render):
